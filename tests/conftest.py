@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "ops_sampler_graph.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_models():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "models.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_meta():
+    import json
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        return json.load(f)
