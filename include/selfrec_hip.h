@@ -1,0 +1,265 @@
+/*
+ * selfrec_hip.h -- C ABI of libselfrec_hip.so, the MI355X (gfx950) engine behind SELFRec's
+ * graph-recommender hot path.
+ *
+ * The reference (Coder-Yu/SELFRec) is pure Python: it has no FFI of its own.  The
+ * "operator interface" it does have is a set of Python call sites inside its model
+ * files; each entry point below is what a ctypes stub bound at that call site calls
+ * (INTEGRATION.md shows the stubs).  Every declaration cites the reference interface it
+ * replaces as  <file>:<lines>  relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain C types only; no torch / C++ types cross this boundary.
+ *   - pointers named d_*  are raw DEVICE addresses on the current HIP device,
+ *     pointers named h_*  are HOST addresses.  All buffers are caller-owned; the library
+ *     allocates only the opaque handles it returns (freed by the matching *_destroy).
+ *   - every device entry point is asynchronous on the `stream` argument (a hipStream_t
+ *     passed as void*); none synchronises, none uses the null stream implicitly.
+ *   - return value: SRH_OK (0) or a negative srh_status_t.  Nothing throws, nothing calls
+ *     exit().  srh_last_error_string() describes the last failure on the calling thread.
+ *   - row-major fp32 matrices with leading dimension == d unless stated.
+ *   - handles are not thread-safe; distinct handles may be used from distinct threads.
+ */
+#ifndef SELFREC_HIP_H
+#define SELFREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t srh_status_t;
+enum {
+  SRH_OK = 0,
+  SRH_ERR_INVALID_ARG = -1,
+  SRH_ERR_HIP = -2,
+  SRH_ERR_UNSUPPORTED = -3,
+  SRH_ERR_NOMEM = -4,
+  SRH_ERR_STATE = -5
+};
+
+/* ABI version: bumped whenever a signature or struct below changes. */
+#define SRH_ABI_VERSION 4
+int32_t srh_abi_version(void);
+const char* srh_last_error_string(void);
+/* Number of visible HIP devices (0 when there is none -- never an error). */
+int32_t srh_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * (a-1) Pairwise sampler -- replaces util/sampler.py:5-28  next_batch_pairwise(data, B, n_negs)
+ *
+ * Host-side, bit-exact replay of the CPython `random` stream the reference consumes:
+ * MT19937 words -> getrandbits(k) -> _randbelow(n) -> shuffle / choice with set rejection.
+ * The handle keeps the persistent order of data.training_data across epochs (the
+ * reference shuffles that shared list in place, sampler.py:7).
+ * ---------------------------------------------------------------------------------- */
+typedef struct srh_sampler srh_sampler_t;
+
+/* h_edge_user/h_edge_item: the id columns of training_data in its CURRENT order
+ * (ids as assigned by data/ui_graph.py:29-38).  Copied. */
+srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_items,
+                                int64_t n_edges, const int32_t* h_edge_user,
+                                const int32_t* h_edge_item);
+void srh_sampler_destroy(srh_sampler_t* s);
+/* MT19937 state exactly as random.getstate()[1]: 624 words followed by the position. */
+srh_status_t srh_sampler_set_state(srh_sampler_t* s, const uint32_t* h_mt624, int32_t pos);
+srh_status_t srh_sampler_get_state(const srh_sampler_t* s, uint32_t* h_mt624, int32_t* pos);
+/* random.seed(int) for 0 <= seed < 2^64 (CPython init_by_array on the 32-bit limbs). */
+srh_status_t srh_sampler_seed(srh_sampler_t* s, uint64_t seed);
+/* random.shuffle(training_data): one Fisher-Yates pass over the persistent order. */
+srh_status_t srh_sampler_shuffle(srh_sampler_t* s);
+/* Current order: h_perm[p] = index into the edge arrays given at create time. */
+srh_status_t srh_sampler_get_order(const srh_sampler_t* s, int64_t* h_perm);
+/* One batch: positions [ptr, ptr+count) of the current order; writes count users, count
+ * positives and count*n_negs negatives.  *out_count receives count
+ * (= min(batch_size, n_edges-ptr), sampler.py:10-14).  */
+srh_status_t srh_sampler_next_batch(srh_sampler_t* s, int64_t ptr, int64_t batch_size,
+                                    int32_t n_negs, int32_t* h_u, int32_t* h_i, int32_t* h_j,
+                                    int64_t* out_count);
+/* A whole epoch = shuffle + every batch, contiguous: h_u/h_i hold n_edges ids, h_j holds
+ * n_edges*n_negs.  When h_uniq_u/h_uniq_i are non-NULL they receive, per batch b, the
+ * sorted unique user / positive-item ids (torch.unique at XSimGCL.py:46-47) at offset
+ * b*batch_size, with the counts in h_n_uniq_u[b] / h_n_uniq_i[b]. */
+srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_negs,
+                               int32_t* h_u, int32_t* h_i, int32_t* h_j,
+                               int32_t* h_uniq_u, int32_t* h_n_uniq_u,
+                               int32_t* h_uniq_i, int32_t* h_n_uniq_i);
+/* random.sample(range(n), k) (data/augmentor.py:35 edge_dropout keep-set; :15-16 node
+ * dropout) replayed on the sampler's MT stream.  h_out receives k indices in draw order. */
+srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out);
+/* random.getrandbits(32) -- lets tests pin how much of the stream was consumed. */
+srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out);
+
+/* ------------------------------------------------------------------------------------
+ * (a-2) Graph normalisation -- replaces data/graph.py:10-24 normalize_graph_mat and
+ * data/ui_graph.py:58-65 convert_to_laplacian_mat on a device-resident CSR.
+ *
+ * The (N x N) bipartite adjacency keeps ONE structure for the graph and all its
+ * edge-dropped views; a view is a value array.  d_edge_id[p] is the position, in the
+ * row-major order of the U x I interaction matrix, of the interaction behind non-zero p
+ * (both the (u,i) and the (i,u) copies carry the same id), d_weight[p] its weight (NULL =
+ * all ones), d_keep[e] != 0 keeps interaction e (NULL = keep all).
+ * Output: d_vals[p] = keep ? (dinv[row] * w) * dinv[col] : 0 with
+ * dinv[r] = (sum of kept weights in row r)^-1/2, 0 for an empty row -- the reference's
+ * inf -> 0 rule (graph.py:15).  d_deg_ws: workspace of n_rows floats.
+ * ---------------------------------------------------------------------------------- */
+srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
+                                   const int32_t* d_indices, const int32_t* d_edge_id,
+                                   const float* d_weight, const uint8_t* d_keep,
+                                   float* d_deg_ws, float* d_vals, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-3, a-4) Sparse propagation -- replaces torch.sparse.mm(adj, dense) at
+ * LightGCN.py:72, XSimGCL.py:88, SimGCL.py:85, SGL.py:104-108 (adj produced by
+ * base/torch_interface.py:8-13), with the per-layer elementwise tail fused in:
+ *   PERTURB : y += sign(y) * normalize(noise_row) * eps        XSimGCL.py:90-91
+ *   MEAN    : mean_out = (sum_t prev[t] + y) / mean_div         XSimGCL.py:95-96, LightGCN.py:74-75
+ *   AXPY    : y = alpha * y + sum_t add_scale[t] * add[t]       (backward accumulation; add[t] may alias y)
+ *
+ * The plan is the row schedule (degree-sorted rows, heavy rows split into segments); it
+ * depends only on indptr and is shared by every value array over the same structure.
+ * ---------------------------------------------------------------------------------- */
+typedef struct srh_spmm_plan srh_spmm_plan_t;
+
+srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
+                                  const int32_t* h_indptr, int32_t split_len /* 0 = default */);
+void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
+
+enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };
+#define SRH_MAX_PREV 8
+#define SRH_MAX_ADD 2
+
+typedef struct srh_spmm_epilogue {
+  int32_t flags;               /* OR of SRH_EPI_* ; 0 = plain y = A x                      */
+  float eps;                   /* PERTURB magnitude                                          */
+  const float* d_noise;        /* PERTURB: U[0,1) noise (n_rows, d) to inject, or NULL       */
+  uint64_t philox_seed;        /* PERTURB with d_noise == NULL: in-kernel Philox4x32-10,     */
+  uint64_t philox_offset;      /*   counter = (philox_offset + *d_philox_step * philox_stride */
+  const int64_t* d_philox_step;/*              + row, lane-quad); d_philox_step may be NULL  */
+  uint64_t philox_stride;
+  int32_t n_prev;              /* MEAN: number of earlier layer tensors                      */
+  int32_t n_add;               /* AXPY: number of addends                                    */
+  const float* d_prev[SRH_MAX_PREV];
+  float mean_div;              /* MEAN: divisor (number of tensors averaged)                 */
+  float alpha;                 /* AXPY: scale of the product (use 1 for a plain add)         */
+  float* d_mean_out;           /* MEAN: (n_rows, d) output                                   */
+  const float* d_add[SRH_MAX_ADD];
+  float add_scale[SRH_MAX_ADD];
+} srh_spmm_epilogue_t;
+
+/* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {32,64,128,256}.
+ * x and y must not alias.  epi may be NULL. */
+srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
+                          const int32_t* d_indices, const float* d_vals, const float* d_x,
+                          float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-5, a-6, a-7) Row gather + BPR + L2 regulariser, forward and backward in one call --
+ * replaces  emb[idx]  (XSimGCL.py:30), util/loss_torch.py:6-10 bpr_loss and :18-22
+ * l2_reg_loss, and their autograd.
+ *
+ * Batch rows b = 0..B-1:  u = U[u_idx[b]], p = I[i_idx[b]], n = I[j_idx[b]].
+ *   bpr  = mean_b( -log(1e-5 + sigmoid(<u,p> - <u,n>)) )
+ *   reg  = reg_coef * ( ||Ru||_F + ||Rp||_F [+ ||Rn||_F] ) / B_rows     (Frobenius, not squared)
+ * where R* are the same gathered rows of the REG source tables (d_reg_user/d_reg_item;
+ * pass the propagated tables for XSimGCL/SimGCL/SGL/MF, the ego tables for LightGCN,
+ * LightGCN.py:25).  reg_coef already contains any extra /batch_size factor.
+ * Gradients (d loss / d table rows, scaled by loss_scale) are ATOMICALLY ACCUMULATED into
+ * d_g_user / d_g_item (the gradient w.r.t. d_user/d_item) and d_greg_user / d_greg_item
+ * (w.r.t. the REG tables; may alias d_g_*).  d_losses[0] += bpr, d_losses[1] += reg
+ * (double, caller zeroes).  d_n_rows: optional device int32 overriding B (graph replay).
+ * d_ws: workspace of at least srh_bpr_ws_bytes(B) bytes.
+ * ---------------------------------------------------------------------------------- */
+int64_t srh_bpr_ws_bytes(int64_t B);
+srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item,
+                                const float* d_reg_user, const float* d_reg_item,
+                                const int32_t* d_u_idx, const int32_t* d_i_idx,
+                                const int32_t* d_j_idx, int64_t B, const int32_t* d_n_rows,
+                                int32_t d, float reg_coef, int32_t reg_include_neg,
+                                float loss_scale, float* d_g_user, float* d_g_item,
+                                float* d_greg_user, float* d_greg_item, double* d_losses,
+                                void* d_ws, void* stream);
+
+/* Plain (non-gathered) forms used by the drop-in autograd functions. */
+srh_status_t srh_bpr_fwd(const float* d_u, const float* d_p, const float* d_n, int64_t B,
+                         int32_t d, double* d_loss_sum /* += sum_b loss_b */, float* d_coef /* B */,
+                         void* stream);
+srh_status_t srh_bpr_bwd(const float* d_u, const float* d_p, const float* d_n,
+                         const float* d_coef, int64_t B, int32_t d, float scale /* gout/B */,
+                         float* d_gu, float* d_gp, float* d_gn, void* stream);
+/* sum of squares of a (rows, d) block:  d_out[0] += sum x^2 (double). */
+srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-8) InfoNCE forward + backward -- replaces util/loss_torch.py:35-50 InfoNCE(view1,
+ * view2, temperature, b_cos=True) at XSimGCL.py:48-49, SimGCL.py:48-49, SGL.py:125.
+ *
+ *   v1 = normalize(V1[idx]), v2 = normalize(V2[idx])   (rows gathered when d_idx != NULL)
+ *   S = v1 v2^T / tau ;  loss = -mean_i log_softmax(S, dim=1)[i,i]
+ * S (n x n) is never materialised: one flash-style pass over row tiles produces the row
+ * log-sum-exp and dL/dv1, a second pass over column tiles produces dL/dv2; the
+ * normalisation backward and the scatter to the source rows are fused in the last pass.
+ * d_loss[0] += loss_scale * loss (double).  Gradients scaled by loss_scale are ADDED to
+ * rows idx of d_g1 / d_g2 (row i when d_idx == NULL; idx must then be unique per call).
+ * d_n: optional device int32 overriding n.  d_ws >= srh_infonce_ws_bytes(n, d) bytes.
+ * ---------------------------------------------------------------------------------- */
+int64_t srh_infonce_ws_bytes(int64_t n, int32_t d);
+srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx,
+                                 int64_t n, const int32_t* d_n, int32_t d, float tau,
+                                 float loss_scale, double* d_loss, float* d_g1, float* d_g2,
+                                 void* d_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-9) Dense Adam -- replaces torch.optim.Adam(...).step() at XSimGCL.py:25,37
+ * (betas, eps as given; no weight decay; bias-corrected).  `step` is 1-based; when
+ * d_step != NULL the step count is read from that device int64 (graph replay).
+ * ---------------------------------------------------------------------------------- */
+srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v,
+                           int64_t n_elem, int64_t step, const int64_t* d_step, float lr,
+                           float beta1, float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-10, a-11) Full-catalogue scoring + training-item mask + top-K -- replaces the per
+ * user loop of base/graph_recommender.py:46-53 (predict = XSimGCL.py:57-60, mask = -10e8,
+ * util/algorithm.py:144-156 find_k_largest).
+ *
+ *   scores[r, :] = item_emb @ user_emb[user_ids[r]]       fp32 MFMA (exact-f32 fma chain)
+ *   scores[r, i] = -1e9 for i in training items of that user (CSR d_r_indptr/d_r_indices)
+ *   top-K by (score desc, id asc), written best-first.
+ * d_scores_ws: (n_query, n_items) fp32 scratch (the caller chunks users so it stays
+ * cache-resident).  d_user_ids may be NULL (rows 0..n_query-1 of d_user_emb).
+ * ---------------------------------------------------------------------------------- */
+srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_ids,
+                                 int64_t n_query, const float* d_item_emb, int64_t n_items,
+                                 int32_t d, const int32_t* d_r_indptr, const int32_t* d_r_indices,
+                                 int32_t k, float* d_scores_ws, int32_t* d_out_ids,
+                                 float* d_out_scores, void* stream);
+/* The scoring GEMM alone: C (m, n) = A (m, d) B (n, d)^T, fp32 MFMA. */
+srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int64_t m,
+                             int64_t n, int32_t d, void* stream);
+/* Row-wise top-K of a (rows, n) fp32 matrix (ld = n). */
+srh_status_t srh_topk_rows(const float* d_scores, int64_t rows, int64_t n, int32_t k,
+                           int32_t* d_out_ids, float* d_out_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small device utilities used by the fused engine.
+ * ---------------------------------------------------------------------------------- */
+/* y = a*x + b*y   (elementwise, n_elem floats; y may be uninitialised when b == 0) */
+srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n_elem, void* stream);
+/* Batch cursor for graph replay: copies batch *d_cursor of the per-epoch index arrays
+ * into fixed staging buffers, publishes its sizes, then increments the cursor and the
+ * optimiser step.  d_meta: int32[4] = {rows, n_uniq_u, n_uniq_i, batch_no}. */
+srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
+                             const int32_t* d_epoch_j, const int32_t* d_epoch_uniq_u,
+                             const int32_t* d_epoch_uniq_i, const int32_t* d_n_uniq_u,
+                             const int32_t* d_n_uniq_i, int64_t n_edges, int64_t batch_size,
+                             int64_t* d_cursor /* [0]=batch no, [1]=adam step */,
+                             int32_t* d_stage_u, int32_t* d_stage_i, int32_t* d_stage_j,
+                             int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
+                             int32_t* d_meta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELFREC_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libselfrec_hip.so (the C ABI declared in include/selfrec_hip.h).
+
+This is the only place the shared library is loaded.  There is no fallback: if the
+library is missing or a call fails, ``SelfrecHipError`` is raised.  ``import torch`` comes
+first on purpose -- torch loads the ROCm runtime (libamdhip64.so.7) and the library's own
+DT_NEEDED entry then resolves to that same copy, so device pointers and streams are shared.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
+ABI_VERSION = 4
+
+SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
+SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
+
+
+class SelfrecHipError(RuntimeError):
+    pass
+
+
+class SpmmEpilogue(C.Structure):
+    """struct srh_spmm_epilogue (include/selfrec_hip.h)."""
+    _fields_ = [
+        ("flags", C.c_int32), ("eps", C.c_float), ("d_noise", C.c_void_p),
+        ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
+        ("d_philox_step", C.c_void_p), ("philox_stride", C.c_uint64),
+        ("n_prev", C.c_int32), ("n_add", C.c_int32),
+        ("d_prev", C.c_void_p * SRH_MAX_PREV),
+        ("mean_div", C.c_float), ("alpha", C.c_float),
+        ("d_mean_out", C.c_void_p),
+        ("d_add", C.c_void_p * SRH_MAX_ADD),
+        ("add_scale", C.c_float * SRH_MAX_ADD),
+    ]
+
+
+_vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); every symbol include/selfrec_hip.h declares
+SIGNATURES = {
+    "srh_abi_version": (_i32, []),
+    "srh_last_error_string": (C.c_char_p, []),
+    "srh_device_count": (_i32, []),
+    "srh_sampler_create": (_i32, [C.POINTER(_vp), _i64, _i64, _i64, _vp, _vp]),
+    "srh_sampler_destroy": (None, [_vp]),
+    "srh_sampler_set_state": (_i32, [_vp, _vp, _i32]),
+    "srh_sampler_get_state": (_i32, [_vp, _vp, C.POINTER(_i32)]),
+    "srh_sampler_seed": (_i32, [_vp, _u64]),
+    "srh_sampler_shuffle": (_i32, [_vp]),
+    "srh_sampler_get_order": (_i32, [_vp, _vp]),
+    "srh_sampler_next_batch": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "srh_sampler_epoch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
+    "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
+    "srh_adj_sym_normalize": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32]),
+    "srh_spmm_plan_destroy": (None, [_vp]),
+    "srh_spmm_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(SpmmEpilogue), _vp]),
+    "srh_bpr_ws_bytes": (_i64, [_i64]),
+    "srh_bpr_l2_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i32, _f32,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_bpr_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "srh_bpr_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "srh_sumsq": (_i32, [_vp, _i64, _vp, _vp]),
+    "srh_infonce_ws_bytes": (_i64, [_i64, _i32]),
+    "srh_infonce_fwd_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "srh_topk_rows": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
+    "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise SelfrecHipError if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SelfrecHipError(
+            f"{LIB_PATH} not found. Build it with `make -C selfrec_amd/csrc` or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SelfrecHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SelfrecHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.srh_abi_version()
+    if got != ABI_VERSION:
+        raise SelfrecHipError(f"{LIB_PATH} has ABI version {got}, binding expects {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().srh_last_error_string()
+        raise SelfrecHipError(f"{what or 'libselfrec_hip'} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def require_gpu() -> None:
+    """The product path needs a HIP device; say so instead of computing anything elsewhere."""
+    if load().srh_device_count() < 1 or not torch.cuda.is_available():
+        raise SelfrecHipError("no HIP device visible: selfrec_amd's compute path is MI355X-only (no CPU fallback)")

@@ -1,0 +1,123 @@
+"""``GraphRecommender`` with the surface of reference base/graph_recommender.py:10-104.
+
+``test()`` is where the full-catalogue ranking happens.  The reference scores one user at a
+time (a device mat-vec, a D2H copy of I floats, a python mask loop and a heap top-K per
+user, :46-53).  Here, when the model exposes ``user_emb`` / ``item_emb`` device tensors (every
+LightGCN-family model does, e.g. XSimGCL.py:41), all test users go through
+``srh_score_mask_topk`` in cache-sized chunks -- fp32 MFMA scores, training items masked to
+-1e9, top-K on device -- and only (users x K) ids and scores come back.  Models with a
+custom ``predict`` keep the per-user loop.  Either way the return value is the reference's:
+``{user: [(item_name, score), ...]}`` best first, length ``max_N``.
+"""
+from os.path import abspath
+from time import localtime, strftime, time
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..data.loader import FileIO
+from ..data.ui_graph import Interaction
+from ..util.algorithm import find_k_largest
+from ..util.evaluation import ranking_evaluation
+from .recommender import Recommender
+
+MASKED_SCORE = -10e8
+# users per scoring call: chunk * n_items * 4 B stays well inside the 256 MiB Infinity Cache
+SCORE_SLAB_BYTES = 96 << 20
+
+
+class GraphRecommender(Recommender):
+    def __init__(self, conf, training_set, test_set, **kwargs):
+        super().__init__(conf, training_set, test_set, **kwargs)
+        self.data = Interaction(conf, training_set, test_set)
+        self.bestPerformance = []
+        self.topN = [int(num) for num in self.ranking]
+        self.max_N = max(self.topN)
+
+    def print_model_info(self):
+        super().print_model_info()
+        tr, te = self.data.training_size(), self.data.test_size()
+        print(f'Training Set Size: (user number: {tr[0]}, item number: {tr[1]}, interaction number: {tr[2]})')
+        print(f'Test Set Size: (user number: {te[0]}, item number: {te[1]}, interaction number: {te[2]})')
+        print('=' * 80)
+
+    # ---- ranking ------------------------------------------------------------------------
+    def _device_embeddings(self):
+        ue, ie = getattr(self, 'user_emb', None), getattr(self, 'item_emb', None)
+        ok = all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 2 for t in (ue, ie))
+        if ok and ue.shape[0] == self.data.user_num and ie.shape[0] == self.data.item_num:
+            return ue.detach().float().contiguous(), ie.detach().float().contiguous()
+        return None
+
+    def rank_on_device(self, user_ids, k=None):
+        """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids."""
+        k = self.max_N if k is None else k
+        ue, ie = self._device_embeddings()
+        g = self.data.device_graph(ie.device)
+        uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=ie.device)
+        chunk = max(32, min(len(user_ids), SCORE_SLAB_BYTES // (4 * ie.shape[0])))
+        slab = torch.empty((chunk, ie.shape[0]), dtype=torch.float32, device=ie.device)
+        ids_parts, sc_parts = [], []
+        for lo in range(0, uid.numel(), chunk):
+            part = uid[lo:lo + chunk]
+            ids, sc = ops.score_mask_topk(ue, part, ie, g.r_indptr, g.r_indices, k, scores_ws=slab[:part.numel()])
+            ids_parts.append(ids)
+            sc_parts.append(sc)
+        return torch.cat(ids_parts).cpu().numpy(), torch.cat(sc_parts).cpu().numpy()
+
+    def test(self):
+        users = list(self.data.test_set)
+        if self._device_embeddings() is not None and users:
+            ids, scores = self.rank_on_device([self.data.user[u] for u in users])
+            id2item = self.data.id2item
+            names = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)[ids]
+            return {u: list(zip(names[r].tolist(), scores[r].tolist())) for r, u in enumerate(users)}
+        rec_list = {}
+        for user in users:                                   # models with a custom predict()
+            candidates = self.predict(user)
+            for item in self.data.user_rated(user)[0]:
+                candidates[self.data.item[item]] = MASKED_SCORE
+            ids, scores = find_k_largest(self.max_N, candidates)
+            rec_list[user] = [(self.data.id2item[i], s) for i, s in zip(ids, scores)]
+        return rec_list
+
+    # ---- reporting (same files and strings as the reference) ----------------------------
+    def evaluate(self, rec_list):
+        self.recOutput.append('userId: recommendations in (itemId, ranking score) pairs, * means the item is hit.\n')
+        for user, truth in self.data.test_set.items():
+            cells = ''.join(f" ({name},{score}){'*' if name in truth else ''}" for name, score in rec_list[user])
+            self.recOutput.append(user + ':' + cells + '\n')
+        stamp = strftime("%Y-%m-%d %H-%M-%S", localtime(time()))
+        name = self.config['model']['name']
+        FileIO.write_file(self.output, f"{name}@{stamp}-top-{self.max_N}items.txt", self.recOutput)
+        print('The result has been output to ', abspath(self.output), '.')
+        self.result = ranking_evaluation(self.data.test_set, rec_list, self.topN)
+        self.model_log.add('###Evaluation Results###')
+        self.model_log.add(self.result)
+        FileIO.write_file(self.output, f"{name}@{stamp}-performance.txt", self.result)
+        print(f'The result of {self.model_name}:\n{"".join(self.result)}')
+
+    def fast_evaluation(self, epoch):
+        print('Evaluating the model...')
+        rec_list = self.test()
+        measure = ranking_evaluation(self.data.test_set, rec_list, [self.max_N])
+        performance = {}
+        for line in measure[1:]:
+            key, value = line.strip().split(':')
+            performance[key] = float(value)
+        improved = not self.bestPerformance
+        if self.bestPerformance:
+            # majority vote over the metrics, as reference graph_recommender.py:88-92
+            votes = sum(1 if self.bestPerformance[1][k] > performance[k] else -1 for k in performance)
+            improved = votes < 0
+        if improved:
+            self.bestPerformance = [epoch + 1, performance]
+            self.save()
+        print('-' * 80)
+        print(f'Real-Time Ranking Performance (Top-{self.max_N} Item Recommendation)')
+        print(f'*Current Performance*\nEpoch: {epoch + 1}, ' + ', '.join(f'{k}: {v}' for k, v in performance.items()))
+        best = ', '.join(f'{k}: {v}' for k, v in self.bestPerformance[1].items())
+        print(f'*Best Performance*\nEpoch: {self.bestPerformance[0]}, {best}')
+        print('-' * 80)
+        return measure

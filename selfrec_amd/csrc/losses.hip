@@ -1,0 +1,536 @@
+// (a-5..a-8) Batch losses of the LightGCN family, forward + backward fused:
+//   * row gather + BPR + L2 regulariser   (reference XSimGCL.py:30-33, util/loss_torch.py:6-10,18-22)
+//   * InfoNCE                               (reference util/loss_torch.py:35-50)
+// These kernels touch only O(batch) rows; what matters is launch count and, for InfoNCE,
+// the 4 x (2 n^2 d) flops of the similarity products, which run on the fp32 MFMA pipe
+// (v_mfma_f32_16x16x4_f32: exact f32 fma chains, so the 1e-4 parity budget is untouched).
+#include "common.h"
+
+namespace {
+using namespace srh;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void atomic_add_f4(float* base, float4 v) {
+  unsafeAtomicAdd(base + 0, v.x);
+  unsafeAtomicAdd(base + 1, v.y);
+  unsafeAtomicAdd(base + 2, v.z);
+  unsafeAtomicAdd(base + 3, v.w);
+}
+
+// ---------------------------------------------------------------------------------------
+// BPR: per-row pieces shared by the gathered (engine) and plain (drop-in) entry points
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void bpr_row(float pos, float neg, float& loss, float& coef) {
+  const float x = pos - neg;
+  const float sig = 1.0f / (1.0f + expf(-x));   // torch.sigmoid
+  const float arg = 10e-6f + sig;               // loss_torch.py:9
+  loss = -logf(arg);
+  coef = -(sig * (1.0f - sig)) / arg;           // d loss / d x
+}
+
+struct BprArgs {
+  const float *user, *item, *reg_user, *reg_item;
+  const int32_t *u_idx, *i_idx, *j_idx;
+  const int32_t* d_n_rows;
+  int B;
+  float reg_coef, loss_scale;
+  int reg_include_neg;
+  float *g_user, *g_item, *greg_user, *greg_item;
+  double* losses;
+  double* sums;    // ws: 3 doubles
+  float* coef;     // ws: B floats
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) {
+  constexpr int G = 64 / LPR;
+  const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool valid = b < rows;
+  const int bu = valid ? a.u_idx[b] : 0, bi = valid ? a.i_idx[b] : 0, bj = valid ? a.j_idx[b] : 0;
+  const float4 u = reinterpret_cast<const float4*>(a.user)[(size_t)bu * LPR + sub];
+  const float4 p = reinterpret_cast<const float4*>(a.item)[(size_t)bi * LPR + sub];
+  const float4 n = reinterpret_cast<const float4*>(a.item)[(size_t)bj * LPR + sub];
+  const float pos = group_sum<LPR>(f4_dot(u, p));
+  const float neg = group_sum<LPR>(f4_dot(u, n));
+  float loss, coef;
+  bpr_row(pos, neg, loss, coef);
+  if (valid && sub == 0) a.coef[b] = coef;
+  float4 ru = u, rp = p, rn = n;
+  if (a.reg_user != a.user) ru = reinterpret_cast<const float4*>(a.reg_user)[(size_t)bu * LPR + sub];
+  if (a.reg_item != a.item) {
+    rp = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bi * LPR + sub];
+    rn = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bj * LPR + sub];
+  }
+  // per-lane partials (each lane owns 4 of the d columns); loss counted once per row
+  double l_part = (valid && sub == 0) ? (double)loss : 0.0;
+  double su = valid ? (double)f4_dot(ru, ru) : 0.0;
+  double sp = valid ? (double)f4_dot(rp, rp) : 0.0;
+  double sn = valid ? (double)f4_dot(rn, rn) : 0.0;
+  l_part = wave_sum_d(l_part);
+  su = wave_sum_d(su);
+  sp = wave_sum_d(sp);
+  sn = wave_sum_d(sn);
+  if (lane == 0 && rows > 0) {
+    atomicAdd(&a.losses[0], (double)a.loss_scale * l_part / (double)rows);
+    atomicAdd(&a.sums[0], su);
+    atomicAdd(&a.sums[1], sp);
+    atomicAdd(&a.sums[2], sn);
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) {
+  constexpr int G = 64 / LPR;
+  const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
+  if (rows <= 0) return;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const float nu = (float)sqrt(a.sums[0]), np = (float)sqrt(a.sums[1]), nn = (float)sqrt(a.sums[2]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float r = nu / (float)rows + np / (float)rows;
+    if (a.reg_include_neg) r += nn / (float)rows;
+    atomicAdd(&a.losses[1], (double)(a.loss_scale * (r * a.reg_coef)));
+  }
+  if (b >= rows) return;
+  const int bu = a.u_idx[b], bi = a.i_idx[b], bj = a.j_idx[b];
+  const float4 u = reinterpret_cast<const float4*>(a.user)[(size_t)bu * LPR + sub];
+  const float4 p = reinterpret_cast<const float4*>(a.item)[(size_t)bi * LPR + sub];
+  const float4 n = reinterpret_cast<const float4*>(a.item)[(size_t)bj * LPR + sub];
+  const float c = a.coef[b] * (a.loss_scale / (float)rows);
+  float4 gu = make_float4(c * (p.x - n.x), c * (p.y - n.y), c * (p.z - n.z), c * (p.w - n.w));
+  float4 gp = f4_scale(u, c);
+  float4 gn = f4_scale(u, -c);
+  // d/dx ( reg_coef * ||X||_F / rows ) = reg_coef / rows * x / ||X||_F   (0 when ||X|| = 0)
+  const float rs = a.reg_coef * a.loss_scale / (float)rows;
+  const float cu = nu > 0.f ? rs / nu : 0.f, cp = np > 0.f ? rs / np : 0.f;
+  const float cn = (a.reg_include_neg && nn > 0.f) ? rs / nn : 0.f;
+  const bool same_u = (a.reg_user == a.user) && (a.greg_user == a.g_user);
+  const bool same_i = (a.reg_item == a.item) && (a.greg_item == a.g_item);
+  float4 ru = u, rp = p, rn = n;
+  if (a.reg_user != a.user) ru = reinterpret_cast<const float4*>(a.reg_user)[(size_t)bu * LPR + sub];
+  if (a.reg_item != a.item) {
+    rp = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bi * LPR + sub];
+    rn = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bj * LPR + sub];
+  }
+  if (same_u) gu = f4_fma(cu, ru, gu);
+  else atomic_add_f4(a.greg_user + ((size_t)bu * LPR + sub) * 4, f4_scale(ru, cu));
+  if (same_i) {
+    gp = f4_fma(cp, rp, gp);
+    gn = f4_fma(cn, rn, gn);
+  } else {
+    atomic_add_f4(a.greg_item + ((size_t)bi * LPR + sub) * 4, f4_scale(rp, cp));
+    if (a.reg_include_neg) atomic_add_f4(a.greg_item + ((size_t)bj * LPR + sub) * 4, f4_scale(rn, cn));
+  }
+  atomic_add_f4(a.g_user + ((size_t)bu * LPR + sub) * 4, gu);
+  atomic_add_f4(a.g_item + ((size_t)bi * LPR + sub) * 4, gp);
+  atomic_add_f4(a.g_item + ((size_t)bj * LPR + sub) * 4, gn);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_plain_fwd(const float4* __restrict__ U, const float4* __restrict__ P,
+                                                     const float4* __restrict__ Nn, int B, double* loss_sum,
+                                                     float* __restrict__ coef) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool valid = b < B;
+  const size_t at = (size_t)(valid ? b : 0) * LPR + sub;
+  const float4 u = U[at], p = P[at], n = Nn[at];
+  const float pos = group_sum<LPR>(f4_dot(u, p));
+  const float neg = group_sum<LPR>(f4_dot(u, n));
+  float loss, c;
+  bpr_row(pos, neg, loss, c);
+  if (valid && sub == 0) coef[b] = c;
+  double part = wave_sum_d((valid && sub == 0) ? (double)loss : 0.0);
+  if (lane == 0) atomicAdd(loss_sum, part);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_plain_bwd(const float4* __restrict__ U, const float4* __restrict__ P,
+                                                     const float4* __restrict__ Nn, const float* __restrict__ coef,
+                                                     int B, float scale, float4* __restrict__ GU,
+                                                     float4* __restrict__ GP, float4* __restrict__ GN) {
+  const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= (size_t)B * LPR) return;
+  const int b = (int)(t / LPR);
+  const float c = coef[b] * scale;
+  const float4 u = U[t], p = P[t], n = Nn[t];
+  GU[t] = make_float4(c * (p.x - n.x), c * (p.y - n.y), c * (p.z - n.z), c * (p.w - n.w));
+  GP[t] = f4_scale(u, c);
+  GN[t] = f4_scale(u, -c);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* out) {
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    acc += (double)v * (double)v;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+// ---------------------------------------------------------------------------------------
+// InfoNCE
+// ---------------------------------------------------------------------------------------
+constexpr int kNceSplits = 8;
+
+struct NceWs {
+  float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
+  int64_t np;
+};
+
+__host__ __device__ inline int64_t nce_pad(int64_t n) { return (n + 63) / 64 * 64; }
+
+inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
+  NceWs w;
+  const int64_t np = nce_pad(n_max);
+  float* p = reinterpret_cast<float*>(ws);
+  w.np = np;
+  w.v1n = p; p += np * d;
+  w.v2n = p; p += np * d;
+  w.opart = p; p += (int64_t)kNceSplits * np * d;
+  w.norm1 = p; p += np;
+  w.norm2 = p; p += np;
+  w.lpart = p; p += (int64_t)kNceSplits * np;
+  w.invl = p; p += np;
+  return w;
+}
+
+// normalise (and gather) the rows of both views; rows >= n are zero-filled
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_prep(const float* __restrict__ V1, const float* __restrict__ V2,
+                                                const int32_t* __restrict__ idx, int n_max,
+                                                const int32_t* __restrict__ d_n, NceWs w) {
+  constexpr int G = 64 / LPR;
+  const int n = d_n ? min(*d_n, n_max) : n_max;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool second = blockIdx.y == 1;
+  const float* V = second ? V2 : V1;
+  float* out = second ? w.v2n : w.v1n;
+  float* nrm = second ? w.norm2 : w.norm1;
+  const bool in_pad = i < (int)w.np;
+  const bool valid = i < n;
+  const int src = valid ? (idx ? idx[i] : i) : 0;
+  float4 v = reinterpret_cast<const float4*>(V)[(size_t)src * LPR + sub];
+  const float ss = group_sum<LPR>(f4_dot(v, v));
+  const float norm = sqrtf(ss);
+  const float den = fmaxf(norm, 1e-12f);           // F.normalize eps
+  float4 o = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+  if (!valid) o = f4_zero();
+  if (in_pad) {
+    reinterpret_cast<float4*>(out)[(size_t)i * LPR + sub] = o;
+    if (sub == 0) nrm[i] = valid ? norm : 0.f;
+  }
+}
+
+// One wave = 16 "query" rows against a slice of the "key" rows.
+//   PASS2 == false : Q = v1n, K = V = v2n, w_ij = exp(s_ij - c)              -> O1, l
+//   PASS2 == true  : Q = v2n, K = V = v1n, w_ij = exp(s_ji - c) / l_(key)    -> O2
+// with s = <q,k>/tau and c = 1/tau >= max s (rows are unit vectors), so no running max.
+// Swapped product (S^T = K Q^T) puts a query's weights for keys 4g+r in lane (q, g), which
+// is exactly the A-operand layout of the following  P V  product -- no LDS, no permutes.
+template <int D, bool PASS2>
+__global__ __launch_bounds__(256) void nce_tile(NceWs w, int n_max, const int32_t* __restrict__ d_n, float inv_tau) {
+  constexpr int DQ = D / 4;      // floats of a row per lane for the S product (k-steps)
+  constexpr int NT = D / 16;     // 16-column n-tiles of the PV product
+  const int n = d_n ? min(*d_n, n_max) : n_max;
+  const int np = (int)w.np;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x * 4 + wv) * 16;
+  const int ks = blockIdx.y;
+  if (q0 >= np) return;
+  const float* Q = PASS2 ? w.v2n : w.v1n;
+  const float* K = PASS2 ? w.v1n : w.v2n;
+  const int per = ((np + kNceSplits - 1) / kNceSplits + 31) / 32 * 32;
+  const int kb = ks * per, ke = min(np, kb + per);
+
+  float qreg[DQ];
+  {
+    const float4* src = reinterpret_cast<const float4*>(Q + (size_t)(q0 + c16) * D + g * DQ);
+#pragma unroll
+    for (int t = 0; t < DQ / 4; ++t) {
+      float4 v = src[t];
+      qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+    }
+  }
+  floatx4 O[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) O[t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+
+  for (int j0 = kb; j0 < ke; j0 += 32) {     // two 16-key tiles per iteration
+    float k0[DQ], k1[DQ];
+    {
+      const float4* s0 = reinterpret_cast<const float4*>(K + (size_t)(j0 + c16) * D + g * DQ);
+      const float4* s1 = reinterpret_cast<const float4*>(K + (size_t)(j0 + 16 + c16) * D + g * DQ);
+#pragma unroll
+      for (int t = 0; t < DQ / 4; ++t) {
+        float4 a = s0[t], b = s1[t];
+        k0[4 * t + 0] = a.x; k0[4 * t + 1] = a.y; k0[4 * t + 2] = a.z; k0[4 * t + 3] = a.w;
+        k1[4 * t + 0] = b.x; k1[4 * t + 1] = b.y; k1[4 * t + 2] = b.z; k1[4 * t + 3] = b.w;
+      }
+    }
+    float vv[2][4][NT];   // value rows for the PV product: key j0 + 16*h + 4g + s
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* vs = reinterpret_cast<const float4*>(K + (size_t)(j0 + 16 * h + 4 * g + s) * D + c16 * NT);
+#pragma unroll
+        for (int t = 0; t < NT / 4; ++t) {
+          float4 x = vs[t];
+          vv[h][s][4 * t + 0] = x.x; vv[h][s][4 * t + 1] = x.y; vv[h][s][4 * t + 2] = x.z; vv[h][s][4 * t + 3] = x.w;
+        }
+      }
+    floatx4 a0 = (floatx4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+    for (int s = 0; s < DQ; ++s) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[s], qreg[s], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[s], qreg[s], a1, 0, 0, 0);
+    }
+    float wgt[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * h + 4 * g + r;
+        const float sraw = (h == 0) ? a0[r] : a1[r];
+        float e = expf(sraw * inv_tau - inv_tau);
+        if (PASS2) e *= w.invl[min(key, np - 1)];
+        wgt[h][r] = (key < n) ? e : 0.f;
+        lsum += wgt[h][r];
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          O[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[h][s], vv[h][s][t], O[t], 0, 0, 0);
+  }
+
+  // O[t][r] = out[query q0 + 4g + r][column NT*c16 + t]
+  float* op = w.opart + ((size_t)ks * np + q0) * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+#pragma unroll
+    for (int t = 0; t < NT / 4; ++t)
+      reinterpret_cast<float4*>(rowp)[t] = make_float4(O[4 * t + 0][r], O[4 * t + 1][r], O[4 * t + 2][r], O[4 * t + 3][r]);
+  }
+  if (!PASS2) {
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (g == 0) w.lpart[(size_t)ks * np + q0 + c16] = lsum;
+  }
+}
+
+struct NceFinishArgs {
+  const int32_t* idx;
+  int n_max;
+  const int32_t* d_n;
+  float inv_tau, loss_scale;
+  double* loss;
+  float *g1, *g2;
+};
+
+template <int LPR, bool PASS2>
+__global__ __launch_bounds__(256) void nce_finish(NceWs w, NceFinishArgs a) {
+  constexpr int G = 64 / LPR;
+  const int n = a.d_n ? min(*a.d_n, a.n_max) : a.n_max;
+  if (n <= 0) return;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool valid = i < n;
+  const int ii = valid ? i : 0;
+  const size_t at = (size_t)ii * LPR + sub;
+  float4 O = f4_zero();
+  float l = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < kNceSplits; ++ks) {
+    O = f4_add(O, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
+    if (!PASS2) l += w.lpart[(size_t)ks * w.np + ii];
+  }
+  const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
+  const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
+  const float coef = a.loss_scale * a.inv_tau / (float)n;
+  float4 dn;                      // gradient w.r.t. the normalised row
+  float norm;
+  float4 self;
+  if (!PASS2) {
+    const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
+    const float lse = a.inv_tau + logf(l);
+    double part = wave_sum_d((valid && sub == 0) ? (double)(lse - sii) : 0.0);
+    if (lane == 0) atomicAdd(a.loss, (double)a.loss_scale * part / (double)n);
+    const float il = 1.0f / l;
+    if (valid && sub == 0) w.invl[i] = il;
+    dn = make_float4(coef * (O.x * il - vb.x), coef * (O.y * il - vb.y), coef * (O.z * il - vb.z), coef * (O.w * il - vb.w));
+    norm = w.norm1[ii];
+    self = va;
+  } else {
+    dn = make_float4(coef * (O.x - va.x), coef * (O.y - va.y), coef * (O.z - va.z), coef * (O.w - va.w));
+    norm = w.norm2[ii];
+    self = vb;
+  }
+  // backward of v / max(||v||, 1e-12)
+  const float proj = group_sum<LPR>(f4_dot(self, dn));
+  float4 dv;
+  if (norm > 1e-12f) {
+    dv = make_float4((dn.x - self.x * proj) / norm, (dn.y - self.y * proj) / norm,
+                     (dn.z - self.z * proj) / norm, (dn.w - self.w * proj) / norm);
+  } else {
+    dv = f4_scale(dn, 1e12f);
+  }
+  if (valid) {
+    const int dst = a.idx ? a.idx[i] : i;
+    float4* gp = reinterpret_cast<float4*>(PASS2 ? a.g2 : a.g1) + (size_t)dst * LPR + sub;
+    float4 cur = *gp;
+    *gp = f4_add(cur, dv);
+  }
+}
+
+template <int D>
+srh_status_t launch_infonce(const float* v1, const float* v2, const int32_t* idx, int n, const int32_t* d_n,
+                            float tau, float loss_scale, double* loss, float* g1, float* g2, void* ws,
+                            hipStream_t st) {
+  constexpr int LPR = D / 4, G = 64 / LPR;
+  NceWs w = carve_nce(ws, n, D);
+  const int np = (int)w.np;
+  const float inv_tau = 1.0f / tau;
+  dim3 gp((np / G + 3) / 4, 2);
+  nce_prep<LPR><<<gp, 256, 0, st>>>(v1, v2, idx, n, d_n, w);
+  SRH_LAUNCH_CHECK();
+  dim3 gt(np / 64, kNceSplits);
+  nce_tile<D, false><<<gt, 256, 0, st>>>(w, n, d_n, inv_tau);
+  SRH_LAUNCH_CHECK();
+  NceFinishArgs fa{idx, n, d_n, inv_tau, loss_scale, loss, g1, g2};
+  const int fb = (np / G + 3) / 4;
+  nce_finish<LPR, false><<<fb, 256, 0, st>>>(w, fa);
+  SRH_LAUNCH_CHECK();
+  nce_tile<D, true><<<gt, 256, 0, st>>>(w, n, d_n, inv_tau);
+  SRH_LAUNCH_CHECK();
+  nce_finish<LPR, true><<<fb, 256, 0, st>>>(w, fa);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+template <int LPR>
+srh_status_t launch_bpr(const BprArgs& a, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const int blocks = ((a.B + G - 1) / G + 3) / 4;
+  SRH_HIP(hipMemsetAsync(a.sums, 0, 3 * sizeof(double), st));
+  bpr_phase1<LPR><<<blocks, 256, 0, st>>>(a);
+  SRH_LAUNCH_CHECK();
+  bpr_phase2<LPR><<<blocks, 256, 0, st>>>(a);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t srh_bpr_ws_bytes(int64_t B) { return 64 + 4 * (B > 0 ? B : 0); }
+
+srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item, const float* d_reg_user,
+                                const float* d_reg_item, const int32_t* d_u_idx, const int32_t* d_i_idx,
+                                const int32_t* d_j_idx, int64_t B, const int32_t* d_n_rows, int32_t d,
+                                float reg_coef, int32_t reg_include_neg, float loss_scale, float* d_g_user,
+                                float* d_g_item, float* d_greg_user, float* d_greg_item, double* d_losses,
+                                void* d_ws, void* stream) {
+  SRH_REQUIRE(d_user && d_item && d_reg_user && d_reg_item && d_u_idx && d_i_idx && d_j_idx, "bpr_l2_fwd_bwd: null input");
+  SRH_REQUIRE(d_g_user && d_g_item && d_greg_user && d_greg_item && d_losses && d_ws, "bpr_l2_fwd_bwd: null output");
+  SRH_REQUIRE(B > 0 && B < (int64_t(1) << 30), "bpr_l2_fwd_bwd: bad batch size");
+  SRH_REQUIRE(srh::dim_supported(d), "bpr_l2_fwd_bwd: d=%d unsupported", d);
+  BprArgs a{d_user, d_item, d_reg_user, d_reg_item, d_u_idx, d_i_idx, d_j_idx, d_n_rows, (int)B,
+            reg_coef, loss_scale, reg_include_neg, d_g_user, d_g_item, d_greg_user, d_greg_item, d_losses,
+            reinterpret_cast<double*>(d_ws), reinterpret_cast<float*>(reinterpret_cast<char*>(d_ws) + 64)};
+  hipStream_t st = srh::as_stream(stream);
+  switch (d) {
+    case 32: return launch_bpr<8>(a, st);
+    case 64: return launch_bpr<16>(a, st);
+    case 128: return launch_bpr<32>(a, st);
+    default: return launch_bpr<64>(a, st);
+  }
+}
+
+srh_status_t srh_bpr_fwd(const float* d_u, const float* d_p, const float* d_n, int64_t B, int32_t d,
+                         double* d_loss_sum, float* d_coef, void* stream) {
+  SRH_REQUIRE(d_u && d_p && d_n && d_loss_sum && d_coef, "bpr_fwd: null argument");
+  SRH_REQUIRE(B > 0 && B < (int64_t(1) << 30), "bpr_fwd: bad batch size");
+  SRH_REQUIRE(srh::dim_supported(d), "bpr_fwd: d=%d unsupported", d);
+  hipStream_t st = srh::as_stream(stream);
+  const float4 *U = reinterpret_cast<const float4*>(d_u), *P = reinterpret_cast<const float4*>(d_p),
+               *N = reinterpret_cast<const float4*>(d_n);
+#define SRH_BPR_FWD(LPR)                                                                       \
+  bpr_plain_fwd<LPR><<<(int)(((B + 64 / LPR - 1) / (64 / LPR) + 3) / 4), 256, 0, st>>>(U, P, N, (int)B, d_loss_sum, d_coef)
+  switch (d) {
+    case 32: SRH_BPR_FWD(8); break;
+    case 64: SRH_BPR_FWD(16); break;
+    case 128: SRH_BPR_FWD(32); break;
+    default: SRH_BPR_FWD(64); break;
+  }
+#undef SRH_BPR_FWD
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_bpr_bwd(const float* d_u, const float* d_p, const float* d_n, const float* d_coef,
+                         int64_t B, int32_t d, float scale, float* d_gu, float* d_gp, float* d_gn, void* stream) {
+  SRH_REQUIRE(d_u && d_p && d_n && d_coef && d_gu && d_gp && d_gn, "bpr_bwd: null argument");
+  SRH_REQUIRE(B > 0 && B < (int64_t(1) << 30), "bpr_bwd: bad batch size");
+  SRH_REQUIRE(srh::dim_supported(d), "bpr_bwd: d=%d unsupported", d);
+  hipStream_t st = srh::as_stream(stream);
+  const int64_t threads = B * (d / 4);
+  const int blocks = (int)((threads + 255) / 256);
+  const float4 *U = reinterpret_cast<const float4*>(d_u), *P = reinterpret_cast<const float4*>(d_p),
+               *N = reinterpret_cast<const float4*>(d_n);
+  float4 *GU = reinterpret_cast<float4*>(d_gu), *GP = reinterpret_cast<float4*>(d_gp), *GN = reinterpret_cast<float4*>(d_gn);
+  switch (d) {
+    case 32: bpr_plain_bwd<8><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
+    case 64: bpr_plain_bwd<16><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
+    case 128: bpr_plain_bwd<32><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
+    default: bpr_plain_bwd<64><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
+  }
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* stream) {
+  SRH_REQUIRE(d_x && d_out && n_elem >= 0, "sumsq: bad argument");
+  if (n_elem == 0) return SRH_OK;
+  const int blocks = (int)std::min<int64_t>((n_elem + 255) / 256, 2048);
+  sumsq_kernel<<<blocks, 256, 0, srh::as_stream(stream)>>>(d_x, n_elem, d_out);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
+  if (n <= 0 || d <= 0) return 0;
+  const int64_t np = nce_pad(n);
+  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 256;
+}
+
+srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,
+                                 const int32_t* d_n, int32_t d, float tau, float loss_scale, double* d_loss,
+                                 float* d_g1, float* d_g2, void* d_ws, void* stream) {
+  SRH_REQUIRE(d_v1 && d_v2 && d_loss && d_g1 && d_g2 && d_ws, "infonce_fwd_bwd: null argument");
+  SRH_REQUIRE(n > 0 && n < (int64_t(1) << 24), "infonce_fwd_bwd: bad n");
+  SRH_REQUIRE(d == 64 || d == 128, "infonce_fwd_bwd: d=%d unsupported (need 64 or 128)", d);
+  if (!(tau >= 0.03f)) {
+    srh::set_error("infonce_fwd_bwd: temperature %g below 0.03 needs a running max (not implemented)", (double)tau);
+    return SRH_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = srh::as_stream(stream);
+  if (d == 64) return launch_infonce<64>(d_v1, d_v2, d_idx, (int)n, d_n, tau, loss_scale, d_loss, d_g1, d_g2, d_ws, st);
+  return launch_infonce<128>(d_v1, d_v2, d_idx, (int)n, d_n, tau, loss_scale, d_loss, d_g1, d_g2, d_ws, st);
+}
+
+}  // extern "C"

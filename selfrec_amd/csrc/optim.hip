@@ -1,0 +1,137 @@
+// (a-9) Dense Adam and the small streaming utilities of the fused step.
+// Replaces torch.optim.Adam(model.parameters(), lr).step() (reference XSimGCL.py:25,37):
+// betas/eps as passed, no weight decay, bias-corrected, one launch over the whole (N, d)
+// table instead of torch's ~10 elementwise launches.  HBM-bound:
+//   algorithmic bytes = 7 * n_elem * 4  (read p, g, m, v; write p, m, v).
+#include "common.h"
+
+namespace {
+using namespace srh;
+
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                   float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                                                   int64_t step, const int64_t* __restrict__ d_step, float lr,
+                                                   float b1, float b2, float eps) {
+  const int64_t t = d_step ? *d_step : step;
+  // torch: bias_correction = 1 - beta ** step (python double), step_size = lr / bc1,
+  //        denom = sqrt(v) / sqrt(bc2) + eps, p -= step_size * m / denom
+  const double bc1 = 1.0 - pow((double)b1, (double)t);
+  const double bc2 = 1.0 - pow((double)b2, (double)t);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 gg = g[i];
+    float4 mm = m[i], vv = v[i], pp = p[i];
+#define SRH_ADAM_LANE(c)                                   \
+    mm.c = mm.c * b1 + omb1 * gg.c;                        \
+    vv.c = vv.c * b2 + omb2 * (gg.c * gg.c);               \
+    pp.c -= step_size * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
+    SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
+#undef SRH_ADAM_LANE
+    m[i] = mm; v[i] = vv; p[i] = pp;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float4* __restrict__ x, float b,
+                                                    float4* __restrict__ y, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 xv = x[i];
+    float4 o;
+    if (b == 0.f) {
+      o = make_float4(a * xv.x, a * xv.y, a * xv.z, a * xv.w);
+    } else {
+      const float4 yv = y[i];
+      o = make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z, a * xv.w + b * yv.w);
+    }
+    y[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void batch_fetch_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
+                                                          const int32_t* __restrict__ ej, const int32_t* __restrict__ uu,
+                                                          const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
+                                                          const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs,
+                                                          int64_t* __restrict__ cursor, int32_t* su, int32_t* si,
+                                                          int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta) {
+  // single workgroup; the cursor is advanced by thread 0 after everyone has read it
+  __shared__ int64_t s_b;
+  if (threadIdx.x == 0) s_b = cursor[0];
+  __syncthreads();
+  const int64_t b = s_b;
+  const int64_t ptr = b * bs;
+  const int64_t rows = (ptr >= n_edges) ? 0 : ((ptr + bs < n_edges) ? bs : n_edges - ptr);
+  for (int64_t i = threadIdx.x; i < rows; i += 256) {
+    su[i] = eu[ptr + i];
+    si[i] = ei[ptr + i];
+    sj[i] = ej[ptr + i];
+  }
+  int32_t a = 0, c = 0;
+  if (uu && rows > 0) {
+    a = nuu[b];
+    c = nui[b];
+    for (int64_t i = threadIdx.x; i < a; i += 256) suu[i] = uu[b * bs + i];
+    for (int64_t i = threadIdx.x; i < c; i += 256) sui[i] = ui[b * bs + i];
+  }
+  if (threadIdx.x == 0) {
+    meta[0] = (int32_t)rows;
+    meta[1] = a;
+    meta[2] = c;
+    meta[3] = (int32_t)b;
+    cursor[0] = b + 1;
+    cursor[1] = cursor[1] + 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_elem,
+                           int64_t step, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                           void* stream) {
+  SRH_REQUIRE(d_param && d_grad && d_m && d_v, "adam_step: null argument");
+  SRH_REQUIRE(n_elem > 0 && n_elem % 4 == 0, "adam_step: n_elem must be a positive multiple of 4");
+  SRH_REQUIRE(d_step || step >= 1, "adam_step: step is 1-based");
+  const int64_t n4 = n_elem / 4;
+  const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+  adam_kernel<<<blocks, 256, 0, srh::as_stream(stream)>>>(
+      reinterpret_cast<float4*>(d_param), reinterpret_cast<const float4*>(d_grad), reinterpret_cast<float4*>(d_m),
+      reinterpret_cast<float4*>(d_v), n4, step, d_step, lr, beta1, beta2, eps);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n_elem, void* stream) {
+  SRH_REQUIRE(d_x && d_y, "axpby: null argument");
+  SRH_REQUIRE(n_elem > 0 && n_elem % 4 == 0, "axpby: n_elem must be a positive multiple of 4");
+  const int64_t n4 = n_elem / 4;
+  const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+  axpby_kernel<<<blocks, 256, 0, srh::as_stream(stream)>>>(a, reinterpret_cast<const float4*>(d_x), b,
+                                                          reinterpret_cast<float4*>(d_y), n4);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i, const int32_t* d_epoch_j,
+                             const int32_t* d_epoch_uniq_u, const int32_t* d_epoch_uniq_i,
+                             const int32_t* d_n_uniq_u, const int32_t* d_n_uniq_i, int64_t n_edges,
+                             int64_t batch_size, int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
+                             int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
+                             int32_t* d_meta, void* stream) {
+  SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
+              "batch_fetch: null argument");
+  const bool uq = d_epoch_uniq_u != nullptr;
+  SRH_REQUIRE(!uq || (d_epoch_uniq_i && d_n_uniq_u && d_n_uniq_i && d_stage_uniq_u && d_stage_uniq_i),
+              "batch_fetch: unique-id arrays must be given together");
+  SRH_REQUIRE(n_edges > 0 && batch_size > 0, "batch_fetch: bad sizes");
+  batch_fetch_kernel<<<1, 256, 0, srh::as_stream(stream)>>>(d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u,
+                                                            d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges,
+                                                            batch_size, d_cursor, d_stage_u, d_stage_i, d_stage_j,
+                                                            d_stage_uniq_u, d_stage_uniq_i, d_meta);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+// (a-1) Pairwise BPR sampler: a bit-exact replay of what the reference does with CPython's
+// global `random` stream in util/sampler.py:5-28, and of random.sample as used by
+// data/augmentor.py:15-16,35.
+//
+// The algorithm is fixed by CPython (Lib/random.py + Modules/_randommodule.c, identical in
+// 3.9-3.12 for the calls used here):
+//   genrand_uint32        MT19937 (Matsumoto & Nishimura 2002 reference implementation)
+//   getrandbits(k<=32)    genrand_uint32() >> (32-k)
+//   _randbelow(n)         k = n.bit_length(); r = getrandbits(k); while r >= n: redraw
+//   shuffle(x)            for i in reversed(range(1,len(x))): j=_randbelow(i+1); swap x[i],x[j]
+//   choice(seq)           seq[_randbelow(len(seq))]
+//   sample(range(n),k)    pool-based partial shuffle when n <= 21 + 4**ceil(log(3k,4)) (k>5),
+//                         else set-based rejection
+// The data-dependent rejection loop makes the stream inherently sequential, so this runs on
+// a host core (tens of ns per draw) and is overlapped with the device step by the caller.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <unordered_set>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct MT19937 {
+  static constexpr int N = 624, M = 397;
+  uint32_t mt[N];
+  int pos = N + 1;
+
+  void init_genrand(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < N; ++i) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    pos = N;
+  }
+  void init_by_array(const uint32_t* key, size_t len) {
+    init_genrand(19650218U);
+    size_t i = 1, j = 0;
+    size_t k = (N > len ? (size_t)N : len);
+    for (; k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525U)) + key[j] + (uint32_t)j;
+      ++i; ++j;
+      if (i >= (size_t)N) { mt[0] = mt[N - 1]; i = 1; }
+      if (j >= len) j = 0;
+    }
+    for (k = N - 1; k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+      ++i;
+      if (i >= (size_t)N) { mt[0] = mt[N - 1]; i = 1; }
+    }
+    mt[0] = 0x80000000U;
+  }
+  void refill() {
+    static const uint32_t mag01[2] = {0x0U, 0x9908b0dfU};
+    int kk;
+    uint32_t y;
+    for (kk = 0; kk < N - M; ++kk) {
+      y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+      mt[kk] = mt[kk + M] ^ (y >> 1) ^ mag01[y & 1U];
+    }
+    for (; kk < N - 1; ++kk) {
+      y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+      mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ mag01[y & 1U];
+    }
+    y = (mt[N - 1] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+    mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ mag01[y & 1U];
+    pos = 0;
+  }
+  inline uint32_t next_u32() {
+    if (pos >= N) refill();
+    uint32_t y = mt[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= (y >> 18);
+    return y;
+  }
+  // n in [1, 2^32)
+  inline uint32_t randbelow(uint32_t n) {
+    const int shift = __builtin_clz(n);  // 32 - bit_length(n)
+    uint32_t r = next_u32() >> shift;
+    while (r >= n) r = next_u32() >> shift;
+    return r;
+  }
+};
+
+}  // namespace
+
+struct srh_sampler {
+  int64_t n_users = 0, n_items = 0, n_edges = 0;
+  std::vector<int32_t> edge_u, edge_i;      // as given at create time
+  std::vector<int64_t> order;               // persistent order of training_data
+  std::vector<int64_t> row_ptr;             // user -> sorted positive items
+  std::vector<int32_t> row_items;
+  MT19937 rng;
+  bool seeded = false;
+
+  inline bool rated(int32_t u, int32_t item) const {
+    const int32_t* b = row_items.data() + row_ptr[u];
+    const int32_t* e = row_items.data() + row_ptr[u + 1];
+    return std::binary_search(b, e, item);
+  }
+};
+
+extern "C" {
+
+srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_items,
+                                int64_t n_edges, const int32_t* h_edge_user,
+                                const int32_t* h_edge_item) {
+  SRH_REQUIRE(out && ((h_edge_user && h_edge_item) || n_edges == 0), "sampler_create: null argument");
+  SRH_REQUIRE(n_users > 0 && n_items > 0 && n_edges >= 0, "sampler_create: bad sizes");
+  SRH_REQUIRE(n_items < (int64_t(1) << 31) && n_users < (int64_t(1) << 31) && n_edges < (int64_t(1) << 32),
+              "sampler_create: sizes beyond 32-bit draws are not supported");
+  srh_sampler* s = new (std::nothrow) srh_sampler();
+  if (!s) { srh::set_error("sampler_create: out of memory"); return SRH_ERR_NOMEM; }
+  s->n_users = n_users; s->n_items = n_items; s->n_edges = n_edges;
+  if (n_edges > 0) {
+    s->edge_u.assign(h_edge_user, h_edge_user + n_edges);
+    s->edge_i.assign(h_edge_item, h_edge_item + n_edges);
+  }
+  s->order.resize(n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) s->order[e] = e;
+  s->row_ptr.assign(n_users + 1, 0);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    int32_t u = s->edge_u[e], it = s->edge_i[e];
+    if (u < 0 || u >= n_users || it < 0 || it >= n_items) {
+      delete s;
+      srh::set_error("sampler_create: edge %lld (%d,%d) out of range", (long long)e, u, it);
+      return SRH_ERR_INVALID_ARG;
+    }
+    s->row_ptr[u + 1]++;
+  }
+  for (int64_t u = 0; u < n_users; ++u) s->row_ptr[u + 1] += s->row_ptr[u];
+  s->row_items.resize(n_edges);
+  std::vector<int64_t> fill(s->row_ptr.begin(), s->row_ptr.end() - 1);
+  for (int64_t e = 0; e < n_edges; ++e) s->row_items[fill[s->edge_u[e]]++] = s->edge_i[e];
+  for (int64_t u = 0; u < n_users; ++u)
+    std::sort(s->row_items.begin() + s->row_ptr[u], s->row_items.begin() + s->row_ptr[u + 1]);
+  *out = s;
+  return SRH_OK;
+}
+
+void srh_sampler_destroy(srh_sampler_t* s) { delete s; }
+
+srh_status_t srh_sampler_set_state(srh_sampler_t* s, const uint32_t* h_mt624, int32_t pos) {
+  SRH_REQUIRE(s && h_mt624, "sampler_set_state: null argument");
+  SRH_REQUIRE(pos >= 0 && pos <= 624, "sampler_set_state: position %d out of [0,624]", pos);
+  std::memcpy(s->rng.mt, h_mt624, sizeof(uint32_t) * 624);
+  s->rng.pos = pos;
+  s->seeded = true;
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_get_state(const srh_sampler_t* s, uint32_t* h_mt624, int32_t* pos) {
+  SRH_REQUIRE(s && h_mt624 && pos, "sampler_get_state: null argument");
+  if (!s->seeded) { srh::set_error("sampler_get_state: generator was never seeded"); return SRH_ERR_STATE; }
+  std::memcpy(h_mt624, s->rng.mt, sizeof(uint32_t) * 624);
+  *pos = s->rng.pos;
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_seed(srh_sampler_t* s, uint64_t seed) {
+  SRH_REQUIRE(s, "sampler_seed: null handle");
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffU), (uint32_t)(seed >> 32)};
+  s->rng.init_by_array(key, key[1] ? 2 : 1);
+  s->seeded = true;
+  return SRH_OK;
+}
+
+static srh_status_t require_seeded(const srh_sampler_t* s, const char* who) {
+  if (!s) { srh::set_error("%s: null handle", who); return SRH_ERR_INVALID_ARG; }
+  if (!s->seeded) {
+    srh::set_error("%s: generator state not set (call srh_sampler_set_state or srh_sampler_seed)", who);
+    return SRH_ERR_STATE;
+  }
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_shuffle(srh_sampler_t* s) {
+  srh_status_t st = require_seeded(s, "sampler_shuffle");
+  if (st) return st;
+  int64_t* x = s->order.data();
+  for (int64_t i = s->n_edges - 1; i >= 1; --i) {
+    uint32_t j = s->rng.randbelow((uint32_t)(i + 1));
+    std::swap(x[i], x[j]);
+  }
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_get_order(const srh_sampler_t* s, int64_t* h_perm) {
+  SRH_REQUIRE(s && h_perm, "sampler_get_order: null argument");
+  std::memcpy(h_perm, s->order.data(), sizeof(int64_t) * s->n_edges);
+  return SRH_OK;
+}
+
+static inline int64_t batch_into(srh_sampler_t* s, int64_t ptr, int64_t batch_size, int32_t n_negs,
+                                 int32_t* u, int32_t* it, int32_t* neg) {
+  const int64_t end = (ptr + batch_size < s->n_edges) ? ptr + batch_size : s->n_edges;
+  const uint32_t n_items = (uint32_t)s->n_items;
+  int64_t w = 0;
+  for (int64_t p = ptr; p < end; ++p) {
+    const int64_t e = s->order[p];
+    const int32_t uu = s->edge_u[e];
+    u[p - ptr] = uu;
+    it[p - ptr] = s->edge_i[e];
+    for (int32_t m = 0; m < n_negs; ++m) {
+      int32_t cand = (int32_t)s->rng.randbelow(n_items);
+      while (s->rated(uu, cand)) cand = (int32_t)s->rng.randbelow(n_items);
+      neg[w++] = cand;
+    }
+  }
+  return end - ptr;
+}
+
+srh_status_t srh_sampler_next_batch(srh_sampler_t* s, int64_t ptr, int64_t batch_size,
+                                    int32_t n_negs, int32_t* h_u, int32_t* h_i, int32_t* h_j,
+                                    int64_t* out_count) {
+  srh_status_t st = require_seeded(s, "sampler_next_batch");
+  if (st) return st;
+  SRH_REQUIRE(h_u && h_i && h_j && out_count, "sampler_next_batch: null argument");
+  SRH_REQUIRE(ptr >= 0 && ptr <= s->n_edges && batch_size > 0 && n_negs >= 1,
+              "sampler_next_batch: bad ptr/batch_size/n_negs");
+  *out_count = batch_into(s, ptr, batch_size, n_negs, h_u, h_i, h_j);
+  return SRH_OK;
+}
+
+static int32_t sorted_unique(const int32_t* src, int64_t n, int32_t* dst, std::vector<int32_t>& tmp) {
+  tmp.assign(src, src + n);
+  std::sort(tmp.begin(), tmp.end());
+  int32_t m = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+  std::memcpy(dst, tmp.data(), sizeof(int32_t) * m);
+  return m;
+}
+
+srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_negs,
+                               int32_t* h_u, int32_t* h_i, int32_t* h_j,
+                               int32_t* h_uniq_u, int32_t* h_n_uniq_u,
+                               int32_t* h_uniq_i, int32_t* h_n_uniq_i) {
+  srh_status_t st = require_seeded(s, "sampler_epoch");
+  if (st) return st;
+  SRH_REQUIRE(h_u && h_i && h_j, "sampler_epoch: null output");
+  SRH_REQUIRE(batch_size > 0 && n_negs >= 1, "sampler_epoch: bad batch_size/n_negs");
+  const bool want_uniq = h_uniq_u || h_uniq_i;
+  SRH_REQUIRE(!want_uniq || (h_uniq_u && h_uniq_i && h_n_uniq_u && h_n_uniq_i),
+              "sampler_epoch: unique outputs must be given together");
+  st = srh_sampler_shuffle(s);
+  if (st) return st;
+  std::vector<int32_t> tmp;
+  int64_t b = 0;
+  for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
+    int64_t cnt = batch_into(s, ptr, batch_size, n_negs, h_u + ptr, h_i + ptr, h_j + ptr * n_negs);
+    if (want_uniq) {
+      h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, tmp);
+      h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, tmp);
+    }
+    ptr += cnt;
+  }
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out) {
+  srh_status_t st = require_seeded(s, "sampler_sample_range");
+  if (st) return st;
+  SRH_REQUIRE(h_out || k == 0, "sampler_sample_range: null output");
+  SRH_REQUIRE(n >= 0 && n < (int64_t(1) << 32), "sampler_sample_range: n out of range");
+  SRH_REQUIRE(k >= 0 && k <= n, "sampler_sample_range: Sample larger than population or is negative");
+  // Lib/random.py sample(): setsize = 21; if k > 5: setsize += 4 ** _ceil(_log(k * 3, 4))
+  double setsize = 21.0;
+  if (k > 5) setsize += std::pow(4.0, std::ceil(std::log((double)(k * 3)) / std::log(4.0)));
+  if ((double)n <= setsize) {
+    std::vector<int64_t> pool((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pool[i] = i;
+    for (int64_t i = 0; i < k; ++i) {
+      uint32_t j = s->rng.randbelow((uint32_t)(n - i));
+      h_out[i] = pool[j];
+      pool[j] = pool[n - i - 1];
+    }
+  } else {
+    std::unordered_set<int64_t> selected;
+    selected.reserve((size_t)k * 2);
+    for (int64_t i = 0; i < k; ++i) {
+      int64_t j = s->rng.randbelow((uint32_t)n);
+      while (selected.count(j)) j = s->rng.randbelow((uint32_t)n);
+      selected.insert(j);
+      h_out[i] = j;
+    }
+  }
+  return SRH_OK;
+}
+
+srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out) {
+  srh_status_t st = require_seeded(s, "sampler_next_u32");
+  if (st) return st;
+  SRH_REQUIRE(out, "sampler_next_u32: null output");
+  *out = s->rng.next_u32();
+  return SRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// (a-3, a-4) CSR SpMM  y = A x  for LightGCN-family propagation, with the per-layer
+// elementwise tail fused into the epilogue.  Replaces torch.sparse.mm at reference
+// LightGCN.py:72, XSimGCL.py:88, SimGCL.py:85, SGL.py:104-108 and the perturb / stack /
+// mean launches of XSimGCL.py:90-96.
+//
+// Bound: HBM / L2 gather bandwidth.  Algorithmic bytes per call:
+//   nnz*8 (int32 col + fp32 val) + (n_rows+1)*4 + n_cols*d*4 (x read once) + n_rows*d*4 (y)
+//
+// Mapping for gfx950 (wave64):
+//   * one embedding row is d fp32 = d/4 lanes x float4 (LPR lanes); a wave therefore holds
+//     G = 64/LPR row-vectors side by side (d=64: 16 lanes per row, 4 rows per wave).
+//   * work unit = "segment" = (row, [start,end)) of at most split_len non-zeros, one wave per
+//     segment.  The wave loads 64 (col,val) pairs with one coalesced dword load each, then
+//     walks them G at a time: group g takes entry k+g via ds_bpermute (__shfl), gathers the
+//     256-byte x row with one dwordx4 per lane, and FMAs.  Four gathers are kept in flight
+//     per group (16 x-rows per wave) before the first use.
+//   * groups are summed with xor-shuffles; the epilogue runs on the reduced row.
+//   * power-law rows: rows longer than split_len are cut into several segments that write
+//     partial sums to a workspace; a second small kernel adds them in a fixed order (no
+//     atomics: results are run-to-run deterministic) and applies the epilogue.
+//   * segments are issued longest-first so the tail of the launch is short rows.
+#include <algorithm>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+using namespace srh;
+
+struct Seg {
+  int32_t row, start, end, slot;  // slot < 0: final result of `row`; else partial[slot]
+};
+struct Heavy {
+  int32_t row, first_slot, n_slots, pad;
+};
+
+struct DevEpilogue {
+  int32_t flags;
+  float eps;
+  const float* noise;
+  uint32_t seed_lo, seed_hi, off_lo, off_hi;
+  const int64_t* philox_step;
+  uint64_t philox_stride;
+  float alpha;
+  int32_t n_prev, n_add;
+  const float* prev[SRH_MAX_PREV];
+  float mean_div;
+  float* mean_out;
+  const float* add[SRH_MAX_ADD];
+  float add_scale[SRH_MAX_ADD];
+};
+
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: no state in memory.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Epilogue on one full row held as float4 per lane of an LPR-lane group.  Executed by all
+// groups of the wave with identical data (they all hold the reduced row); `store` selects
+// the group that writes.
+template <int LPR>
+__device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
+                                             const DevEpilogue& ep) {
+  const size_t at = (size_t)row * LPR + sub;
+  if (ep.flags & SRH_EPI_AXPY) {
+    y = f4_scale(y, ep.alpha);
+    for (int t = 0; t < ep.n_add; ++t) {
+      float4 a = reinterpret_cast<const float4*>(ep.add[t])[at];
+      y = f4_fma(ep.add_scale[t], a, y);
+    }
+  }
+  if (ep.flags & SRH_EPI_PERTURB) {
+    float4 nu;
+    if (ep.noise) {
+      nu = reinterpret_cast<const float4*>(ep.noise)[at];
+    } else {
+      uint64_t ctr = (((uint64_t)ep.off_hi << 32) | ep.off_lo) + (uint64_t)row;
+      if (ep.philox_step) ctr += (uint64_t)(*ep.philox_step) * ep.philox_stride;
+      uint4 r = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sub, 0u),
+                              make_uint2(ep.seed_lo, ep.seed_hi));
+      nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    }
+    float ss = group_sum<LPR>(f4_dot(nu, nu));
+    float nrm = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: v / max(||v||, eps)
+    y.x += (sgnf(y.x) * (nu.x / nrm)) * ep.eps;
+    y.y += (sgnf(y.y) * (nu.y / nrm)) * ep.eps;
+    y.z += (sgnf(y.z) * (nu.z / nrm)) * ep.eps;
+    y.w += (sgnf(y.w) * (nu.w / nrm)) * ep.eps;
+  }
+  if (store) Y[at] = y;
+  if (ep.flags & SRH_EPI_MEAN) {
+    float4 m;
+    if (ep.n_prev > 0) {
+      m = reinterpret_cast<const float4*>(ep.prev[0])[at];
+      for (int t = 1; t < ep.n_prev; ++t) m = f4_add(m, reinterpret_cast<const float4*>(ep.prev[t])[at]);
+      m = f4_add(m, y);
+    } else {
+      m = y;
+    }
+    if (store) {
+      float4 o = make_float4(m.x / ep.mean_div, m.y / ep.mean_div, m.z / ep.mean_div, m.w / ep.mean_div);
+      reinterpret_cast<float4*>(ep.mean_out)[at] = o;
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ segs, int n_segs,
+                                                       const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ vals,
+                                                       const float4* __restrict__ X, float4* __restrict__ Y,
+                                                       float4* __restrict__ partial, DevEpilogue ep) {
+  constexpr int G = 64 / LPR;      // row-vectors per wave
+  constexpr int STEP = 4 * G;      // entries consumed per unrolled iteration
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_segs) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  const Seg sg = segs[wave];
+  const int row = __builtin_amdgcn_readfirstlane(sg.row);
+  const int s = __builtin_amdgcn_readfirstlane(sg.start);
+  const int e = __builtin_amdgcn_readfirstlane(sg.end);
+  const int slot = __builtin_amdgcn_readfirstlane(sg.slot);
+
+  float4 acc = f4_zero();
+  for (int base = s; base < e; base += 64) {
+    const int j = base + lane;
+    const bool in = j < e;
+    const int c = in ? indices[j] : 0;       // padded entries: value 0 times row 0
+    const float v = in ? vals[j] : 0.f;
+    const int cnt = min(64, e - base);
+    const int cnt_up = (cnt + STEP - 1) / STEP * STEP;   // <= 64 because STEP divides 64
+    for (int k = 0; k < cnt_up; k += STEP) {
+      const int c0 = __shfl(c, k + g), c1 = __shfl(c, k + G + g);
+      const int c2 = __shfl(c, k + 2 * G + g), c3 = __shfl(c, k + 3 * G + g);
+      const float v0 = __shfl(v, k + g), v1 = __shfl(v, k + G + g);
+      const float v2 = __shfl(v, k + 2 * G + g), v3 = __shfl(v, k + 3 * G + g);
+      const float4 x0 = X[(size_t)c0 * LPR + sub];
+      const float4 x1 = X[(size_t)c1 * LPR + sub];
+      const float4 x2 = X[(size_t)c2 * LPR + sub];
+      const float4 x3 = X[(size_t)c3 * LPR + sub];
+      acc = f4_fma(v0, x0, acc);
+      acc = f4_fma(v1, x1, acc);
+      acc = f4_fma(v2, x2, acc);
+      acc = f4_fma(v3, x3, acc);
+    }
+  }
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+
+  if (slot >= 0) {
+    if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+  } else {
+    row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict__ heavy, int n_heavy,
+                                                         const float4* __restrict__ partial,
+                                                         float4* __restrict__ Y, DevEpilogue ep) {
+  constexpr int G = 64 / LPR;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_heavy) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  const Heavy h = heavy[wave];
+  const int row = __builtin_amdgcn_readfirstlane(h.row);
+  const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
+  const int n = __builtin_amdgcn_readfirstlane(h.n_slots);
+  float4 acc = f4_zero();
+  for (int t = g; t < n; t += G) acc = f4_add(acc, partial[(size_t)(first + t) * LPR + sub]);
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+  row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+}
+
+}  // namespace
+
+struct srh_spmm_plan {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
+  Seg* d_segs = nullptr;
+  Heavy* d_heavy = nullptr;
+  float* d_partial = nullptr;      // n_slots * 256 floats (enough for d <= 256)
+  int32_t partial_d = 0;
+};
+
+extern "C" {
+
+srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
+                                  const int32_t* h_indptr, int32_t split_len) {
+  SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
+  SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
+  SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
+  if (split_len <= 0) split_len = 256;
+  SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
+  SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
+  std::vector<Seg> segs;
+  std::vector<Heavy> heavy;
+  segs.reserve((size_t)n_rows + 1024);
+  int32_t n_slots = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const int32_t s = h_indptr[r], e = h_indptr[r + 1];
+    if (e < s) { srh::set_error("spmm_plan_create: indptr not monotone at row %lld", (long long)r); return SRH_ERR_INVALID_ARG; }
+    const int32_t len = e - s;
+    if (len <= split_len) {
+      segs.push_back({(int32_t)r, s, e, -1});
+    } else {
+      const int32_t pieces = (len + split_len - 1) / split_len;
+      heavy.push_back({(int32_t)r, n_slots, pieces, 0});
+      for (int32_t p = 0; p < pieces; ++p)
+        segs.push_back({(int32_t)r, s + p * split_len, std::min(e, s + (p + 1) * split_len), n_slots + p});
+      n_slots += pieces;
+    }
+  }
+  // longest first; ties keep row order (stable) so neighbouring waves touch neighbouring y rows
+  std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); });
+
+  srh_spmm_plan* p = new (std::nothrow) srh_spmm_plan();
+  if (!p) { srh::set_error("spmm_plan_create: out of memory"); return SRH_ERR_NOMEM; }
+  p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
+  p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
+  p->split_len = split_len;
+  hipError_t err = hipMalloc(&p->d_segs, sizeof(Seg) * segs.size());
+  if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess && !heavy.empty()) {
+    err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
+    if (err == hipSuccess) err = hipMemcpy(p->d_heavy, heavy.data(), sizeof(Heavy) * heavy.size(), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc(&p->d_partial, sizeof(float) * 256 * (size_t)n_slots);
+  }
+  if (err != hipSuccess) {
+    srh::set_error("spmm_plan_create: %s", hipGetErrorString(err));
+    srh_spmm_plan_destroy(p);
+    return SRH_ERR_HIP;
+  }
+  *out = p;
+  return SRH_OK;
+}
+
+void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
+  if (!p) return;
+  if (p->d_segs) (void)hipFree(p->d_segs);
+  if (p->d_heavy) (void)hipFree(p->d_heavy);
+  if (p->d_partial) (void)hipFree(p->d_partial);
+  delete p;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <int LPR>
+srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
+                         const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
+  const int blocks = (p->n_segs + 3) / 4;
+  spmm_seg_kernel<LPR><<<blocks, 256, 0, st>>>(p->d_segs, p->n_segs, d_indices, d_vals,
+                                               reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
+                                               reinterpret_cast<float4*>(p->d_partial), ep);
+  SRH_LAUNCH_CHECK();
+  if (p->n_heavy > 0) {
+    const int hb = (p->n_heavy + 3) / 4;
+    spmm_heavy_kernel<LPR><<<hb, 256, 0, st>>>(p->d_heavy, p->n_heavy, reinterpret_cast<const float4*>(p->d_partial),
+                                               reinterpret_cast<float4*>(d_y), ep);
+    SRH_LAUNCH_CHECK();
+  }
+  return SRH_OK;
+}
+
+}  // namespace
+
+extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
+                                     const int32_t* d_indices, const float* d_vals, const float* d_x,
+                                     float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
+  (void)d_indptr;  // the schedule in `plan` already encodes the row extents
+  SRH_REQUIRE(plan && d_indices && d_vals && d_x && d_y, "spmm_f32: null argument");
+  SRH_REQUIRE(srh::dim_supported(d), "spmm_f32: d=%d unsupported (need 32, 64, 128 or 256)", d);
+  SRH_REQUIRE(d_x != d_y, "spmm_f32: x and y must not alias");
+  DevEpilogue ep{};
+  if (epi) {
+    SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY)) == 0, "spmm_f32: unknown epilogue flag");
+    ep.flags = epi->flags;
+    ep.eps = epi->eps;
+    ep.noise = epi->d_noise;
+    ep.seed_lo = (uint32_t)epi->philox_seed; ep.seed_hi = (uint32_t)(epi->philox_seed >> 32);
+    ep.off_lo = (uint32_t)epi->philox_offset; ep.off_hi = (uint32_t)(epi->philox_offset >> 32);
+    ep.philox_step = epi->d_philox_step;
+    ep.philox_stride = epi->philox_stride;
+    if (epi->flags & SRH_EPI_MEAN) {
+      SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,
+                  "spmm_f32: bad MEAN epilogue");
+      ep.n_prev = epi->n_prev;
+      for (int t = 0; t < epi->n_prev; ++t) {
+        SRH_REQUIRE(epi->d_prev[t], "spmm_f32: null prev[%d]", t);
+        ep.prev[t] = epi->d_prev[t];
+      }
+      ep.mean_div = epi->mean_div;
+      ep.mean_out = epi->d_mean_out;
+    }
+    if (epi->flags & SRH_EPI_AXPY) {
+      SRH_REQUIRE(epi->n_add >= 0 && epi->n_add <= SRH_MAX_ADD, "spmm_f32: bad AXPY epilogue");
+      ep.n_add = epi->n_add;
+      ep.alpha = epi->alpha;
+      for (int t = 0; t < epi->n_add; ++t) {
+        SRH_REQUIRE(epi->d_add[t], "spmm_f32: null add[%d]", t);
+        ep.add[t] = epi->d_add[t];
+        ep.add_scale[t] = epi->add_scale[t];
+      }
+    }
+  }
+  hipStream_t st = srh::as_stream(stream);
+  switch (d) {
+    case 32: return launch_spmm<8>(plan, d_indices, d_vals, d_x, d_y, ep, st);
+    case 64: return launch_spmm<16>(plan, d_indices, d_vals, d_x, d_y, ep, st);
+    case 128: return launch_spmm<32>(plan, d_indices, d_vals, d_x, d_y, ep, st);
+    default: return launch_spmm<64>(plan, d_indices, d_vals, d_x, d_y, ep, st);
+  }
+}

@@ -1,0 +1,62 @@
+"""HBM-resident mirrors of the interaction graph.
+
+Layout (all int32 structure / fp32 values, sized for one MI355X's 288 GB):
+  r_indptr, r_indices          R  (U x I) CSR, columns sorted       -> eval mask, edge ids
+  adj.indptr / adj.indices     A  (N x N), N = U + I: rows 0..U-1 are R's rows with columns
+                               shifted by U, rows U..N-1 are R^T's rows
+  edge_id[p]                   position in R's row-major order of the interaction behind
+                               non-zero p (both copies of an edge share it) -- this is the
+                               index space of GraphAugmentor.edge_dropout's keep-set
+                               (reference data/augmentor.py:33-37: sp_adj.nonzero() order)
+  weight[p]                    interaction weight (None when all ones; duplicates in the
+                               training file sum, as scipy does for the reference)
+  adj.vals                     D^-1/2 A D^-1/2 computed on device by srh_adj_sym_normalize
+Edge-dropped views share the structure and own only a value array (``dropped_view``).
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .. import ops
+
+
+class DeviceGraph:
+    def __init__(self, interaction_mat, device=None):
+        r = interaction_mat.tocsr()
+        r.sum_duplicates()
+        r.sort_indices()
+        self.n_users, self.n_items = r.shape
+        self.n_nodes = self.n_users + self.n_items
+        self.n_edges = r.nnz
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.device = dev
+        eid = np.arange(r.nnz, dtype=np.int64)
+        # transpose with edge ids riding along as the data
+        rt = sp.csr_matrix((eid + 1, r.indices, r.indptr), shape=r.shape).tocsc()
+        rt.sort_indices()
+        indptr = np.concatenate([r.indptr, r.indptr[-1] + rt.indptr[1:]]).astype(np.int32)
+        indices = np.concatenate([r.indices.astype(np.int64) + self.n_users, rt.indices]).astype(np.int32)
+        edge_id = np.concatenate([eid, rt.data - 1]).astype(np.int32)
+        self.r_indptr = torch.from_numpy(r.indptr.astype(np.int32)).to(dev)
+        self.r_indices = torch.from_numpy(r.indices.astype(np.int32)).to(dev)
+        self.edge_id = torch.from_numpy(edge_id).to(dev)
+        w = r.data.astype(np.float32)
+        self.weight = None
+        if not np.all(w == 1.0):
+            self.weight = torch.from_numpy(np.concatenate([w, w[rt.data - 1]])).to(dev)
+        self.h_r_indptr, self.h_r_indices = r.indptr.astype(np.int32), r.indices.astype(np.int32)
+        self._deg_ws = torch.empty(self.n_nodes, dtype=torch.float32, device=dev)
+        self.adj = ops.DeviceCSR(indptr, indices, torch.zeros(indices.size, dtype=torch.float32, device=dev),
+                                 (self.n_nodes, self.n_nodes), device=dev)
+        ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, None, self.n_nodes,
+                              weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws)
+
+    def dropped_view(self, keep_mask: torch.Tensor, out: torch.Tensor | None = None) -> "ops.DeviceCSR":
+        """Normalised adjacency of the graph restricted to interactions with keep_mask != 0
+        (uint8, indexed by R's row-major edge order).  Degrees are those of the dropped
+        graph, as reference ui_graph.py:58-65 recomputes them."""
+        if out is None:
+            out = torch.empty_like(self.adj.vals)
+        ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep_mask, self.n_nodes,
+                              weight=self.weight, out=out, deg_ws=self._deg_ws)
+        return self.adj.with_values(out)

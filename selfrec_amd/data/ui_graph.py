@@ -1,0 +1,162 @@
+"""User-item interaction data with the attribute surface of reference data/ui_graph.py:8-122,
+plus device-resident mirrors for the HIP kernels.
+
+Same observable results as the reference's ``Interaction``:
+  * ids in first-appearance order of the training list (ui_graph.py:29-38),
+  * ``test_set`` restricted to users and items seen in training (:41-45),
+  * ``ui_adj`` / ``norm_adj`` / ``interaction_mat`` as scipy CSR fp32 (:47-56, :67-71),
+  * ``convert_to_laplacian_mat`` for dropped interaction matrices (:58-65).
+Differences are internal: one pass builds flat int32 id arrays (``train_u`` / ``train_i``) that
+feed the C++ sampler and the device CSR; the dict-of-dict views (``training_set_u`` ...) and
+the scipy matrices are materialised on first use.
+"""
+from collections import defaultdict
+
+import numpy as np
+import scipy.sparse as sp
+
+from .data import Data
+from .graph import Graph
+
+
+class Interaction(Data, Graph):
+    def __init__(self, conf, training, test):
+        Graph.__init__(self)
+        Data.__init__(self, conf, training, test)
+        self.user, self.item = {}, {}
+        n = len(self.training_data)
+        self.train_u = np.empty(n, dtype=np.int32)
+        self.train_i = np.empty(n, dtype=np.int32)
+        user, item = self.user, self.item
+        for pos, rec in enumerate(self.training_data):
+            uid = user.get(rec[0])
+            if uid is None:
+                uid = user[rec[0]] = len(user)
+            iid = item.get(rec[1])
+            if iid is None:
+                iid = item[rec[1]] = len(item)
+            self.train_u[pos] = uid
+            self.train_i[pos] = iid
+        self.id2user = {v: k for k, v in user.items()}
+        self.id2item = {v: k for k, v in item.items()}
+        self.user_num, self.item_num = len(user), len(item)
+        self.test_set = defaultdict(dict)
+        self.test_set_item = set()
+        for rec in self.test_data:
+            if rec[0] in user and rec[1] in item:
+                self.test_set[rec[0]][rec[1]] = 1
+                self.test_set_item.add(rec[1])
+        self._cache = {}
+
+    # ---- lazily built views ---------------------------------------------------------
+    def _lazy(self, key, build):
+        if key not in self._cache:
+            self._cache[key] = build()
+        return self._cache[key]
+
+    def _edge_ids_in_list_order(self):
+        """ids of the CURRENT training_data order (the sampler shuffles that list in place)."""
+        u = np.fromiter((self.user[r[0]] for r in self.training_data), dtype=np.int32, count=len(self.training_data))
+        i = np.fromiter((self.item[r[1]] for r in self.training_data), dtype=np.int32, count=len(self.training_data))
+        return u, i
+
+    @property
+    def training_set_u(self):
+        def build():
+            out = defaultdict(dict)
+            id2user, id2item = self.id2user, self.id2item
+            for u, i in zip(self.train_u.tolist(), self.train_i.tolist()):
+                out[id2user[u]][id2item[i]] = 1
+            return out
+        return self._lazy('tsu', build)
+
+    @property
+    def training_set_i(self):
+        def build():
+            out = defaultdict(dict)
+            id2user, id2item = self.id2user, self.id2item
+            for u, i in zip(self.train_u.tolist(), self.train_i.tolist()):
+                out[id2item[i]][id2user[u]] = 1
+            return out
+        return self._lazy('tsi', build)
+
+    @property
+    def interaction_mat(self):
+        def build():
+            ones = np.ones(self.train_u.size, dtype=np.float32)
+            return sp.csr_matrix((ones, (self.train_u, self.train_i)), shape=(self.user_num, self.item_num),
+                                 dtype=np.float32)
+        return self._lazy('R', build)
+
+    @property
+    def ui_adj(self):
+        def build():
+            n = self.user_num + self.item_num
+            ones = np.ones(self.train_u.size, dtype=np.float32)
+            upper = sp.csr_matrix((ones, (self.train_u, self.train_i.astype(np.int64) + self.user_num)),
+                                  shape=(n, n), dtype=np.float32)
+            return upper + upper.T
+        return self._lazy('A', build)
+
+    @property
+    def norm_adj(self):
+        return self._lazy('Ahat', lambda: self.normalize_graph_mat(self.ui_adj))
+
+    def convert_to_laplacian_mat(self, adj_mat):
+        lazy = getattr(adj_mat, 'to_device_laplacian', None)
+        if lazy is not None:           # device-resident dropped view (data/augmentor.py fast path)
+            return lazy(self)
+        nu, ni = adj_mat.shape
+        rows, cols = adj_mat.nonzero()
+        lifted = sp.csr_matrix((adj_mat.data, (rows, cols + nu)), shape=(nu + ni, nu + ni), dtype=np.float32)
+        return self.normalize_graph_mat(lifted + lifted.T)
+
+    def device_graph(self, device=None):
+        """Device CSR mirrors (built once): see data/device_graph.py."""
+        from .device_graph import DeviceGraph
+        return self._lazy('dev', lambda: DeviceGraph(self.interaction_mat, device=device))
+
+    # ---- accessors of the reference surface -----------------------------------------
+    def get_user_id(self, u):
+        return self.user.get(u)
+
+    def get_item_id(self, i):
+        return self.item.get(i)
+
+    def training_size(self):
+        return len(self.user), len(self.item), len(self.training_data)
+
+    def test_size(self):
+        return len(self.test_set), len(self.test_set_item), len(self.test_data)
+
+    def contain(self, u, i):
+        return u in self.user and i in self.training_set_u[u]
+
+    def contain_user(self, u):
+        return u in self.user
+
+    def contain_item(self, i):
+        return i in self.item
+
+    def user_rated(self, u):
+        row = self.training_set_u[u]
+        return list(row.keys()), list(row.values())
+
+    def item_rated(self, i):
+        col = self.training_set_i[i]
+        return list(col.keys()), list(col.values())
+
+    def row(self, u):
+        vec = np.zeros(self.item_num, dtype=np.float32)
+        names, ratings = self.user_rated(self.id2user[u])
+        vec[[self.item[n] for n in names]] = ratings
+        return vec
+
+    def col(self, i):
+        vec = np.zeros(self.user_num, dtype=np.float32)
+        names, ratings = self.item_rated(self.id2item[i])
+        vec[[self.user[n] for n in names]] = ratings
+        return vec
+
+    def matrix(self):
+        return np.minimum(self.interaction_mat.toarray(), 1.0).astype(np.float32)

@@ -1,0 +1,410 @@
+"""Fused training step of the LightGCN family on one MI355X.
+
+What a model file of the reference spells as ~60 ATen launches per step --
+cat, L x sparse.mm, rand_like/normalize/sign/mul/add, stack, mean, 3 fancy-index gathers,
+bpr/l2/InfoNCE elementwise chains, their autograd mirror images, dense Adam -- is issued here
+as ~25 hand-written HIP kernels whose sequence is *numerically specified by* those model
+files:
+
+    model      encoder passes / step               spec (reference file:lines)
+    MF         none (F = E0)                       model/graph/MF.py:13-31
+    LightGCN   1, mean over layers 0..L            model/graph/LightGCN.py:17-36,68-78
+    XSimGCL    1 perturbed, mean over 1..L, CL     model/graph/XSimGCL.py:23-50,83-101
+               view = layer l*
+    SimGCL     1 clean + 2 perturbed               model/graph/SimGCL.py:21-50,81-93
+    SGL        1 + 2 on edge-dropped graphs        model/graph/SGL.py:24-47,98-125
+
+Data layout in HBM (fp32 row-major, one allocation each, never re-created):
+    E0   (N, d)  the parameter table; user_emb = E0[:U], item_emb = E0[U:] are views, so the
+                 reference's torch.cat is free;   m, v  Adam moments, same shape
+    Y_k  (N, d)  layer outputs, F (N, d) their mean, written by the SpMM epilogue
+    gF, gCL, gE0, H_a, H_b (N, d) gradient buffers
+Backward uses two facts of the model family: the perturbation has identity Jacobian
+(sign() has zero gradient, XSimGCL.py:91), and A_hat is symmetric, so every backward
+product is the same SpMM kernel; encoder passes that share A_hat and the layer mean share
+one backward chain because it is linear (SimGCL: gradients of the three passes are summed
+before a single chain).
+
+Indices: the C++ sampler produces a whole epoch (shuffle + batches + sorted unique ids) on a
+host thread; it is uploaded once per epoch, and a one-block kernel (srh_batch_fetch) stages
+batch b into fixed buffers and publishes its sizes in device memory.  Every kernel of the
+step reads sizes from there, so the step has no host-dependent argument and can be
+captured once in a hipGraph and replayed.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import SelfrecHipError
+
+MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
+
+
+class FusedTrainer:
+    def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
+                 tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
+                 noise_fn=None, philox_seed=0x5E1F0EC, use_graph=False, device=None):
+        if model not in MODELS:
+            raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
+        ops._lib.require_gpu()
+        self.model, self.data = model, data
+        self.d, self.L = int(emb_size), (0 if model == "MF" else int(n_layers))
+        self.lr, self.reg, self.cl_rate, self.eps, self.tau = float(lr), float(reg), float(cl_rate), float(eps), float(tau)
+        if model == "SimGCL":
+            self.tau = 0.2                       # hard-coded in the reference, SimGCL.py:48-49
+        self.layer_cl, self.drop_rate, self.aug_type = int(layer_cl), float(drop_rate), int(aug_type)
+        self.B = int(batch_size)
+        self.noise_fn = noise_fn                  # (N, d) -> tensor; None = in-kernel Philox
+        self.philox_seed = int(philox_seed)
+        if model != "MF" and self.L < 1:
+            raise SelfrecHipError("n_layers must be >= 1")
+        if model == "XSimGCL" and not (0 <= self.layer_cl <= self.L):
+            raise SelfrecHipError("l_star must be in [0, n_layer]")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.dev = dev
+        self.graph = data.device_graph(dev)
+        g = self.graph
+        self.U, self.I, self.N = g.n_users, g.n_items, g.n_nodes
+        N, d, B = self.N, self.d, self.B
+
+        def buf():
+            return torch.zeros((N, d), dtype=torch.float32, device=dev)
+
+        self.E0 = buf()
+        if user_emb is None or item_emb is None:
+            ue = torch.nn.init.xavier_uniform_(torch.empty(self.U, d))      # XSimGCL.py:76-80
+            ie = torch.nn.init.xavier_uniform_(torch.empty(self.I, d))
+        else:
+            ue, ie = torch.as_tensor(user_emb, dtype=torch.float32), torch.as_tensor(item_emb, dtype=torch.float32)
+        self.E0[:self.U].copy_(ue)
+        self.E0[self.U:].copy_(ie)
+        self.m, self.v = buf(), buf()
+        self.gE0 = buf()
+        self.F = self.E0 if model == "MF" else buf()
+        self.gF = self.gE0 if model == "MF" else buf()
+        self.Y = [buf() for _ in range(self.L)]
+        self.Ha, self.Hb = (buf(), buf()) if self.L >= 1 else (None, None)
+        self.gCL = buf() if model == "XSimGCL" else None
+        self.views = []                           # SimGCL / SGL: extra passes [(F_v, Y_v list, gF_v)]
+        if model in ("SimGCL", "SGL"):
+            for _ in range(2):
+                self.views.append({"F": buf(), "Y": [buf() for _ in range(self.L)], "gF": buf()})
+        self.view_adj = [None, None]              # SGL: dropped adjacencies (DeviceCSR)
+        self._view_vals = [torch.empty_like(g.adj.vals), torch.empty_like(g.adj.vals)] if model == "SGL" else None
+        self.losses = torch.zeros(4, dtype=torch.float64, device=dev)      # bpr, reg, cl
+        self.stage = {k: torch.zeros(B, dtype=torch.int32, device=dev) for k in ("u", "i", "j", "uniq_u", "uniq_i")}
+        self.stage_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev)  # SGL: [uniq users ; uniq items + U]
+        self.meta = torch.zeros(4, dtype=torch.int32, device=dev)          # rows, n_uniq_u, n_uniq_i, batch no
+        self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)        # batch no, adam step
+        self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.bpr_ws = ops.bpr_ws(B, dev)
+        self.nce_ws = ops.infonce_ws(2 * B if model == "SGL" else B, d, dev) if model in ("XSimGCL", "SimGCL", "SGL") else None
+        self.sampler = ops.Sampler(data.train_u, data.train_i, self.U, self.I)
+        E = self.sampler.n_edges
+        self.epoch_batches = (E + B - 1) // B
+        sizes = {"u": E, "i": E, "j": E, "uniq_u": self.epoch_batches * B, "uniq_i": self.epoch_batches * B,
+                 "n_uniq_u": self.epoch_batches, "n_uniq_i": self.epoch_batches}
+        # fixed addresses: a captured hipGraph keeps pointing at them across epochs
+        self._epoch_dev = {k: torch.zeros(n, dtype=torch.int32, device=dev) for k, n in sizes.items()}
+        self._epoch_ready = False
+        self.step_count = 0
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._noise_call = 0
+
+    # ------------------------------------------------------------------------------------
+    # views of the tables
+    # ------------------------------------------------------------------------------------
+    @property
+    def user_emb(self):
+        return self.E0[:self.U]
+
+    @property
+    def item_emb(self):
+        return self.E0[self.U:]
+
+    def _u(self, t):
+        return t[:self.U]
+
+    def _i(self, t):
+        return t[self.U:]
+
+    # ------------------------------------------------------------------------------------
+    # sampling
+    # ------------------------------------------------------------------------------------
+    def seed_sampler_from_python(self):
+        """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it)."""
+        self.sampler.set_state_from_python()
+
+    def sample_epoch_host(self):
+        """Host part of an epoch: SGL's two edge-dropped views are drawn first (SGL.py:28-29),
+        then shuffle + batches.  Pure host work -- safe to run on a worker thread."""
+        out = {}
+        if self.model == "SGL":
+            masks = []
+            for _ in range(2):
+                if self.aug_type == 0:
+                    raise SelfrecHipError("SGL aug_type 0 (node dropout) is not wired into the fused engine")
+                e = self.graph.n_edges
+                keep = self.sampler.sample_range(e, int(e * (1 - self.drop_rate)))
+                mk = np.zeros(e, dtype=np.uint8)
+                mk[keep] = 1
+                masks.append(mk)
+            out["masks"] = masks
+        out.update(self.sampler.epoch(self.B, 1, with_unique=True))
+        return out
+
+    def upload_epoch(self, host):
+        dev = self.dev
+        if "masks" in host:
+            for v, mk in enumerate(host["masks"]):
+                self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
+        for k, t in self._epoch_dev.items():
+            t.copy_(torch.from_numpy(host[k]), non_blocking=True)
+        self._epoch_host = host
+        self._epoch_ready = True
+        self.cursor[0:1].zero_()
+
+    def begin_epoch(self):
+        self.upload_epoch(self.sample_epoch_host())
+        return self.epoch_batches
+
+    # ------------------------------------------------------------------------------------
+    # encoder
+    # ------------------------------------------------------------------------------------
+    def _noise(self):
+        if self.noise_fn is None:
+            return None
+        t = self.noise_fn((self.N, self.d))
+        return torch.as_tensor(t, dtype=torch.float32).to(self.dev).contiguous()
+
+    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, training=True):
+        """L SpMMs; layer k's epilogue perturbs (optional) and the last one also writes the
+        layer mean into F.  Returns nothing; the CL view of XSimGCL is Ys[l*-1] (or E0)."""
+        L = self.L
+        x = self.E0
+        for k in range(L):
+            kw = {}
+            if perturbed:
+                noise = self._noise()
+                kw.update(perturb_eps=self.eps, noise=noise, philox_seed=self.philox_seed,
+                          philox_offset=(self._noise_call * self.N) & ((1 << 62) - 1),
+                          philox_step=self.cursor[1:2] if noise is None else None,
+                          philox_stride=self.N * 16)
+                self._noise_call += 1
+            if k == L - 1:
+                prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
+                kw.update(prev=prev, mean_div=float(L + 1 if include_ego else L), mean_out=F)
+            ops.spmm(adj, x, out=Ys[k], epilogue=ops.make_epilogue(**kw) if kw else None)
+            x = Ys[k]
+
+    def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None):
+        """gE0 += d loss / d E0 through one encoder pass.
+
+        H_L = s gF + [l*==L] gCL ;  H_k = A H_{k+1} + s gF + [l*==k] gCL ;
+        gE0 += A H_1 + [ego] s gF + [l*==0] gCL (+ extra)       with s = 1/#averaged layers.
+        """
+        L = self.L
+        s = 1.0 / (L + 1 if include_ego else L)
+        cl_at = layer_cl if gCL is not None else None
+        if cl_at == L:
+            H = self.Ha
+            ops.axpby(s, gF, 0.0, H)
+            ops.axpby(1.0, gCL, 1.0, H)
+            src, alpha = H, 1.0
+        else:
+            src, alpha = gF, s                     # A (s gF) = s (A gF): no materialised H_L
+        bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
+        for k in range(L - 1, 0, -1):              # produce H_k
+            add, sc = [gF], [s]
+            if cl_at == k:
+                add.append(gCL)
+                sc.append(1.0)
+            dst = bufs[0]
+            ops.spmm(adj, src, out=dst, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha))
+            src, alpha = dst, 1.0
+            bufs.reverse()
+        add, sc = [self.gE0], [1.0]                # accumulate into gE0 (aliasing y is allowed)
+        if include_ego:
+            add.append(gF)
+            sc.append(s)
+        if cl_at == 0:
+            add.append(gCL)
+            sc.append(1.0)
+        if extra is not None:
+            add.append(extra)
+            sc.append(1.0)
+        while len(add) > 2:                        # epilogue takes two addends: fold the rest first
+            ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
+        ops.spmm(adj, src, out=self.gE0, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha))
+
+    # ------------------------------------------------------------------------------------
+    # one training step on the staged batch
+    # ------------------------------------------------------------------------------------
+    def _step_kernels(self):
+        m, st, U = self.model, self.stage, self.U
+        g = self.graph
+        rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
+        ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta)
+        self._noise_call = 0      # Philox counter = (adam step, perturbed-layer call no, row)
+        self.losses.zero_()
+        self.gE0.zero_()
+        if self.gF is not self.gE0:
+            self.gF.zero_()
+        if self.gCL is not None:
+            self.gCL.zero_()
+        for v in self.views:
+            v["gF"].zero_()
+
+        include_ego = m in ("LightGCN", "SGL")
+        if m != "MF":
+            self._forward_pass(g.adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego)
+        F = self.F
+        # ---- recommendation loss + regulariser (a-5..a-7)
+        if m == "LightGCN":
+            # regulariser on the EGO rows; its gradient lands in gE0 directly (LightGCN.py:25)
+            reg_u, reg_i, greg_u, greg_i = self._u(self.E0), self._i(self.E0), self._u(self.gE0), self._i(self.gE0)
+            reg_coef, inc_neg = self.reg / self.B, True
+        elif m == "MF":
+            reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
+            reg_coef, inc_neg = self.reg / self.B, True                     # MF.py:21
+        else:
+            reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
+            reg_coef, inc_neg = self.reg, (m == "SGL")                      # XSimGCL.py:33, SGL.py:36
+        ops.bpr_l2_fwd_bwd(self._u(F), self._i(F), reg_u, reg_i, st["u"], st["i"], st["j"], batch=self.B,
+                           n_rows_dev=rows_dev, reg_coef=reg_coef, reg_include_neg=inc_neg, loss_scale=1.0,
+                           g_user=self._u(self.gF), g_item=self._i(self.gF), greg_user=greg_u, greg_item=greg_i,
+                           losses=self.losses[0:2], ws=self.bpr_ws)
+        # ---- contrastive loss (a-8)
+        if m == "XSimGCL":
+            CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
+            for lo, idx, n_dev in ((0, st["uniq_u"], nuu_dev), (U, st["uniq_i"], nui_dev)):
+                ops.infonce_fwd_bwd(F[lo:lo + (U if lo == 0 else self.I)], CL[lo:lo + (U if lo == 0 else self.I)],
+                                    idx, self.B, n_dev=n_dev, tau=self.tau, loss_scale=self.cl_rate,
+                                    loss=self.losses[2:3], g1=self.gF[lo:lo + (U if lo == 0 else self.I)],
+                                    g2=self.gCL[lo:lo + (U if lo == 0 else self.I)], ws=self.nce_ws)
+        elif m in ("SimGCL", "SGL"):
+            for vi, v in enumerate(self.views):
+                adj = g.adj if m == "SimGCL" else self.view_adj[vi]
+                self._forward_pass(adj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego)
+            a, b = self.views
+            if m == "SimGCL":
+                for lo, hi, idx, n_dev in ((0, U, st["uniq_u"], nuu_dev), (U, self.N, st["uniq_i"], nui_dev)):
+                    ops.infonce_fwd_bwd(a["F"][lo:hi], b["F"][lo:hi], idx, self.B, n_dev=n_dev, tau=self.tau,
+                                        loss_scale=self.cl_rate, loss=self.losses[2:3], g1=a["gF"][lo:hi],
+                                        g2=b["gF"][lo:hi], ws=self.nce_ws)
+            else:
+                self._build_cat_index()
+                ops.infonce_fwd_bwd(a["F"], b["F"], self.stage_cat, 2 * self.B, n_dev=self.n_cat, tau=self.tau,
+                                    loss_scale=self.cl_rate, loss=self.losses[2:3], g1=a["gF"], g2=b["gF"],
+                                    ws=self.nce_ws)
+        # ---- backward through the encoder (a-4) and optimiser (a-9)
+        if m == "MF":
+            pass                                     # gF is gE0
+        elif m == "XSimGCL":
+            self._backward_chain(g.adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl)
+        elif m == "LightGCN":
+            self._backward_chain(g.adj, self.gF, include_ego=True)
+        elif m == "SimGCL":
+            ops.axpby(1.0, self.views[0]["gF"], 1.0, self.gF)     # same linear operator for all passes
+            ops.axpby(1.0, self.views[1]["gF"], 1.0, self.gF)
+            self._backward_chain(g.adj, self.gF, include_ego=False)
+        else:                                        # SGL: three operators, three chains
+            self._backward_chain(g.adj, self.gF, include_ego=True)
+            for vi, v in enumerate(self.views):
+                self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True)
+        ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.cursor[1:2], lr=self.lr)
+
+    def _build_cat_index(self):
+        """SGL: InfoNCE over [unique users ; unique items] of the batch (SGL.py:120-125), as one
+        index list into the (N, d) tables.  Sizes stay on the device."""
+        B, U = self.B, self.U
+        pos = torch.arange(2 * B, device=self.dev, dtype=torch.int32)
+        nu, ni = self.meta[1], self.meta[2]
+        from_u = self.stage["uniq_u"][pos.clamp(max=B - 1).long()]
+        item_pos = (pos - nu).clamp(min=0, max=B - 1).long()
+        from_i = self.stage["uniq_i"][item_pos] + U
+        self.stage_cat.copy_(torch.where(pos < nu, from_u, from_i))
+        self.n_cat.copy_((nu + ni).reshape(1))
+
+    def step(self):
+        """Run one training step on the next batch of the current epoch."""
+        if not self._epoch_ready:
+            raise SelfrecHipError("call begin_epoch() first")
+        if self.use_graph and self.noise_fn is None:
+            if self._graph is None:
+                self._capture()
+            else:
+                self._graph.replay()
+        else:
+            self._step_kernels()
+        self.step_count += 1
+
+    def _capture(self):
+        # warm up once eagerly on a side stream (allocator + lazy module loads), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        snapshot = (self.E0.clone(), self.m.clone(), self.v.clone(), self.cursor.clone())
+        with torch.cuda.stream(side):
+            self._step_kernels()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._step_kernels()
+        self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
+        self._graph.replay()
+
+    def read_losses(self):
+        """(bpr, reg, cl) of the last step -- a device-to-host sync, call sparingly."""
+        bpr, reg, cl = self.losses[:3].tolist()
+        return bpr, reg, cl
+
+    # ------------------------------------------------------------------------------------
+    # inference-time embeddings (model() with no perturbation, XSimGCL.py:40-41)
+    # ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def embeddings(self):
+        if self.model == "MF":
+            return self.user_emb, self.item_emb
+        out = torch.empty_like(self.E0)
+        Ys = [torch.empty_like(self.E0) for _ in range(self.L)]
+        self._forward_pass(self.graph.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
+        return out[:self.U], out[self.U:]
+
+
+class EpochPrefetcher:
+    """Runs ``trainer.sample_epoch_host()`` for epoch e+1 on a host thread while the device
+    works on epoch e.  The sampler is sequential by construction (one MT19937 stream with
+    data-dependent rejection), so a single producer is all there is to overlap."""
+
+    def __init__(self, trainer: FusedTrainer):
+        self.trainer = trainer
+        self._thread = None
+        self._result = None
+        self._error = None
+
+    def _work(self):
+        try:
+            self._result = self.trainer.sample_epoch_host()
+        except BaseException as e:  # surfaced on the consumer side
+            self._error = e
+
+    def start(self):
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
+
+    def take(self):
+        if self._thread is None:
+            self.start()
+        self._thread.join()
+        self._thread = None
+        if self._error is not None:
+            raise self._error
+        res, self._result = self._result, None
+        return res

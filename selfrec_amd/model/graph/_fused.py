@@ -1,0 +1,66 @@
+"""Common body of the engine-backed LightGCN-family recommenders.
+
+Each concrete class (MF, LightGCN, XSimGCL, SimGCL, SGL in this package) reads the same
+``conf`` keys as its reference namesake and exposes the same lifecycle
+(``train / save / predict``, ``user_emb / item_emb / best_user_emb / best_item_emb``), but its
+``train()`` drives ``selfrec_amd.engine.FusedTrainer`` instead of a python loop of ATen ops.
+"""
+import random
+
+import torch
+
+from ...base.graph_recommender import GraphRecommender
+from ...engine import EpochPrefetcher, FusedTrainer
+
+
+class FusedGraphModel(GraphRecommender):
+    engine_model = None            # "MF" | "LightGCN" | ...
+
+    def engine_kwargs(self):
+        return {}
+
+    def should_evaluate(self, epoch):
+        return True
+
+    def __init__(self, conf, training_set, test_set, **kwargs):
+        super().__init__(conf, training_set, test_set, **kwargs)
+        get = getattr(self.config, 'get', lambda k, d=None: d)
+        self.trainer = FusedTrainer(self.data, self.emb_size, model=self.engine_model, lr=self.lRate,
+                                    reg=self.reg, batch_size=self.batch_size,
+                                    use_graph=bool(get('engine.hipgraph', True)), **self.engine_kwargs())
+        self.exact_sampling = bool(get('sampler.python_state', True))
+
+    def train(self):
+        tr = self.trainer
+        if self.exact_sampling:           # consume the global `random` stream like the reference
+            tr.seed_sampler_from_python()
+        else:
+            tr.sampler.seed(random.getrandbits(63))
+        prefetch = EpochPrefetcher(tr)
+        prefetch.start()
+        for epoch in range(self.maxEpoch):
+            tr.upload_epoch(prefetch.take())
+            evaluate_now = self.should_evaluate(epoch)
+            if epoch + 1 < self.maxEpoch:
+                prefetch.start()          # host samples epoch e+1 while the device runs epoch e
+            for n in range(tr.epoch_batches):
+                tr.step()
+                if n % 100 == 0 and n > 0:
+                    bpr, reg, cl = tr.read_losses()
+                    print('training:', epoch + 1, 'batch', n, 'rec_loss:', bpr, 'cl_loss', cl)
+            self.user_emb, self.item_emb = tr.embeddings()
+            if evaluate_now:
+                self.fast_evaluation(epoch)
+        if self.exact_sampling:
+            tr.sampler.push_state_to_python()
+        if hasattr(self, 'best_user_emb'):
+            self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
+
+    def save(self):
+        ue, ie = self.trainer.embeddings()
+        self.best_user_emb, self.best_item_emb = ue.clone(), ie.clone()
+
+    def predict(self, u):
+        uid = self.data.get_user_id(u)
+        with torch.no_grad():
+            return torch.matmul(self.user_emb[uid], self.item_emb.transpose(0, 1)).cpu().numpy()

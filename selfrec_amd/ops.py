@@ -1,0 +1,374 @@
+"""Torch-tensor front end of the C ABI: pointer extraction, shape checks, stream plumbing.
+
+PyTorch is the memory container here and nothing else: every function hands raw device
+addresses (``tensor.data_ptr()``) and the current HIP stream to libselfrec_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random as _pyrandom
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SelfrecHipError, SpmmEpilogue, check
+
+__all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
+           "sumsq", "infonce_fwd_bwd", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
+           "axpby", "batch_fetch", "SelfrecHipError"]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None, name="tensor"):
+    """Device address of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SelfrecHipError(f"{name}: expected a HIP device tensor (the product path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise SelfrecHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise SelfrecHipError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------------------
+# (a-1) sampler
+# ----------------------------------------------------------------------------------------
+class Sampler:
+    """Host-side bit-exact replay of util/sampler.py:5-28 (see csrc/sampler.cpp)."""
+
+    def __init__(self, edge_user, edge_item, n_users: int, n_items: int):
+        self._lib = _lib.load()
+        eu, pu = _np(edge_user, np.int32)
+        ei, pi = _np(edge_item, np.int32)
+        if eu.shape != ei.shape or eu.ndim != 1:
+            raise SelfrecHipError("Sampler: edge arrays must be 1-D and of equal length")
+        self.n_users, self.n_items, self.n_edges = int(n_users), int(n_items), int(eu.size)
+        h = C.c_void_p()
+        check(self._lib.srh_sampler_create(C.byref(h), n_users, n_items, eu.size, pu, pi), "srh_sampler_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.srh_sampler_destroy(h)
+            self._h = None
+
+    # -- RNG state ------------------------------------------------------------------
+    def set_state_from_python(self, state=None):
+        """Adopt ``random.getstate()`` (version 3 tuple: 624 words + position)."""
+        state = _pyrandom.getstate() if state is None else state
+        if state[0] != 3 or len(state[1]) != 625:
+            raise SelfrecHipError("unsupported random.getstate() layout")
+        words = np.asarray(state[1][:624], dtype=np.uint32)
+        check(self._lib.srh_sampler_set_state(self._h, words.ctypes.data_as(C.c_void_p), int(state[1][624])))
+        self._gauss = state[2]
+
+    def python_state(self):
+        """The generator state as a tuple ``random.setstate`` accepts."""
+        words = np.empty(624, dtype=np.uint32)
+        pos = C.c_int32()
+        check(self._lib.srh_sampler_get_state(self._h, words.ctypes.data_as(C.c_void_p), C.byref(pos)))
+        return (3, tuple(int(x) for x in words) + (int(pos.value),), getattr(self, "_gauss", None))
+
+    def push_state_to_python(self):
+        _pyrandom.setstate(self.python_state())
+
+    def seed(self, seed: int):
+        check(self._lib.srh_sampler_seed(self._h, int(seed)), "srh_sampler_seed")
+        self._gauss = None
+
+    # -- draws ----------------------------------------------------------------------
+    def shuffle(self):
+        check(self._lib.srh_sampler_shuffle(self._h), "srh_sampler_shuffle")
+
+    def order(self) -> np.ndarray:
+        perm = np.empty(self.n_edges, dtype=np.int64)
+        check(self._lib.srh_sampler_get_order(self._h, perm.ctypes.data_as(C.c_void_p)))
+        return perm
+
+    def next_batch(self, ptr: int, batch_size: int, n_negs: int = 1):
+        cnt = min(batch_size, self.n_edges - ptr)
+        u = np.empty(cnt, dtype=np.int32)
+        i = np.empty(cnt, dtype=np.int32)
+        j = np.empty(cnt * n_negs, dtype=np.int32)
+        out = C.c_int64()
+        check(self._lib.srh_sampler_next_batch(self._h, ptr, batch_size, n_negs, u.ctypes.data_as(C.c_void_p),
+                                               i.ctypes.data_as(C.c_void_p), j.ctypes.data_as(C.c_void_p),
+                                               C.byref(out)), "srh_sampler_next_batch")
+        assert out.value == cnt
+        return u, i, j
+
+    def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False):
+        """shuffle + all batches.  Returns dict of numpy arrays (see srh_sampler_epoch)."""
+        e = self.n_edges
+        nb = (e + batch_size - 1) // batch_size
+        u = np.empty(e, dtype=np.int32)
+        i = np.empty(e, dtype=np.int32)
+        j = np.empty(e * n_negs, dtype=np.int32)
+        res = {"u": u, "i": i, "j": j, "n_batches": nb}
+        uu = ui = nuu = nui = None
+        if with_unique:
+            uu = np.zeros(nb * batch_size, dtype=np.int32)
+            ui = np.zeros(nb * batch_size, dtype=np.int32)
+            nuu = np.zeros(nb, dtype=np.int32)
+            nui = np.zeros(nb, dtype=np.int32)
+            res.update(uniq_u=uu, uniq_i=ui, n_uniq_u=nuu, n_uniq_i=nui)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        check(self._lib.srh_sampler_epoch(self._h, batch_size, n_negs, vp(u), vp(i), vp(j), vp(uu), vp(nuu),
+                                          vp(ui), vp(nui)), "srh_sampler_epoch")
+        return res
+
+    def sample_range(self, n: int, k: int) -> np.ndarray:
+        out = np.empty(k, dtype=np.int64)
+        check(self._lib.srh_sampler_sample_range(self._h, n, k, out.ctypes.data_as(C.c_void_p)),
+              "srh_sampler_sample_range")
+        return out
+
+    def next_u32(self) -> int:
+        v = C.c_uint32()
+        check(self._lib.srh_sampler_next_u32(self._h, C.byref(v)))
+        return int(v.value)
+
+
+# ----------------------------------------------------------------------------------------
+# (a-2..a-4) device CSR, normalisation, SpMM
+# ----------------------------------------------------------------------------------------
+class DeviceCSR:
+    """CSR matrix resident in HBM (int32 structure, fp32 values) plus its SpMM schedule.
+
+    ``structure_of`` shares indptr/indices/plan with another DeviceCSR (edge-dropped views
+    are new value arrays over the same structure).
+    """
+
+    def __init__(self, indptr, indices, vals, shape, device=None, split_len: int = 0, structure_of=None):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.shape = (int(shape[0]), int(shape[1]))
+        if structure_of is not None:
+            self.indptr, self.indices, self._plan_owner = structure_of.indptr, structure_of.indices, structure_of
+            self.h_indptr = structure_of.h_indptr
+            self._plan = structure_of._plan
+        else:
+            h_indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+            if h_indptr.size != self.shape[0] + 1:
+                raise SelfrecHipError("DeviceCSR: indptr length != n_rows + 1")
+            self.h_indptr = h_indptr
+            self.indptr = torch.from_numpy(h_indptr).to(device)
+            self.indices = torch.as_tensor(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
+            h = C.c_void_p()
+            check(self._lib.srh_spmm_plan_create(C.byref(h), self.shape[0], self.shape[1],
+                                                 h_indptr.ctypes.data_as(C.c_void_p), split_len),
+                  "srh_spmm_plan_create")
+            self._plan = h
+            self._plan_owner = None
+        if isinstance(vals, torch.Tensor):
+            self.vals = vals.to(device=device, dtype=torch.float32).contiguous()
+        else:
+            self.vals = torch.as_tensor(np.ascontiguousarray(vals, dtype=np.float32)).to(device)
+        self.nnz = int(self.indices.numel())
+        if self.vals.numel() != self.nnz:
+            raise SelfrecHipError("DeviceCSR: values / indices length mismatch")
+
+    def __del__(self):
+        if getattr(self, "_plan_owner", 1) is None and getattr(self, "_plan", None):
+            self._lib.srh_spmm_plan_destroy(self._plan)
+            self._plan = None
+
+    @classmethod
+    def from_scipy(cls, mat, device=None, split_len: int = 0):
+        m = mat.tocsr()
+        m.sort_indices()
+        return cls(m.indptr, m.indices, m.data, m.shape, device=device, split_len=split_len)
+
+    def with_values(self, vals):
+        return DeviceCSR(None, None, vals, self.shape, device=self.vals.device, structure_of=self)
+
+
+def make_epilogue(*, perturb_eps=None, noise=None, philox_seed=0, philox_offset=0, philox_step=None,
+                  philox_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0):
+    ep = SpmmEpilogue()
+    keep = []
+    flags = 0
+    if perturb_eps is not None:
+        flags |= _lib.SRH_EPI_PERTURB
+        ep.eps = float(perturb_eps)
+        ep.d_noise = _p(noise, torch.float32, "noise")
+        ep.philox_seed, ep.philox_offset = int(philox_seed), int(philox_offset)
+        ep.d_philox_step = _p(philox_step, torch.int64, "philox_step")
+        ep.philox_stride = int(philox_stride)
+        keep += [noise, philox_step]
+    if mean_out is not None:
+        flags |= _lib.SRH_EPI_MEAN
+        prev = list(prev or [])
+        if len(prev) > _lib.SRH_MAX_PREV:
+            raise SelfrecHipError(f"at most {_lib.SRH_MAX_PREV} earlier layers can be averaged in the epilogue")
+        ep.n_prev = len(prev)
+        for t, x in enumerate(prev):
+            ep.d_prev[t] = _p(x, torch.float32, "prev")
+        ep.mean_div = float(mean_div)
+        ep.d_mean_out = _p(mean_out, torch.float32, "mean_out")
+        keep += prev + [mean_out]
+    if add or alpha != 1.0:
+        add = list(add or [])
+        flags |= _lib.SRH_EPI_AXPY
+        ep.alpha = float(alpha)
+        if len(add) > _lib.SRH_MAX_ADD:
+            raise SelfrecHipError(f"at most {_lib.SRH_MAX_ADD} addends")
+        ep.n_add = len(add)
+        for t, x in enumerate(add):
+            ep.d_add[t] = _p(x, torch.float32, "add")
+            ep.add_scale[t] = float(add_scale[t])
+        keep += list(add)
+    ep.flags = flags
+    ep._keepalive = keep
+    return ep
+
+
+def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilogue: SpmmEpilogue | None = None):
+    """out = csr @ x (+ fused epilogue).  x: (n_cols, d) fp32."""
+    if x.dim() != 2 or x.shape[0] != csr.shape[1]:
+        raise SelfrecHipError(f"spmm: x has shape {tuple(x.shape)}, expected ({csr.shape[1]}, d)")
+    d = int(x.shape[1])
+    if out is None:
+        out = torch.empty((csr.shape[0], d), dtype=torch.float32, device=x.device)
+    check(_lib.load().srh_spmm_f32(csr._plan, _p(csr.indptr, torch.int32), _p(csr.indices, torch.int32),
+                                   _p(csr.vals, torch.float32, "vals"), _p(x, torch.float32, "x"),
+                                   _p(out, torch.float32, "out"), d,
+                                   C.byref(epilogue) if epilogue is not None else None, _stream()), "srh_spmm_f32")
+    return out
+
+
+def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None):
+    dev = indices.device
+    if out is None:
+        out = torch.empty(indices.numel(), dtype=torch.float32, device=dev)
+    if deg_ws is None:
+        deg_ws = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    check(_lib.load().srh_adj_sym_normalize(n_rows, _p(indptr, torch.int32), _p(indices, torch.int32),
+                                            _p(edge_id, torch.int32), _p(weight, torch.float32),
+                                            _p(keep, torch.uint8), _p(deg_ws, torch.float32),
+                                            _p(out, torch.float32), _stream()), "srh_adj_sym_normalize")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# (a-5..a-8) losses
+# ----------------------------------------------------------------------------------------
+def bpr_ws(batch: int, device):
+    return torch.empty(int(_lib.load().srh_bpr_ws_bytes(batch)), dtype=torch.uint8, device=device)
+
+
+def bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
+                   reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, ws):
+    d = int(user.shape[1])
+    check(_lib.load().srh_bpr_l2_fwd_bwd(
+        _p(user, torch.float32), _p(item, torch.float32), _p(reg_user, torch.float32), _p(reg_item, torch.float32),
+        _p(u_idx, torch.int32), _p(i_idx, torch.int32), _p(j_idx, torch.int32), int(batch),
+        _p(n_rows_dev, torch.int32), d, float(reg_coef), int(bool(reg_include_neg)), float(loss_scale),
+        _p(g_user, torch.float32), _p(g_item, torch.float32), _p(greg_user, torch.float32),
+        _p(greg_item, torch.float32), _p(losses, torch.float64), _p(ws), _stream()), "srh_bpr_l2_fwd_bwd")
+
+
+def bpr_fwd(u, p, n, loss_sum, coef):
+    check(_lib.load().srh_bpr_fwd(_p(u, torch.float32), _p(p, torch.float32), _p(n, torch.float32), u.shape[0],
+                                  int(u.shape[1]), _p(loss_sum, torch.float64), _p(coef, torch.float32), _stream()),
+          "srh_bpr_fwd")
+
+
+def bpr_bwd(u, p, n, coef, scale, gu, gp, gn):
+    check(_lib.load().srh_bpr_bwd(_p(u, torch.float32), _p(p, torch.float32), _p(n, torch.float32),
+                                  _p(coef, torch.float32), u.shape[0], int(u.shape[1]), float(scale),
+                                  _p(gu, torch.float32), _p(gp, torch.float32), _p(gn, torch.float32), _stream()),
+          "srh_bpr_bwd")
+
+
+def sumsq(x, out):
+    check(_lib.load().srh_sumsq(_p(x, torch.float32), x.numel(), _p(out, torch.float64), _stream()), "srh_sumsq")
+
+
+def infonce_ws(n: int, d: int, device):
+    return torch.empty(int(_lib.load().srh_infonce_ws_bytes(n, d)), dtype=torch.uint8, device=device)
+
+
+def infonce_fwd_bwd(v1, v2, idx, n, *, n_dev=None, tau, loss_scale, loss, g1, g2, ws):
+    d = int(v1.shape[1])
+    need = int(_lib.load().srh_infonce_ws_bytes(n, d))
+    if ws.numel() * ws.element_size() < need:
+        raise SelfrecHipError(f"infonce workspace too small: {ws.numel() * ws.element_size()} < {need}")
+    check(_lib.load().srh_infonce_fwd_bwd(_p(v1, torch.float32), _p(v2, torch.float32), _p(idx, torch.int32), int(n),
+                                          _p(n_dev, torch.int32), d, float(tau), float(loss_scale),
+                                          _p(loss, torch.float64), _p(g1, torch.float32), _p(g2, torch.float32),
+                                          _p(ws), _stream()), "srh_infonce_fwd_bwd")
+
+
+# ----------------------------------------------------------------------------------------
+# (a-9) optimiser, (a-10/11) evaluation, utilities
+# ----------------------------------------------------------------------------------------
+def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(_lib.load().srh_adam_step(_p(param, torch.float32), _p(grad, torch.float32), _p(m, torch.float32),
+                                    _p(v, torch.float32), param.numel(), int(step), _p(step_dev, torch.int64),
+                                    float(lr), float(beta1), float(beta2), float(eps), _stream()), "srh_adam_step")
+
+
+def score_mask_topk(user_emb, user_ids, item_emb, r_indptr, r_indices, k, scores_ws=None):
+    nq = int(user_ids.numel()) if user_ids is not None else int(user_emb.shape[0])
+    n_items, d = int(item_emb.shape[0]), int(item_emb.shape[1])
+    dev = item_emb.device
+    if scores_ws is None:
+        scores_ws = torch.empty((nq, n_items), dtype=torch.float32, device=dev)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    check(_lib.load().srh_score_mask_topk(_p(user_emb, torch.float32), _p(user_ids, torch.int32), nq,
+                                          _p(item_emb, torch.float32), n_items, d, _p(r_indptr, torch.int32),
+                                          _p(r_indices, torch.int32), int(k), _p(scores_ws, torch.float32),
+                                          _p(ids, torch.int32), _p(sc, torch.float32), _stream()),
+          "srh_score_mask_topk")
+    return ids, sc
+
+
+def gemm_nt(a, b, out=None):
+    m, d = int(a.shape[0]), int(a.shape[1])
+    n = int(b.shape[0])
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    check(_lib.load().srh_gemm_nt_f32(_p(a, torch.float32), _p(b, torch.float32), _p(out, torch.float32), m, n, d,
+                                      _stream()), "srh_gemm_nt_f32")
+    return out
+
+
+def topk_rows(scores, k):
+    rows, n = int(scores.shape[0]), int(scores.shape[1])
+    ids = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
+    sc = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    check(_lib.load().srh_topk_rows(_p(scores, torch.float32), rows, n, int(k), _p(ids, torch.int32),
+                                    _p(sc, torch.float32), _stream()), "srh_topk_rows")
+    return ids, sc
+
+
+def axpby(a, x, b, y):
+    check(_lib.load().srh_axpby(float(a), _p(x, torch.float32), float(b), _p(y, torch.float32), x.numel(), _stream()),
+          "srh_axpby")
+    return y
+
+
+def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta):
+    """ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
+    check(_lib.load().srh_batch_fetch(
+        _p(ep["u"], torch.int32), _p(ep["i"], torch.int32), _p(ep["j"], torch.int32),
+        _p(ep.get("uniq_u"), torch.int32), _p(ep.get("uniq_i"), torch.int32),
+        _p(ep.get("n_uniq_u"), torch.int32), _p(ep.get("n_uniq_i"), torch.int32), int(n_edges), int(batch_size),
+        _p(cursor, torch.int64), _p(stage["u"], torch.int32), _p(stage["i"], torch.int32),
+        _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
+        _p(meta, torch.int32), _stream()), "srh_batch_fetch")

@@ -1,0 +1,37 @@
+"""``find_k_largest`` with the result contract of reference util/algorithm.py:144-156
+(ids and scores of the K largest entries, best first).
+
+The reference keeps a size-K min-heap of ``(score, id)`` and replaces the root only on a
+strictly larger score; for distinct scores that is simply "top-K by score".  This host
+version (used only by models with a custom ``predict``; the LightGCN family goes through the
+fused device kernel) selects with numpy and falls back to the literal heap walk when scores
+tie around the K-th place, so its output equals the reference's in every case.
+"""
+import heapq
+
+import numpy as np
+
+
+def _heap_walk(K, candidates):
+    heap = [(float(s), i) for i, s in enumerate(candidates[:K])]
+    heapq.heapify(heap)
+    for off, s in enumerate(candidates[K:]):
+        if s > heap[0][0]:
+            heapq.heapreplace(heap, (float(s), off + K))
+    heap.sort(key=lambda pair: pair[0], reverse=True)
+    return [pair[1] for pair in heap], [pair[0] for pair in heap]
+
+
+def find_k_largest(K, candidates):
+    cand = np.asarray(candidates)
+    n = cand.shape[0]
+    if K >= n:
+        return _heap_walk(K, cand)
+    part = np.argpartition(-cand, K)[:K + 1]
+    vals = cand[part]
+    order = np.argsort(-vals, kind='stable')
+    top = vals[order]
+    if np.any(top[1:] == top[:-1]):          # a tie among the K+1 best: order is heap-specific
+        return _heap_walk(K, cand)
+    sel = part[order[:K]]
+    return sel.tolist(), cand[sel].astype(float).tolist()

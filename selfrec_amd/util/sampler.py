@@ -1,0 +1,44 @@
+"""``next_batch_pairwise`` with the generator protocol of reference util/sampler.py:5-28,
+backed by the C++ MT19937 replay (csrc/sampler.cpp).
+
+Bit-exact contract: for the same ``random.getstate()`` on entry, this yields the same
+``(u_idx, i_idx, j_idx)`` lists as the reference, leaves the global ``random`` state where
+the reference would leave it (after every batch, so interleaved ``random`` calls by the
+caller see the same stream), and shuffles ``data.training_data`` in place into the same
+order.
+"""
+import random
+
+from .. import ops
+
+
+def _sampler_for(data):
+    """One C++ sampler per data object, rebuilt if the training list was replaced."""
+    cached = getattr(data, '_srh_sampler', None)
+    if cached is not None and cached[1] is data.training_data and cached[2] == len(data.training_data):
+        return cached[0]
+    edge_u, edge_i = data._edge_ids_in_list_order() if hasattr(data, '_edge_ids_in_list_order') else (
+        [data.user[r[0]] for r in data.training_data], [data.item[r[1]] for r in data.training_data])
+    smp = ops.Sampler(edge_u, edge_i, len(data.user), len(data.item))
+    data._srh_sampler = (smp, data.training_data, len(data.training_data))
+    return smp
+
+
+def next_batch_pairwise(data, batch_size, n_negs=1):
+    smp = _sampler_for(data)
+    smp.set_state_from_python()
+    before = smp.order()
+    smp.shuffle()
+    after = smp.order()
+    # replay the in-place shuffle on the caller-visible list (sampler.py:7)
+    rank = {int(e): p for p, e in enumerate(before)}
+    td = data.training_data
+    td[:] = [td[rank[int(e)]] for e in after]
+    smp.push_state_to_python()
+    ptr, size = 0, smp.n_edges
+    while ptr < size:
+        smp.set_state_from_python()
+        u, i, j = smp.next_batch(ptr, batch_size, n_negs)
+        smp.push_state_to_python()
+        ptr += len(u)
+        yield u.tolist(), i.tolist(), j.tolist()

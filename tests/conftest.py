@@ -30,3 +30,25 @@ def golden_meta():
     import json
     with open(os.path.join(GOLDEN, "meta.json")) as f:
         return json.load(f)
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container (run on the GPU box with -m gpu)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def tiny_data(golden_ops):
+    """Interaction object over the golden 200 x 300 graph (names = raw ids as strings)."""
+    from selfrec_amd import synth
+    from selfrec_amd.data.ui_graph import Interaction
+    g = golden_ops
+    gm = __import__("numpy").load(os.path.join(GOLDEN, "models.npz"))
+    train = synth.as_triples(g["graph_train_u_raw"], g["graph_train_i_raw"])
+    test = synth.as_triples(gm["test_u_ids_raw"], gm["test_i_ids_raw"])
+    return Interaction({}, train, test)

@@ -1,0 +1,120 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/selfrec_hip.h
+declares, and its host entry points (the sampler) reproduce the reference's streams."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from selfrec_amd import _lib, ops
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "selfrec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libselfrec_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"ctypes binding lacks {n}"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.srh_abi_version() == _lib.ABI_VERSION
+
+
+def test_error_reporting_does_not_throw():
+    lib = _lib.load()
+    rc = lib.srh_sampler_shuffle(None)
+    assert rc == -1 and b"null handle" in lib.srh_last_error_string()
+    with pytest.raises(_lib.SelfrecHipError):
+        _lib.check(rc, "srh_sampler_shuffle")
+
+
+def test_device_ops_refuse_cpu_tensors():
+    import torch
+    with pytest.raises(ops.SelfrecHipError):
+        ops.axpby(1.0, torch.zeros(8), 0.0, torch.zeros(8))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_sampler_matches_reference_stream(golden_ops, tag):
+    g = golden_ops
+    bs, negs, seed = (int(x) for x in g[f"sampler_{tag}_meta"])
+    s = ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300)
+    s.seed(seed)
+    us, is_, js, uq = [], [], [], []
+    for _ in range(2):
+        r = s.epoch(bs, negs, with_unique=True)
+        us.append(r["u"]); is_.append(r["i"]); js.append(r["j"]); uq.append(r)
+    assert np.array_equal(np.concatenate(us), g[f"sampler_{tag}_u"])
+    assert np.array_equal(np.concatenate(is_), g[f"sampler_{tag}_i"])
+    assert np.array_equal(np.concatenate(js), g[f"sampler_{tag}_j"])
+    assert s.next_u32() == int(g[f"sampler_{tag}_next_u32"][0])
+    order = s.order()
+    assert np.array_equal(g["graph_train_u_ids"][order], g[f"sampler_{tag}_final_order_u"])
+    # unique ids == torch.unique of each batch
+    r = uq[-1]
+    for b in range(r["n_batches"]):
+        lo, hi = b * bs, min((b + 1) * bs, s.n_edges)
+        assert np.array_equal(r["uniq_u"][b * bs:b * bs + r["n_uniq_u"][b]], np.unique(r["u"][lo:hi]))
+        assert np.array_equal(r["uniq_i"][b * bs:b * bs + r["n_uniq_i"][b]], np.unique(r["i"][lo:hi]))
+
+
+def test_sampler_per_batch_and_python_state_roundtrip(golden_ops):
+    g = golden_ops
+    bs, negs, seed = (int(x) for x in g["sampler_b_meta"])
+    random.seed(seed)
+    s = ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300)
+    s.set_state_from_python()
+    s.shuffle()
+    us, js, ptr = [], [], 0
+    while ptr < s.n_edges:
+        u, _, j = s.next_batch(ptr, bs, negs)
+        ptr += len(u); us.append(u); js.append(j)
+    n = s.n_edges
+    assert np.array_equal(np.concatenate(us), g["sampler_b_u"][:n])
+    assert np.array_equal(np.concatenate(js), g["sampler_b_j"][:n * negs])
+    s.push_state_to_python()
+    # the python generator continues exactly where the reference's would
+    s2 = ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300)
+    random.seed(seed)
+    s2.set_state_from_python(); s2.epoch(bs, negs)
+    assert random.getstate() != s2.python_state()  # reference state unchanged until pushed
+    s2.push_state_to_python()
+    assert random.getstate()[1] == s.python_state()[1]
+
+
+def test_sampler_edge_cases():
+    s = ops.Sampler([0, 0, 1], [0, 1, 2], 2, 4)
+    with pytest.raises(ops.SelfrecHipError):       # unseeded generator must not silently run
+        s.shuffle()
+    s.seed(0)
+    r = s.epoch(2, 2)
+    assert r["n_batches"] == 2 and len(r["j"]) == 6
+    assert all(j not in ({0, 1} if u == 0 else {2}) for u, j in zip(np.repeat(r["u"], 2), r["j"]))
+    with pytest.raises(ops.SelfrecHipError):
+        ops.Sampler([0, 5], [0, 1], 2, 4)          # user id out of range
+    # random.sample replay: pool path (k large) and set path (k small)
+    for n, k, seed in ((1000, 900, 3), (100000, 50, 5), (7, 7, 1), (10, 0, 2)):
+        random.seed(seed)
+        ref = random.sample(range(n), k)
+        s.seed(seed)
+        assert s.sample_range(n, k).tolist() == ref
+    with pytest.raises(ops.SelfrecHipError):
+        s.sample_range(5, 6)
+
+
+def test_seed_matches_cpython_for_wide_seeds():
+    s = ops.Sampler([0], [0], 1, 2)
+    for seed in (0, 1, 2**31, 2**32 + 17, 2**63 - 1):
+        random.seed(seed)
+        want = [random.getrandbits(32) for _ in range(3)]
+        s.seed(seed)
+        assert [s.next_u32() for _ in range(3)] == want
