@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: XSimGCL training throughput (user-item pairs/s) on a synthetic
+Yelp2018-shaped graph (BASELINE.json config 3: 31,668 x 38,048, ~1.26 M train edges, d=64,
+B=2048, L=3, l*=1, eps=0.2, lambda=0.2, tau=0.2), plus full-rank eval users/s.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU via torchrun)
+
+A "step" is one pass of the whole hot path over one batch: host sampling of that batch (C++
+MT19937 replay, on a worker thread, one epoch ahead), index staging, L propagation SpMMs with
+fused perturbation/mean, BPR + L2 + 2 x InfoNCE forward/backward, L backward SpMMs, dense Adam.
+Inputs (graph, tables, sampled epoch) are resident in HBM when the timed region starts; the
+region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is reported.
+
+One JSON line on rank 0 with the contract fields plus
+  "roofline":     dominant kernel (CSR SpMM, HBM-bound): algorithmic bytes per launch / mean
+                  launch duration measured with HIP events on the launch stream
+  "cpu_baseline": the CPU oracle ("port" of the reference's torch-CPU step) timed on this box's
+                  host cores on a bounded sample of the same workload (rank 0, N=1 only)
+  "eval":         full-rank top-20 throughput over the test users (kernels only / end to end)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1300)     # > 2 epochs of 616 batches
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--model", default="XSimGCL")
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--emb", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--tau", type=float, default=0.2)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--seed", type=int, default=2024)
+    return ap.parse_args()
+
+
+def build_data(shape, seed):
+    from selfrec_amd import synth
+    from selfrec_amd.data.ui_graph import Interaction
+    tu, ti, su, si, U, I = synth.make_dataset(shape, seed=seed)
+    data = Interaction({}, synth.as_triples(tu, ti), synth.as_triples(su, si))
+    return data, (tu, ti, su, si, U, I)
+
+
+def spmm_alg_bytes(nnz, n_rows, n_cols, d):
+    """compulsory traffic of one CSR SpMM with perfect reuse of x."""
+    return nnz * 8 + (n_rows + 1) * 4 + n_cols * d * 4 + n_rows * d * 4
+
+
+def step_alg_bytes(model, nnz, N, d, L, B):
+    passes = {"MF": 0, "LightGCN": 1, "XSimGCL": 1, "SimGCL": 3, "SGL": 3}[model]
+    bwd = {"MF": 0, "LightGCN": 1, "XSimGCL": 1, "SimGCL": 1, "SGL": 3}[model]
+    spmm = (passes + bwd) * L * spmm_alg_bytes(nnz, N, N, d)
+    return spmm + 7 * N * d * 4 + N * d * 4 + 2 * 3 * B * d * 4 + 4 * 2 * B * d * 4
+
+
+def time_spmm_kernel(trainer, iters=50):
+    """Mean duration of one propagation SpMM launch (perturb epilogue, as in the step), HIP events
+    on the launch stream."""
+    from selfrec_amd import ops
+    adj = trainer.graph.adj
+    x, y = trainer.E0, trainer.Ha
+    ep = ops.make_epilogue(perturb_eps=trainer.eps, philox_seed=1, philox_offset=0)
+    for _ in range(5):
+        ops.spmm(adj, x, out=y, epilogue=ep)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        ops.spmm(adj, x, out=y, epilogue=ep)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def cpu_baseline(args, raw, seconds):
+    """The CPU oracle's XSimGCL step (torch-CPU fp32, python sampler) on this host's cores."""
+    import random
+    from oracle import selfrec_oracle as O
+    tu, ti, su, si, U, I = raw
+    torch.manual_seed(args.seed)
+    kw = dict(n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau, layer_cl=1,
+              batch_size=args.batch)
+    tr = O.OracleTrainer(args.model, tu, ti, U, I, args.emb, **kw)
+    smp = O.PairwiseSampler(tu, ti, U, I)
+    random.seed(args.seed)
+    t0 = time.time()
+    it = smp.epoch(args.batch)
+    first = next(it)                                  # includes the once-per-epoch python shuffle
+    t_first = time.time() - t0
+    tr.step(*first)                                   # warm-up
+    n, t_steps, t_sample = 0, 0.0, 0.0
+    t_begin = time.time()
+    while time.time() - t_begin < seconds or n < 3:
+        t1 = time.time(); batch = next(it); t2 = time.time()
+        tr.step(*batch)
+        t3 = time.time()
+        t_sample += t2 - t1; t_steps += t3 - t2; n += 1
+    per_batch_sample = t_sample / n
+    shuffle_amortised = max(t_first - per_batch_sample, 0.0) / max(1, (len(tu) + args.batch - 1) // args.batch)
+    step_s = t_steps / n + per_batch_sample + shuffle_amortised
+    return {"value": round(args.batch / step_s, 1), "unit": "pairs/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{n} XSimGCL steps (B={args.batch}, L={args.layers}) of the oracle on the same graph, "
+                      f"{t_steps / n * 1e3:.0f} ms compute + {per_batch_sample * 1e3:.1f} ms python sampling per step, "
+                      f"shuffle {t_first:.2f} s amortised over the epoch"}
+
+
+def eval_throughput(trainer, data, k=20):
+    from selfrec_amd.base.graph_recommender import GraphRecommender
+    users = list(data.test_set)
+    if not users:
+        return None
+    rec = GraphRecommender.__new__(GraphRecommender)
+    rec.data, rec.max_N = data, k
+    rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())
+    uid = [data.user[u] for u in users]
+    rec.rank_on_device(uid[:256])                                         # warm-up
+    torch.cuda.synchronize(); t0 = time.time()
+    ids, sc = rec.rank_on_device(uid)
+    torch.cuda.synchronize(); t_kernel = time.time() - t0
+    t0 = time.time()
+    out = rec.test()
+    t_e2e = time.time() - t0
+    flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
+    return {"users": len(uid), "k": k, "device_users_per_s": round(len(uid) / t_kernel, 1),
+            "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
+            "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    from selfrec_amd import _lib
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+
+    data, raw = build_data(args.shape, args.seed)
+    torch.manual_seed(args.seed)
+    kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
+              layer_cl=1, batch_size=args.batch, use_graph=not args.no_graph)
+    if world > 1:
+        from selfrec_amd.dist import ShardedTrainer
+        trainer = ShardedTrainer(data, args.emb, **kw)
+    else:
+        from selfrec_amd.engine import FusedTrainer
+        trainer = FusedTrainer(data, args.emb, **kw)
+    from selfrec_amd.engine import EpochPrefetcher
+    trainer.sampler.seed(args.seed)
+    pre = EpochPrefetcher(trainer)
+    pre.start()
+
+    state = {"left": 0}
+
+    def run(n_steps):
+        done = 0
+        while done < n_steps:
+            if state["left"] == 0:
+                trainer.upload_epoch(pre.take())
+                pre.start()                       # host samples the next epoch while this one runs
+                state["left"] = trainer.epoch_batches
+            take = min(state["left"], n_steps - done)
+            for _ in range(take):
+                trainer.step()
+            state["left"] -= take
+            done += take
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = trainer.read_losses()
+
+    # The graph is row-sharded: the global batch is fixed at B pairs per step for every N (strong scaling).
+    pairs = args.steps * args.batch
+    value = pairs / elapsed
+    g = trainer.graph
+    out = {
+        "metric": "train pairs/sec (XSimGCL, Yelp2018-shape)", "value": round(value, 1), "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
+                               f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
+                               f"d={args.emb}, B={args.batch}, Adam lr=1e-3; sampling on a host thread inside the timed region",
+                   "global_batch": args.batch, "parallelism": "single" if world == 1 else f"row-sharded x{world}",
+                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+        "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
+    }
+    if rank == 0:
+        t_spmm = time_spmm_kernel(trainer) if world == 1 else None
+        if t_spmm:
+            alg = spmm_alg_bytes(g.adj.nnz, g.n_nodes, g.n_nodes, args.emb)
+            ach = alg / t_spmm / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "spmm_seg_kernel<16> (propagation SpMM + perturb epilogue)",
+                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "alg_bytes_per_launch": alg, "launch_us": round(t_spmm * 1e6, 2),
+                               "step_alg_bytes": step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch),
+                               "step_GBps": round(step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch)
+                                                  / (elapsed / args.steps) / 1e9, 1)}
+        if not args.no_eval and world == 1:
+            out["eval"] = eval_throughput(trainer, data)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+#!/bin/bash
+# One gpurun call = tests + smoke + bench + profiles; everything lands in gpurun_out/.
+# usage: tools/gpu_session.sh [tests] [smoke] [bench] [prof] [pmc]
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+OUT=gpurun_out; mkdir -p $OUT
+STAGES="${*:-smoke tests bench prof}"
+echo "== stages: $STAGES"; rocm-smi --showproductname 2>/dev/null | grep -m2 -i "card\|gfx" ; nproc
+for s in $STAGES; do
+case $s in
+smoke)
+  timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -5 $OUT/smoke.log;;
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests exit $?"
+  grep -E "^(FAILED|ERROR)|passed|failed" $OUT/tests.log | tail -40;;
+bench)
+  timeout 900 python bench.py --steps ${BENCH_STEPS:-1300} --warmup 50 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"
+  tail -3 $OUT/bench.err; tail -2 $OUT/bench.log;;
+benchquick)
+  timeout 600 python bench.py --steps 300 --warmup 30 --no-cpu-baseline > $OUT/benchquick.log 2> $OUT/benchquick.err; echo "benchquick exit $?"
+  tail -3 $OUT/benchquick.err; tail -2 $OUT/benchquick.log;;
+eager)
+  timeout 600 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OUT/bench_eager.log 2> $OUT/bench_eager.err; echo "eager exit $?"
+  tail -3 $OUT/bench_eager.err; tail -2 $OUT/bench_eager.log;;
+prof)
+  rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); echo "stats: $f"; [ -n "$f" ] && head -30 "$f"
+  find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; tail -2 $OUT/prof.log;;
+pmc)
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmc_$tag
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmc_$tag -o pmc -- python $OLDPWD/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/pmc_$tag.log 2>&1); echo "pmc $c exit $?"
+    f=$(find $OUT/pmc_$tag -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/pmc_$tag.summary.txt 2>&1 && cat $OUT/pmc_$tag.summary.txt | head -20
+    find $OUT/pmc_$tag -name "*.csv" -size +10M -delete
+  done;;
+esac
+done
+echo "== done"
