@@ -42,9 +42,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(scope="session")
-def tiny_data(golden_ops):
-    """Interaction object over the golden 200 x 300 graph (names = raw ids as strings)."""
+def _tiny_interaction(golden_ops):
     from selfrec_amd import synth
     from selfrec_amd.data.ui_graph import Interaction
     g = golden_ops
@@ -52,3 +50,15 @@ def tiny_data(golden_ops):
     train = synth.as_triples(g["graph_train_u_raw"], g["graph_train_i_raw"])
     test = synth.as_triples(gm["test_u_ids_raw"], gm["test_i_ids_raw"])
     return Interaction({}, train, test)
+
+
+@pytest.fixture(scope="session")
+def tiny_data(golden_ops):
+    """Interaction object over the golden 200 x 300 graph (names = raw ids as strings).
+    Shared: tests must not mutate it (use fresh_tiny_data with the drop-in sampler)."""
+    return _tiny_interaction(golden_ops)
+
+
+@pytest.fixture()
+def fresh_tiny_data(golden_ops):
+    return _tiny_interaction(golden_ops)

@@ -41,9 +41,9 @@ class ClientEncoder(torch.nn.Module):
         return mean[:self.data.user_num], mean[self.data.user_num:]
 
 
-def test_client_training_loop_matches_oracle(golden_models, golden_meta, tiny_data):
+def test_client_training_loop_matches_oracle(golden_models, golden_meta, fresh_tiny_data):
     gm, m = golden_models, golden_meta["LightGCN"]
-    data = tiny_data
+    data = fresh_tiny_data
     enc = ClientEncoder(data, m["emb"], 3, gm["LightGCN_init_user"], gm["LightGCN_init_item"]).cuda()
     assert isinstance(enc.sparse_norm_adj, SparseAdjHandle)
     opt = torch.optim.Adam(enc.parameters(), lr=m["lr"])
@@ -62,8 +62,6 @@ def test_client_training_loop_matches_oracle(golden_models, golden_meta, tiny_da
     with torch.no_grad():
         fu, fi = enc()
     assert rel_err(fu.cpu().numpy(), gm["LightGCN_final_user"]) < 1e-4
-    # restore list order for other tests sharing the fixture
-    data._srh_sampler = None
 
 
 def test_handle_rectangular_backward_uses_transpose():
