@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 4
+#define SRH_ABI_VERSION 5
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -103,10 +103,15 @@ srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out);
  * Output: d_vals[p] = keep ? (dinv[row] * w) * dinv[col] : 0 with
  * dinv[r] = (sum of kept weights in row r)^-1/2, 0 for an empty row -- the reference's
  * inf -> 0 rule (graph.py:15).  d_deg_ws: workspace of n_rows floats.
+ * d_inv_sqrt_table (optional, table_len entries): table[k] = float32(k)^-1/2 as the HOST's
+ * numpy computes it; integral degrees below table_len are looked up there, which makes the
+ * values bit-identical to the reference's np.power(rowsum, -0.5) (numpy's fp32 pow is not
+ * correctly rounded, so no device formula can match it in every last bit).
  * ---------------------------------------------------------------------------------- */
 srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
                                    const int32_t* d_indices, const int32_t* d_edge_id,
                                    const float* d_weight, const uint8_t* d_keep,
+                                   const float* d_inv_sqrt_table, int32_t table_len,
                                    float* d_deg_ws, float* d_vals, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -16,7 +16,9 @@ using namespace srh;
 __global__ __launch_bounds__(256) void degree_kernel(int n_rows, const int32_t* __restrict__ indptr,
                                                      const int32_t* __restrict__ edge_id,
                                                      const float* __restrict__ weight,
-                                                     const uint8_t* __restrict__ keep, float* __restrict__ dinv) {
+                                                     const uint8_t* __restrict__ keep,
+                                                     const float* __restrict__ table, int table_len,
+                                                     float* __restrict__ dinv) {
   const int row = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -30,7 +32,10 @@ __global__ __launch_bounds__(256) void degree_kernel(int n_rows, const int32_t* 
   acc = wave_sum_f(acc);  // weights are small integers: exact in fp32 in any order
   if (lane == 0) {
     // numpy: np.power(rowsum, -0.5) in fp32, inf -> 0 (graph.py:14-15)
-    dinv[row] = (acc > 0.f) ? (float)(1.0 / sqrt((double)acc)) : 0.f;
+    float r = (acc > 0.f) ? (float)(1.0 / sqrt((double)acc)) : 0.f;
+    const int k = (int)acc;
+    if (table && acc >= 0.f && acc < (float)table_len && (float)k == acc) r = table[k];   // host numpy's value
+    dinv[row] = r;
   }
 }
 
@@ -57,13 +62,15 @@ __global__ __launch_bounds__(256) void normalize_kernel(int n_rows, const int32_
 extern "C" srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
                                               const int32_t* d_indices, const int32_t* d_edge_id,
                                               const float* d_weight, const uint8_t* d_keep,
+                                              const float* d_inv_sqrt_table, int32_t table_len,
                                               float* d_deg_ws, float* d_vals, void* stream) {
   SRH_REQUIRE(d_indptr && d_indices && d_deg_ws && d_vals, "adj_sym_normalize: null argument");
   SRH_REQUIRE(n_rows > 0 && n_rows < (int64_t(1) << 31), "adj_sym_normalize: bad n_rows");
   SRH_REQUIRE(!d_keep || d_edge_id, "adj_sym_normalize: a keep mask needs edge ids");
   hipStream_t st = srh::as_stream(stream);
   const int blocks = (int)((n_rows + 3) / 4);
-  degree_kernel<<<blocks, 256, 0, st>>>((int)n_rows, d_indptr, d_edge_id, d_weight, d_keep, d_deg_ws);
+  degree_kernel<<<blocks, 256, 0, st>>>((int)n_rows, d_indptr, d_edge_id, d_weight, d_keep,
+                                        d_inv_sqrt_table, d_inv_sqrt_table ? table_len : 0, d_deg_ws);
   SRH_LAUNCH_CHECK();
   normalize_kernel<<<blocks, 256, 0, st>>>((int)n_rows, d_indptr, d_indices, d_edge_id, d_weight, d_keep, d_deg_ws, d_vals);
   SRH_LAUNCH_CHECK();

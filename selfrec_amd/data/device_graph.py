@@ -46,10 +46,17 @@ class DeviceGraph:
             self.weight = torch.from_numpy(np.concatenate([w, w[rt.data - 1]])).to(dev)
         self.h_r_indptr, self.h_r_indices = r.indptr.astype(np.int32), r.indices.astype(np.int32)
         self._deg_ws = torch.empty(self.n_nodes, dtype=torch.float32, device=dev)
+        # k^-1/2 exactly as the host's numpy evaluates np.power(float32(k), -0.5) (graph.py:14)
+        max_deg = int(max(np.diff(r.indptr).max(initial=0), np.diff(rt.indptr).max(initial=0)))
+        with np.errstate(divide='ignore'):
+            table = np.power(np.arange(max_deg + 1, dtype=np.float32), -0.5)
+        table[0] = 0.0
+        self._inv_sqrt = torch.from_numpy(table.astype(np.float32)).to(dev)
         self.adj = ops.DeviceCSR(indptr, indices, torch.zeros(indices.size, dtype=torch.float32, device=dev),
                                  (self.n_nodes, self.n_nodes), device=dev)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, None, self.n_nodes,
-                              weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws)
+                              weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws,
+                              inv_sqrt_table=self._inv_sqrt)
 
     def dropped_view(self, keep_mask: torch.Tensor, out: torch.Tensor | None = None) -> "ops.DeviceCSR":
         """Normalised adjacency of the graph restricted to interactions with keep_mask != 0
@@ -58,5 +65,5 @@ class DeviceGraph:
         if out is None:
             out = torch.empty_like(self.adj.vals)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep_mask, self.n_nodes,
-                              weight=self.weight, out=out, deg_ws=self._deg_ws)
+                              weight=self.weight, out=out, deg_ws=self._deg_ws, inv_sqrt_table=self._inv_sqrt)
         return self.adj.with_values(out)

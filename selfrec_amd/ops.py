@@ -250,7 +250,8 @@ def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilo
     return out
 
 
-def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None):
+def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None,
+                      inv_sqrt_table=None):
     dev = indices.device
     if out is None:
         out = torch.empty(indices.numel(), dtype=torch.float32, device=dev)
@@ -258,7 +259,9 @@ def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, 
         deg_ws = torch.empty(n_rows, dtype=torch.float32, device=dev)
     check(_lib.load().srh_adj_sym_normalize(n_rows, _p(indptr, torch.int32), _p(indices, torch.int32),
                                             _p(edge_id, torch.int32), _p(weight, torch.float32),
-                                            _p(keep, torch.uint8), _p(deg_ws, torch.float32),
+                                            _p(keep, torch.uint8), _p(inv_sqrt_table, torch.float32),
+                                            0 if inv_sqrt_table is None else int(inv_sqrt_table.numel()),
+                                            _p(deg_ws, torch.float32),
                                             _p(out, torch.float32), _stream()), "srh_adj_sym_normalize")
     return out
 

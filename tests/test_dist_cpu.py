@@ -1,0 +1,94 @@
+"""world_size-2 (and 3) gloo runs of the row-sharded trainer on CPU: same result as the
+single-process oracle on the same batches and injected noise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import selfrec_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, model, out_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from selfrec_amd import synth
+    from selfrec_amd.data.ui_graph import Interaction
+    from selfrec_amd.dist import ShardedTrainer
+    from tests.cpu_backend import CpuBackend
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    torch.manual_seed(0)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
+    gen = torch.Generator().manual_seed(7)
+    tr = ShardedTrainer(data, 64, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
+                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), backend=CpuBackend())
+    tr.sampler.seed(11)
+    tr.begin_epoch()
+    losses = []
+    for _ in range(3):
+        tr.step()
+        losses.append(tr.read_losses())
+    pu, pi = tr.parameters_full()
+    fu, fi = tr.embeddings()
+    if rank == 0:
+        host = tr._host
+        np.savez(out_path, pu=pu.numpy(), pi=pi.numpy(), fu=fu.numpy(), fi=fi.numpy(), losses=np.asarray(losses),
+                 u=host["u"], i=host["i"], j=host["j"], train_u=data.train_u, train_i=data.train_i,
+                 ue=ue.numpy(), ie=ie.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3)])
+def test_sharded_equals_single_process_oracle(tmp_path, model, world):
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), model, out), nprocs=world, join=True)
+    r = np.load(out)
+    gen = torch.Generator().manual_seed(7)
+    ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, 64, n_layers=3, batch_size=1000, layer_cl=2,
+                          tau=0.2, eps=0.2, cl_rate=0.2, user_emb=r["ue"], item_emb=r["ie"],
+                          noise_fn=lambda s: torch.rand(s, generator=gen))
+    want = []
+    for b in range(3):
+        lo, hi = b * 1000, (b + 1) * 1000
+        want.append(ref.step(r["u"][lo:hi].tolist(), r["i"][lo:hi].tolist(), r["j"][lo:hi].tolist()))
+    np.testing.assert_allclose(r["losses"], np.asarray(want), rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(r["pu"], ref.user_emb.detach().numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["pi"], ref.item_emb.detach().numpy(), rtol=1e-4, atol=2e-6)
+    fu, fi = ref.embeddings()
+    np.testing.assert_allclose(r["fu"], fu, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["fi"], fi, rtol=1e-4, atol=2e-6)
+
+
+def test_shard_adjacency_layout():
+    import scipy.sparse as sp
+    from selfrec_amd.dist import shard_adjacency
+    rng = np.random.default_rng(0)
+    a = sp.random(23, 23, density=0.2, random_state=1, dtype=np.float32).tocsr()
+    x = rng.standard_normal((23, 4)).astype(np.float32)
+    world = 4
+    n_pad = 6
+    gathered = np.zeros((world * n_pad, 4), dtype=np.float32)
+    for q in range(23):
+        gathered[(q % world) * n_pad + q // world] = x[q]
+    full = a @ x
+    for r in range(world):
+        indptr, indices, vals, npad = shard_adjacency(a, r, world)
+        assert npad == n_pad and len(indptr) == n_pad + 1
+        loc = sp.csr_matrix((vals, indices, indptr), shape=(n_pad, world * n_pad)) @ gathered
+        own = np.arange(r, 23, world)
+        np.testing.assert_allclose(loc[:len(own)], full[own], rtol=1e-6)
+        assert not loc[len(own):].any()

@@ -126,7 +126,9 @@ def test_full_size_properties_yelp_shape():
     axy = ops.spmm(g.adj, 2.0 * x - 0.5 * y)
     assert rel_err(axy.cpu().numpy(), (2.0 * ax - 0.5 * ay).cpu().numpy()) < 1e-5
     # A_hat (D^1/2 1) = D^1/2 1  for every non-isolated node
-    deg = torch.from_numpy(np.bincount(np.concatenate([tu, ti + U]), minlength=N).astype(np.float32)).cuda()
+    # (node ids are the first-appearance ids Interaction assigned, not the generator's raw ids)
+    deg = torch.from_numpy(np.bincount(np.concatenate([data.train_u, data.train_i.astype(np.int64) + U]),
+                                       minlength=N).astype(np.float32)).cuda()
     v = deg.sqrt().unsqueeze(1).repeat(1, d).contiguous()
     assert rel_err(ops.spmm(g.adj, v).cpu().numpy(), v.cpu().numpy()) < 1e-5
     # top-K: sorted, unmasked, consistent with the scores it came from

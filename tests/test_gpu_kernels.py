@@ -123,7 +123,7 @@ def test_device_normalisation_matches_reference(golden_ops, tiny_data):
     assert np.array_equal(g.adj.indptr.cpu().numpy(), golden_ops["norm_adj_indptr"])
     assert np.array_equal(g.adj.indices.cpu().numpy(), golden_ops["norm_adj_indices"])
     got = g.adj.vals.cpu().numpy()
-    np.testing.assert_allclose(got, golden_ops["norm_adj_data"], rtol=2e-7, atol=0)
+    assert np.array_equal(got, golden_ops["norm_adj_data"])          # bit-exact (host pow table)
     # edge-dropped, re-normalised view (SGL.py:89-96) from the reference keep-set
     keep = np.zeros(g.n_edges, dtype=np.uint8)
     keep[golden_ops["edge_dropout_keep"]] = 1
@@ -134,7 +134,7 @@ def test_device_normalisation_matches_reference(golden_ops, tiny_data):
     dense.sort_indices()
     assert np.array_equal(dense.indptr, golden_ops["edge_dropout_lap_indptr"])
     assert np.array_equal(dense.indices, golden_ops["edge_dropout_lap_indices"])
-    np.testing.assert_allclose(dense.data, golden_ops["edge_dropout_lap_data"], rtol=2e-7, atol=0)
+    assert np.array_equal(dense.data, golden_ops["edge_dropout_lap_data"])
 
 
 def test_normalisation_isolated_nodes_and_weights():
@@ -143,14 +143,14 @@ def test_normalisation_isolated_nodes_and_weights():
     from selfrec_amd.data.device_graph import DeviceGraph
     g = DeviceGraph(r)
     want = O.laplacian_of(r).tocsr(); want.sort_indices()
-    np.testing.assert_allclose(g.adj.vals.cpu().numpy(), want.data, rtol=2e-7)
+    np.testing.assert_allclose(g.adj.vals.cpu().numpy(), want.data, rtol=3e-7)
     keep = torch.tensor([1, 1, 1, 0], dtype=torch.uint8, device=DEV)
     v = g.dropped_view(keep).vals.cpu().numpy()
     r2 = r.copy(); r2.data[3] = 0; r2.eliminate_zeros()
     with np.errstate(divide="ignore"):
         want2 = O.laplacian_of(r2).toarray()
     got2 = sp.csr_matrix((v, g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()), shape=(6, 6)).toarray()
-    np.testing.assert_allclose(got2, want2, rtol=2e-7)
+    np.testing.assert_allclose(got2, want2, rtol=3e-7)
     assert np.isfinite(v).all()
 
 
@@ -163,7 +163,7 @@ def test_loss_functions_match_reference_outputs(golden_ops, n):
     g = golden_ops
     u, p, q = (torch.tensor(x, device=DEV, requires_grad=True) for x in g[f"ops_{n}_in"])
     bpr, reg, nce = L.bpr_loss(u, p, q), L.l2_reg_loss(1e-4, u, p, q), L.InfoNCE(u, p, 0.2)
-    np.testing.assert_allclose([bpr.item(), reg.item(), nce.item()], g[f"ops_{n}_loss"], rtol=2e-6)
+    np.testing.assert_allclose([bpr.item(), reg.item(), nce.item()], g[f"ops_{n}_loss"], rtol=2e-6, atol=5e-7)
     gb = torch.stack(torch.autograd.grad(bpr, (u, p, q))).cpu().numpy()
     gr = torch.stack(torch.autograd.grad(reg, (u, p, q))).cpu().numpy()
     gn = torch.stack(torch.autograd.grad(nce, (u, p))).cpu().numpy()
@@ -183,7 +183,8 @@ def test_infonce_gathered_matches_oracle(n, d, tau):
     loss = 0.3 * O.info_nce(a[idx.astype(np.int64)], b[idx.astype(np.int64)], tau)
     loss.backward()
     d1, d2 = torch.from_numpy(t1).to(DEV), torch.from_numpy(t2).to(DEV)
-    g1 = torch.full((rows, d), 0.5, device=DEV); g2 = torch.zeros((rows, d), device=DEV)
+    base = 1e-5                          # g1 is accumulated into, not overwritten
+    g1 = torch.full((rows, d), base, device=DEV); g2 = torch.zeros((rows, d), device=DEV)
     out = torch.zeros(1, dtype=torch.float64, device=DEV)
     nmax = n + 100                       # device-side count smaller than the launch bound
     ws = ops.infonce_ws(nmax, d, DEV)
@@ -191,7 +192,7 @@ def test_infonce_gathered_matches_oracle(n, d, tau):
     ops.infonce_fwd_bwd(d1, d2, didx, nmax, n_dev=torch.tensor([n], dtype=torch.int32, device=DEV), tau=tau,
                         loss_scale=0.3, loss=out, g1=g1, g2=g2, ws=ws)
     assert abs(out.item() - loss.item()) / abs(loss.item()) < 1e-5
-    assert rel_err((g1 - 0.5).cpu().numpy(), a.grad.numpy()) < 2e-5      # accumulates into g1
+    assert rel_err((g1.double() - base).cpu().numpy(), a.grad.numpy()) < 2e-5
     assert rel_err(g2.cpu().numpy(), b.grad.numpy()) < 2e-5
 
 
