@@ -16,9 +16,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def rel_err(got, want):
+def rel_err(got, want, floor=1e-7):
+    """max |got - want| relative to the largest reference magnitude (floored: an all-zero
+    reference, e.g. the InfoNCE gradient at n=1, is compared absolutely)."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), floor))
 
 
 def powerlaw_csr(n_rows, n_cols, nnz, seed, heavy_rows=0, heavy_len=0, empty_rows=0):

@@ -25,15 +25,15 @@ eager)
   tail -3 $OUT/bench_eager.err; tail -2 $OUT/bench_eager.log;;
 prof)
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
-  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); echo "stats: $f"; [ -n "$f" ] && head -30 "$f"
-  find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; tail -2 $OUT/prof.log;;
+  f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/prof_kernel_stats.txt && head -24 $OUT/prof_kernel_stats.txt
+  find $OUT/prof -name "*.db" -size +40M -delete;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmc_$tag
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmc_$tag -o pmc -- python $OLDPWD/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/pmc_$tag.log 2>&1); echo "pmc $c exit $?"
-    f=$(find $OUT/pmc_$tag -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/pmc_$tag.summary.txt 2>&1 && cat $OUT/pmc_$tag.summary.txt | head -20
-    find $OUT/pmc_$tag -name "*.csv" -size +10M -delete
+    f=$(find $OUT/pmc_$tag -name "*.db" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/pmc_$tag.summary.txt 2>&1 && head -12 $OUT/pmc_$tag.summary.txt
+    find $OUT/pmc_$tag -name "*.db" -size +40M -delete
   done;;
 esac
 done

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 counter_collection.csv: per kernel name, mean of each counter per dispatch."""
+"""Summarise PMC counters from a rocprofv3 rocpd sqlite database: per kernel, per counter,
+number of dispatches and the mean value per dispatch.
+usage: tools/pmc_summary.py results.db"""
 import collections
-import csv
+import re
+import sqlite3
 import sys
 
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        name = r.get("Kernel_Name", "?").split("(")[0][:70]
-        rows[name][r.get("Counter_Name", "?")].append(float(r.get("Counter_Value", 0) or 0))
-for name, ctrs in sorted(rows.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
-    parts = [f"{c}: n={len(v)} mean={sum(v) / len(v):.4g}" for c, v in sorted(ctrs.items())]
-    print(f"{name:70s} " + " | ".join(parts))
+for name, ctr, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+    short = re.sub(r'^void ', '', name.replace('(anonymous namespace)::', ''))
+    rows[re.sub(r'\(.*$', '', short)[:60]][ctr].append(float(val))
+for name, ctrs in sorted(rows.items(), key=lambda kv: -max(sum(v) for v in kv[1].values())):
+    parts = [f"{c}: n={len(v)} mean={sum(v) / len(v):.5g}" for c, v in sorted(ctrs.items())]
+    print(f"{name:60s} " + " | ".join(parts))
