@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 5
+#define SRH_ABI_VERSION 6
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -127,8 +127,11 @@ srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
  * ---------------------------------------------------------------------------------- */
 typedef struct srh_spmm_plan srh_spmm_plan_t;
 
+/* xcd_split_row: 0, or the first row of the second node class of a bipartite adjacency (= number
+ * of users): rows below it are issued to XCDs 0-3, the rest to XCDs 4-7 (L2 locality only). */
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
-                                  const int32_t* h_indptr, int32_t split_len /* 0 = default */);
+                                  const int32_t* h_indptr, int32_t split_len /* 0 = default */,
+                                  int64_t xcd_split_row);
 void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
 
 enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };
@@ -151,6 +154,13 @@ typedef struct srh_spmm_epilogue {
   float* d_mean_out;           /* MEAN: (n_rows, d) output                                   */
   const float* d_add[SRH_MAX_ADD];
   float add_scale[SRH_MAX_ADD];
+  /* Activity marks (any epilogue): a row / column is live iff mark[i] == (int32)*d_mark_stamp.
+   * d_row_mark: rows that are not live are skipped entirely (y, mean_out keep their old
+   * content).  d_col_mark: entries whose column is not live are treated as zero (the caller
+   * guarantees x is zero there).  NULL = everything live. */
+  const int32_t* d_row_mark;
+  const int32_t* d_col_mark;
+  const int64_t* d_mark_stamp;
 } srh_spmm_epilogue_t;
 
 /* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {32,64,128,256}.
@@ -262,7 +272,17 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              int64_t* d_cursor /* [0]=batch no, [1]=adam step */,
                              int32_t* d_stage_u, int32_t* d_stage_i, int32_t* d_stage_j,
                              int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
-                             int32_t* d_meta, void* stream);
+                             int32_t* d_meta,
+                             int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = new step */,
+                             int32_t mark_item_offset, void* stream);
+/* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
+ * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
+ * d_counts[k] is NULL).  The sparse counterpart of a memset for gradient buffers that only
+ * ever receive O(batch) non-zero rows.  Array arguments are HOST arrays of device pointers. */
+#define SRH_MAX_ZERO_LISTS 8
+srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_t* const* d_idx,
+                           const int32_t* const* d_counts, const int32_t* n_max,
+                           const int32_t* row_offset, int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -36,6 +36,7 @@ class SpmmEpilogue(C.Structure):
         ("d_mean_out", C.c_void_p),
         ("d_add", C.c_void_p * SRH_MAX_ADD),
         ("add_scale", C.c_float * SRH_MAX_ADD),
+        ("d_row_mark", C.c_void_p), ("d_col_mark", C.c_void_p), ("d_mark_stamp", C.c_void_p),
     ]
 
 
@@ -58,7 +59,7 @@ SIGNATURES = {
     "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
     "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "srh_adj_sym_normalize": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32]),
+    "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32, _i64]),
     "srh_spmm_plan_destroy": (None, [_vp]),
     "srh_spmm_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(SpmmEpilogue), _vp]),
     "srh_bpr_ws_bytes": (_i64, [_i64]),
@@ -74,7 +75,9 @@ SIGNATURES = {
     "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "srh_topk_rows": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
-    "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i32, _vp]),
+    "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
 }
 
 _lib = None

@@ -38,8 +38,9 @@ struct BprArgs {
   int reg_include_neg;
   float *g_user, *g_item, *greg_user, *greg_item;
   double* losses;
-  double* sums;    // ws: 3 doubles
+  double* part;    // ws: 4 doubles per phase-1 workgroup {loss, |Ru|^2, |Rp|^2, |Rn|^2}
   float* coef;     // ws: B floats
+  int n_blocks;
 };
 
 template <int LPR>
@@ -69,16 +70,19 @@ __global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) {
   double su = valid ? (double)f4_dot(ru, ru) : 0.0;
   double sp = valid ? (double)f4_dot(rp, rp) : 0.0;
   double sn = valid ? (double)f4_dot(rn, rn) : 0.0;
+  // same-address atomics serialise at ~11 ns each on this chip (2048 of them cost 22 us):
+  // reduce inside the workgroup and leave one partial record per workgroup instead
+  __shared__ double s_part[4][4];
   l_part = wave_sum_d(l_part);
   su = wave_sum_d(su);
   sp = wave_sum_d(sp);
   sn = wave_sum_d(sn);
-  if (lane == 0 && rows > 0) {
-    atomicAdd(&a.losses[0], (double)a.loss_scale * l_part / (double)rows);
-    atomicAdd(&a.sums[0], su);
-    atomicAdd(&a.sums[1], sp);
-    atomicAdd(&a.sums[2], sn);
-  }
+  const int wv = threadIdx.x >> 6;
+  if (lane == 0) { s_part[wv][0] = l_part; s_part[wv][1] = su; s_part[wv][2] = sp; s_part[wv][3] = sn; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    a.part[(size_t)blockIdx.x * 4 + threadIdx.x] =
+        s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
 }
 
 template <int LPR>
@@ -88,11 +92,23 @@ __global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) {
   if (rows <= 0) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
-  const float nu = (float)sqrt(a.sums[0]), np = (float)sqrt(a.sums[1]), nn = (float)sqrt(a.sums[2]);
+  __shared__ double s_tot[4];
+  if (threadIdx.x < 64) {                 // wave 0 folds the per-workgroup partials (fixed order)
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int k = threadIdx.x; k < a.n_blocks; k += 64) {
+      t0 += a.part[(size_t)k * 4 + 0]; t1 += a.part[(size_t)k * 4 + 1];
+      t2 += a.part[(size_t)k * 4 + 2]; t3 += a.part[(size_t)k * 4 + 3];
+    }
+    t0 = wave_sum_d(t0); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2); t3 = wave_sum_d(t3);
+    if (threadIdx.x == 0) { s_tot[0] = t0; s_tot[1] = t1; s_tot[2] = t2; s_tot[3] = t3; }
+  }
+  __syncthreads();
+  const float nu = (float)sqrt(s_tot[1]), np = (float)sqrt(s_tot[2]), nn = (float)sqrt(s_tot[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float r = nu / (float)rows + np / (float)rows;
     if (a.reg_include_neg) r += nn / (float)rows;
-    atomicAdd(&a.losses[1], (double)(a.loss_scale * (r * a.reg_coef)));
+    a.losses[0] += (double)a.loss_scale * s_tot[0] / (double)rows;
+    a.losses[1] += (double)(a.loss_scale * (r * a.reg_coef));
   }
   if (b >= rows) return;
   const int bu = a.u_idx[b], bi = a.i_idx[b], bj = a.j_idx[b];
@@ -181,6 +197,7 @@ constexpr int kNceSplits = 8;
 
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
+  double* losspart;     // one partial per finish wave
   int64_t np;
 };
 
@@ -198,6 +215,7 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
   w.norm2 = p; p += np;
   w.lpart = p; p += (int64_t)kNceSplits * np;
   w.invl = p; p += np;
+  w.losspart = reinterpret_cast<double*>(p);     // np doubles (np is a multiple of 64: 8-byte aligned)
   return w;
 }
 
@@ -368,13 +386,20 @@ __global__ __launch_bounds__(256) void nce_finish(NceWs w, NceFinishArgs a) {
     const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
     const float lse = a.inv_tau + logf(l);
     double part = wave_sum_d((valid && sub == 0) ? (double)(lse - sii) : 0.0);
-    if (lane == 0) atomicAdd(a.loss, (double)a.loss_scale * part / (double)n);
+    if (lane == 0) w.losspart[(blockIdx.x * 256u + threadIdx.x) >> 6] = part;   // folded by the PASS2 launch
     const float il = 1.0f / l;
     if (valid && sub == 0) w.invl[i] = il;
     dn = make_float4(coef * (O.x * il - vb.x), coef * (O.y * il - vb.y), coef * (O.z * il - vb.z), coef * (O.w * il - vb.w));
     norm = w.norm1[ii];
     self = va;
   } else {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {     // fixed-order fold of the per-wave loss partials
+      const int n_waves = (int)(w.np / G);
+      double t = 0.0;
+      for (int k = threadIdx.x; k < n_waves; k += 64) t += w.losspart[k];
+      t = wave_sum_d(t);
+      if (threadIdx.x == 0) a.loss[0] += (double)a.loss_scale * t / (double)n;
+    }
     dn = make_float4(coef * (O.x - va.x), coef * (O.y - va.y), coef * (O.z - va.z), coef * (O.w - va.w));
     norm = w.norm2[ii];
     self = vb;
@@ -425,10 +450,11 @@ template <int LPR>
 srh_status_t launch_bpr(const BprArgs& a, hipStream_t st) {
   constexpr int G = 64 / LPR;
   const int blocks = ((a.B + G - 1) / G + 3) / 4;
-  SRH_HIP(hipMemsetAsync(a.sums, 0, 3 * sizeof(double), st));
-  bpr_phase1<LPR><<<blocks, 256, 0, st>>>(a);
+  BprArgs b = a;
+  b.n_blocks = blocks;
+  bpr_phase1<LPR><<<blocks, 256, 0, st>>>(b);
   SRH_LAUNCH_CHECK();
-  bpr_phase2<LPR><<<blocks, 256, 0, st>>>(a);
+  bpr_phase2<LPR><<<blocks, 256, 0, st>>>(b);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }
@@ -437,7 +463,9 @@ srh_status_t launch_bpr(const BprArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int64_t srh_bpr_ws_bytes(int64_t B) { return 64 + 4 * (B > 0 ? B : 0); }
+// 32 B per phase-1 workgroup (at most B/4 + 1 of them) followed by one float per batch row
+static inline int64_t bpr_part_bytes(int64_t B) { return 32 * ((B > 0 ? B : 0) / 4 + 2); }
+int64_t srh_bpr_ws_bytes(int64_t B) { return bpr_part_bytes(B) + 4 * (B > 0 ? B : 0) + 64; }
 
 srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item, const float* d_reg_user,
                                 const float* d_reg_item, const int32_t* d_u_idx, const int32_t* d_i_idx,
@@ -451,7 +479,7 @@ srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item, const 
   SRH_REQUIRE(srh::dim_supported(d), "bpr_l2_fwd_bwd: d=%d unsupported", d);
   BprArgs a{d_user, d_item, d_reg_user, d_reg_item, d_u_idx, d_i_idx, d_j_idx, d_n_rows, (int)B,
             reg_coef, loss_scale, reg_include_neg, d_g_user, d_g_item, d_greg_user, d_greg_item, d_losses,
-            reinterpret_cast<double*>(d_ws), reinterpret_cast<float*>(reinterpret_cast<char*>(d_ws) + 64)};
+            reinterpret_cast<double*>(d_ws), reinterpret_cast<float*>(reinterpret_cast<char*>(d_ws) + bpr_part_bytes(B)), 0};
   hipStream_t st = srh::as_stream(stream);
   switch (d) {
     case 32: return launch_bpr<8>(a, st);
@@ -515,7 +543,7 @@ srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* st
 int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
-  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 256;
+  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np + 256;
 }
 
 srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,

@@ -50,30 +50,32 @@ __global__ __launch_bounds__(256) void axpby_kernel(float a, const float4* __res
   }
 }
 
-__global__ __launch_bounds__(256) void batch_fetch_kernel(const int32_t* __restrict__ eu, const int32_t* __restrict__ ei,
-                                                          const int32_t* __restrict__ ej, const int32_t* __restrict__ uu,
-                                                          const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
-                                                          const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs,
-                                                          int64_t* __restrict__ cursor, int32_t* su, int32_t* si,
-                                                          int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta) {
+constexpr int kFetchThreads = 1024;
+__global__ __launch_bounds__(kFetchThreads) void batch_fetch_kernel(
+    const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const int32_t* __restrict__ ej,
+    const int32_t* __restrict__ uu, const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
+    const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, int64_t* __restrict__ cursor, int32_t* su,
+    int32_t* si, int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta, int32_t* __restrict__ mark,
+    int32_t item_offset) {
   // single workgroup; the cursor is advanced by thread 0 after everyone has read it
-  __shared__ int64_t s_b;
-  if (threadIdx.x == 0) s_b = cursor[0];
+  __shared__ int64_t s_b, s_step;
+  if (threadIdx.x == 0) { s_b = cursor[0]; s_step = cursor[1]; }
   __syncthreads();
   const int64_t b = s_b;
+  const int32_t stamp = (int32_t)(s_step + 1);          // the optimiser step this batch belongs to
   const int64_t ptr = b * bs;
   const int64_t rows = (ptr >= n_edges) ? 0 : ((ptr + bs < n_edges) ? bs : n_edges - ptr);
-  for (int64_t i = threadIdx.x; i < rows; i += 256) {
-    su[i] = eu[ptr + i];
-    si[i] = ei[ptr + i];
-    sj[i] = ej[ptr + i];
+  for (int64_t i = threadIdx.x; i < rows; i += kFetchThreads) {
+    const int32_t u = eu[ptr + i], p = ei[ptr + i], n = ej[ptr + i];
+    su[i] = u; si[i] = p; sj[i] = n;
+    if (mark) { mark[u] = stamp; mark[item_offset + p] = stamp; mark[item_offset + n] = stamp; }
   }
   int32_t a = 0, c = 0;
   if (uu && rows > 0) {
     a = nuu[b];
     c = nui[b];
-    for (int64_t i = threadIdx.x; i < a; i += 256) suu[i] = uu[b * bs + i];
-    for (int64_t i = threadIdx.x; i < c; i += 256) sui[i] = ui[b * bs + i];
+    for (int64_t i = threadIdx.x; i < a; i += kFetchThreads) suu[i] = uu[b * bs + i];
+    for (int64_t i = threadIdx.x; i < c; i += kFetchThreads) sui[i] = ui[b * bs + i];
   }
   if (threadIdx.x == 0) {
     meta[0] = (int32_t)rows;
@@ -81,8 +83,30 @@ __global__ __launch_bounds__(256) void batch_fetch_kernel(const int32_t* __restr
     meta[2] = c;
     meta[3] = (int32_t)b;
     cursor[0] = b + 1;
-    cursor[1] = cursor[1] + 1;
+    cursor[1] = s_step + 1;
   }
+}
+
+struct ZeroList {
+  float* table[SRH_MAX_ZERO_LISTS];
+  const int32_t* idx[SRH_MAX_ZERO_LISTS];
+  const int32_t* d_n[SRH_MAX_ZERO_LISTS];
+  int32_t n_max[SRH_MAX_ZERO_LISTS];
+  int32_t offset[SRH_MAX_ZERO_LISTS];
+  int32_t n_lists;
+};
+
+// zero the listed rows of (.., d) tables: the sparse counterpart of a dense memset for
+// gradient buffers that only ever receive O(batch) non-zero rows
+__global__ __launch_bounds__(256) void zero_rows_kernel(ZeroList z, int lpr) {
+  const int list = blockIdx.y;
+  if (list >= z.n_lists) return;
+  const int n = z.d_n[list] ? min(*z.d_n[list], z.n_max[list]) : z.n_max[list];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = t / lpr;
+  if (r >= n) return;
+  const int64_t row = (int64_t)z.idx[list][r] + z.offset[list];
+  reinterpret_cast<float4*>(z.table[list])[row * lpr + (t % lpr)] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 }  // namespace
 
@@ -119,17 +143,40 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              const int32_t* d_n_uniq_u, const int32_t* d_n_uniq_i, int64_t n_edges,
                              int64_t batch_size, int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
                              int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
-                             int32_t* d_meta, void* stream) {
+                             int32_t* d_meta, int32_t* d_row_mark, int32_t mark_item_offset, void* stream) {
   SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
               "batch_fetch: null argument");
   const bool uq = d_epoch_uniq_u != nullptr;
   SRH_REQUIRE(!uq || (d_epoch_uniq_i && d_n_uniq_u && d_n_uniq_i && d_stage_uniq_u && d_stage_uniq_i),
               "batch_fetch: unique-id arrays must be given together");
   SRH_REQUIRE(n_edges > 0 && batch_size > 0, "batch_fetch: bad sizes");
-  batch_fetch_kernel<<<1, 256, 0, srh::as_stream(stream)>>>(d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u,
-                                                            d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges,
-                                                            batch_size, d_cursor, d_stage_u, d_stage_i, d_stage_j,
-                                                            d_stage_uniq_u, d_stage_uniq_i, d_meta);
+  batch_fetch_kernel<<<1, kFetchThreads, 0, srh::as_stream(stream)>>>(
+      d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u, d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges, batch_size,
+      d_cursor, d_stage_u, d_stage_i, d_stage_j, d_stage_uniq_u, d_stage_uniq_i, d_meta, d_row_mark,
+      mark_item_offset);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_t* const* d_idx,
+                           const int32_t* const* d_counts, const int32_t* n_max, const int32_t* row_offset,
+                           int32_t d, void* stream) {
+  SRH_REQUIRE(n_lists >= 1 && n_lists <= SRH_MAX_ZERO_LISTS, "zero_rows: 1..%d lists", SRH_MAX_ZERO_LISTS);
+  SRH_REQUIRE(d_tables && d_idx && d_counts && n_max && row_offset, "zero_rows: null argument");
+  SRH_REQUIRE(d > 0 && d % 4 == 0, "zero_rows: d must be a positive multiple of 4");
+  ZeroList z{};
+  int32_t most = 0;
+  for (int k = 0; k < n_lists; ++k) {
+    SRH_REQUIRE(d_tables[k] && d_idx[k] && n_max[k] >= 0, "zero_rows: bad list %d", k);
+    z.table[k] = d_tables[k]; z.idx[k] = d_idx[k]; z.d_n[k] = d_counts[k];
+    z.n_max[k] = n_max[k]; z.offset[k] = row_offset[k];
+    most = std::max(most, n_max[k]);
+  }
+  z.n_lists = n_lists;
+  if (most == 0) return SRH_OK;
+  const int lpr = d / 4;
+  dim3 grid((unsigned)(((int64_t)most * lpr + 255) / 256), (unsigned)n_lists);
+  zero_rows_kernel<<<grid, 256, 0, srh::as_stream(stream)>>>(z, lpr);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

@@ -16,9 +16,20 @@
 //     per group (16 x-rows per wave) before the first use.
 //   * groups are summed with xor-shuffles; the epilogue runs on the reduced row.
 //   * power-law rows: rows longer than split_len are cut into several segments that write
-//     partial sums to a workspace; a second small kernel adds them in a fixed order (no
-//     atomics: results are run-to-run deterministic) and applies the epilogue.
+//     partial sums to a workspace; the segment that arrives last (agent-scope release ->
+//     relaxed ticket -> acquire, cdna_hip_programming.md G16) adds them in slot order -- a fixed
+//     order, so results are run-to-run deterministic -- and applies the epilogue.  No second
+//     launch.
 //   * segments are issued longest-first so the tail of the launch is short rows.
+//   * XCD-aware issue order for the bipartite adjacency: measured on MI355X the kernel is bound
+//     by L2-miss traffic (43% TCC hit rate, ~400 MB fetched per launch for 56 MB algorithmic,
+//     profiles/r01_a_pmc_*): every XCD gathers from both the user and the item half of x
+//     (17.8 MB at Yelp shape) through a 4 MiB L2.  Workgroup b runs on XCD b % 8, so the plan
+//     hands user rows to XCDs 0-3 and item rows to XCDs 4-7: each L2 then serves one half of x.
+//   * the (col, val) stream is read once: non-temporal loads keep it from evicting x rows.
+//   * optional row / column activity marks skip whole rows (last forward layer: only the batch's
+//     rows are needed) and zero columns (first backward layer: the incoming gradient is
+//     non-zero only on the batch's rows); zero-valued entries never issue their gather.
 #include <algorithm>
 #include <new>
 #include <numeric>
@@ -36,6 +47,7 @@ struct Seg {
 struct Heavy {
   int32_t row, first_slot, n_slots, pad;
 };
+// slot -> index into the Heavy array (one int per partial slot)
 
 struct DevEpilogue {
   int32_t flags;
@@ -51,6 +63,9 @@ struct DevEpilogue {
   float* mean_out;
   const float* add[SRH_MAX_ADD];
   float add_scale[SRH_MAX_ADD];
+  const int32_t* row_mark;
+  const int32_t* col_mark;
+  const int64_t* mark_stamp;
 };
 
 // Philox4x32-10 (Salmon et al., SC'11), counter-based: no state in memory.
@@ -122,7 +137,10 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
                                                        const int32_t* __restrict__ indices,
                                                        const float* __restrict__ vals,
                                                        const float4* __restrict__ X, float4* __restrict__ Y,
-                                                       float4* __restrict__ partial, DevEpilogue ep) {
+                                                       float4* __restrict__ partial,
+                                                       const Heavy* __restrict__ heavy,
+                                                       const int32_t* __restrict__ slot_owner,
+                                                       int32_t* __restrict__ tickets, DevEpilogue ep) {
   constexpr int G = 64 / LPR;      // row-vectors per wave
   constexpr int STEP = 4 * G;      // entries consumed per unrolled iteration
   const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
@@ -134,13 +152,16 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   const int s = __builtin_amdgcn_readfirstlane(sg.start);
   const int e = __builtin_amdgcn_readfirstlane(sg.end);
   const int slot = __builtin_amdgcn_readfirstlane(sg.slot);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  if (ep.row_mark && ep.row_mark[row] != stamp) return;     // row not needed this step
 
   float4 acc = f4_zero();
   for (int base = s; base < e; base += 64) {
     const int j = base + lane;
     const bool in = j < e;
-    const int c = in ? indices[j] : 0;       // padded entries: value 0 times row 0
-    const float v = in ? vals[j] : 0.f;
+    const int c = in ? __builtin_nontemporal_load(indices + j) : 0;
+    float v = in ? __builtin_nontemporal_load(vals + j) : 0.f;
+    if (ep.col_mark && in && ep.col_mark[c] != stamp) v = 0.f;   // x row known to be zero
     const int cnt = min(64, e - base);
     const int cnt_up = (cnt + STEP - 1) / STEP * STEP;   // <= 64 because STEP divides 64
     for (int k = 0; k < cnt_up; k += STEP) {
@@ -148,10 +169,11 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
       const int c2 = __shfl(c, k + 2 * G + g), c3 = __shfl(c, k + 3 * G + g);
       const float v0 = __shfl(v, k + g), v1 = __shfl(v, k + G + g);
       const float v2 = __shfl(v, k + 2 * G + g), v3 = __shfl(v, k + 3 * G + g);
-      const float4 x0 = X[(size_t)c0 * LPR + sub];
-      const float4 x1 = X[(size_t)c1 * LPR + sub];
-      const float4 x2 = X[(size_t)c2 * LPR + sub];
-      const float4 x3 = X[(size_t)c3 * LPR + sub];
+      float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
+      if (v0 != 0.f) x0 = X[(size_t)c0 * LPR + sub];      // zero entries (padding, dropped edges,
+      if (v1 != 0.f) x1 = X[(size_t)c1 * LPR + sub];      // inactive columns) issue no gather
+      if (v2 != 0.f) x2 = X[(size_t)c2 * LPR + sub];
+      if (v3 != 0.f) x3 = X[(size_t)c3 * LPR + sub];
       acc = f4_fma(v0, x0, acc);
       acc = f4_fma(v1, x1, acc);
       acc = f4_fma(v2, x2, acc);
@@ -161,31 +183,30 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
 
-  if (slot >= 0) {
-    if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
-  } else {
+  if (slot < 0) {
     row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+    return;
   }
-}
-
-template <int LPR>
-__global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict__ heavy, int n_heavy,
-                                                         const float4* __restrict__ partial,
-                                                         float4* __restrict__ Y, DevEpilogue ep) {
-  constexpr int G = 64 / LPR;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_heavy) return;
-  const int lane = threadIdx.x & 63;
-  const int g = lane / LPR, sub = lane % LPR;
-  const Heavy h = heavy[wave];
-  const int row = __builtin_amdgcn_readfirstlane(h.row);
+  // ---- split row: publish the partial, the last segment to arrive reduces and finishes ----
+  if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+  const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+  const Heavy h = heavy[hid];
   const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
   const int n = __builtin_amdgcn_readfirstlane(h.n_slots);
-  float4 acc = f4_zero();
-  for (int t = g; t < n; t += G) acc = f4_add(acc, partial[(size_t)(first + t) * LPR + sub]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep the wait the compiler may drop (G16 pitfall)
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != n - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+  float4 sum = f4_zero();
+  for (int t = g; t < n; t += G) sum = f4_add(sum, partial[(size_t)(first + t) * LPR + sub]);
 #pragma unroll
-  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-  row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+  for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
+  row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
 }
 
 }  // namespace
@@ -195,22 +216,25 @@ struct srh_spmm_plan {
   int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
   Seg* d_segs = nullptr;
   Heavy* d_heavy = nullptr;
+  int32_t* d_slot_owner = nullptr;
+  int32_t* d_tickets = nullptr;    // one arrival counter per split row, self re-arming
   float* d_partial = nullptr;      // n_slots * 256 floats (enough for d <= 256)
-  int32_t partial_d = 0;
 };
 
 extern "C" {
 
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
-                                  const int32_t* h_indptr, int32_t split_len) {
+                                  const int32_t* h_indptr, int32_t split_len, int64_t xcd_split_row) {
   SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
   if (split_len <= 0) split_len = 256;
   SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
   SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
+  SRH_REQUIRE(xcd_split_row >= 0 && xcd_split_row <= n_rows, "spmm_plan_create: xcd_split_row out of range");
   std::vector<Seg> segs;
   std::vector<Heavy> heavy;
+  std::vector<int32_t> slot_owner;
   segs.reserve((size_t)n_rows + 1024);
   int32_t n_slots = 0;
   for (int64_t r = 0; r < n_rows; ++r) {
@@ -222,13 +246,35 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     } else {
       const int32_t pieces = (len + split_len - 1) / split_len;
       heavy.push_back({(int32_t)r, n_slots, pieces, 0});
-      for (int32_t p = 0; p < pieces; ++p)
+      for (int32_t p = 0; p < pieces; ++p) {
         segs.push_back({(int32_t)r, s + p * split_len, std::min(e, s + (p + 1) * split_len), n_slots + p});
+        slot_owner.push_back((int32_t)heavy.size() - 1);
+      }
       n_slots += pieces;
     }
   }
   // longest first; ties keep row order (stable) so neighbouring waves touch neighbouring y rows
-  std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); });
+  auto longer = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
+  if (xcd_split_row > 0 && xcd_split_row < n_rows) {
+    // workgroup b (4 segments) runs on XCD b % 8 (observed dispatch rule, performance only):
+    // XCDs 0-3 take rows < xcd_split_row, XCDs 4-7 the rest, so each L2 caches one half of x
+    std::vector<Seg> lo, hi;
+    for (const Seg& sgm : segs) (sgm.row < xcd_split_row ? lo : hi).push_back(sgm);
+    std::stable_sort(lo.begin(), lo.end(), longer);
+    std::stable_sort(hi.begin(), hi.end(), longer);
+    segs.clear();
+    size_t il = 0, ih = 0;
+    for (size_t blk = 0; il < lo.size() || ih < hi.size(); ++blk) {
+      const bool want_lo = (blk % 8) < 4;
+      for (int w = 0; w < 4; ++w) {
+        const bool take_lo = (want_lo && il < lo.size()) || ih >= hi.size();
+        if (take_lo && il < lo.size()) segs.push_back(lo[il++]);
+        else if (ih < hi.size()) segs.push_back(hi[ih++]);
+      }
+    }
+  } else {
+    std::stable_sort(segs.begin(), segs.end(), longer);
+  }
 
   srh_spmm_plan* p = new (std::nothrow) srh_spmm_plan();
   if (!p) { srh::set_error("spmm_plan_create: out of memory"); return SRH_ERR_NOMEM; }
@@ -241,6 +287,10 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
     if (err == hipSuccess) err = hipMemcpy(p->d_heavy, heavy.data(), sizeof(Heavy) * heavy.size(), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMalloc(&p->d_partial, sizeof(float) * 256 * (size_t)n_slots);
+    if (err == hipSuccess) err = hipMalloc(&p->d_slot_owner, sizeof(int32_t) * slot_owner.size());
+    if (err == hipSuccess) err = hipMemcpy(p->d_slot_owner, slot_owner.data(), sizeof(int32_t) * slot_owner.size(), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc(&p->d_tickets, sizeof(int32_t) * heavy.size());
+    if (err == hipSuccess) err = hipMemset(p->d_tickets, 0, sizeof(int32_t) * heavy.size());
   }
   if (err != hipSuccess) {
     srh::set_error("spmm_plan_create: %s", hipGetErrorString(err));
@@ -256,6 +306,8 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_segs) (void)hipFree(p->d_segs);
   if (p->d_heavy) (void)hipFree(p->d_heavy);
   if (p->d_partial) (void)hipFree(p->d_partial);
+  if (p->d_slot_owner) (void)hipFree(p->d_slot_owner);
+  if (p->d_tickets) (void)hipFree(p->d_tickets);
   delete p;
 }
 
@@ -269,14 +321,9 @@ srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const
   const int blocks = (p->n_segs + 3) / 4;
   spmm_seg_kernel<LPR><<<blocks, 256, 0, st>>>(p->d_segs, p->n_segs, d_indices, d_vals,
                                                reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
-                                               reinterpret_cast<float4*>(p->d_partial), ep);
+                                               reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,
+                                               p->d_tickets, ep);
   SRH_LAUNCH_CHECK();
-  if (p->n_heavy > 0) {
-    const int hb = (p->n_heavy + 3) / 4;
-    spmm_heavy_kernel<LPR><<<hb, 256, 0, st>>>(p->d_heavy, p->n_heavy, reinterpret_cast<const float4*>(p->d_partial),
-                                               reinterpret_cast<float4*>(d_y), ep);
-    SRH_LAUNCH_CHECK();
-  }
   return SRH_OK;
 }
 
@@ -299,6 +346,10 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.off_lo = (uint32_t)epi->philox_offset; ep.off_hi = (uint32_t)(epi->philox_offset >> 32);
     ep.philox_step = epi->d_philox_step;
     ep.philox_stride = epi->philox_stride;
+    ep.row_mark = epi->d_row_mark;
+    ep.col_mark = epi->d_col_mark;
+    ep.mark_stamp = epi->d_mark_stamp;
+    SRH_REQUIRE(!(ep.row_mark || ep.col_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
     if (epi->flags & SRH_EPI_MEAN) {
       SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,
                   "spmm_f32: bad MEAN epilogue");

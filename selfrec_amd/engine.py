@@ -89,6 +89,12 @@ class FusedTrainer:
         self.Y = [buf() for _ in range(self.L)]
         self.Ha, self.Hb = (buf(), buf()) if self.L >= 1 else (None, None)
         self.gCL = buf() if model == "XSimGCL" else None
+        self.gReg = buf() if model == "LightGCN" else None    # ego-row regulariser gradient (sparse rows)
+        # activity marks: mark[node] == optimiser step  <=>  the node is a row of the current batch
+        self.mark = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.use_marks = True
+        # models whose gradient buffers only ever hold O(batch) non-zero rows are reset row-wise
+        self.sparse_reset = model in ("MF", "LightGCN", "XSimGCL")
         self.views = []                           # SimGCL / SGL: extra passes [(F_v, Y_v list, gF_v)]
         if model in ("SimGCL", "SGL"):
             for _ in range(2):
@@ -182,9 +188,12 @@ class FusedTrainer:
         t = self.noise_fn((self.N, self.d))
         return torch.as_tensor(t, dtype=torch.float32).to(self.dev).contiguous()
 
-    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, training=True):
+    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False):
         """L SpMMs; layer k's epilogue perturbs (optional) and the last one also writes the
-        layer mean into F.  Returns nothing; the CL view of XSimGCL is Ys[l*-1] (or E0)."""
+        layer mean into F.  Returns nothing; the CL view of XSimGCL is Ys[l*-1] (or E0).
+        batch_rows_only: the last layer's output (and F) feed nothing but the batch losses, so
+        only the rows marked for this step are computed (the others keep stale values that are
+        never read)."""
         L = self.L
         x = self.E0
         for k in range(L):
@@ -199,11 +208,13 @@ class FusedTrainer:
             if k == L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
                 kw.update(prev=prev, mean_div=float(L + 1 if include_ego else L), mean_out=F)
+                if batch_rows_only and self.use_marks:
+                    kw.update(row_mark=self.mark, mark_stamp=self.cursor[1:2])
             ops.spmm(adj, x, out=Ys[k], epilogue=ops.make_epilogue(**kw) if kw else None)
             x = Ys[k]
 
-    def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None):
-        """gE0 += d loss / d E0 through one encoder pass.
+    def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None, accumulate=False):
+        """gE0 (+)= d loss / d E0 through one encoder pass (accumulate=False overwrites gE0).
 
         H_L = s gF + [l*==L] gCL ;  H_k = A H_{k+1} + s gF + [l*==k] gCL ;
         gE0 += A H_1 + [ego] s gF + [l*==0] gCL (+ extra)       with s = 1/#averaged layers.
@@ -218,6 +229,9 @@ class FusedTrainer:
             src, alpha = H, 1.0
         else:
             src, alpha = gF, s                     # A (s gF) = s (A gF): no materialised H_L
+        # the incoming gradient is non-zero only on this step's batch rows: the first product
+        # skips every other column
+        sparse_src = dict(col_mark=self.mark, mark_stamp=self.cursor[1:2]) if self.use_marks else {}
         bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
         for k in range(L - 1, 0, -1):              # produce H_k
             add, sc = [gF], [s]
@@ -225,10 +239,10 @@ class FusedTrainer:
                 add.append(gCL)
                 sc.append(1.0)
             dst = bufs[0]
-            ops.spmm(adj, src, out=dst, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha))
-            src, alpha = dst, 1.0
+            ops.spmm(adj, src, out=dst, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **sparse_src))
+            src, alpha, sparse_src = dst, 1.0, {}
             bufs.reverse()
-        add, sc = [self.gE0], [1.0]                # accumulate into gE0 (aliasing y is allowed)
+        add, sc = ([self.gE0], [1.0]) if accumulate else ([], [])   # (aliasing y is allowed)
         if include_ego:
             add.append(gF)
             sc.append(s)
@@ -239,8 +253,11 @@ class FusedTrainer:
             add.append(extra)
             sc.append(1.0)
         while len(add) > 2:                        # epilogue takes two addends: fold the rest first
+            if not accumulate:
+                raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
-        ops.spmm(adj, src, out=self.gE0, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha))
+        ops.spmm(adj, src, out=self.gE0,
+                 epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **sparse_src))
 
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch
@@ -249,25 +266,25 @@ class FusedTrainer:
         m, st, U = self.model, self.stage, self.U
         g = self.graph
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
-        ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta)
+        ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
+                        row_mark=self.mark, mark_item_offset=U)
         self._noise_call = 0      # Philox counter = (adam step, perturbed-layer call no, row)
         self.losses.zero_()
-        self.gE0.zero_()
-        if self.gF is not self.gE0:
+        if not self.sparse_reset:     # SimGCL / SGL: dense gradient buffers, dense memsets
+            self.gE0.zero_()
             self.gF.zero_()
-        if self.gCL is not None:
-            self.gCL.zero_()
-        for v in self.views:
-            v["gF"].zero_()
+            for v in self.views:
+                v["gF"].zero_()
 
         include_ego = m in ("LightGCN", "SGL")
         if m != "MF":
-            self._forward_pass(g.adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego)
+            self._forward_pass(g.adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
+                               batch_rows_only=True)
         F = self.F
         # ---- recommendation loss + regulariser (a-5..a-7)
         if m == "LightGCN":
-            # regulariser on the EGO rows; its gradient lands in gE0 directly (LightGCN.py:25)
-            reg_u, reg_i, greg_u, greg_i = self._u(self.E0), self._i(self.E0), self._u(self.gE0), self._i(self.gE0)
+            # regulariser on the EGO rows (LightGCN.py:25); its gradient joins gE0 in the last product
+            reg_u, reg_i, greg_u, greg_i = self._u(self.E0), self._i(self.E0), self._u(self.gReg), self._i(self.gReg)
             reg_coef, inc_neg = self.reg / self.B, True
         elif m == "MF":
             reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
@@ -290,7 +307,8 @@ class FusedTrainer:
         elif m in ("SimGCL", "SGL"):
             for vi, v in enumerate(self.views):
                 adj = g.adj if m == "SimGCL" else self.view_adj[vi]
-                self._forward_pass(adj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego)
+                self._forward_pass(adj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego,
+                                   batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
                 for lo, hi, idx, n_dev in ((0, U, st["uniq_u"], nuu_dev), (U, self.N, st["uniq_i"], nui_dev)):
@@ -308,7 +326,7 @@ class FusedTrainer:
         elif m == "XSimGCL":
             self._backward_chain(g.adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl)
         elif m == "LightGCN":
-            self._backward_chain(g.adj, self.gF, include_ego=True)
+            self._backward_chain(g.adj, self.gF, include_ego=True, extra=self.gReg)
         elif m == "SimGCL":
             ops.axpby(1.0, self.views[0]["gF"], 1.0, self.gF)     # same linear operator for all passes
             ops.axpby(1.0, self.views[1]["gF"], 1.0, self.gF)
@@ -316,8 +334,19 @@ class FusedTrainer:
         else:                                        # SGL: three operators, three chains
             self._backward_chain(g.adj, self.gF, include_ego=True)
             for vi, v in enumerate(self.views):
-                self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True)
+                self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True)
         ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.cursor[1:2], lr=self.lr)
+        if self.sparse_reset:
+            # the gradient buffers hold non-zeros only on this batch's rows: clear just those
+            B = self.B
+            lists = [(self.gF, st["u"], rows_dev, B, 0), (self.gF, st["i"], rows_dev, B, U),
+                     (self.gF, st["j"], rows_dev, B, U)]
+            if self.gCL is not None:
+                lists += [(self.gCL, st["uniq_u"], nuu_dev, B, 0), (self.gCL, st["uniq_i"], nui_dev, B, U)]
+            if self.gReg is not None:
+                lists += [(self.gReg, st["u"], rows_dev, B, 0), (self.gReg, st["i"], rows_dev, B, U),
+                          (self.gReg, st["j"], rows_dev, B, U)]
+            ops.zero_rows(lists, self.d)
 
     def _build_cat_index(self):
         """SGL: InfoNCE over [unique users ; unique items] of the batch (SGL.py:120-125), as one

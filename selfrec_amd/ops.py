@@ -16,7 +16,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
-           "axpby", "batch_fetch", "SelfrecHipError"]
+           "axpby", "batch_fetch", "zero_rows", "SelfrecHipError"]
 
 
 def _stream() -> int:
@@ -151,7 +151,8 @@ class DeviceCSR:
     are new value arrays over the same structure).
     """
 
-    def __init__(self, indptr, indices, vals, shape, device=None, split_len: int = 0, structure_of=None):
+    def __init__(self, indptr, indices, vals, shape, device=None, split_len: int = 0, structure_of=None,
+                 xcd_split_row: int = 0):
         self._lib = _lib.load()
         _lib.require_gpu()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -169,7 +170,7 @@ class DeviceCSR:
             self.indices = torch.as_tensor(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
             h = C.c_void_p()
             check(self._lib.srh_spmm_plan_create(C.byref(h), self.shape[0], self.shape[1],
-                                                 h_indptr.ctypes.data_as(C.c_void_p), split_len),
+                                                 h_indptr.ctypes.data_as(C.c_void_p), split_len, int(xcd_split_row)),
                   "srh_spmm_plan_create")
             self._plan = h
             self._plan_owner = None
@@ -197,7 +198,8 @@ class DeviceCSR:
 
 
 def make_epilogue(*, perturb_eps=None, noise=None, philox_seed=0, philox_offset=0, philox_step=None,
-                  philox_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0):
+                  philox_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
+                  row_mark=None, col_mark=None, mark_stamp=None):
     ep = SpmmEpilogue()
     keep = []
     flags = 0
@@ -231,6 +233,11 @@ def make_epilogue(*, perturb_eps=None, noise=None, philox_seed=0, philox_offset=
             ep.d_add[t] = _p(x, torch.float32, "add")
             ep.add_scale[t] = float(add_scale[t])
         keep += list(add)
+    if row_mark is not None or col_mark is not None:
+        ep.d_row_mark = _p(row_mark, torch.int32, "row_mark")
+        ep.d_col_mark = _p(col_mark, torch.int32, "col_mark")
+        ep.d_mark_stamp = _p(mark_stamp, torch.int64, "mark_stamp")
+        keep += [row_mark, col_mark, mark_stamp]
     ep.flags = flags
     ep._keepalive = keep
     return ep
@@ -366,7 +373,19 @@ def axpby(a, x, b, y):
     return y
 
 
-def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta):
+def zero_rows(lists, d):
+    """lists: [(table, idx, count_dev_or_None, n_max, row_offset), ...] (at most 8)."""
+    n = len(lists)
+    vp = C.c_void_p * n
+    tables = vp(*[_p(t, torch.float32, "table") for t, *_ in lists])
+    idx = vp(*[_p(i, torch.int32, "idx") for _, i, *_ in lists])
+    cnt = vp(*[_p(c, torch.int32, "count") for _, _, c, *_ in lists])
+    n_max = (C.c_int32 * n)(*[int(m) for *_, m, _ in lists])
+    off = (C.c_int32 * n)(*[int(o) for *_, o in lists])
+    check(_lib.load().srh_zero_rows(n, tables, idx, cnt, n_max, off, int(d), _stream()), "srh_zero_rows")
+
+
+def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0):
     """ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
     check(_lib.load().srh_batch_fetch(
         _p(ep["u"], torch.int32), _p(ep["i"], torch.int32), _p(ep["j"], torch.int32),
@@ -374,4 +393,4 @@ def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta):
         _p(ep.get("n_uniq_u"), torch.int32), _p(ep.get("n_uniq_i"), torch.int32), int(n_edges), int(batch_size),
         _p(cursor, torch.int64), _p(stage["u"], torch.int32), _p(stage["i"], torch.int32),
         _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
-        _p(meta, torch.int32), _stream()), "srh_batch_fetch")
+        _p(meta, torch.int32), _p(row_mark, torch.int32), int(mark_item_offset), _stream()), "srh_batch_fetch")

@@ -119,6 +119,25 @@ def test_full_size_properties_yelp_shape():
     x = torch.randn((N, d), device="cuda", generator=gen)
     y = torch.randn((N, d), device="cuda", generator=gen)
     ax, ay = ops.spmm(g.adj, x), ops.spmm(g.adj, y)
+    # against scipy on the host at full size (741 split rows reduced by their last-arriving segment,
+    # all 256 CUs busy: the load pattern under which a hand-off bug would show), twice for determinism
+    import scipy.sparse as sp
+    host = sp.csr_matrix((g.adj.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()), shape=(N, N))
+    want = host.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+    assert rel_err(ax.cpu().numpy(), want) < 2e-6
+    for _ in range(20):
+        assert torch.equal(ops.spmm(g.adj, x), ax)
+    # activity marks: only marked rows are written; unmarked columns are treated as zero
+    stamp = torch.tensor([7], dtype=torch.int64, device="cuda")
+    mark = torch.zeros(N, dtype=torch.int32, device="cuda")
+    live = torch.randperm(N, device="cuda")[:6000]
+    mark[live] = 7
+    out = torch.full_like(x, -5.0)
+    ops.spmm(g.adj, x, out=out, epilogue=ops.make_epilogue(row_mark=mark, mark_stamp=stamp))
+    assert torch.equal(out[live], ax[live]) and bool((out[mark != 7] == -5.0).all())
+    xz = torch.zeros_like(x); xz[live] = x[live]
+    got = ops.spmm(g.adj, x, epilogue=ops.make_epilogue(col_mark=mark, mark_stamp=stamp))
+    assert rel_err(got.cpu().numpy(), ops.spmm(g.adj, xz).cpu().numpy()) < 2e-6
     # symmetry of A_hat:  <y, A x> == <x, A y>
     l, r = (y.double() * ax.double()).sum().item(), (x.double() * ay.double()).sum().item()
     assert abs(l - r) / abs(l) < 1e-6
