@@ -31,6 +31,7 @@
 //     rows are needed) and zero columns (first backward layer: the incoming gradient is
 //     non-zero only on the batch's rows); zero-valued entries never issue their gather.
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -132,7 +133,9 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   }
 }
 
-template <int LPR>
+// FLAGS: 1 = non-temporal (col,val) loads, 2 = skip the gather of zero-valued entries,
+//        4 = split rows are finished in-kernel by the last arriver (else by spmm_heavy_kernel)
+template <int LPR, int FLAGS>
 __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ segs, int n_segs,
                                                        const int32_t* __restrict__ indices,
                                                        const float* __restrict__ vals,
@@ -159,8 +162,12 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   for (int base = s; base < e; base += 64) {
     const int j = base + lane;
     const bool in = j < e;
-    const int c = in ? __builtin_nontemporal_load(indices + j) : 0;
-    float v = in ? __builtin_nontemporal_load(vals + j) : 0.f;
+    int c = 0;
+    float v = 0.f;
+    if (in) {
+      if (FLAGS & 1) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
+      else { c = indices[j]; v = vals[j]; }
+    }
     if (ep.col_mark && in && ep.col_mark[c] != stamp) v = 0.f;   // x row known to be zero
     const int cnt = min(64, e - base);
     const int cnt_up = (cnt + STEP - 1) / STEP * STEP;   // <= 64 because STEP divides 64
@@ -170,10 +177,17 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
       const float v0 = __shfl(v, k + g), v1 = __shfl(v, k + G + g);
       const float v2 = __shfl(v, k + 2 * G + g), v3 = __shfl(v, k + 3 * G + g);
       float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
-      if (v0 != 0.f) x0 = X[(size_t)c0 * LPR + sub];      // zero entries (padding, dropped edges,
-      if (v1 != 0.f) x1 = X[(size_t)c1 * LPR + sub];      // inactive columns) issue no gather
-      if (v2 != 0.f) x2 = X[(size_t)c2 * LPR + sub];
-      if (v3 != 0.f) x3 = X[(size_t)c3 * LPR + sub];
+      if (FLAGS & 2) {
+        if (v0 != 0.f) x0 = X[(size_t)c0 * LPR + sub];    // zero entries (padding, dropped edges,
+        if (v1 != 0.f) x1 = X[(size_t)c1 * LPR + sub];    // inactive columns) issue no gather
+        if (v2 != 0.f) x2 = X[(size_t)c2 * LPR + sub];
+        if (v3 != 0.f) x3 = X[(size_t)c3 * LPR + sub];
+      } else {
+        x0 = X[(size_t)c0 * LPR + sub];
+        x1 = X[(size_t)c1 * LPR + sub];
+        x2 = X[(size_t)c2 * LPR + sub];
+        x3 = X[(size_t)c3 * LPR + sub];
+      }
       acc = f4_fma(v0, x0, acc);
       acc = f4_fma(v1, x1, acc);
       acc = f4_fma(v2, x2, acc);
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   }
   // ---- split row: publish the partial, the last segment to arrive reduces and finishes ----
   if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+  if (!(FLAGS & 4)) return;                               // two-pass mode: spmm_heavy_kernel finishes
   const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
   const Heavy h = heavy[hid];
   const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
@@ -209,11 +224,34 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
 }
 
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict__ heavy, int n_heavy,
+                                                         const float4* __restrict__ partial,
+                                                         float4* __restrict__ Y, DevEpilogue ep) {
+  constexpr int G = 64 / LPR;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_heavy) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  const Heavy h = heavy[wave];
+  const int row = __builtin_amdgcn_readfirstlane(h.row);
+  const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
+  const int n = __builtin_amdgcn_readfirstlane(h.n_slots);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  if (ep.row_mark && ep.row_mark[row] != stamp) return;
+  float4 acc = f4_zero();
+  for (int t = g; t < n; t += G) acc = f4_add(acc, partial[(size_t)(first + t) * LPR + sub]);
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+  row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+}
+
 }  // namespace
 
 struct srh_spmm_plan {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
+  int32_t flags = 0;               // kernel variant, see spmm_seg_kernel
   Seg* d_segs = nullptr;
   Heavy* d_heavy = nullptr;
   int32_t* d_slot_owner = nullptr;
@@ -281,6 +319,8 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
   p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
   p->split_len = split_len;
+  p->flags = 1 | 2 | 4;
+  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 7;   // A/B knob for tools/spmm_ab.py
   hipError_t err = hipMalloc(&p->d_segs, sizeof(Seg) * segs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess && !heavy.empty()) {
@@ -315,16 +355,37 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
 
 namespace {
 
+template <int LPR, int FLAGS>
+srh_status_t launch_variant(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
+                            const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
+  const int blocks = (p->n_segs + 3) / 4;
+  spmm_seg_kernel<LPR, FLAGS><<<blocks, 256, 0, st>>>(p->d_segs, p->n_segs, d_indices, d_vals,
+                                                      reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
+                                                      reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,
+                                                      p->d_tickets, ep);
+  SRH_LAUNCH_CHECK();
+  if (!(FLAGS & 4) && p->n_heavy > 0) {
+    spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
+                                                                reinterpret_cast<const float4*>(p->d_partial),
+                                                                reinterpret_cast<float4*>(d_y), ep);
+    SRH_LAUNCH_CHECK();
+  }
+  return SRH_OK;
+}
+
 template <int LPR>
 srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
                          const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
-  const int blocks = (p->n_segs + 3) / 4;
-  spmm_seg_kernel<LPR><<<blocks, 256, 0, st>>>(p->d_segs, p->n_segs, d_indices, d_vals,
-                                               reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
-                                               reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,
-                                               p->d_tickets, ep);
-  SRH_LAUNCH_CHECK();
-  return SRH_OK;
+  switch (p->flags & 7) {
+    case 0: return launch_variant<LPR, 0>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 1: return launch_variant<LPR, 1>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 2: return launch_variant<LPR, 2>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 3: return launch_variant<LPR, 3>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 4: return launch_variant<LPR, 4>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 5: return launch_variant<LPR, 5>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    case 6: return launch_variant<LPR, 6>(p, d_indices, d_vals, d_x, d_y, ep, st);
+    default: return launch_variant<LPR, 7>(p, d_indices, d_vals, d_x, d_y, ep, st);
+  }
 }
 
 }  // namespace

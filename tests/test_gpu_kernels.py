@@ -171,7 +171,10 @@ def test_loss_functions_match_reference_outputs(golden_ops, n):
     gn = torch.stack(torch.autograd.grad(nce, (u, p))).cpu().numpy()
     assert rel_err(gb, g[f"ops_{n}_g_bpr"]) < 1e-5
     assert rel_err(gr, g[f"ops_{n}_g_reg"]) < 1e-5
-    assert rel_err(gn, g[f"ops_{n}_g_nce"]) < 1e-5
+    if n == 1:      # a single row: the loss is identically 0 and so is its gradient; ours is rounding noise
+        assert np.abs(gn).max() < 1e-7 and not g[f"ops_{n}_g_nce"].any()
+    else:
+        assert rel_err(gn, g[f"ops_{n}_g_nce"]) < 1e-5
 
 
 @pytest.mark.parametrize("n,d,tau", [(2048, 64, 0.2), (1500, 64, 0.15), (700, 128, 0.2), (17, 64, 0.5)])

@@ -27,6 +27,8 @@ prof)
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
   f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/prof_kernel_stats.txt && head -24 $OUT/prof_kernel_stats.txt
   find $OUT/prof -name "*.db" -size +40M -delete;;
+ab)
+  timeout 600 python tools/spmm_ab.py > $OUT/spmm_ab.log 2>&1; echo "ab exit $?"; tail -45 $OUT/spmm_ab.log;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmc_$tag
