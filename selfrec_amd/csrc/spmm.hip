@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <new>
 #include <numeric>
+#include <queue>
 #include <vector>
 
 #include "common.h"
@@ -224,6 +225,100 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
 }
 
+// Persistent, software-pipelined variant (the default).  Profiling the one-wave-per-segment kernel
+// showed it is latency-bound, not bandwidth-bound: with x folded into an L2-resident 1 MB it ran
+// exactly as fast (tools/spmm_ab.py, profiles/r01_b_spmm_ab.txt), because every wave serialises
+// three memory latencies -- segment descriptor -> (col,val) chunk -> x gathers -> store -- and only
+// the third carries payload.  Here a fixed set of resident waves each walks its own list of
+// segments (balanced on the host, longest first) and keeps the next descriptor and the next
+// (col,val) chunk in flight while the current chunk's gathers are outstanding; 8 gathers per
+// row-group (32 x-rows per wave at d=64) are issued before the first use.
+template <int LPR, int FLAGS>
+__global__ __launch_bounds__(256) void spmm_stream_kernel(const Seg* __restrict__ wsegs,
+                                                          const int32_t* __restrict__ wave_ptr, int n_waves,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ vals,
+                                                          const float4* __restrict__ X, float4* __restrict__ Y,
+                                                          float4* __restrict__ partial, DevEpilogue ep) {
+  constexpr int G = 64 / LPR;
+  constexpr int STEP = (8 * G < 64) ? 8 * G : 64;     // entries per inner iteration
+  constexpr int NLOAD = STEP / G;                     // gathers in flight per row-group
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  int li = __builtin_amdgcn_readfirstlane(wave_ptr[wave]);
+  const int le = __builtin_amdgcn_readfirstlane(wave_ptr[wave + 1]);
+  if (li >= le) return;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+
+  Seg cur = wsegs[li];
+  Seg nxt = (li + 1 < le) ? wsegs[li + 1] : cur;
+  int row = __builtin_amdgcn_readfirstlane(cur.row), e = __builtin_amdgcn_readfirstlane(cur.end);
+  int slot = __builtin_amdgcn_readfirstlane(cur.slot), base = __builtin_amdgcn_readfirstlane(cur.start);
+  bool live = !ep.row_mark || ep.row_mark[row] == stamp;
+  int c = 0;
+  float v = 0.f;
+  if (live && base + lane < e) { c = indices[base + lane]; v = vals[base + lane]; }
+  float4 acc = f4_zero();
+
+  while (true) {
+    // ---- where the next chunk comes from (uniform control flow) ----
+    int nbase = base + 64;
+    const bool seg_done = nbase >= e;
+    int nrow = row, ne = e, nslot = slot;
+    bool nlive = live, more = true;
+    if (seg_done) {
+      ++li;
+      if (li < le) {
+        nrow = __builtin_amdgcn_readfirstlane(nxt.row); ne = __builtin_amdgcn_readfirstlane(nxt.end);
+        nslot = __builtin_amdgcn_readfirstlane(nxt.slot); nbase = __builtin_amdgcn_readfirstlane(nxt.start);
+        nlive = !ep.row_mark || ep.row_mark[nrow] == stamp;
+        if (li + 1 < le) nxt = wsegs[li + 1];              // descriptor after next: in flight early
+      } else {
+        more = false;
+      }
+    }
+    // ---- prefetch the next chunk's (col,val) before touching the current gathers ----
+    int cn = 0;
+    float vn = 0.f;
+    if (more && nlive && nbase + lane < ne) { cn = indices[nbase + lane]; vn = vals[nbase + lane]; }
+    // ---- current chunk ----
+    if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;     // x row known to be zero
+    const int cnt = live ? min(64, e - base) : 0;
+    for (int k = 0; k < cnt; k += STEP) {
+      int cc[NLOAD];
+      float vv[NLOAD];
+      float4 xx[NLOAD];
+#pragma unroll
+      for (int t = 0; t < NLOAD; ++t) {
+        const int src = (k + t * G + g) & 63;
+        cc[t] = __shfl(c, src);
+        vv[t] = (k + t * G + g < 64) ? __shfl(v, src) : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < NLOAD; ++t) {
+        xx[t] = f4_zero();
+        if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];    // padding / dropped / dead columns: no gather
+      }
+#pragma unroll
+      for (int t = 0; t < NLOAD; ++t) acc = f4_fma(vv[t], xx[t], acc);
+    }
+    // ---- end of a segment: reduce the row-groups, finish or publish ----
+    if (seg_done) {
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+      if (live) {
+        if (slot < 0) row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+        else if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+      }
+      acc = f4_zero();
+    }
+    if (!more) break;
+    row = nrow; e = ne; slot = nslot; live = nlive; base = nbase; c = cn; v = vn;
+  }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict__ heavy, int n_heavy,
                                                          const float4* __restrict__ partial,
@@ -251,7 +346,10 @@ __global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict
 struct srh_spmm_plan {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
-  int32_t flags = 0;               // kernel variant, see spmm_seg_kernel
+  int32_t flags = 0;               // kernel variant, see spmm_seg_kernel; bit 8 = streaming kernel
+  int32_t n_waves = 0;             // streaming kernel: resident waves, each with its own segment list
+  Seg* d_wsegs = nullptr;          // segments grouped by wave
+  int32_t* d_wave_ptr = nullptr;   // n_waves + 1 offsets into d_wsegs
   Seg* d_segs = nullptr;
   Heavy* d_heavy = nullptr;
   int32_t* d_slot_owner = nullptr;
@@ -266,7 +364,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
-  if (split_len <= 0) split_len = 256;
+  if (split_len <= 0) split_len = 1024;
   SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
   SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
   SRH_REQUIRE(xcd_split_row >= 0 && xcd_split_row <= n_rows, "spmm_plan_create: xcd_split_row out of range");
@@ -319,10 +417,43 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
   p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
   p->split_len = split_len;
-  p->flags = 1 | 2 | 4;
-  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 7;   // A/B knob for tools/spmm_ab.py
+  p->flags = 8 | 2;
+  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 15;  // A/B knob for tools/spmm_ab.py
+  // ---- streaming kernel: balance the segments over a fixed set of resident waves (LPT greedy) ----
+  std::vector<Seg> wsegs;
+  std::vector<int32_t> wave_ptr;
+  {
+    int n_waves = 256 * 6 * 4;                       // 6 workgroups of 4 waves per CU (<= 85 VGPRs)
+    if (const char* env = getenv("SRH_SPMM_WAVES")) n_waves = std::max(4, atoi(env) / 4 * 4);
+    n_waves = std::min<int64_t>(n_waves, ((int64_t)segs.size() + 3) / 4 * 4);
+    const bool two_class = xcd_split_row > 0 && xcd_split_row < n_rows && n_waves >= 64;
+    std::vector<std::vector<int32_t>> lists(n_waves);
+    using Load = std::pair<int64_t, int32_t>;        // (assigned cost, wave)
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap[2];
+    for (int w = 0; w < n_waves; ++w) heap[two_class ? (((w / 4) % 8) < 4 ? 0 : 1) : 0].push({0, w});
+    std::vector<int32_t> order(segs.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+      return (segs[a].end - segs[a].start) > (segs[b].end - segs[b].start); });
+    for (int32_t si : order) {
+      auto& hq = heap[two_class ? (segs[si].row < xcd_split_row ? 0 : 1) : 0];
+      Load top = hq.top(); hq.pop();
+      lists[top.second].push_back(si);
+      hq.push({top.first + (segs[si].end - segs[si].start) + 24, top.second});   // 24 ~ per-segment overhead
+    }
+    wave_ptr.assign(n_waves + 1, 0);
+    for (int w = 0; w < n_waves; ++w) {
+      for (int32_t si : lists[w]) wsegs.push_back(segs[si]);
+      wave_ptr[w + 1] = (int32_t)wsegs.size();
+    }
+    p->n_waves = n_waves;
+  }
   hipError_t err = hipMalloc(&p->d_segs, sizeof(Seg) * segs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(&p->d_wsegs, sizeof(Seg) * wsegs.size());
+  if (err == hipSuccess) err = hipMemcpy(p->d_wsegs, wsegs.data(), sizeof(Seg) * wsegs.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(&p->d_wave_ptr, sizeof(int32_t) * wave_ptr.size());
+  if (err == hipSuccess) err = hipMemcpy(p->d_wave_ptr, wave_ptr.data(), sizeof(int32_t) * wave_ptr.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess && !heavy.empty()) {
     err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
     if (err == hipSuccess) err = hipMemcpy(p->d_heavy, heavy.data(), sizeof(Heavy) * heavy.size(), hipMemcpyHostToDevice);
@@ -348,6 +479,8 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_partial) (void)hipFree(p->d_partial);
   if (p->d_slot_owner) (void)hipFree(p->d_slot_owner);
   if (p->d_tickets) (void)hipFree(p->d_tickets);
+  if (p->d_wsegs) (void)hipFree(p->d_wsegs);
+  if (p->d_wave_ptr) (void)hipFree(p->d_wave_ptr);
   delete p;
 }
 
@@ -376,6 +509,19 @@ srh_status_t launch_variant(const srh_spmm_plan* p, const int32_t* d_indices, co
 template <int LPR>
 srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
                          const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
+  if (p->flags & 8) {
+    spmm_stream_kernel<LPR, 0><<<p->n_waves / 4, 256, 0, st>>>(
+        p->d_wsegs, p->d_wave_ptr, p->n_waves, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+        reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+    SRH_LAUNCH_CHECK();
+    if (p->n_heavy > 0) {
+      spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
+                                                                  reinterpret_cast<const float4*>(p->d_partial),
+                                                                  reinterpret_cast<float4*>(d_y), ep);
+      SRH_LAUNCH_CHECK();
+    }
+    return SRH_OK;
+  }
   switch (p->flags & 7) {
     case 0: return launch_variant<LPR, 0>(p, d_indices, d_vals, d_x, d_y, ep, st);
     case 1: return launch_variant<LPR, 1>(p, d_indices, d_vals, d_x, d_y, ep, st);

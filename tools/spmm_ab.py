@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """A/B the SpMM kernel variants on the Yelp2018-shaped adjacency, interleaved in one process
 (cdna_hip_programming.md rule 24).  Variants: SRH_SPMM_FLAGS bits (1 nt loads, 2 skip zero
-gathers, 4 in-kernel split-row finish) x xcd_split on/off x split_len."""
-import itertools
+gathers, 4 in-kernel split-row finish) x xcd_split on/off x split_len, plus two diagnostic
+matrices: column ids folded into 4096 rows (x stays L2-resident: the kernel's speed without
+L2 misses) and a degree-sorted relabelling."""
 import os
 import sys
 
@@ -19,20 +20,34 @@ g = data.device_graph()
 N, d = U + I, 64
 x = torch.randn((N, d), device="cuda")
 y = torch.empty_like(x)
-h_indptr, idx, vals = g.adj.h_indptr, g.adj.indices, g.adj.vals
+h_indptr, h_idx, vals = g.adj.h_indptr, g.adj.indices.cpu().numpy(), g.adj.vals
 variants = {}
-for flags, split, slen in itertools.product(range(8), (0, U), (256, 1024)):
-    if slen == 1024 and flags not in (0, 4, 7):
-        continue
+
+
+def add(name, flags, split, slen, idx=None):
     os.environ["SRH_SPMM_FLAGS"] = str(flags)
-    csr = ops.DeviceCSR(h_indptr, idx.cpu().numpy(), vals, (N, N), split_len=slen, xcd_split_row=split)
-    variants[(flags, "xcd" if split else "mix", slen)] = csr
+    variants[name] = ops.DeviceCSR(h_indptr, h_idx if idx is None else idx, vals, (N, N), split_len=slen,
+                                   xcd_split_row=split)
+
+
+add("seg     f0  xcd split1024", 0, U, 1024)
+for waves in (2048, 4096, 6144, 8192, 12288):
+    os.environ["SRH_SPMM_WAVES"] = str(waves)
+    add(f"stream  f10 xcd split1024 waves{waves}", 10, U, 1024)
+os.environ["SRH_SPMM_WAVES"] = "6144"
+add("stream  f10 mix split1024 waves6144", 10, 0, 1024)
+add("stream  f10 xcd split512  waves6144", 10, U, 512)
+add("stream  f10 xcd split2048 waves6144", 10, U, 2048)
+add("stream  f10 xcd split1024 waves6144 cols%4096", 10, U, 1024, (h_idx % 4096).astype(np.int32))
 ref = None
 for k, csr in variants.items():
+    if "cols%" in k:
+        continue
     out = ops.spmm(csr, x)
     if ref is None:
         ref = out
-    assert (out - ref).abs().max().item() < 1e-4, k
+    err = (out - ref).abs().max().item()
+    assert err < 1e-4, (k, err)
 ep = ops.make_epilogue(perturb_eps=0.2, philox_seed=1)
 times = {k: [] for k in variants}
 for rnd in range(7):
@@ -45,6 +60,16 @@ for rnd in range(7):
         b.record()
         torch.cuda.synchronize()
         times[k].append(a.elapsed_time(b) / 20 * 1e3)
-print(f"{'flags':>5s} {'order':>5s} {'split':>5s} {'median_us':>10s} {'min_us':>8s}")
+# reference points: a 56 MB device copy and the plain (no-epilogue) product
+src = torch.empty(56 * 2**20 // 4, device="cuda"); dst = torch.empty_like(src)
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    dst.copy_(src)
+a.record()
+for _ in range(20):
+    dst.copy_(src)
+b.record(); torch.cuda.synchronize()
+print(f"copy of 56 MiB (read+write 112 MiB): {a.elapsed_time(b) / 20 * 1e3:.2f} us")
+print(f"{'variant':52s} {'median_us':>10s} {'min_us':>8s}")
 for k, v in sorted(times.items(), key=lambda kv: np.median(kv[1])):
-    print(f"{k[0]:5d} {k[1]:>5s} {k[2]:5d} {np.median(v):10.2f} {min(v):8.2f}")
+    print(f"{k:52s} {np.median(v):10.2f} {min(v):8.2f}")
