@@ -79,7 +79,7 @@ def time_spmm_kernel(trainer, iters=50):
     from selfrec_amd import ops
     adj = trainer.graph.adj
     x, y = trainer.E0, trainer.Ha
-    ep = ops.make_epilogue(perturb_eps=trainer.eps, philox_seed=1, philox_offset=0)
+    ep = ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0)
     for _ in range(5):
         ops.spmm(adj, x, out=y, epilogue=ep)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -142,10 +142,10 @@ typedef struct srh_spmm_epilogue {
   int32_t flags;               /* OR of SRH_EPI_* ; 0 = plain y = A x                      */
   float eps;                   /* PERTURB magnitude                                          */
   const float* d_noise;        /* PERTURB: U[0,1) noise (n_rows, d) to inject, or NULL       */
-  uint64_t philox_seed;        /* PERTURB with d_noise == NULL: in-kernel Philox4x32-10,     */
-  uint64_t philox_offset;      /*   counter = (philox_offset + *d_philox_step * philox_stride */
-  const int64_t* d_philox_step;/*              + row, lane-quad); d_philox_step may be NULL  */
-  uint64_t philox_stride;
+  uint64_t rng_seed;        /* PERTURB with d_noise == NULL: in-kernel counter RNG,           */
+  uint64_t rng_offset;      /*   counter = (rng_offset + *d_rng_step * rng_stride */
+  const int64_t* d_rng_step;/*              + row, lane-quad); d_rng_step may be NULL  */
+  uint64_t rng_stride;
   int32_t n_prev;              /* MEAN: number of earlier layer tensors                      */
   int32_t n_add;               /* AXPY: number of addends                                    */
   const float* d_prev[SRH_MAX_PREV];

@@ -28,8 +28,8 @@ class SpmmEpilogue(C.Structure):
     """struct srh_spmm_epilogue (include/selfrec_hip.h)."""
     _fields_ = [
         ("flags", C.c_int32), ("eps", C.c_float), ("d_noise", C.c_void_p),
-        ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
-        ("d_philox_step", C.c_void_p), ("philox_stride", C.c_uint64),
+        ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
+        ("d_rng_step", C.c_void_p), ("rng_stride", C.c_uint64),
         ("n_prev", C.c_int32), ("n_add", C.c_int32),
         ("d_prev", C.c_void_p * SRH_MAX_PREV),
         ("mean_div", C.c_float), ("alpha", C.c_float),

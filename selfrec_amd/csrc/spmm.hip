@@ -56,12 +56,12 @@ struct DevEpilogue {
   float eps;
   const float* noise;
   uint32_t seed_lo, seed_hi, off_lo, off_hi;
-  const int64_t* philox_step;
-  uint64_t philox_stride;
+  const int64_t* rng_step;
+  uint64_t rng_stride;
   float alpha;
   int32_t n_prev, n_add;
   const float* prev[SRH_MAX_PREV];
-  float mean_div;
+  float mean_rcp;
   float* mean_out;
   const float* add[SRH_MAX_ADD];
   float add_scale[SRH_MAX_ADD];
@@ -70,18 +70,21 @@ struct DevEpilogue {
   const int64_t* mark_stamp;
 };
 
-// Philox4x32-10 (Salmon et al., SC'11), counter-based: no state in memory.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-    key.x += W0;
-    key.y += W1;
-  }
-  return ctr;
+// Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
+// so there is no generator state in memory and a captured graph replays with fresh noise by
+// bumping one device-side counter.  The mixer is the 2-multiply "lowbias32" integer hash (full
+// avalanche, bias < 0.2 bits): the perturbation only needs decorrelated U[0,1) draws, and
+// profiling showed the row epilogue -- not memory -- bounding the kernel, where Philox4x32-10
+// costs ~100 VALU ops per float4 against ~35 here.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint4 counter_rng4(uint64_t ctr, uint32_t sub, uint32_t seed_lo, uint32_t seed_hi) {
+  const uint32_t key = lowbias32((uint32_t)ctr ^ seed_lo) + lowbias32((uint32_t)(ctr >> 32) ^ seed_hi);
+  const uint32_t base = key + sub * 0x9E3779B1U;
+  return make_uint4(lowbias32(base), lowbias32(base + 0x85EBCA6BU), lowbias32(base + 0xC2B2AE35U),
+                    lowbias32(base + 0x27D4EB2FU));
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
@@ -105,17 +108,17 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
       nu = reinterpret_cast<const float4*>(ep.noise)[at];
     } else {
       uint64_t ctr = (((uint64_t)ep.off_hi << 32) | ep.off_lo) + (uint64_t)row;
-      if (ep.philox_step) ctr += (uint64_t)(*ep.philox_step) * ep.philox_stride;
-      uint4 r = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sub, 0u),
-                              make_uint2(ep.seed_lo, ep.seed_hi));
+      if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+      uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
       nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
     }
     float ss = group_sum<LPR>(f4_dot(nu, nu));
-    float nrm = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: v / max(||v||, eps)
-    y.x += (sgnf(y.x) * (nu.x / nrm)) * ep.eps;
-    y.y += (sgnf(y.y) * (nu.y / nrm)) * ep.eps;
-    y.z += (sgnf(y.z) * (nu.z / nrm)) * ep.eps;
-    y.w += (sgnf(y.w) * (nu.w / nrm)) * ep.eps;
+    // F.normalize: v / max(||v||, 1e-12); one reciprocal instead of four divisions (<= 1 ulp apart)
+    const float scale = ep.eps / fmaxf(sqrtf(ss), 1e-12f);
+    y.x += sgnf(y.x) * (nu.x * scale);
+    y.y += sgnf(y.y) * (nu.y * scale);
+    y.z += sgnf(y.z) * (nu.z * scale);
+    y.w += sgnf(y.w) * (nu.w * scale);
   }
   if (store) Y[at] = y;
   if (ep.flags & SRH_EPI_MEAN) {
@@ -128,7 +131,7 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
       m = y;
     }
     if (store) {
-      float4 o = make_float4(m.x / ep.mean_div, m.y / ep.mean_div, m.z / ep.mean_div, m.w / ep.mean_div);
+      float4 o = f4_scale(m, ep.mean_rcp);
       reinterpret_cast<float4*>(ep.mean_out)[at] = o;
     }
   }
@@ -223,6 +226,111 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
   row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Default kernel.  The two earlier variants turned out to be bound by instruction issue, not by
+// memory (same speed with x folded into 1 MB of L2; profiles/r01_b_*): ~400 wave-instructions per
+// short row, most of them the per-row epilogue run redundantly by all four row-groups and the
+// ds_bpermute broadcasts of (col,val).  This kernel
+//   * broadcasts (col,val) inside each 16-lane DPP row with v_mov_dpp row_newbcast (one VALU op,
+//     no LDS traffic): the lanes of a DPP row hold 16 consecutive entries and round t uses lane t;
+//   * gives every row-group its OWN short row (<= 64 non-zeros; 4 rows per wave at d=64), so the
+//     epilogue -- noise, normalisation, mean, stores -- runs once per wave for G rows and needs no
+//     cross-group reduction; rows are issued longest-first, so the G rows of a wave have (nearly)
+//     the same length;
+//   * keeps one wave per long row / split segment ("coop" tasks): there each row-group takes a
+//     block of 16 entries of a 16*G-entry chunk and the groups are summed at the end.
+// ---------------------------------------------------------------------------------------------
+struct Task {
+  int32_t kind, first, count, pad;   // kind 0: coop on segs[first]; kind 1: rows segs[first .. first+count)
+};
+constexpr int kShortRow = 64;
+
+template <int K>
+__device__ __forceinline__ int row_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xf, 0xf, false); }
+template <int K>
+__device__ __forceinline__ float row_bcast_f(float x) { return __int_as_float(row_bcast_i<K>(__float_as_int(x))); }
+
+// entries T0 .. T0+7 of the 16 that this lane's DPP row holds: 8 gathers in flight, then 8 FMAs
+template <int LPR, int T0>
+__device__ __forceinline__ void gather8(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
+  int cc[8];
+  float vv[8];
+  float4 xx[8];
+#define SRH_BC(T) cc[T] = row_bcast_i<T0 + T>(c); vv[T] = row_bcast_f<T0 + T>(v);
+  SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3) SRH_BC(4) SRH_BC(5) SRH_BC(6) SRH_BC(7)
+#undef SRH_BC
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    xx[t] = f4_zero();
+    if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];     // padding / dropped / dead columns: no gather
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                        const Seg* __restrict__ segs,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals,
+                                                        const float4* __restrict__ X, float4* __restrict__ Y,
+                                                        float4* __restrict__ partial, DevEpilogue ep) {
+  constexpr int G = 64 / LPR;          // row-groups per wave
+  constexpr int CH = 16 * G;           // entries per coop chunk
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
+  const Task tk = tasks[wave];
+  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
+  const int first = __builtin_amdgcn_readfirstlane(tk.first);
+  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  float4 acc = f4_zero();
+
+  if (kind == 0) {
+    const Seg sg = segs[first];
+    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
+    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    for (int base = s; base < e; base += CH) {
+      const int j = base + 16 * g + e16;
+      int c = 0;
+      float v = 0.f;
+      if (j < e) { c = indices[j]; v = vals[j]; }
+      if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
+      gather8<LPR, 0>(c, v, X, sub, acc);
+      if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+    }
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    if (slot < 0) row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+    else if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+    return;
+  }
+
+  // ---- one short row per row-group ----
+  const bool have = g < count;
+  const Seg sg = segs[first + (have ? g : 0)];
+  const int row = sg.row, s = sg.start;
+  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
+  const int e = live ? sg.end : s;
+  int maxlen = e - s;
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  for (int q = 0; q * 16 < maxlen; ++q) {
+    const int j = s + 16 * q + e16;
+    int c = 0;
+    float v = 0.f;
+    if (j < e) { c = indices[j]; v = vals[j]; }
+    if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
+    gather8<LPR, 0>(c, v, X, sub, acc);
+    if (maxlen - 16 * q > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+  }
+  row_epilogue<LPR>(acc, row, sub, live, Y, ep);
 }
 
 // Persistent, software-pipelined variant (the default).  Profiling the one-wave-per-segment kernel
@@ -347,6 +455,10 @@ struct srh_spmm_plan {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
   int32_t flags = 0;               // kernel variant, see spmm_seg_kernel; bit 8 = streaming kernel
+  // default kernel: one task per wave; a task list per row-group count (index log2(LPR / 8))
+  int32_t n_tasks[4] = {0, 0, 0, 0};
+  Task* d_tasks[4] = {nullptr, nullptr, nullptr, nullptr};
+  Seg* d_tsegs = nullptr;          // segments in task order
   int32_t n_waves = 0;             // streaming kernel: resident waves, each with its own segment list
   Seg* d_wsegs = nullptr;          // segments grouped by wave
   int32_t* d_wave_ptr = nullptr;   // n_waves + 1 offsets into d_wsegs
@@ -417,8 +529,52 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
   p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
   p->split_len = split_len;
-  p->flags = 8 | 2;
-  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 15;  // A/B knob for tools/spmm_ab.py
+  p->flags = 16;
+  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 31;  // A/B knob for tools/spmm_ab.py
+  // ---- default kernel: coop tasks (long rows / split pieces) then G short rows per task ----
+  // tsegs = coop(class 0) ++ coop(class 1) ++ short(class 0) ++ short(class 1), each longest first;
+  // one task list per row-group count G = 64/LPR in {8, 4, 2, 1}
+  std::vector<Seg> tsegs;
+  std::vector<Task> tasks[4];
+  {
+    const bool two_class = xcd_split_row > 0 && xcd_split_row < n_rows;
+    std::vector<Seg> coop[2], shorts[2];
+    for (const Seg& sgm : segs) {
+      const int cls = (two_class && sgm.row >= xcd_split_row) ? 1 : 0;
+      (((sgm.end - sgm.start) > kShortRow || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
+    }
+    auto longer2 = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
+    int32_t off[4];
+    for (int c = 0; c < 2; ++c) { std::stable_sort(coop[c].begin(), coop[c].end(), longer2); }
+    for (int c = 0; c < 2; ++c) { std::stable_sort(shorts[c].begin(), shorts[c].end(), longer2); }
+    off[0] = 0; off[1] = (int32_t)coop[0].size(); off[2] = off[1] + (int32_t)coop[1].size();
+    off[3] = off[2] + (int32_t)shorts[0].size();
+    for (int c = 0; c < 2; ++c) tsegs.insert(tsegs.end(), coop[c].begin(), coop[c].end());
+    for (int c = 0; c < 2; ++c) tsegs.insert(tsegs.end(), shorts[c].begin(), shorts[c].end());
+    for (int gi = 0; gi < 4; ++gi) {
+      const int Gr = 8 >> gi;                            // rows per wave for LPR = 8, 16, 32, 64
+      std::vector<Task>& out_t = tasks[gi];
+      size_t blk = 0;
+      // workgroup b = 4 consecutive tasks runs on XCD b % 8: class 0 -> XCDs 0-3, class 1 -> XCDs 4-7
+      auto emit = [&](size_t n0, size_t n1, int kind, int32_t base0, int32_t base1, int unit) {
+        size_t i0 = 0, i1 = 0;
+        while (i0 < n0 || i1 < n1) {
+          const bool want0 = (blk % 8) < 4;
+          for (int w = 0; w < 4 && (i0 < n0 || i1 < n1); ++w) {
+            const bool take0 = (want0 && i0 < n0) || i1 >= n1;
+            size_t& i = take0 ? i0 : i1;
+            const size_t n = take0 ? n0 : n1;
+            const int32_t cnt = (int32_t)std::min<size_t>(unit, n - i);
+            out_t.push_back({kind, (take0 ? base0 : base1) + (int32_t)i, cnt, 0});
+            i += cnt;
+          }
+          ++blk;
+        }
+      };
+      emit(coop[0].size(), coop[1].size(), 0, off[0], off[1], 1);
+      emit(shorts[0].size(), shorts[1].size(), 1, off[2], off[3], Gr);
+    }
+  }
   // ---- streaming kernel: balance the segments over a fixed set of resident waves (LPT greedy) ----
   std::vector<Seg> wsegs;
   std::vector<int32_t> wave_ptr;
@@ -450,6 +606,13 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   }
   hipError_t err = hipMalloc(&p->d_segs, sizeof(Seg) * segs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(&p->d_tsegs, sizeof(Seg) * tsegs.size());
+  if (err == hipSuccess) err = hipMemcpy(p->d_tsegs, tsegs.data(), sizeof(Seg) * tsegs.size(), hipMemcpyHostToDevice);
+  for (int gi = 0; gi < 4 && err == hipSuccess; ++gi) {
+    p->n_tasks[gi] = (int32_t)tasks[gi].size();
+    err = hipMalloc(&p->d_tasks[gi], sizeof(Task) * tasks[gi].size());
+    if (err == hipSuccess) err = hipMemcpy(p->d_tasks[gi], tasks[gi].data(), sizeof(Task) * tasks[gi].size(), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMalloc(&p->d_wsegs, sizeof(Seg) * wsegs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_wsegs, wsegs.data(), sizeof(Seg) * wsegs.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(&p->d_wave_ptr, sizeof(int32_t) * wave_ptr.size());
@@ -479,6 +642,8 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_partial) (void)hipFree(p->d_partial);
   if (p->d_slot_owner) (void)hipFree(p->d_slot_owner);
   if (p->d_tickets) (void)hipFree(p->d_tickets);
+  if (p->d_tsegs) (void)hipFree(p->d_tsegs);
+  for (int gi = 0; gi < 4; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
   if (p->d_wsegs) (void)hipFree(p->d_wsegs);
   if (p->d_wave_ptr) (void)hipFree(p->d_wave_ptr);
   delete p;
@@ -509,6 +674,20 @@ srh_status_t launch_variant(const srh_spmm_plan* p, const int32_t* d_indices, co
 template <int LPR>
 srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
                          const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
+  if ((p->flags & 16) && LPR >= 16) {        // (a DPP row is 16 lanes: d = 32 keeps the shuffle kernel)
+    constexpr int gi = (LPR == 8) ? 0 : (LPR == 16) ? 1 : (LPR == 32) ? 2 : 3;
+    spmm_rows_kernel<LPR><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+        p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+        reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+    SRH_LAUNCH_CHECK();
+    if (p->n_heavy > 0) {
+      spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
+                                                                  reinterpret_cast<const float4*>(p->d_partial),
+                                                                  reinterpret_cast<float4*>(d_y), ep);
+      SRH_LAUNCH_CHECK();
+    }
+    return SRH_OK;
+  }
   if (p->flags & 8) {
     spmm_stream_kernel<LPR, 0><<<p->n_waves / 4, 256, 0, st>>>(
         p->d_wsegs, p->d_wave_ptr, p->n_waves, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
@@ -549,10 +728,10 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.flags = epi->flags;
     ep.eps = epi->eps;
     ep.noise = epi->d_noise;
-    ep.seed_lo = (uint32_t)epi->philox_seed; ep.seed_hi = (uint32_t)(epi->philox_seed >> 32);
-    ep.off_lo = (uint32_t)epi->philox_offset; ep.off_hi = (uint32_t)(epi->philox_offset >> 32);
-    ep.philox_step = epi->d_philox_step;
-    ep.philox_stride = epi->philox_stride;
+    ep.seed_lo = (uint32_t)epi->rng_seed; ep.seed_hi = (uint32_t)(epi->rng_seed >> 32);
+    ep.off_lo = (uint32_t)epi->rng_offset; ep.off_hi = (uint32_t)(epi->rng_offset >> 32);
+    ep.rng_step = epi->d_rng_step;
+    ep.rng_stride = epi->rng_stride;
     ep.row_mark = epi->d_row_mark;
     ep.col_mark = epi->d_col_mark;
     ep.mark_stamp = epi->d_mark_stamp;
@@ -565,7 +744,7 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
         SRH_REQUIRE(epi->d_prev[t], "spmm_f32: null prev[%d]", t);
         ep.prev[t] = epi->d_prev[t];
       }
-      ep.mean_div = epi->mean_div;
+      ep.mean_rcp = 1.0f / epi->mean_div;
       ep.mean_out = epi->d_mean_out;
     }
     if (epi->flags & SRH_EPI_AXPY) {

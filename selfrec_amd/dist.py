@@ -50,7 +50,7 @@ class HipBackend:
         kw = {}
         if perturb is not None:
             eps, noise, seed, offset = perturb
-            kw.update(perturb_eps=eps, noise=noise, philox_seed=seed, philox_offset=offset)
+            kw.update(perturb_eps=eps, noise=noise, rng_seed=seed, rng_offset=offset)
         if mean is not None:
             prev, div, mean_out = mean
             kw.update(prev=prev, mean_div=div, mean_out=mean_out)
@@ -110,7 +110,7 @@ class ShardedTrainer:
     ranks of the default process group.  Same numerical spec as engine.FusedTrainer."""
 
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2,
-                 layer_cl=1, batch_size=2048, user_emb=None, item_emb=None, noise_fn=None, philox_seed=0x5E1F0EC,
+                 layer_cl=1, batch_size=2048, user_emb=None, item_emb=None, noise_fn=None, rng_seed=0x5E1F0EC,
                  backend=None, use_graph=False, **_unused):
         if model not in ("MF", "LightGCN", "XSimGCL"):
             raise SelfrecHipError(f"ShardedTrainer: model {model!r} is not sharded yet (MF, LightGCN, XSimGCL are)")
@@ -122,7 +122,7 @@ class ShardedTrainer:
         self.model, self.d, self.L = model, int(emb_size), (0 if model == "MF" else int(n_layers))
         self.lr, self.reg, self.cl_rate, self.eps, self.tau = float(lr), float(reg), float(cl_rate), float(eps), float(tau)
         self.layer_cl, self.B = int(layer_cl), int(batch_size)
-        self.noise_fn, self.philox_seed = noise_fn, int(philox_seed)
+        self.noise_fn, self.rng_seed = noise_fn, int(rng_seed)
         self.U, self.I = data.user_num, data.item_num
         self.N = self.U + self.I
         G, r, N, d = self.G, self.rank, self.N, self.d
@@ -211,7 +211,7 @@ class ShardedTrainer:
             kw = {}
             if perturbed:
                 off = (self.step_count * 16 + self._noise_call) * self.n_pad * self.G + self.rank * self.n_pad
-                kw["perturb"] = (self.eps, self._noise_shard(), self.philox_seed, off)
+                kw["perturb"] = (self.eps, self._noise_shard(), self.rng_seed, off)
                 self._noise_call += 1
             if k == self.L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:self.L - 1]

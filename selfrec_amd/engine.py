@@ -47,7 +47,7 @@ MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
 class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
-                 noise_fn=None, philox_seed=0x5E1F0EC, use_graph=False, device=None):
+                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None):
         if model not in MODELS:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
         ops._lib.require_gpu()
@@ -58,8 +58,8 @@ class FusedTrainer:
             self.tau = 0.2                       # hard-coded in the reference, SimGCL.py:48-49
         self.layer_cl, self.drop_rate, self.aug_type = int(layer_cl), float(drop_rate), int(aug_type)
         self.B = int(batch_size)
-        self.noise_fn = noise_fn                  # (N, d) -> tensor; None = in-kernel Philox
-        self.philox_seed = int(philox_seed)
+        self.noise_fn = noise_fn                  # (N, d) -> tensor; None = in-kernel counter RNG
+        self.rng_seed = int(rng_seed)
         if model != "MF" and self.L < 1:
             raise SelfrecHipError("n_layers must be >= 1")
         if model == "XSimGCL" and not (0 <= self.layer_cl <= self.L):
@@ -200,10 +200,10 @@ class FusedTrainer:
             kw = {}
             if perturbed:
                 noise = self._noise()
-                kw.update(perturb_eps=self.eps, noise=noise, philox_seed=self.philox_seed,
-                          philox_offset=(self._noise_call * self.N) & ((1 << 62) - 1),
-                          philox_step=self.cursor[1:2] if noise is None else None,
-                          philox_stride=self.N * 16)
+                kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed,
+                          rng_offset=(self._noise_call * self.N) & ((1 << 62) - 1),
+                          rng_step=self.cursor[1:2] if noise is None else None,
+                          rng_stride=self.N * 16)
                 self._noise_call += 1
             if k == L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
@@ -268,7 +268,7 @@ class FusedTrainer:
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
                         row_mark=self.mark, mark_item_offset=U)
-        self._noise_call = 0      # Philox counter = (adam step, perturbed-layer call no, row)
+        self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
         self.losses.zero_()
         if not self.sparse_reset:     # SimGCL / SGL: dense gradient buffers, dense memsets
             self.gE0.zero_()

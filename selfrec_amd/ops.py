@@ -197,8 +197,8 @@ class DeviceCSR:
         return DeviceCSR(None, None, vals, self.shape, device=self.vals.device, structure_of=self)
 
 
-def make_epilogue(*, perturb_eps=None, noise=None, philox_seed=0, philox_offset=0, philox_step=None,
-                  philox_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
+def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
+                  rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
                   row_mark=None, col_mark=None, mark_stamp=None):
     ep = SpmmEpilogue()
     keep = []
@@ -207,10 +207,10 @@ def make_epilogue(*, perturb_eps=None, noise=None, philox_seed=0, philox_offset=
         flags |= _lib.SRH_EPI_PERTURB
         ep.eps = float(perturb_eps)
         ep.d_noise = _p(noise, torch.float32, "noise")
-        ep.philox_seed, ep.philox_offset = int(philox_seed), int(philox_offset)
-        ep.d_philox_step = _p(philox_step, torch.int64, "philox_step")
-        ep.philox_stride = int(philox_stride)
-        keep += [noise, philox_step]
+        ep.rng_seed, ep.rng_offset = int(rng_seed), int(rng_offset)
+        ep.d_rng_step = _p(rng_step, torch.int64, "rng_step")
+        ep.rng_stride = int(rng_stride)
+        keep += [noise, rng_step]
     if mean_out is not None:
         flags |= _lib.SRH_EPI_MEAN
         prev = list(prev or [])

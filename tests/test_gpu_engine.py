@@ -92,7 +92,7 @@ def test_engine_backed_model_class_ranks_like_reference(golden_models, golden_me
 
 @pytest.mark.parametrize("name", ["XSimGCL", "SGL", "LightGCN"])
 def test_hipgraph_replay_equals_eager(golden_models, golden_meta, tiny_data, name):
-    """Same Philox stream, same batches: a captured step replayed == the eager launch sequence."""
+    """Same RNG stream, same batches: a captured step replayed == the eager launch sequence."""
     outs = []
     for use_graph in (False, True):
         tr = make_trainer(name, golden_models, golden_meta, tiny_data, noise_fn=None, use_graph=use_graph)

@@ -94,16 +94,16 @@ def test_spmm_epilogues_match_oracle():
     assert rel_err(out.cpu().numpy(), want) < 2e-6
 
 
-def test_spmm_philox_perturbation_properties():
+def test_spmm_rng_perturbation_properties():
     d, n = 64, 500
     m = powerlaw_csr(n, n, 6000, seed=9)
     x = np.random.default_rng(2).standard_normal((n, d)).astype(np.float32)
     csr = ops.DeviceCSR.from_scipy(m)
     tx = torch.from_numpy(x).to(DEV)
     base = ops.spmm(csr, tx)
-    a = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, philox_seed=7, philox_offset=0))
-    b = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, philox_seed=7, philox_offset=0))
-    c = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, philox_seed=7, philox_offset=n))
+    a = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=7, rng_offset=0))
+    b = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=7, rng_offset=0))
+    c = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=7, rng_offset=n))
     assert torch.equal(a, b) and not torch.equal(a, c)          # counter-based: reproducible, offset-dependent
     delta = (a - base).cpu().numpy()
     nz = np.abs(base.cpu().numpy()).sum(1) > 0
@@ -111,9 +111,9 @@ def test_spmm_philox_perturbation_properties():
     assert np.allclose(np.linalg.norm(delta[nz], axis=1), 0.2, rtol=1e-4)
     assert np.all(delta * np.sign(base.cpu().numpy()) >= -1e-7)
     step = torch.tensor([3], dtype=torch.int64, device=DEV)
-    e = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, philox_seed=7, philox_offset=0,
-                                                     philox_step=step, philox_stride=n))
-    f = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, philox_seed=7, philox_offset=3 * n))
+    e = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=7, rng_offset=0,
+                                                     rng_step=step, rng_stride=n))
+    f = ops.spmm(csr, tx, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=7, rng_offset=3 * n))
     assert torch.equal(e, f)
 
 

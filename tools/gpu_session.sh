@@ -27,6 +27,8 @@ prof)
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
   f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/prof_kernel_stats.txt && head -24 $OUT/prof_kernel_stats.txt
   find $OUT/prof -name "*.db" -size +40M -delete;;
+gather)
+  mkdir -p $OUT; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_bw.hip -o /tmp/gather_bw && timeout 300 /tmp/gather_bw > $OUT/gather_bw.log 2>&1; echo "gather exit $?"; cat $OUT/gather_bw.log;;
 ab)
   timeout 600 python tools/spmm_ab.py > $OUT/spmm_ab.log 2>&1; echo "ab exit $?"; tail -45 $OUT/spmm_ab.log;;
 pmc)

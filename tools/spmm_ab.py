@@ -31,14 +31,12 @@ def add(name, flags, split, slen, idx=None):
 
 
 add("seg     f0  xcd split1024", 0, U, 1024)
-for waves in (2048, 4096, 6144, 8192, 12288):
-    os.environ["SRH_SPMM_WAVES"] = str(waves)
-    add(f"stream  f10 xcd split1024 waves{waves}", 10, U, 1024)
 os.environ["SRH_SPMM_WAVES"] = "6144"
-add("stream  f10 mix split1024 waves6144", 10, 0, 1024)
-add("stream  f10 xcd split512  waves6144", 10, U, 512)
-add("stream  f10 xcd split2048 waves6144", 10, U, 2048)
-add("stream  f10 xcd split1024 waves6144 cols%4096", 10, U, 1024, (h_idx % 4096).astype(np.int32))
+add("stream  f10 xcd split1024 waves6144", 10, U, 1024)
+for slen in (512, 1024, 2048):
+    add(f"rows    f16 xcd split{slen}", 16, U, slen)
+add("rows    f16 mix split1024", 16, 0, 1024)
+add("rows    f16 xcd split1024 cols%4096", 16, U, 1024, (h_idx % 4096).astype(np.int32))
 ref = None
 for k, csr in variants.items():
     if "cols%" in k:
@@ -48,9 +46,19 @@ for k, csr in variants.items():
         ref = out
     err = (out - ref).abs().max().item()
     assert err < 1e-4, (k, err)
-ep = ops.make_epilogue(perturb_eps=0.2, philox_seed=1)
-times = {k: [] for k in variants}
+ep = ops.make_epilogue(perturb_eps=0.2, rng_seed=1)
+plain = {f"{k} [no epilogue]": v for k, v in variants.items() if k.startswith(("rows    f16 xcd split1024", "seg"))}
+times = {k: [] for k in list(variants) + list(plain)}
 for rnd in range(7):
+    for k, csr in plain.items():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(20):
+            ops.spmm(csr, x, out=y)
+        b.record()
+        torch.cuda.synchronize()
+        times[k].append(a.elapsed_time(b) / 20 * 1e3)
     for k, csr in variants.items():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
