@@ -476,7 +476,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
-  if (split_len <= 0) split_len = 1024;
+  if (split_len <= 0) split_len = 512;
   SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
   SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
   SRH_REQUIRE(xcd_split_row >= 0 && xcd_split_row <= n_rows, "spmm_plan_create: xcd_split_row out of range");
