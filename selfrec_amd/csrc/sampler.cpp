@@ -14,6 +14,7 @@
 // The data-dependent rejection loop makes the stream inherently sequential, so this runs on
 // a host core (tens of ns per draw) and is overlapped with the device step by the caller.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -90,16 +91,30 @@ struct MT19937 {
 struct srh_sampler {
   int64_t n_users = 0, n_items = 0, n_edges = 0;
   std::vector<int32_t> edge_u, edge_i;      // as given at create time
-  std::vector<int64_t> order;               // persistent order of training_data
+  std::vector<uint32_t> order;              // persistent order of training_data (edge numbers)
   std::vector<int64_t> row_ptr;             // user -> sorted positive items
   std::vector<int32_t> row_items;
+  // Membership signature per user: a bitmap of >= 16 bits per positive item (256 bits minimum, a
+  // few MB in total, cache resident).  A clear bit proves "not rated" without touching the user's
+  // item list -- the common case by far; once the bitmap is as large as the catalogue it is exact.
+  std::vector<uint64_t> sig;
+  std::vector<uint32_t> sig_off;            // first 64-bit word of user u's bitmap
+  std::vector<uint8_t> sig_log2;            // log2(bits) of user u's bitmap; 255 = exact item bitmap
+  std::vector<uint64_t> seen_u, seen_i;     // scratch bitmaps for the per-batch sorted unique ids
   MT19937 rng;
   bool seeded = false;
 
+  inline uint32_t sig_bit(int32_t u, int32_t item) const {
+    const uint8_t lg = sig_log2[u];
+    return lg == 255 ? (uint32_t)item : ((uint32_t)item * 0x9E3779B1U) >> (32 - lg);
+  }
   inline bool rated(int32_t u, int32_t item) const {
-    const int32_t* b = row_items.data() + row_ptr[u];
-    const int32_t* e = row_items.data() + row_ptr[u + 1];
-    return std::binary_search(b, e, item);
+    const uint32_t b = sig_bit(u, item);
+    if (!((sig[(size_t)sig_off[u] + (b >> 6)] >> (b & 63)) & 1ULL)) return false;
+    if (sig_log2[u] == 255) return true;
+    const int32_t* lo = row_items.data() + row_ptr[u];
+    const int32_t* hi = row_items.data() + row_ptr[u + 1];
+    return std::binary_search(lo, hi, item);
   }
 };
 
@@ -120,7 +135,7 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
     s->edge_i.assign(h_edge_item, h_edge_item + n_edges);
   }
   s->order.resize(n_edges);
-  for (int64_t e = 0; e < n_edges; ++e) s->order[e] = e;
+  for (int64_t e = 0; e < n_edges; ++e) s->order[e] = (uint32_t)e;
   s->row_ptr.assign(n_users + 1, 0);
   for (int64_t e = 0; e < n_edges; ++e) {
     int32_t u = s->edge_u[e], it = s->edge_i[e];
@@ -137,6 +152,30 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
   for (int64_t e = 0; e < n_edges; ++e) s->row_items[fill[s->edge_u[e]]++] = s->edge_i[e];
   for (int64_t u = 0; u < n_users; ++u)
     std::sort(s->row_items.begin() + s->row_ptr[u], s->row_items.begin() + s->row_ptr[u + 1]);
+  s->sig_off.resize(n_users);
+  s->sig_log2.resize(n_users);
+  size_t words = 0;
+  for (int64_t u = 0; u < n_users; ++u) {
+    const int64_t deg = s->row_ptr[u + 1] - s->row_ptr[u];
+    int lg = 8;
+    while ((int64_t(1) << lg) < 16 * deg) ++lg;
+    s->sig_off[u] = (uint32_t)words;
+    if ((int64_t(1) << lg) >= n_items) {                  // as large as the catalogue: make it exact
+      s->sig_log2[u] = 255;
+      words += (size_t)(n_items + 63) / 64;
+    } else {
+      s->sig_log2[u] = (uint8_t)lg;
+      words += (size_t)1 << (lg - 6);
+    }
+  }
+  s->sig.assign(words, 0);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    const int32_t u = s->edge_u[e];
+    const uint32_t b = s->sig_bit(u, s->edge_i[e]);
+    s->sig[(size_t)s->sig_off[u] + (b >> 6)] |= 1ULL << (b & 63);
+  }
+  s->seen_u.assign((size_t)(n_users + 63) / 64, 0);
+  s->seen_i.assign((size_t)(n_items + 63) / 64, 0);
   *out = s;
   return SRH_OK;
 }
@@ -180,17 +219,28 @@ static srh_status_t require_seeded(const srh_sampler_t* s, const char* who) {
 srh_status_t srh_sampler_shuffle(srh_sampler_t* s) {
   srh_status_t st = require_seeded(s, "sampler_shuffle");
   if (st) return st;
-  int64_t* x = s->order.data();
-  for (int64_t i = s->n_edges - 1; i >= 1; --i) {
-    uint32_t j = s->rng.randbelow((uint32_t)(i + 1));
-    std::swap(x[i], x[j]);
+  // Fisher-Yates.  The draws do not depend on the data, so they run a few iterations ahead of
+  // the swaps and their targets are prefetched: the random access into the (5 MB at Yelp
+  // shape) order array is what costs, not the generator.
+  uint32_t* x = s->order.data();
+  constexpr int kAhead = 16;
+  uint32_t js[kAhead];
+  int64_t i = s->n_edges - 1;
+  while (i >= 1) {
+    const int n = (int)std::min<int64_t>(kAhead, i);
+    for (int k = 0; k < n; ++k) {
+      js[k] = s->rng.randbelow((uint32_t)(i - k + 1));
+      __builtin_prefetch(x + js[k], 1);
+    }
+    for (int k = 0; k < n; ++k) std::swap(x[i - k], x[js[k]]);
+    i -= n;
   }
   return SRH_OK;
 }
 
 srh_status_t srh_sampler_get_order(const srh_sampler_t* s, int64_t* h_perm) {
   SRH_REQUIRE(s && h_perm, "sampler_get_order: null argument");
-  std::memcpy(h_perm, s->order.data(), sizeof(int64_t) * s->n_edges);
+  for (int64_t e = 0; e < s->n_edges; ++e) h_perm[e] = (int64_t)s->order[e];
   return SRH_OK;
 }
 
@@ -199,7 +249,18 @@ static inline int64_t batch_into(srh_sampler_t* s, int64_t ptr, int64_t batch_si
   const int64_t end = (ptr + batch_size < s->n_edges) ? ptr + batch_size : s->n_edges;
   const uint32_t n_items = (uint32_t)s->n_items;
   int64_t w = 0;
+  constexpr int64_t kAhead = 32;
   for (int64_t p = ptr; p < end; ++p) {
+    if (p + kAhead < end) {                       // hide the two dependent random accesses
+      const uint32_t ea = s->order[p + kAhead];
+      __builtin_prefetch(s->edge_u.data() + ea);
+      __builtin_prefetch(s->edge_i.data() + ea);
+    }
+    if (p + kAhead / 2 < end) {
+      const int32_t un = s->edge_u[s->order[p + kAhead / 2]];
+      __builtin_prefetch(s->sig_off.data() + un);
+      __builtin_prefetch(s->sig_log2.data() + un);
+    }
     const int64_t e = s->order[p];
     const int32_t uu = s->edge_u[e];
     u[p - ptr] = uu;
@@ -225,11 +286,24 @@ srh_status_t srh_sampler_next_batch(srh_sampler_t* s, int64_t ptr, int64_t batch
   return SRH_OK;
 }
 
-static int32_t sorted_unique(const int32_t* src, int64_t n, int32_t* dst, std::vector<int32_t>& tmp) {
-  tmp.assign(src, src + n);
-  std::sort(tmp.begin(), tmp.end());
-  int32_t m = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
-  std::memcpy(dst, tmp.data(), sizeof(int32_t) * m);
+// sorted unique ids of one batch: mark a bitmap, then sweep the touched 64-bit words in order
+static int32_t sorted_unique(const int32_t* src, int64_t n, int32_t* dst, std::vector<uint64_t>& seen) {
+  int32_t lo = INT32_MAX, hi = -1;
+  for (int64_t k = 0; k < n; ++k) {
+    const int32_t v = src[k];
+    seen[(size_t)v >> 6] |= 1ULL << (v & 63);
+    lo = std::min(lo, v >> 6);
+    hi = std::max(hi, v >> 6);
+  }
+  int32_t m = 0;
+  for (int32_t wd = lo; wd <= hi; ++wd) {
+    uint64_t bits = seen[wd];
+    seen[wd] = 0;
+    while (bits) {
+      dst[m++] = (wd << 6) + __builtin_ctzll(bits);
+      bits &= bits - 1;
+    }
+  }
   return m;
 }
 
@@ -246,13 +320,12 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
               "sampler_epoch: unique outputs must be given together");
   st = srh_sampler_shuffle(s);
   if (st) return st;
-  std::vector<int32_t> tmp;
   int64_t b = 0;
   for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
     int64_t cnt = batch_into(s, ptr, batch_size, n_negs, h_u + ptr, h_i + ptr, h_j + ptr * n_negs);
     if (want_uniq) {
-      h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, tmp);
-      h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, tmp);
+      h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, s->seen_u);
+      h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, s->seen_i);
     }
     ptr += cnt;
   }
