@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 6
+#define SRH_ABI_VERSION 7
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -224,6 +224,22 @@ srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int
                                  int64_t n, const int32_t* d_n, int32_t d, float tau,
                                  float loss_scale, double* d_loss, float* d_g1, float* d_g2,
                                  void* d_ws, void* stream);
+
+/* Several InfoNCE problems in one set of launches (XSimGCL's user side and item side share every
+ * kernel: half the launches, twice the resident waves).  d_ws must hold the SUM of
+ * srh_infonce_ws_bytes(problems[k].n, d); at most 4 problems per call.  `problems` is a HOST array. */
+typedef struct srh_infonce_problem {
+  const float* d_v1;
+  const float* d_v2;
+  const int32_t* d_idx;
+  int64_t n;
+  const int32_t* d_n;
+  float* d_g1;
+  float* d_g2;
+} srh_infonce_problem_t;
+srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems,
+                                       int32_t d, float tau, float loss_scale, double* d_loss,
+                                       void* d_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-9) Dense Adam -- replaces torch.optim.Adam(...).step() at XSimGCL.py:25,37

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -22,6 +22,12 @@ SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
 
 class SelfrecHipError(RuntimeError):
     pass
+
+
+class InfonceProblem(C.Structure):
+    """struct srh_infonce_problem (include/selfrec_hip.h)."""
+    _fields_ = [("d_v1", C.c_void_p), ("d_v2", C.c_void_p), ("d_idx", C.c_void_p), ("n", C.c_int64),
+                ("d_n", C.c_void_p), ("d_g1", C.c_void_p), ("d_g2", C.c_void_p)]
 
 
 class SpmmEpilogue(C.Structure):
@@ -70,6 +76,7 @@ SIGNATURES = {
     "srh_sumsq": (_i32, [_vp, _i64, _vp, _vp]),
     "srh_infonce_ws_bytes": (_i64, [_i64, _i32]),
     "srh_infonce_fwd_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "srh_infonce_fwd_bwd_multi": (_i32, [C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
     "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
     "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),

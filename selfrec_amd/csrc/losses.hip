@@ -199,6 +199,17 @@ struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
   double* losspart;     // one partial per finish wave
   int64_t np;
+  // the problem this workspace belongs to (several InfoNCE problems share each launch: blockIdx.z)
+  const float *src1, *src2;
+  const int32_t* idx;
+  const int32_t* d_n;
+  int n_max;
+  float *g1, *g2;
+};
+constexpr int kNceMaxProblems = 4;
+struct NceBatch {
+  NceWs w[kNceMaxProblems];
+  int count;
 };
 
 __host__ __device__ inline int64_t nce_pad(int64_t n) { return (n + 63) / 64 * 64; }
@@ -221,11 +232,14 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
 
 // normalise (and gather) the rows of both views; rows >= n are zero-filled
 template <int LPR>
-__global__ __launch_bounds__(256) void nce_prep(const float* __restrict__ V1, const float* __restrict__ V2,
-                                                const int32_t* __restrict__ idx, int n_max,
-                                                const int32_t* __restrict__ d_n, NceWs w) {
+__global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
   constexpr int G = 64 / LPR;
-  const int n = d_n ? min(*d_n, n_max) : n_max;
+  const NceWs& w = batch.w[blockIdx.z];
+  const float* V1 = w.src1;
+  const float* V2 = w.src2;
+  const int32_t* idx = w.idx;
+  const int n_max = w.n_max;
+  const int n = w.d_n ? min(*w.d_n, n_max) : n_max;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
   const bool second = blockIdx.y == 1;
@@ -254,10 +268,11 @@ __global__ __launch_bounds__(256) void nce_prep(const float* __restrict__ V1, co
 // Swapped product (S^T = K Q^T) puts a query's weights for keys 4g+r in lane (q, g), which
 // is exactly the A-operand layout of the following  P V  product -- no LDS, no permutes.
 template <int D, bool PASS2>
-__global__ __launch_bounds__(256) void nce_tile(NceWs w, int n_max, const int32_t* __restrict__ d_n, float inv_tau) {
+__global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
   constexpr int DQ = D / 4;      // floats of a row per lane for the S product (k-steps)
   constexpr int NT = D / 16;     // 16-column n-tiles of the PV product
-  const int n = d_n ? min(*d_n, n_max) : n_max;
+  const NceWs& w = batch.w[blockIdx.z];
+  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
   const int np = (int)w.np;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -351,18 +366,15 @@ __global__ __launch_bounds__(256) void nce_tile(NceWs w, int n_max, const int32_
 }
 
 struct NceFinishArgs {
-  const int32_t* idx;
-  int n_max;
-  const int32_t* d_n;
   float inv_tau, loss_scale;
   double* loss;
-  float *g1, *g2;
 };
 
 template <int LPR, bool PASS2>
-__global__ __launch_bounds__(256) void nce_finish(NceWs w, NceFinishArgs a) {
+__global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs a) {
   constexpr int G = 64 / LPR;
-  const int n = a.d_n ? min(*a.d_n, a.n_max) : a.n_max;
+  const NceWs& w = batch.w[blockIdx.z];
+  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
   if (n <= 0) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256) void nce_finish(NceWs w, NceFinishArgs a) {
       double t = 0.0;
       for (int k = threadIdx.x; k < n_waves; k += 64) t += w.losspart[k];
       t = wave_sum_d(t);
-      if (threadIdx.x == 0) a.loss[0] += (double)a.loss_scale * t / (double)n;
+      if (threadIdx.x == 0) atomicAdd(a.loss, (double)a.loss_scale * t / (double)n);   // one per problem
     }
     dn = make_float4(coef * (O.x - va.x), coef * (O.y - va.y), coef * (O.z - va.z), coef * (O.w - va.w));
     norm = w.norm2[ii];
@@ -414,34 +426,43 @@ __global__ __launch_bounds__(256) void nce_finish(NceWs w, NceFinishArgs a) {
     dv = f4_scale(dn, 1e12f);
   }
   if (valid) {
-    const int dst = a.idx ? a.idx[i] : i;
-    float4* gp = reinterpret_cast<float4*>(PASS2 ? a.g2 : a.g1) + (size_t)dst * LPR + sub;
+    const int dst = w.idx ? w.idx[i] : i;
+    float4* gp = reinterpret_cast<float4*>(PASS2 ? w.g2 : w.g1) + (size_t)dst * LPR + sub;
     float4 cur = *gp;
     *gp = f4_add(cur, dv);
   }
 }
 
 template <int D>
-srh_status_t launch_infonce(const float* v1, const float* v2, const int32_t* idx, int n, const int32_t* d_n,
-                            float tau, float loss_scale, double* loss, float* g1, float* g2, void* ws,
-                            hipStream_t st) {
+srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float tau, float loss_scale, double* loss,
+                            void* ws, hipStream_t st) {
   constexpr int LPR = D / 4, G = 64 / LPR;
-  NceWs w = carve_nce(ws, n, D);
-  const int np = (int)w.np;
+  NceBatch batch{};
+  batch.count = count;
+  int np_max = 0;
+  char* cursor = reinterpret_cast<char*>(ws);
+  for (int k = 0; k < count; ++k) {
+    NceWs w = carve_nce(cursor, pr[k].n, D);
+    cursor += srh_infonce_ws_bytes(pr[k].n, D);
+    w.src1 = pr[k].d_v1; w.src2 = pr[k].d_v2; w.idx = pr[k].d_idx; w.d_n = pr[k].d_n; w.n_max = (int)pr[k].n;
+    w.g1 = pr[k].d_g1; w.g2 = pr[k].d_g2;
+    batch.w[k] = w;
+    np_max = std::max(np_max, (int)w.np);
+  }
   const float inv_tau = 1.0f / tau;
-  dim3 gp((np / G + 3) / 4, 2);
-  nce_prep<LPR><<<gp, 256, 0, st>>>(v1, v2, idx, n, d_n, w);
+  dim3 gp((np_max / G + 3) / 4, 2, count);
+  nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
   SRH_LAUNCH_CHECK();
-  dim3 gt(np / 64, kNceSplits);
-  nce_tile<D, false><<<gt, 256, 0, st>>>(w, n, d_n, inv_tau);
+  dim3 gt(np_max / 64, kNceSplits, count);
+  nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
-  NceFinishArgs fa{idx, n, d_n, inv_tau, loss_scale, loss, g1, g2};
-  const int fb = (np / G + 3) / 4;
-  nce_finish<LPR, false><<<fb, 256, 0, st>>>(w, fa);
+  NceFinishArgs fa{inv_tau, loss_scale, loss};
+  dim3 fb((np_max / G + 3) / 4, 1, count);
+  nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
-  nce_tile<D, true><<<gt, 256, 0, st>>>(w, n, d_n, inv_tau);
+  nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
-  nce_finish<LPR, true><<<fb, 256, 0, st>>>(w, fa);
+  nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }
@@ -546,19 +567,30 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np + 256;
 }
 
-srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,
-                                 const int32_t* d_n, int32_t d, float tau, float loss_scale, double* d_loss,
-                                 float* d_g1, float* d_g2, void* d_ws, void* stream) {
-  SRH_REQUIRE(d_v1 && d_v2 && d_loss && d_g1 && d_g2 && d_ws, "infonce_fwd_bwd: null argument");
-  SRH_REQUIRE(n > 0 && n < (int64_t(1) << 24), "infonce_fwd_bwd: bad n");
+srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,
+                                       float tau, float loss_scale, double* d_loss, void* d_ws, void* stream) {
+  SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
+  SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);
   SRH_REQUIRE(d == 64 || d == 128, "infonce_fwd_bwd: d=%d unsupported (need 64 or 128)", d);
+  for (int k = 0; k < n_problems; ++k) {
+    const srh_infonce_problem_t& p = problems[k];
+    SRH_REQUIRE(p.d_v1 && p.d_v2 && p.d_g1 && p.d_g2, "infonce_fwd_bwd: null tensor in problem %d", k);
+    SRH_REQUIRE(p.n > 0 && p.n < (int64_t(1) << 24), "infonce_fwd_bwd: bad n in problem %d", k);
+  }
   if (!(tau >= 0.03f)) {
     srh::set_error("infonce_fwd_bwd: temperature %g below 0.03 needs a running max (not implemented)", (double)tau);
     return SRH_ERR_UNSUPPORTED;
   }
   hipStream_t st = srh::as_stream(stream);
-  if (d == 64) return launch_infonce<64>(d_v1, d_v2, d_idx, (int)n, d_n, tau, loss_scale, d_loss, d_g1, d_g2, d_ws, st);
-  return launch_infonce<128>(d_v1, d_v2, d_idx, (int)n, d_n, tau, loss_scale, d_loss, d_g1, d_g2, d_ws, st);
+  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st);
+  return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st);
+}
+
+srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,
+                                 const int32_t* d_n, int32_t d, float tau, float loss_scale, double* d_loss,
+                                 float* d_g1, float* d_g2, void* d_ws, void* stream) {
+  srh_infonce_problem_t p{d_v1, d_v2, d_idx, n, d_n, d_g1, d_g2};
+  return srh_infonce_fwd_bwd_multi(&p, 1, d, tau, loss_scale, d_loss, d_ws, stream);
 }
 
 }  // extern "C"

@@ -108,7 +108,10 @@ class FusedTrainer:
         self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)        # batch no, adam step
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
-        self.nce_ws = ops.infonce_ws(2 * B if model == "SGL" else B, d, dev) if model in ("XSimGCL", "SimGCL", "SGL") else None
+        self.nce_ws = None
+        if model in ("XSimGCL", "SimGCL", "SGL"):       # user side + item side share one workspace / launch set
+            one = ops.infonce_ws(2 * B if model == "SGL" else B, d, dev)
+            self.nce_ws = torch.empty(one.numel() * (1 if model == "SGL" else 2), dtype=torch.uint8, device=dev)
         self.sampler = ops.Sampler(data.train_u, data.train_i, self.U, self.I)
         E = self.sampler.n_edges
         self.epoch_batches = (E + B - 1) // B
@@ -299,11 +302,9 @@ class FusedTrainer:
         # ---- contrastive loss (a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
-            for lo, idx, n_dev in ((0, st["uniq_u"], nuu_dev), (U, st["uniq_i"], nui_dev)):
-                ops.infonce_fwd_bwd(F[lo:lo + (U if lo == 0 else self.I)], CL[lo:lo + (U if lo == 0 else self.I)],
-                                    idx, self.B, n_dev=n_dev, tau=self.tau, loss_scale=self.cl_rate,
-                                    loss=self.losses[2:3], g1=self.gF[lo:lo + (U if lo == 0 else self.I)],
-                                    g2=self.gCL[lo:lo + (U if lo == 0 else self.I)], ws=self.nce_ws)
+            ops.infonce_multi([(F[:U], CL[:U], st["uniq_u"], self.B, nuu_dev, self.gF[:U], self.gCL[:U]),
+                               (F[U:], CL[U:], st["uniq_i"], self.B, nui_dev, self.gF[U:], self.gCL[U:])],
+                              d=self.d, tau=self.tau, loss_scale=self.cl_rate, loss=self.losses[2:3], ws=self.nce_ws)
         elif m in ("SimGCL", "SGL"):
             for vi, v in enumerate(self.views):
                 adj = g.adj if m == "SimGCL" else self.view_adj[vi]
@@ -311,10 +312,10 @@ class FusedTrainer:
                                    batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
-                for lo, hi, idx, n_dev in ((0, U, st["uniq_u"], nuu_dev), (U, self.N, st["uniq_i"], nui_dev)):
-                    ops.infonce_fwd_bwd(a["F"][lo:hi], b["F"][lo:hi], idx, self.B, n_dev=n_dev, tau=self.tau,
-                                        loss_scale=self.cl_rate, loss=self.losses[2:3], g1=a["gF"][lo:hi],
-                                        g2=b["gF"][lo:hi], ws=self.nce_ws)
+                ops.infonce_multi([(a["F"][:U], b["F"][:U], st["uniq_u"], self.B, nuu_dev, a["gF"][:U], b["gF"][:U]),
+                                   (a["F"][U:], b["F"][U:], st["uniq_i"], self.B, nui_dev, a["gF"][U:], b["gF"][U:])],
+                                  d=self.d, tau=self.tau, loss_scale=self.cl_rate, loss=self.losses[2:3],
+                                  ws=self.nce_ws)
             else:
                 self._build_cat_index()
                 ops.infonce_fwd_bwd(a["F"], b["F"], self.stage_cat, 2 * self.B, n_dev=self.n_cat, tau=self.tau,

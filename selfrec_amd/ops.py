@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "infonce_fwd_bwd", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
+           "sumsq", "infonce_fwd_bwd", "infonce_multi", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
            "axpby", "batch_fetch", "zero_rows", "SelfrecHipError"]
 
 
@@ -321,6 +321,22 @@ def infonce_fwd_bwd(v1, v2, idx, n, *, n_dev=None, tau, loss_scale, loss, g1, g2
                                           _p(n_dev, torch.int32), d, float(tau), float(loss_scale),
                                           _p(loss, torch.float64), _p(g1, torch.float32), _p(g2, torch.float32),
                                           _p(ws), _stream()), "srh_infonce_fwd_bwd")
+
+
+def infonce_multi(problems, *, d, tau, loss_scale, loss, ws):
+    """problems: [(v1, v2, idx, n_max, n_dev, g1, g2), ...] evaluated by one set of launches."""
+    lib = _lib.load()
+    arr = (_lib.InfonceProblem * len(problems))()
+    need = 0
+    for k, (v1, v2, idx, n, n_dev, g1, g2) in enumerate(problems):
+        arr[k].d_v1, arr[k].d_v2 = _p(v1, torch.float32), _p(v2, torch.float32)
+        arr[k].d_idx, arr[k].n, arr[k].d_n = _p(idx, torch.int32), int(n), _p(n_dev, torch.int32)
+        arr[k].d_g1, arr[k].d_g2 = _p(g1, torch.float32), _p(g2, torch.float32)
+        need += int(lib.srh_infonce_ws_bytes(n, d))
+    if ws.numel() * ws.element_size() < need:
+        raise SelfrecHipError(f"infonce workspace too small: {ws.numel() * ws.element_size()} < {need}")
+    check(lib.srh_infonce_fwd_bwd_multi(arr, len(problems), int(d), float(tau), float(loss_scale),
+                                        _p(loss, torch.float64), _p(ws), _stream()), "srh_infonce_fwd_bwd_multi")
 
 
 # ----------------------------------------------------------------------------------------
