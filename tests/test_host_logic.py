@@ -88,3 +88,28 @@ def test_synthetic_generator_invariants():
     assert len(np.unique(keys)) == len(keys)
     tu2, *_ = synth.make_dataset("small")
     assert np.array_equal(tu, tu2)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model/graph"), reason="reference checkout not present")
+def test_reference_model_files_import_against_the_mirrors():
+    """dropin.install(): the reference's unmodified model files resolve base.* / util.* / data.* to
+    this package (construction needs a GPU; resolution does not)."""
+    import importlib
+    import sys
+    from selfrec_amd import dropin
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("base", "data", "util", "model")}
+    sys.dont_write_bytecode = True
+    dropin.install()
+    sys.path.insert(0, "/root/reference")
+    try:
+        for name in ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL"):
+            mod = importlib.import_module(f"model.graph.{name}")
+            cls = getattr(mod, name)
+            assert cls.__mro__[1].__module__ == "selfrec_amd.base.graph_recommender"
+            assert mod.next_batch_pairwise.__module__ == "selfrec_amd.util.sampler"
+            assert mod.bpr_loss.__module__ == "selfrec_amd.util.loss_torch"
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k.split(".")[0] in ("base", "data", "util", "model")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
