@@ -4,6 +4,8 @@
 // These kernels touch only O(batch) rows; what matters is launch count and, for InfoNCE,
 // the 4 x (2 n^2 d) flops of the similarity products, which run on the fp32 MFMA pipe
 // (v_mfma_f32_16x16x4_f32: exact f32 fma chains, so the 1e-4 parity budget is untouched).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -198,6 +200,11 @@ constexpr int kNceSplits = 8;
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
   double* losspart;     // one partial per finish wave
+  // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
+  //   kq_*[view]  row-major (np, D): K / Q operands of the similarity product
+  //   vt_*[view]  (np/32, D, 32): per 32-key block, per column, the 32 keys in MFMA k-order
+  //               (position 8g + 4h + r  <->  key 16h + 4g + r): V operand of the P.V product
+  uint16_t *kq_hi[2], *kq_lo[2], *vt_hi[2], *vt_lo[2];
   int64_t np;
   // the problem this workspace belongs to (several InfoNCE problems share each launch: blockIdx.z)
   const float *src1, *src2;
@@ -227,6 +234,13 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
   w.lpart = p; p += (int64_t)kNceSplits * np;
   w.invl = p; p += np;
   w.losspart = reinterpret_cast<double*>(p);     // np doubles (np is a multiple of 64: 8-byte aligned)
+  uint16_t* h = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(p) + np);
+  for (int v = 0; v < 2; ++v) {
+    w.kq_hi[v] = h; h += np * d;
+    w.kq_lo[v] = h; h += np * d;
+    w.vt_hi[v] = h; h += np * d;
+    w.vt_lo[v] = h; h += np * d;
+  }
   return w;
 }
 
@@ -258,6 +272,30 @@ __global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
   if (in_pad) {
     reinterpret_cast<float4*>(out)[(size_t)i * LPR + sub] = o;
     if (sub == 0) nrm[i] = valid ? norm : 0.f;
+    // split-bf16 images for the MFMA passes
+    const int view = second ? 1 : 0;
+    constexpr int D = LPR * 4;
+    const float f[4] = {o.x, o.y, o.z, o.w};
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const __bf16 bh = (__bf16)f[t];
+      const __bf16 bl = (__bf16)(f[t] - (float)bh);
+      hi[t] = __builtin_bit_cast(uint16_t, bh);
+      lo[t] = __builtin_bit_cast(uint16_t, bl);
+    }
+    uint2 ph = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+    uint2 pl = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+    *reinterpret_cast<uint2*>(w.kq_hi[view] + (size_t)i * D + 4 * sub) = ph;
+    *reinterpret_cast<uint2*>(w.kq_lo[view] + (size_t)i * D + 4 * sub) = pl;
+    const int blk = i >> 5, k = i & 31;
+    const int pos = 8 * ((k & 15) >> 2) + 4 * (k >> 4) + (k & 3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const size_t at = ((size_t)blk * D + 4 * sub + t) * 32 + pos;
+      w.vt_hi[view][at] = hi[t];
+      w.vt_lo[view][at] = lo[t];
+    }
   }
 }
 
@@ -365,6 +403,117 @@ __global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
   }
 }
 
+// Split-bf16 version of nce_tile (the default): every f32 operand x is carried as hi + lo with
+// hi = bf16(x), lo = bf16(x - hi), and a product a.b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
+// on v_mfma_f32_16x16x32_bf16 with f32 accumulation -- 3 MFMAs at 16x the f32-MFMA rate.  The dropped
+// a_lo b_lo term is 2^-16 relative; measured against fp64 at n = 2048, d = 64, tau = 0.2 the logits are
+// off by 1.9e-5 absolute, the loss by 1e-8 and the gradients by 8.5e-7 relative (the f32 MFMA path:
+// 1.6e-6 / 2e-8 / 7e-8), far inside the 1e-4 budget.  Same dataflow as nce_tile: swapped S^T = K Q^T so
+// a lane's 8 weights of a 32-key block ARE its A-operand fragment of the P.V product, whose V operand
+// is read from the key-blocked transposed image (one 16-byte load per n-tile).  The summation index
+// of every product may be permuted freely as long as both operands use the same permutation.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const uint16_t* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+
+template <int D, bool PASS2>
+__global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_tau) {
+  constexpr int NT = D / 16;     // 16-column n-tiles of the P.V product
+  constexpr int KS = D / 32;     // k-slices of 32 dims per S product
+  const NceWs& w = batch.w[blockIdx.z];
+  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+  const int np = (int)w.np;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x * 4 + wv) * 16;
+  const int ks = blockIdx.y;
+  if (q0 >= np) return;
+  const int qv = PASS2 ? 1 : 0, kv = PASS2 ? 0 : 1;    // pass 1: Q = v1, K = V = v2; pass 2 the other way
+  const int per = ((np + kNceSplits - 1) / kNceSplits + 31) / 32 * 32;
+  const int kb = ks * per, ke = min(np, kb + per);
+
+  // lane (c16, g) owns dims [ (D/4) g, (D/4)(g+1) ) of row c16: slice s covers 8 of them
+  bf16x8 qh[KS], ql[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const size_t at = (size_t)(q0 + c16) * D + (D / 4) * g + 8 * s;
+    qh[s] = ld_bf16x8(w.kq_hi[qv] + at);
+    ql[s] = ld_bf16x8(w.kq_lo[qv] + at);
+  }
+  floatx4 O[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) O[t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+
+  for (int j0 = kb; j0 < ke; j0 += 32) {
+    bf16x8 kh[2][KS], kl[2][KS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const size_t at = (size_t)(j0 + 16 * h + c16) * D + (D / 4) * g + 8 * s;
+        kh[h][s] = ld_bf16x8(w.kq_hi[kv] + at);
+        kl[h][s] = ld_bf16x8(w.kq_lo[kv] + at);
+      }
+    bf16x8 vh[NT], vl[NT];
+    {
+      const size_t base = ((size_t)(j0 >> 5) * D + (size_t)NT * c16) * 32 + 8 * g;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        vh[t] = ld_bf16x8(w.vt_hi[kv] + base + (size_t)t * 32);
+        vl[t] = ld_bf16x8(w.vt_lo[kv] + base + (size_t)t * 32);
+      }
+    }
+    floatx4 a[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[s], a[h], 0, 0, 0);
+        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[s], a[h], 0, 0, 0);
+        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[s], a[h], 0, 0, 0);
+      }
+    }
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * h + 4 * g + r;
+        float e = expf(a[h][r] * inv_tau - inv_tau);
+        if (PASS2) e *= w.invl[min(key, np - 1)];
+        const float wt = (key < n) ? e : 0.f;
+        lsum += wt;
+        const __bf16 bh = (__bf16)wt;
+        ph[4 * h + r] = bh;
+        pl[4 * h + r] = (__bf16)(wt - (float)bh);
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[t], O[t], 0, 0, 0);
+      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[t], O[t], 0, 0, 0);
+      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[t], O[t], 0, 0, 0);
+    }
+  }
+
+  float* op = w.opart + ((size_t)ks * np + q0) * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+#pragma unroll
+    for (int t = 0; t < NT / 4; ++t)
+      reinterpret_cast<float4*>(rowp)[t] = make_float4(O[4 * t + 0][r], O[4 * t + 1][r], O[4 * t + 2][r], O[4 * t + 3][r]);
+  }
+  if (!PASS2) {
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (g == 0) w.lpart[(size_t)ks * np + q0 + c16] = lsum;
+  }
+}
+
 struct NceFinishArgs {
   float inv_tau, loss_scale;
   double* loss;
@@ -454,13 +603,16 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
   SRH_LAUNCH_CHECK();
   dim3 gt(np_max / 64, kNceSplits, count);
-  nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
+  static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
+  if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
+  else nce_tile_bf16<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
   nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
-  nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
+  if (f32_path) nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
+  else nce_tile_bf16<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
@@ -564,7 +716,8 @@ srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* st
 int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
-  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np + 256;
+  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
+         16 * np * d + 256;
 }
 
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,

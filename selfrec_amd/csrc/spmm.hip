@@ -270,7 +270,7 @@ __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
-template <int LPR>
+template <int LPR, bool NT>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
                                                         const Seg* __restrict__ segs,
                                                         const int32_t* __restrict__ indices,
@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
       const int j = base + 16 * g + e16;
       int c = 0;
       float v = 0.f;
-      if (j < e) { c = indices[j]; v = vals[j]; }
+      if (j < e) {
+        if (NT) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
+        else { c = indices[j]; v = vals[j]; }
+      }
       if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
       gather8<LPR, 0>(c, v, X, sub, acc);
       if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
@@ -325,7 +328,10 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
     const int j = s + 16 * q + e16;
     int c = 0;
     float v = 0.f;
-    if (j < e) { c = indices[j]; v = vals[j]; }
+    if (j < e) {
+      if (NT) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
+      else { c = indices[j]; v = vals[j]; }
+    }
     if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
     gather8<LPR, 0>(c, v, X, sub, acc);
     if (maxlen - 16 * q > 8) gather8<LPR, 8>(c, v, X, sub, acc);
@@ -676,9 +682,14 @@ srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const
                          const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
   if ((p->flags & 16) && LPR >= 16) {        // (a DPP row is 16 lanes: d = 32 keeps the shuffle kernel)
     constexpr int gi = (LPR == 8) ? 0 : (LPR == 16) ? 1 : (LPR == 32) ? 2 : 3;
-    spmm_rows_kernel<LPR><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
-        p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-        reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+    if (p->flags & 1)
+      spmm_rows_kernel<LPR, true><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+    else
+      spmm_rows_kernel<LPR, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
     SRH_LAUNCH_CHECK();
     if (p->n_heavy > 0) {
       spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,

@@ -138,3 +138,93 @@ if __name__ == "__main__":
     check_nce(128, 70, 128)
     check_gemm(64)
     check_gemm(128, 33, 65)
+
+
+# ---- split-bf16 InfoNCE tile (nce_tile_bf16): layout check with exact arithmetic (lo parts = 0) ----
+def mfma16x32(a, b, c):
+    """a, b: (64, 8) per-lane fragments; A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15]."""
+    A = np.zeros((16, 32)); B = np.zeros((32, 16))
+    for l in range(64):
+        for e in range(8):
+            A[l & 15, 8 * (l >> 4) + e] = a[l, e]
+            B[8 * (l >> 4) + e, l & 15] = b[l, e]
+    Dm = A @ B
+    out = c.copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += Dm[(l >> 4) * 4 + r, l & 15]
+    return out
+
+
+def vt_image(V):
+    """nce_prep's key-blocked transposed image: vt[blk][col][8*((k&15)>>2) + 4*(k>>4) + (k&3)] = V[32 blk + k][col]."""
+    n, D = V.shape
+    vt = np.zeros((n // 32, D, 32))
+    for i in range(n):
+        k = i & 31
+        vt[i >> 5, :, 8 * ((k & 15) >> 2) + 4 * (k >> 4) + (k & 3)] = V[i]
+    return vt
+
+
+def nce_tile_bf16_wave(Q, K, q0, kb, ke, n, inv_tau, invl=None):
+    D = Q.shape[1]; NT = D // 16; KS = D // 32; DG = D // 4
+    lanes = np.arange(64); c16 = lanes & 15; g = lanes >> 4
+    vt = vt_image(K)
+    qf = [np.stack([Q[q0 + c16[l], DG * g[l] + 8 * s: DG * g[l] + 8 * s + 8] for l in range(64)]) for s in range(KS)]
+    O = np.zeros((NT, 64, 4)); lsum = np.zeros(64)
+    for j0 in range(kb, ke, 32):
+        acc = []
+        for h in range(2):
+            a = np.zeros((64, 4))
+            for s in range(KS):
+                kf = np.stack([K[j0 + 16 * h + c16[l], DG * g[l] + 8 * s: DG * g[l] + 8 * s + 8] for l in range(64)])
+                a = mfma16x32(kf, qf[s], a)
+            acc.append(a)
+        p = np.zeros((64, 8))
+        for l in range(64):
+            for h in range(2):
+                for r in range(4):
+                    key = j0 + 16 * h + 4 * g[l] + r
+                    e = np.exp(acc[h][l, r] * inv_tau - inv_tau)
+                    if invl is not None:
+                        e *= invl[min(key, len(invl) - 1)]
+                    wt = e if key < n else 0.0
+                    lsum[l] += wt
+                    p[l, 4 * h + r] = wt
+        for t in range(NT):
+            vf = np.stack([vt[j0 >> 5, NT * c16[l] + t, 8 * g[l]: 8 * g[l] + 8] for l in range(64)])
+            O[t] = mfma16x32(p, vf, O[t])
+    out = np.zeros((16, D))
+    for l in range(64):
+        for r in range(4):
+            for t in range(NT):
+                out[4 * g[l] + r, NT * c16[l] + t] = O[t][l, r]
+    lq = np.zeros(16)
+    for l in range(64):
+        lq[c16[l]] += lsum[l]
+    return out, lq
+
+
+def check_nce_bf16(D=64, n=45, np_=64, tau=0.2, seed=3):
+    rng = np.random.default_rng(seed)
+    v1 = np.zeros((np_, D)); v2 = np.zeros((np_, D))
+    a = rng.standard_normal((n, D)); b = rng.standard_normal((n, D))
+    v1[:n] = a / np.linalg.norm(a, axis=1, keepdims=True)
+    v2[:n] = b / np.linalg.norm(b, axis=1, keepdims=True)
+    it = 1 / tau
+    W = np.exp(v1[:n] @ v2[:n].T * it - it)
+    O = np.zeros((np_, D)); l = np.zeros(np_)
+    for q0 in range(0, np_, 16):
+        O[q0:q0 + 16], l[q0:q0 + 16] = nce_tile_bf16_wave(v1, v2, q0, 0, np_, n, it)
+    assert np.allclose(O[:n], W @ v2[:n]) and np.allclose(l[:n], W.sum(1)), "bf16 pass1 mismatch"
+    invl = np.zeros(np_); invl[:n] = 1 / W.sum(1)
+    O2 = np.zeros((np_, D))
+    for q0 in range(0, np_, 16):
+        O2[q0:q0 + 16], _ = nce_tile_bf16_wave(v2, v1, q0, 0, np_, n, it, invl)
+    assert np.allclose(O2[:n], (W / W.sum(1)[:, None]).T @ v1[:n]), "bf16 pass2 mismatch"
+    print(f"nce_tile_bf16 emulation OK (D={D}, n={n})")
+
+
+if __name__ == "__main__":
+    check_nce_bf16(64, 45, 64)
+    check_nce_bf16(128, 100, 128)

@@ -30,13 +30,10 @@ def add(name, flags, split, slen, idx=None):
                                    xcd_split_row=split)
 
 
-add("seg     f0  xcd split1024", 0, U, 1024)
-os.environ["SRH_SPMM_WAVES"] = "6144"
-add("stream  f10 xcd split1024 waves6144", 10, U, 1024)
-for slen in (512, 1024, 2048):
+for slen in (256, 512, 1024):
     add(f"rows    f16 xcd split{slen}", 16, U, slen)
-add("rows    f16 mix split1024", 16, 0, 1024)
-add("rows    f16 xcd split1024 cols%4096", 16, U, 1024, (h_idx % 4096).astype(np.int32))
+    add(f"rows+nt f17 xcd split{slen}", 17, U, slen)
+add("rows    f16 xcd split512 cols%4096", 16, U, 512, (h_idx % 4096).astype(np.int32))
 ref = None
 for k, csr in variants.items():
     if "cols%" in k:
@@ -47,7 +44,7 @@ for k, csr in variants.items():
     err = (out - ref).abs().max().item()
     assert err < 1e-4, (k, err)
 ep = ops.make_epilogue(perturb_eps=0.2, rng_seed=1)
-plain = {f"{k} [no epilogue]": v for k, v in variants.items() if k.startswith(("rows    f16 xcd split1024", "seg"))}
+plain = {f"{k} [no epilogue]": v for k, v in variants.items() if "split512" in k and "cols" not in k}
 times = {k: [] for k in list(variants) + list(plain)}
 for rnd in range(7):
     for k, csr in plain.items():
