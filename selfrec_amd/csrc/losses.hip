@@ -195,15 +195,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // ---------------------------------------------------------------------------------------
 // InfoNCE
 // ---------------------------------------------------------------------------------------
-constexpr int kNceSplits = 8;
+constexpr int kNceSplits = 16;      // workspace is sized for this many key splits; batch.splits <= it are used
 
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
   double* losspart;     // one partial per finish wave
   // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
-  //   kq_*[view]  row-major (np, D): K / Q operands of the similarity product
-  //   vt_*[view]  (np/32, D, 32): per 32-key block, per column, the 32 keys in MFMA k-order
-  //               (position 8g + 4h + r  <->  key 16h + 4g + r): V operand of the P.V product
+  // both stored FRAGMENT-LINEAR: the 64 lanes of one MFMA operand load read one contiguous 1 KB
+  //   kq_*[view]  [row/16][k-slice s][lane][8]: lane (c16 = lane&15, g = lane>>4) holds row 16*tile + c16,
+  //               dims (D/4) g + 8 s + e -- K / Q operands of the similarity product
+  //   vt_*[view]  [row/32][n-tile t][lane][8]: lane holds column NT*c16 + t of the 8 keys
+  //               32*blk + {4g..4g+3, 16+4g..16+4g+3} -- V operand of the P.V product
   uint16_t *kq_hi[2], *kq_lo[2], *vt_hi[2], *vt_lo[2];
   int64_t np;
   // the problem this workspace belongs to (several InfoNCE problems share each launch: blockIdx.z)
@@ -217,6 +219,7 @@ constexpr int kNceMaxProblems = 4;
 struct NceBatch {
   NceWs w[kNceMaxProblems];
   int count;
+  int splits;      // key-range splits per query tile (1..kNceSplits)
 };
 
 __host__ __device__ inline int64_t nce_pad(int64_t n) { return (n + 63) / 64 * 64; }
@@ -284,20 +287,27 @@ __global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
       hi[t] = __builtin_bit_cast(uint16_t, bh);
       lo[t] = __builtin_bit_cast(uint16_t, bl);
     }
-    uint2 ph = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-    uint2 pl = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
-    *reinterpret_cast<uint2*>(w.kq_hi[view] + (size_t)i * D + 4 * sub) = ph;
-    *reinterpret_cast<uint2*>(w.kq_lo[view] + (size_t)i * D + 4 * sub) = pl;
+    // this lane holds columns 4*sub .. 4*sub+3 of row i
+    constexpr int DG = D / 4, KSL = D / 32, NTL = D / 16;
+    {
+      const int col0 = 4 * sub;
+      const int gk = col0 / DG, within = col0 % DG, sk = within / 8, e0 = within % 8;   // 4 consecutive e
+      const size_t at = ((((size_t)(i >> 4) * KSL + sk) * 64) + 16 * gk + (i & 15)) * 8 + e0;
+      *reinterpret_cast<uint2*>(w.kq_hi[view] + at) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+      *reinterpret_cast<uint2*>(w.kq_lo[view] + at) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+    }
     const int blk = i >> 5, k = i & 31;
-    const int pos = 8 * ((k & 15) >> 2) + 4 * (k >> 4) + (k & 3);
+    const int gv = (k & 15) >> 2, ev = 4 * (k >> 4) + (k & 3);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const size_t at = ((size_t)blk * D + 4 * sub + t) * 32 + pos;
+      const int col = 4 * sub + t, c16v = col / NTL, nt = col % NTL;
+      const size_t at = ((((size_t)blk * NTL + nt) * 64) + 16 * gv + c16v) * 8 + ev;
       w.vt_hi[view][at] = hi[t];
       w.vt_lo[view][at] = lo[t];
     }
   }
 }
+
 
 // One wave = 16 "query" rows against a slice of the "key" rows.
 //   PASS2 == false : Q = v1n, K = V = v2n, w_ij = exp(s_ij - c)              -> O1, l
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
   if (q0 >= np) return;
   const float* Q = PASS2 ? w.v2n : w.v1n;
   const float* K = PASS2 ? w.v1n : w.v2n;
-  const int per = ((np + kNceSplits - 1) / kNceSplits + 31) / 32 * 32;
+  const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
   const int kb = ks * per, ke = min(np, kb + per);
 
   float qreg[DQ];
@@ -431,14 +441,14 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
   const int ks = blockIdx.y;
   if (q0 >= np) return;
   const int qv = PASS2 ? 1 : 0, kv = PASS2 ? 0 : 1;    // pass 1: Q = v1, K = V = v2; pass 2 the other way
-  const int per = ((np + kNceSplits - 1) / kNceSplits + 31) / 32 * 32;
+  const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
   const int kb = ks * per, ke = min(np, kb + per);
 
   // lane (c16, g) owns dims [ (D/4) g, (D/4)(g+1) ) of row c16: slice s covers 8 of them
   bf16x8 qh[KS], ql[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    const size_t at = (size_t)(q0 + c16) * D + (D / 4) * g + 8 * s;
+    const size_t at = (((size_t)(q0 >> 4) * KS + s) * 64 + lane) * 8;
     qh[s] = ld_bf16x8(w.kq_hi[qv] + at);
     ql[s] = ld_bf16x8(w.kq_lo[qv] + at);
   }
@@ -453,17 +463,17 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const size_t at = (size_t)(j0 + 16 * h + c16) * D + (D / 4) * g + 8 * s;
+        const size_t at = (((size_t)((j0 >> 4) + h) * KS + s) * 64 + lane) * 8;
         kh[h][s] = ld_bf16x8(w.kq_hi[kv] + at);
         kl[h][s] = ld_bf16x8(w.kq_lo[kv] + at);
       }
     bf16x8 vh[NT], vl[NT];
     {
-      const size_t base = ((size_t)(j0 >> 5) * D + (size_t)NT * c16) * 32 + 8 * g;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        vh[t] = ld_bf16x8(w.vt_hi[kv] + base + (size_t)t * 32);
-        vl[t] = ld_bf16x8(w.vt_lo[kv] + base + (size_t)t * 32);
+        const size_t at = (((size_t)(j0 >> 5) * NT + t) * 64 + lane) * 8;
+        vh[t] = ld_bf16x8(w.vt_hi[kv] + at);
+        vl[t] = ld_bf16x8(w.vt_lo[kv] + at);
       }
     }
     floatx4 a[2];
@@ -532,8 +542,7 @@ __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs 
   const size_t at = (size_t)ii * LPR + sub;
   float4 O = f4_zero();
   float l = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < kNceSplits; ++ks) {
+  for (int ks = 0; ks < batch.splits; ++ks) {
     O = f4_add(O, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
     if (!PASS2) l += w.lpart[(size_t)ks * w.np + ii];
   }
@@ -588,6 +597,8 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   constexpr int LPR = D / 4, G = 64 / LPR;
   NceBatch batch{};
   batch.count = count;
+  batch.splits = 8;
+  if (const char* env = getenv("SRH_NCE_SPLITS")) batch.splits = std::min(kNceSplits, std::max(1, atoi(env)));
   int np_max = 0;
   char* cursor = reinterpret_cast<char*>(ws);
   for (int k = 0; k < count; ++k) {
@@ -602,7 +613,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   dim3 gp((np_max / G + 3) / 4, 2, count);
   nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
   SRH_LAUNCH_CHECK();
-  dim3 gt(np_max / 64, kNceSplits, count);
+  dim3 gt(np_max / 64, batch.splits, count);
   static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
   if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   else nce_tile_bf16<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);

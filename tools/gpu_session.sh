@@ -29,6 +29,14 @@ prof)
   find $OUT/prof -name "*.db" -size +40M -delete;;
 gather)
   mkdir -p $OUT; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_bw.hip -o /tmp/gather_bw && timeout 300 /tmp/gather_bw > $OUT/gather_bw.log 2>&1; echo "gather exit $?"; cat $OUT/gather_bw.log;;
+nce)
+  timeout 600 python tools/nce_ab.py > $OUT/nce_ab.log 2>&1; echo "nce exit $?"; cat $OUT/nce_ab.log;;
+ncepmc)
+  for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM" "SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $c | tr ' ' '_' | cut -c1-40); rm -rf $OUT/ncepmc_$tag
+    (cd /tmp && SRH_NCE_SPLITS=8 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/ncepmc_$tag -o pmc -- python $OLDPWD/tools/nce_ab.py child 2048 > $OLDPWD/$OUT/ncepmc_$tag.log 2>&1); echo "ncepmc exit $?"
+    f=$(find $OUT/ncepmc_$tag -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -i "nce_" | head -8
+  done;;
 ab)
   timeout 600 python tools/spmm_ab.py > $OUT/spmm_ab.log 2>&1; echo "ab exit $?"; tail -45 $OUT/spmm_ab.log;;
 pmc)
