@@ -270,7 +270,26 @@ __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
-template <int LPR, bool NT>
+// all 16 entries of the DPP row: 16 gathers in flight before the first FMA
+template <int LPR>
+__device__ __forceinline__ void gather16(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
+  int cc[16];
+  float vv[16];
+  float4 xx[16];
+#define SRH_BC(T) cc[T] = row_bcast_i<T>(c); vv[T] = row_bcast_f<T>(v);
+  SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3) SRH_BC(4) SRH_BC(5) SRH_BC(6) SRH_BC(7)
+  SRH_BC(8) SRH_BC(9) SRH_BC(10) SRH_BC(11) SRH_BC(12) SRH_BC(13) SRH_BC(14) SRH_BC(15)
+#undef SRH_BC
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    xx[t] = f4_zero();
+    if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc = f4_fma(vv[t], xx[t], acc);
+}
+
+template <int LPR, bool NT, bool DEEP>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
                                                         const Seg* __restrict__ segs,
                                                         const int32_t* __restrict__ indices,
@@ -304,8 +323,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
         else { c = indices[j]; v = vals[j]; }
       }
       if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
-      gather8<LPR, 0>(c, v, X, sub, acc);
-      if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+      if (DEEP && e - base > 8) {
+        gather16<LPR>(c, v, X, sub, acc);
+      } else {
+        gather8<LPR, 0>(c, v, X, sub, acc);
+        if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+      }
     }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -324,6 +347,27 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  if (DEEP) {
+    // all (col,val) chunks of the row up front (one latency), then 16 gathers in flight per round
+    int cq[kShortRow / 16];
+    float vq[kShortRow / 16];
+#pragma unroll
+    for (int q = 0; q < kShortRow / 16; ++q) {
+      const int j = s + 16 * q + e16;
+      cq[q] = 0; vq[q] = 0.f;
+      if (j < e) { cq[q] = indices[j]; vq[q] = vals[j]; }
+      if (ep.col_mark && vq[q] != 0.f && ep.col_mark[cq[q]] != stamp) vq[q] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < kShortRow / 16; ++q) {
+      if (q * 16 < maxlen) {
+        if (maxlen - 16 * q > 8) gather16<LPR>(cq[q], vq[q], X, sub, acc);
+        else gather8<LPR, 0>(cq[q], vq[q], X, sub, acc);
+      }
+    }
+    row_epilogue<LPR>(acc, row, sub, live, Y, ep);
+    return;
+  }
   for (int q = 0; q * 16 < maxlen; ++q) {
     const int j = s + 16 * q + e16;
     int c = 0;
@@ -683,11 +727,15 @@ srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const
   if ((p->flags & 16) && LPR >= 16) {        // (a DPP row is 16 lanes: d = 32 keeps the shuffle kernel)
     constexpr int gi = (LPR == 8) ? 0 : (LPR == 16) ? 1 : (LPR == 32) ? 2 : 3;
     if (p->flags & 1)
-      spmm_rows_kernel<LPR, true><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+      spmm_rows_kernel<LPR, true, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+    else if (p->flags & 2)
+      spmm_rows_kernel<LPR, false, true><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
           p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
           reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
     else
-      spmm_rows_kernel<LPR, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
+      spmm_rows_kernel<LPR, false, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
           p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
           reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
     SRH_LAUNCH_CHECK();
