@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 7
+#define SRH_ABI_VERSION 8
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -278,18 +278,20 @@ srh_status_t srh_topk_rows(const float* d_scores, int64_t rows, int64_t n, int32
  * ---------------------------------------------------------------------------------- */
 /* y = a*x + b*y   (elementwise, n_elem floats; y may be uninitialised when b == 0) */
 srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n_elem, void* stream);
-/* Batch cursor for graph replay: copies batch *d_cursor of the per-epoch index arrays
- * into fixed staging buffers, publishes its sizes, then increments the cursor and the
- * optimiser step.  d_meta: int32[4] = {rows, n_uniq_u, n_uniq_i, batch_no}. */
+/* Batch cursor for graph replay.  d_cursor: int64[2] = {batch number within the epoch, optimiser
+ * step (1-based)} in device memory.  srh_batch_fetch copies batch d_cursor[0] of the per-epoch index
+ * arrays into fixed staging buffers and publishes its sizes (d_meta: int32[4] = {rows, n_uniq_u,
+ * n_uniq_i, batch_no}); it only READS the cursor.  The cursor is advanced by the last kernel of the
+ * step: srh_zero_rows(..., d_cursor_advance, ...) or srh_cursor_advance. */
 srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              const int32_t* d_epoch_j, const int32_t* d_epoch_uniq_u,
                              const int32_t* d_epoch_uniq_i, const int32_t* d_n_uniq_u,
                              const int32_t* d_n_uniq_i, int64_t n_edges, int64_t batch_size,
-                             int64_t* d_cursor /* [0]=batch no, [1]=adam step */,
+                             const int64_t* d_cursor /* [0]=batch no, [1]=adam step */,
                              int32_t* d_stage_u, int32_t* d_stage_i, int32_t* d_stage_j,
                              int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
                              int32_t* d_meta,
-                             int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = new step */,
+                             int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = step */,
                              int32_t mark_item_offset, void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
@@ -298,7 +300,9 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
 #define SRH_MAX_ZERO_LISTS 8
 srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_t* const* d_idx,
                            const int32_t* const* d_counts, const int32_t* n_max,
-                           const int32_t* row_offset, int32_t d, void* stream);
+                           const int32_t* row_offset, int32_t d,
+                           int64_t* d_cursor_advance /* optional: {batch, step} += 1 */, void* stream);
+srh_status_t srh_cursor_advance(int64_t* d_cursor, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,22 +50,23 @@ __global__ __launch_bounds__(256) void axpby_kernel(float a, const float4* __res
   }
 }
 
-constexpr int kFetchThreads = 1024;
-__global__ __launch_bounds__(kFetchThreads) void batch_fetch_kernel(
+// Stages batch *cursor[0] of the epoch arrays into fixed buffers, publishes its sizes and stamps the
+// activity marks with the current optimiser step *cursor[1].  Read-only on the cursor, so any number of
+// workgroups can share the copy; the cursor is advanced at the END of the step (zero_rows_kernel /
+// cursor_advance_kernel), after the last kernel that reads it.
+constexpr int kFetchBlocks = 8;
+__global__ __launch_bounds__(256) void batch_fetch_kernel(
     const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const int32_t* __restrict__ ej,
     const int32_t* __restrict__ uu, const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
-    const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, int64_t* __restrict__ cursor, int32_t* su,
+    const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, const int64_t* __restrict__ cursor, int32_t* su,
     int32_t* si, int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta, int32_t* __restrict__ mark,
     int32_t item_offset) {
-  // single workgroup; the cursor is advanced by thread 0 after everyone has read it
-  __shared__ int64_t s_b, s_step;
-  if (threadIdx.x == 0) { s_b = cursor[0]; s_step = cursor[1]; }
-  __syncthreads();
-  const int64_t b = s_b;
-  const int32_t stamp = (int32_t)(s_step + 1);          // the optimiser step this batch belongs to
+  const int64_t b = cursor[0];
+  const int32_t stamp = (int32_t)cursor[1];
   const int64_t ptr = b * bs;
   const int64_t rows = (ptr >= n_edges) ? 0 : ((ptr + bs < n_edges) ? bs : n_edges - ptr);
-  for (int64_t i = threadIdx.x; i < rows; i += kFetchThreads) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int64_t i = tid; i < rows; i += nth) {
     const int32_t u = eu[ptr + i], p = ei[ptr + i], n = ej[ptr + i];
     su[i] = u; si[i] = p; sj[i] = n;
     if (mark) { mark[u] = stamp; mark[item_offset + p] = stamp; mark[item_offset + n] = stamp; }
@@ -74,17 +75,19 @@ __global__ __launch_bounds__(kFetchThreads) void batch_fetch_kernel(
   if (uu && rows > 0) {
     a = nuu[b];
     c = nui[b];
-    for (int64_t i = threadIdx.x; i < a; i += kFetchThreads) suu[i] = uu[b * bs + i];
-    for (int64_t i = threadIdx.x; i < c; i += kFetchThreads) sui[i] = ui[b * bs + i];
+    for (int64_t i = tid; i < a; i += nth) suu[i] = uu[b * bs + i];
+    for (int64_t i = tid; i < c; i += nth) sui[i] = ui[b * bs + i];
   }
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     meta[0] = (int32_t)rows;
     meta[1] = a;
     meta[2] = c;
     meta[3] = (int32_t)b;
-    cursor[0] = b + 1;
-    cursor[1] = s_step + 1;
   }
+}
+
+__global__ void cursor_advance_kernel(int64_t* cursor) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cursor[0] += 1; cursor[1] += 1; }
 }
 
 struct ZeroList {
@@ -94,11 +97,13 @@ struct ZeroList {
   int32_t n_max[SRH_MAX_ZERO_LISTS];
   int32_t offset[SRH_MAX_ZERO_LISTS];
   int32_t n_lists;
+  int64_t* cursor;     // optional: advanced by one batch / one step when this (last) kernel of the step runs
 };
 
 // zero the listed rows of (.., d) tables: the sparse counterpart of a dense memset for
 // gradient buffers that only ever receive O(batch) non-zero rows
 __global__ __launch_bounds__(256) void zero_rows_kernel(ZeroList z, int lpr) {
+  if (z.cursor && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { z.cursor[0] += 1; z.cursor[1] += 1; }
   const int list = blockIdx.y;
   if (list >= z.n_lists) return;
   const int n = z.d_n[list] ? min(*z.d_n[list], z.n_max[list]) : z.n_max[list];
@@ -141,7 +146,7 @@ srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n
 srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i, const int32_t* d_epoch_j,
                              const int32_t* d_epoch_uniq_u, const int32_t* d_epoch_uniq_i,
                              const int32_t* d_n_uniq_u, const int32_t* d_n_uniq_i, int64_t n_edges,
-                             int64_t batch_size, int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
+                             int64_t batch_size, const int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
                              int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
                              int32_t* d_meta, int32_t* d_row_mark, int32_t mark_item_offset, void* stream) {
   SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
@@ -150,7 +155,7 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
   SRH_REQUIRE(!uq || (d_epoch_uniq_i && d_n_uniq_u && d_n_uniq_i && d_stage_uniq_u && d_stage_uniq_i),
               "batch_fetch: unique-id arrays must be given together");
   SRH_REQUIRE(n_edges > 0 && batch_size > 0, "batch_fetch: bad sizes");
-  batch_fetch_kernel<<<1, kFetchThreads, 0, srh::as_stream(stream)>>>(
+  batch_fetch_kernel<<<kFetchBlocks, 256, 0, srh::as_stream(stream)>>>(
       d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u, d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges, batch_size,
       d_cursor, d_stage_u, d_stage_i, d_stage_j, d_stage_uniq_u, d_stage_uniq_i, d_meta, d_row_mark,
       mark_item_offset);
@@ -158,9 +163,16 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
   return SRH_OK;
 }
 
+srh_status_t srh_cursor_advance(int64_t* d_cursor, void* stream) {
+  SRH_REQUIRE(d_cursor, "cursor_advance: null argument");
+  cursor_advance_kernel<<<1, 64, 0, srh::as_stream(stream)>>>(d_cursor);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
 srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_t* const* d_idx,
                            const int32_t* const* d_counts, const int32_t* n_max, const int32_t* row_offset,
-                           int32_t d, void* stream) {
+                           int32_t d, int64_t* d_cursor_advance, void* stream) {
   SRH_REQUIRE(n_lists >= 1 && n_lists <= SRH_MAX_ZERO_LISTS, "zero_rows: 1..%d lists", SRH_MAX_ZERO_LISTS);
   SRH_REQUIRE(d_tables && d_idx && d_counts && n_max && row_offset, "zero_rows: null argument");
   SRH_REQUIRE(d > 0 && d % 4 == 0, "zero_rows: d must be a positive multiple of 4");
@@ -173,7 +185,8 @@ srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_
     most = std::max(most, n_max[k]);
   }
   z.n_lists = n_lists;
-  if (most == 0) return SRH_OK;
+  z.cursor = d_cursor_advance;
+  if (most == 0) return d_cursor_advance ? srh_cursor_advance(d_cursor_advance, stream) : SRH_OK;
   const int lpr = d / 4;
   dim3 grid((unsigned)(((int64_t)most * lpr + 255) / 256), (unsigned)n_lists);
   zero_rows_kernel<<<grid, 256, 0, srh::as_stream(stream)>>>(z, lpr);

@@ -105,7 +105,7 @@ class FusedTrainer:
         self.stage = {k: torch.zeros(B, dtype=torch.int32, device=dev) for k in ("u", "i", "j", "uniq_u", "uniq_i")}
         self.stage_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev)  # SGL: [uniq users ; uniq items + U]
         self.meta = torch.zeros(4, dtype=torch.int32, device=dev)          # rows, n_uniq_u, n_uniq_i, batch no
-        self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)        # batch no, adam step
+        self.cursor = torch.tensor([0, 1], dtype=torch.int64, device=dev)  # batch no, optimiser step (1-based)
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -347,7 +347,9 @@ class FusedTrainer:
             if self.gReg is not None:
                 lists += [(self.gReg, st["u"], rows_dev, B, 0), (self.gReg, st["i"], rows_dev, B, U),
                           (self.gReg, st["j"], rows_dev, B, U)]
-            ops.zero_rows(lists, self.d)
+            ops.zero_rows(lists, self.d, cursor_advance=self.cursor)      # last kernel of the step
+        else:
+            ops.cursor_advance(self.cursor)
 
     def _build_cat_index(self):
         """SGL: InfoNCE over [unique users ; unique items] of the batch (SGL.py:120-125), as one

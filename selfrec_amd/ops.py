@@ -16,7 +16,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_multi", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
-           "axpby", "batch_fetch", "zero_rows", "SelfrecHipError"]
+           "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
 
 def _stream() -> int:
@@ -389,7 +389,11 @@ def axpby(a, x, b, y):
     return y
 
 
-def zero_rows(lists, d):
+def cursor_advance(cursor):
+    check(_lib.load().srh_cursor_advance(_p(cursor, torch.int64), _stream()), "srh_cursor_advance")
+
+
+def zero_rows(lists, d, cursor_advance=None):
     """lists: [(table, idx, count_dev_or_None, n_max, row_offset), ...] (at most 8)."""
     n = len(lists)
     vp = C.c_void_p * n
@@ -398,7 +402,8 @@ def zero_rows(lists, d):
     cnt = vp(*[_p(c, torch.int32, "count") for _, _, c, *_ in lists])
     n_max = (C.c_int32 * n)(*[int(m) for *_, m, _ in lists])
     off = (C.c_int32 * n)(*[int(o) for *_, o in lists])
-    check(_lib.load().srh_zero_rows(n, tables, idx, cnt, n_max, off, int(d), _stream()), "srh_zero_rows")
+    check(_lib.load().srh_zero_rows(n, tables, idx, cnt, n_max, off, int(d), _p(cursor_advance, torch.int64),
+                                    _stream()), "srh_zero_rows")
 
 
 def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0):

@@ -169,3 +169,41 @@ def test_full_size_properties_yelp_shape():
     bpr, reg, cl = tr.read_losses()
     assert np.isfinite([bpr, reg, cl]).all() and 0.3 < bpr < 1.0 and cl > 0
     assert torch.isfinite(tr.E0).all() and (tr.E0 != before).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("name", ["XSimGCL", "LightGCN"])
+def test_sharded_trainer_on_hip_backend_single_rank(golden_models, golden_meta, tiny_data, name):
+    """The row-sharded trainer through RCCL ("nccl") with the real HIP kernels, world size 1 (one GPU box):
+    same reference run as the fused engine.  World sizes 2 and 3 are covered on CPU (tests/test_dist_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from selfrec_amd.dist import ShardedTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        gm, meta = golden_models, golden_meta
+        m = meta[name]; c = m["conf"]
+        gen = torch.Generator().manual_seed(m["noise_seed"])
+        tr = ShardedTrainer(tiny_data, m["emb"], model=name, n_layers=int(c["n_layer"]), lr=m["lr"], reg=m["reg"],
+                            cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)),
+                            tau=float(c.get("tau", 0.2)), layer_cl=int(c.get("l_star", 1)), batch_size=m["batch"],
+                            user_emb=gm[f"{name}_init_user"], item_emb=gm[f"{name}_init_item"],
+                            noise_fn=lambda shape: torch.rand(shape, generator=gen))
+        random.seed(m["sampler_seed"])
+        tr.sampler.set_state_from_python()
+        bpr = []
+        for _ in range(tr.begin_epoch()):
+            tr.step()
+            bpr.append(tr.read_losses()[0])
+        np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+        pu, pi = tr.parameters_full()
+        assert rel_err(pu.cpu().numpy(), gm[f"{name}_param_user"]) < 1e-4
+        assert rel_err(pi.cpu().numpy(), gm[f"{name}_param_item"]) < 1e-4
+        fu, _ = tr.embeddings()
+        assert rel_err(fu.cpu().numpy(), gm[f"{name}_final_user"]) < 1e-4
+    finally:
+        if created:
+            dist.destroy_process_group()
