@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
 //   * keeps one wave per long row / split segment ("coop" tasks): there each row-group takes a
 //     block of 16 entries of a 16*G-entry chunk and the groups are summed at the end.
 // ---------------------------------------------------------------------------------------------
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
 struct Task {
   int32_t kind, first, count, pad;   // kind 0: coop on segs[first]; kind 1: rows segs[first .. first+count)
 };
@@ -289,13 +291,27 @@ __device__ __forceinline__ void gather16(int c, float v, const float4* __restric
   for (int t = 0; t < 16; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
-template <int LPR, bool NT, bool DEEP>
+// 16-byte write-through store (sc1): the partial goes straight to memory and is not left dirty in this
+// XCD's L2, so publishing it needs no L2 write-back fence (cdna_hip_programming.md G16, form R1)
+__device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
+  floatx4_t x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
+// FINISH: split rows are completed inside this launch by whichever of their segments arrives last
+// (write-through partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver takes one agent
+// acquire, adds the partials in slot order -- bitwise reproducible -- runs the epilogue and re-arms the
+// ticket).  Otherwise spmm_heavy_kernel does it in a second launch.
+template <int LPR, bool NT, bool DEEP, bool FINISH>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
                                                         const Seg* __restrict__ segs,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,
-                                                        float4* __restrict__ partial, DevEpilogue ep) {
+                                                        float4* __restrict__ partial,
+                                                        const Heavy* __restrict__ heavy,
+                                                        const int32_t* __restrict__ slot_owner,
+                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
   constexpr int G = 64 / LPR;          // row-groups per wave
   constexpr int CH = 16 * G;           // entries per coop chunk
   const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
@@ -332,8 +348,31 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
     }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-    if (slot < 0) row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
-    else if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+    if (slot < 0) {
+      row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+      return;
+    }
+    if (!FINISH) {
+      if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
+      return;
+    }
+    if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, acc);
+    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+    const Heavy h = heavy[hid];
+    const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
+    const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != hn - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's L1 before reading the others' partials
+    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    float4 sum = f4_zero();
+    for (int t = g; t < hn; t += G) sum = f4_add(sum, partial[(size_t)(hfirst + t) * LPR + sub]);
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
+    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
     return;
   }
 
@@ -579,7 +618,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
   p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
   p->split_len = split_len;
-  p->flags = 16;
+  p->flags = 16 | 4;
   if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 31;  // A/B knob for tools/spmm_ab.py
   // ---- default kernel: coop tasks (long rows / split pieces) then G short rows per task ----
   // tsegs = coop(class 0) ++ coop(class 1) ++ short(class 0) ++ short(class 1), each longest first;
@@ -726,20 +765,18 @@ srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const
                          const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
   if ((p->flags & 16) && LPR >= 16) {        // (a DPP row is 16 lanes: d = 32 keeps the shuffle kernel)
     constexpr int gi = (LPR == 8) ? 0 : (LPR == 16) ? 1 : (LPR == 32) ? 2 : 3;
-    if (p->flags & 1)
-      spmm_rows_kernel<LPR, true, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
-          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
-    else if (p->flags & 2)
-      spmm_rows_kernel<LPR, false, true><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
-          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
-    else
-      spmm_rows_kernel<LPR, false, false><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(
-          p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-          reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
+#define SRH_ROWS(NTF, DEEPF, FINF)                                                                              \
+  spmm_rows_kernel<LPR, NTF, DEEPF, FINF><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(                             \
+      p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),       \
+      reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,     \
+      p->d_tickets, ep)
+    const bool finish = (p->flags & 4) != 0;
+    if (p->flags & 1) { if (finish) SRH_ROWS(true, false, true); else SRH_ROWS(true, false, false); }
+    else if (p->flags & 2) { if (finish) SRH_ROWS(false, true, true); else SRH_ROWS(false, true, false); }
+    else { if (finish) SRH_ROWS(false, false, true); else SRH_ROWS(false, false, false); }
+#undef SRH_ROWS
     SRH_LAUNCH_CHECK();
-    if (p->n_heavy > 0) {
+    if (p->n_heavy > 0 && !finish) {
       spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
                                                                   reinterpret_cast<const float4*>(p->d_partial),
                                                                   reinterpret_cast<float4*>(d_y), ep);

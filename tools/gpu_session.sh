@@ -29,6 +29,10 @@ prof)
   find $OUT/prof -name "*.db" -size +40M -delete;;
 gather)
   mkdir -p $OUT; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_bw.hip -o /tmp/gather_bw && timeout 300 /tmp/gather_bw > $OUT/gather_bw.log 2>&1; echo "gather exit $?"; cat $OUT/gather_bw.log;;
+zipf)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_zipf.hip -o /tmp/gather_zipf 2>/dev/null && timeout 300 /tmp/gather_zipf > $OUT/gather_zipf.log 2>&1; echo "zipf exit $?"; cat $OUT/gather_zipf.log;;
+matrix)
+  timeout 900 python tools/model_matrix.py > $OUT/model_matrix.log 2>&1; echo "matrix exit $?"; cat $OUT/model_matrix.log | grep -v amdgpu.ids;;
 nce)
   timeout 600 python tools/nce_ab.py > $OUT/nce_ab.log 2>&1; echo "nce exit $?"; cat $OUT/nce_ab.log;;
 ncepmc)

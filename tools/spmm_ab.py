@@ -30,11 +30,10 @@ def add(name, flags, split, slen, idx=None):
                                    xcd_split_row=split)
 
 
-for slen in (256, 512, 1024, 2048):
-    add(f"rows      f16 xcd split{slen}", 16, U, slen)
-    add(f"rows+deep f18 xcd split{slen}", 18, U, slen)
-add("rows      f16 xcd split512 cols%4096", 16, U, 512, (h_idx % 4096).astype(np.int32))
-add("rows+deep f18 xcd split512 cols%4096", 18, U, 512, (h_idx % 4096).astype(np.int32))
+for slen in (256, 512, 1024):
+    add(f"rows        f16 xcd split{slen}", 16, U, slen)
+    add(f"rows+finish f20 xcd split{slen}", 20, U, slen)
+add("rows+finish f20 xcd split128", 20, U, 128)
 ref = None
 for k, csr in variants.items():
     if "cols%" in k:
