@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 8
+#define SRH_ABI_VERSION 9
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -161,6 +161,10 @@ typedef struct srh_spmm_epilogue {
   const int32_t* d_row_mark;
   const int32_t* d_col_mark;
   const int64_t* d_mark_stamp;
+  /* AXPY: bit t of add_sparse_mask says addend t is zero on every row whose d_add_mark entry is not
+   * live, so it is only read on live rows (the batch-row gradients gF / gCL of the backward chain). */
+  const int32_t* d_add_mark;
+  int32_t add_sparse_mask;
 } srh_spmm_epilogue_t;
 
 /* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {32,64,128,256}.

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -43,6 +43,7 @@ class SpmmEpilogue(C.Structure):
         ("d_add", C.c_void_p * SRH_MAX_ADD),
         ("add_scale", C.c_float * SRH_MAX_ADD),
         ("d_row_mark", C.c_void_p), ("d_col_mark", C.c_void_p), ("d_mark_stamp", C.c_void_p),
+        ("d_add_mark", C.c_void_p), ("add_sparse_mask", C.c_int32),
     ]
 
 

@@ -428,7 +428,9 @@ __device__ __forceinline__ bf16x8 ld_bf16x8(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
 }
 
-template <int D, bool PASS2>
+// QT query tiles (16 queries each) per wave share every K / V fragment load: the kernel is bound by
+// operand traffic from L2 (each query tile re-reads all keys), not by the matrix pipe.
+template <int D, bool PASS2, int QT>
 __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_tau) {
   constexpr int NT = D / 16;     // 16-column n-tiles of the P.V product
   constexpr int KS = D / 32;     // k-slices of 32 dims per S product
@@ -437,25 +439,31 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
   const int np = (int)w.np;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
-  const int q0 = (blockIdx.x * 4 + wv) * 16;
+  const int q0 = (blockIdx.x * 4 + wv) * (16 * QT);
   const int ks = blockIdx.y;
   if (q0 >= np) return;
   const int qv = PASS2 ? 1 : 0, kv = PASS2 ? 0 : 1;    // pass 1: Q = v1, K = V = v2; pass 2 the other way
   const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
   const int kb = ks * per, ke = min(np, kb + per);
 
-  // lane (c16, g) owns dims [ (D/4) g, (D/4)(g+1) ) of row c16: slice s covers 8 of them
-  bf16x8 qh[KS], ql[KS];
+  bf16x8 qh[QT][KS], ql[QT][KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const size_t at = (((size_t)(q0 >> 4) * KS + s) * 64 + lane) * 8;
-    qh[s] = ld_bf16x8(w.kq_hi[qv] + at);
-    ql[s] = ld_bf16x8(w.kq_lo[qv] + at);
-  }
-  floatx4 O[NT];
+  for (int t = 0; t < QT; ++t)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) O[t] = (floatx4){0.f, 0.f, 0.f, 0.f};
-  float lsum = 0.f;
+    for (int s = 0; s < KS; ++s) {
+      const int tile = min((q0 >> 4) + t, (np >> 4) - 1);          // np is a multiple of 64: clamp is for safety only
+      const size_t at = (((size_t)tile * KS + s) * 64 + lane) * 8;
+      qh[t][s] = ld_bf16x8(w.kq_hi[qv] + at);
+      ql[t][s] = ld_bf16x8(w.kq_lo[qv] + at);
+    }
+  floatx4 O[QT][NT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) O[t][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float lsum[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) lsum[t] = 0.f;
 
   for (int j0 = kb; j0 < ke; j0 += 32) {
     bf16x8 kh[2][KS], kl[2][KS];
@@ -468,59 +476,74 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
         kl[h][s] = ld_bf16x8(w.kq_lo[kv] + at);
       }
     bf16x8 vh[NT], vl[NT];
-    {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const size_t at = (((size_t)(j0 >> 5) * NT + t) * 64 + lane) * 8;
-        vh[t] = ld_bf16x8(w.vt_hi[kv] + at);
-        vl[t] = ld_bf16x8(w.vt_lo[kv] + at);
-      }
+    for (int u = 0; u < NT; ++u) {
+      const size_t at = (((size_t)(j0 >> 5) * NT + u) * 64 + lane) * 8;
+      vh[u] = ld_bf16x8(w.vt_hi[kv] + at);
+      vl[u] = ld_bf16x8(w.vt_lo[kv] + at);
     }
-    floatx4 a[2];
+    float il[2][4];
+    if (PASS2) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[s], a[h], 0, 0, 0);
-        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[s], a[h], 0, 0, 0);
-        a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[s], a[h], 0, 0, 0);
-      }
+        for (int r = 0; r < 4; ++r) il[h][r] = w.invl[min(j0 + 16 * h + 4 * g + r, np - 1)];
     }
-    bf16x8 ph, pl;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int t = 0; t < QT; ++t) {
+      floatx4 a[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = j0 + 16 * h + 4 * g + r;
-        float e = expf(a[h][r] * inv_tau - inv_tau);
-        if (PASS2) e *= w.invl[min(key, np - 1)];
-        const float wt = (key < n) ? e : 0.f;
-        lsum += wt;
-        const __bf16 bh = (__bf16)wt;
-        ph[4 * h + r] = bh;
-        pl[4 * h + r] = (__bf16)(wt - (float)bh);
+      for (int h = 0; h < 2; ++h) {
+        a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
+          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
+          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
+        }
       }
+      bf16x8 ph, pl;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[t], O[t], 0, 0, 0);
-      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[t], O[t], 0, 0, 0);
-      O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[t], O[t], 0, 0, 0);
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j0 + 16 * h + 4 * g + r;
+          float e = expf(a[h][r] * inv_tau - inv_tau);
+          if (PASS2) e *= il[h][r];
+          const float wt = (key < n) ? e : 0.f;
+          lsum[t] += wt;
+          const __bf16 bh = (__bf16)wt;
+          ph[4 * h + r] = bh;
+          pl[4 * h + r] = (__bf16)(wt - (float)bh);
+        }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], O[t][u], 0, 0, 0);
+        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
+        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
+      }
     }
   }
 
-  float* op = w.opart + ((size_t)ks * np + q0) * D;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+  for (int t = 0; t < QT; ++t) {
+    const int qt0 = q0 + 16 * t;
+    if (qt0 >= np) break;
+    float* op = w.opart + ((size_t)ks * np + qt0) * D;
 #pragma unroll
-    for (int t = 0; t < NT / 4; ++t)
-      reinterpret_cast<float4*>(rowp)[t] = make_float4(O[4 * t + 0][r], O[4 * t + 1][r], O[4 * t + 2][r], O[4 * t + 3][r]);
-  }
-  if (!PASS2) {
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    if (g == 0) w.lpart[(size_t)ks * np + q0 + c16] = lsum;
+    for (int r = 0; r < 4; ++r) {
+      float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+#pragma unroll
+      for (int u = 0; u < NT / 4; ++u)
+        reinterpret_cast<float4*>(rowp)[u] =
+            make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
+    }
+    if (!PASS2) {
+      float l = lsum[t];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (g == 0) w.lpart[(size_t)ks * np + qt0 + c16] = l;
+    }
   }
 }
 
@@ -615,15 +638,19 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   SRH_LAUNCH_CHECK();
   dim3 gt(np_max / 64, batch.splits, count);
   static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
+  static const int qt = getenv("SRH_NCE_QT") ? atoi(getenv("SRH_NCE_QT")) : 2;      // query tiles per wave (A/B knob)
+  dim3 gt2((np_max + 127) / 128, batch.splits, count);
   if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
-  else nce_tile_bf16<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
+  else if (qt == 2) nce_tile_bf16<D, false, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
+  else nce_tile_bf16<D, false, 1><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
   nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   if (f32_path) nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
-  else nce_tile_bf16<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
+  else if (qt == 2) nce_tile_bf16<D, true, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
+  else nce_tile_bf16<D, true, 1><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();

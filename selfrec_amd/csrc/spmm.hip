@@ -68,6 +68,8 @@ struct DevEpilogue {
   const int32_t* row_mark;
   const int32_t* col_mark;
   const int64_t* mark_stamp;
+  const int32_t* add_mark;       // AXPY: addends flagged in add_sparse are zero outside marked rows
+  int32_t add_sparse;
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -97,7 +99,10 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   const size_t at = (size_t)row * LPR + sub;
   if (ep.flags & SRH_EPI_AXPY) {
     y = f4_scale(y, ep.alpha);
+    // addends that are non-zero only on this step's batch rows are not even read elsewhere
+    const bool marked = !ep.add_mark || ep.add_mark[row] == (int)(*ep.mark_stamp);
     for (int t = 0; t < ep.n_add; ++t) {
+      if (((ep.add_sparse >> t) & 1) && !marked) continue;
       float4 a = reinterpret_cast<const float4*>(ep.add[t])[at];
       y = f4_fma(ep.add_scale[t], a, y);
     }
@@ -831,7 +836,9 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.row_mark = epi->d_row_mark;
     ep.col_mark = epi->d_col_mark;
     ep.mark_stamp = epi->d_mark_stamp;
-    SRH_REQUIRE(!(ep.row_mark || ep.col_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
+    ep.add_mark = epi->d_add_mark;
+    ep.add_sparse = epi->add_sparse_mask;
+    SRH_REQUIRE(!(ep.row_mark || ep.col_mark || ep.add_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
     if (epi->flags & SRH_EPI_MEAN) {
       SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,
                   "spmm_f32: bad MEAN epilogue");

@@ -235,6 +235,13 @@ class FusedTrainer:
         # the incoming gradient is non-zero only on this step's batch rows: the first product
         # skips every other column
         sparse_src = dict(col_mark=self.mark, mark_stamp=self.cursor[1:2]) if self.use_marks else {}
+        # gF, gCL and the regulariser gradient are zero outside the batch rows: read them only there
+        batch_sparse = {id(gF), id(gCL), id(extra)} - {id(None)} if self.use_marks else set()
+
+        def sparse_add(add):
+            if not batch_sparse:
+                return {}
+            return dict(add_mark=self.mark, mark_stamp=self.cursor[1:2], add_sparse=[id(a) in batch_sparse for a in add])
         bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
         for k in range(L - 1, 0, -1):              # produce H_k
             add, sc = [gF], [s]
@@ -242,7 +249,8 @@ class FusedTrainer:
                 add.append(gCL)
                 sc.append(1.0)
             dst = bufs[0]
-            ops.spmm(adj, src, out=dst, epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **sparse_src))
+            ops.spmm(adj, src, out=dst,
+                     epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **{**sparse_add(add), **sparse_src}))
             src, alpha, sparse_src = dst, 1.0, {}
             bufs.reverse()
         add, sc = ([self.gE0], [1.0]) if accumulate else ([], [])   # (aliasing y is allowed)
@@ -260,7 +268,7 @@ class FusedTrainer:
                 raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
         ops.spmm(adj, src, out=self.gE0,
-                 epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **sparse_src))
+                 epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **{**sparse_add(add), **sparse_src}))
 
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch

@@ -199,7 +199,7 @@ class DeviceCSR:
 
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
-                  row_mark=None, col_mark=None, mark_stamp=None):
+                  row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None):
     ep = SpmmEpilogue()
     keep = []
     flags = 0
@@ -233,11 +233,13 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
             ep.d_add[t] = _p(x, torch.float32, "add")
             ep.add_scale[t] = float(add_scale[t])
         keep += list(add)
-    if row_mark is not None or col_mark is not None:
+    if row_mark is not None or col_mark is not None or add_mark is not None:
         ep.d_row_mark = _p(row_mark, torch.int32, "row_mark")
         ep.d_col_mark = _p(col_mark, torch.int32, "col_mark")
         ep.d_mark_stamp = _p(mark_stamp, torch.int64, "mark_stamp")
-        keep += [row_mark, col_mark, mark_stamp]
+        ep.d_add_mark = _p(add_mark, torch.int32, "add_mark")
+        ep.add_sparse_mask = sum(1 << t for t, f in enumerate(add_sparse or []) if f)
+        keep += [row_mark, col_mark, mark_stamp, add_mark]
     ep.flags = flags
     ep._keepalive = keep
     return ep

@@ -28,11 +28,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     b.record(); torch.cuda.synchronize()
     print(f"{a.elapsed_time(b) / 50 * 1e3:8.2f} us", flush=True)
 else:
-    for n in (1024, 2048):
-        for f32 in (False, True):
+    for n in (2048,):
+        for qt in (1, 2):
             for splits in (4, 8, 16):
-                env = dict(os.environ, SRH_NCE_SPLITS=str(splits))
-                if f32:
-                    env["SRH_NCE_F32"] = "1"
+                env = dict(os.environ, SRH_NCE_SPLITS=str(splits), SRH_NCE_QT=str(qt))
                 out = subprocess.run([sys.executable, __file__, "child", str(n)], env=env, capture_output=True, text=True)
-                print(f"n={n} path={'f32 ' if f32 else 'bf16x3'} splits={splits:2d}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-200:]}", flush=True)
+                print(f"n={n} bf16x3 qt={qt} splits={splits:2d}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
