@@ -159,10 +159,12 @@ def main():
     from selfrec_amd import _lib
     _lib.require_gpu()
     torch.cuda.set_device(local)
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("SRH_FORCE_SHARDED"))     # (knob: exercise the N>1 path on one GPU)
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist = None
 
@@ -170,7 +172,7 @@ def main():
     torch.manual_seed(args.seed)
     kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
               layer_cl=1, batch_size=args.batch, use_graph=not args.no_graph)
-    if world > 1:
+    if sharded:
         from selfrec_amd.dist import ShardedTrainer
         trainer = ShardedTrainer(data, args.emb, **kw)
     else:
@@ -226,12 +228,12 @@ def main():
         "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; sampling on a host thread inside the timed region",
-                   "global_batch": args.batch, "parallelism": "single" if world == 1 else f"row-sharded x{world}",
-                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+                   "global_batch": args.batch, "parallelism": f"row-sharded x{world}" if sharded else "single",
+                   "launch": "eager" if (args.no_graph or sharded) else "hipGraph replay"},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     if rank == 0:
-        t_spmm = time_spmm_kernel(trainer) if world == 1 else None
+        t_spmm = time_spmm_kernel(trainer) if not sharded else None
         if t_spmm:
             alg = spmm_alg_bytes(g.adj.nnz, g.n_nodes, g.n_nodes, args.emb)
             ach = alg / t_spmm / 1e9
@@ -242,9 +244,9 @@ def main():
                                "step_alg_bytes": step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch),
                                "step_GBps": round(step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch)
                                                   / (elapsed / args.steps) / 1e9, 1)}
-        if not args.no_eval and world == 1:
+        if not args.no_eval and not sharded:
             out["eval"] = eval_throughput(trainer, data)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:

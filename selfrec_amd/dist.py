@@ -162,7 +162,12 @@ class ShardedTrainer:
         return self.sampler.epoch(self.B, 1, with_unique=True)
 
     def upload_epoch(self, host):
+        """Node ids of the whole epoch go to the device once; a step only slices them (no host sync)."""
         self._host, self._batch_no = host, 0
+        U = self.U
+        dev = lambda a, off=0: torch.from_numpy(a.astype(np.int64) + off).to(self.dev)   # noqa: E731
+        self._ep = {"u": dev(host["u"]), "p": dev(host["i"], U), "n": dev(host["j"], U),
+                    "uu": dev(host["uniq_u"]), "ui": dev(host["uniq_i"], U)}
 
     def begin_epoch(self):
         self.upload_epoch(self.sample_epoch_host())
@@ -173,20 +178,19 @@ class ShardedTrainer:
         dist.all_gather_into_tensor(self.full, local)
         return self.full
 
-    def _owner_rows(self, node_ids):
-        """For global node ids: (mask of ids this rank owns, their local rows)."""
-        ids = torch.as_tensor(node_ids, dtype=torch.int64, device=self.dev)
-        return (ids % self.G) == self.rank, ids // self.G
+    def _owner_rows(self, ids):
+        """For global node ids (device int64): (0/1 float mask of ids this rank owns, their local rows).
+        Every id has a valid local row on every rank (loc < n_pad), so gathers need no compaction."""
+        return ((ids % self.G) == self.rank).to(torch.float32).unsqueeze(1), ids // self.G
 
     def _collect_rows(self, tables_and_ids):
         """One all-reduce assembling rows of sharded tables: [(local_table, global ids), ...] ->
-        list of dense (len(ids), d) tensors, identical on every rank."""
+        list of dense (len(ids), d) tensors, identical on every rank.  Sync-free: non-owned rows are
+        gathered from whatever lives at that local row and multiplied by zero."""
         parts, metas = [], []
         for table, ids in tables_and_ids:
             own, loc = self._owner_rows(ids)
-            rows = torch.zeros((len(ids), self.d), dtype=torch.float32, device=self.dev)
-            rows[own] = table[loc[own]]
-            parts.append(rows)
+            parts.append(table[loc] * own)
             metas.append((own, loc))
         flat = torch.cat(parts)
         dist.all_reduce(flat)
@@ -251,11 +255,9 @@ class ShardedTrainer:
     def step(self):
         if self._host is None:
             raise SelfrecHipError("call begin_epoch() first")
-        h, b, B, U = self._host, self._batch_no, self.B, self.U
+        h, b, B, U, ep = self._host, self._batch_no, self.B, self.U, self._ep
         lo, hi = b * B, min((b + 1) * B, len(h["u"]))
-        u_ids = h["u"][lo:hi].astype(np.int64)
-        p_ids = h["i"][lo:hi].astype(np.int64) + U
-        n_ids = h["j"][lo:hi].astype(np.int64) + U
+        u_ids, p_ids, n_ids = ep["u"][lo:hi], ep["p"][lo:hi], ep["n"][lo:hi]
         self._batch_no += 1
         self._noise_call = 0
         m = self.model
@@ -270,8 +272,8 @@ class ShardedTrainer:
         if m == "LightGCN":
             want += [(self.E0, u_ids), (self.E0, p_ids), (self.E0, n_ids)]
         if m == "XSimGCL":
-            uu = h["uniq_u"][b * B:b * B + h["n_uniq_u"][b]].astype(np.int64)
-            ui = h["uniq_i"][b * B:b * B + h["n_uniq_i"][b]].astype(np.int64) + U
+            uu = ep["uu"][b * B:b * B + int(h["n_uniq_u"][b])]
+            ui = ep["ui"][b * B:b * B + int(h["n_uniq_i"][b])]
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
             want += [(self.F, uu), (CL, uu), (self.F, ui), (CL, ui)]
         rows, metas = self._collect_rows(want)
@@ -280,20 +282,20 @@ class ShardedTrainer:
             eu, ep_, en = rows[3], rows[4], rows[5]
             g = self.k.bpr_l2(ru, rp, rn, eu, ep_, en, self.reg / self.B, True, self.losses)
             for (own, loc), grad in zip(metas[3:6], g[3:6]):
-                self.gE0.index_add_(0, loc[own], grad[own])
+                self.gE0.index_add_(0, loc, grad * own)
         else:
             coef = self.reg / self.B if m == "MF" else self.reg
             g = self.k.bpr_l2(ru, rp, rn, ru, rp, rn, coef, m == "MF", self.losses)
         for (own, loc), grad in zip(metas[0:3], g[0:3]):
-            self.gF.index_add_(0, loc[own], grad[own])
+            self.gF.index_add_(0, loc, grad * own)
         if m == "XSimGCL":
             base = 3
             for side in range(2):
                 v1, v2 = rows[base + 2 * side], rows[base + 2 * side + 1]
                 g1, g2 = self.k.infonce(v1, v2, self.tau, self.cl_rate, self.losses[2:3])
                 (own, loc) = metas[base + 2 * side]
-                self.gF.index_add_(0, loc[own], g1[own])
-                self.gCL.index_add_(0, loc[own], g2[own])
+                self.gF.index_add_(0, loc, g1 * own)
+                self.gCL.index_add_(0, loc, g2 * own)
         if m == "XSimGCL":
             self._backward(self.gF, False, gCL=self.gCL, layer_cl=self.layer_cl)
         elif m == "LightGCN":

@@ -29,6 +29,8 @@ prof)
   find $OUT/prof -name "*.db" -size +40M -delete;;
 gather)
   mkdir -p $OUT; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_bw.hip -o /tmp/gather_bw && timeout 300 /tmp/gather_bw > $OUT/gather_bw.log 2>&1; echo "gather exit $?"; cat $OUT/gather_bw.log;;
+sharded1)
+  SRH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench_sharded1.log 2> $OUT/bench_sharded1.err; echo "sharded1 exit $?"; tail -3 $OUT/bench_sharded1.err; tail -1 $OUT/bench_sharded1.log | cut -c1-400;;
 zipf)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_zipf.hip -o /tmp/gather_zipf 2>/dev/null && timeout 300 /tmp/gather_zipf > $OUT/gather_zipf.log 2>&1; echo "zipf exit $?"; cat $OUT/gather_zipf.log;;
 matrix)
