@@ -248,10 +248,13 @@ def main():
             out["eval"] = eval_throughput(trainer, data)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)        # RCCL's banner goes through C stdio: keep the JSON line last
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
