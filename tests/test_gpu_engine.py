@@ -207,3 +207,34 @@ def test_sharded_trainer_on_hip_backend_single_rank(golden_models, golden_meta, 
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,d", [("XSimGCL", 128), ("SGL", 128), ("LightGCN", 32), ("LightGCN", 256), ("MF", 128)])
+def test_other_embedding_sizes_match_oracle(name, d):
+    """d = 128 is BASELINE.json config 4's size (two rows per wave, D=128 InfoNCE tiles); d = 32 / 256 use the
+    8- and 64-lane row shapes.  Three steps against the CPU oracle on the same batches and injected noise."""
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    torch.manual_seed(3)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, d)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, d))
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    kw = dict(n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=2, drop_rate=0.1, batch_size=1500)
+    tr = FusedTrainer(data, d, model=name, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=g1), **kw)
+    ref = O.OracleTrainer(name, data.train_u, data.train_i, U, I, d, user_emb=ue, item_emb=ie,
+                          noise_fn=lambda s: torch.rand(s, generator=g2), **kw)
+    random.seed(17)
+    tr.seed_sampler_from_python()
+    nb = tr.begin_epoch()
+    host = tr._epoch_host
+    if name == "SGL":                       # the oracle draws its two dropped views from the same stream
+        random.seed(17)
+        ref.resample_views()
+    for b in range(min(nb, 3)):
+        tr.step()
+        got = tr.read_losses()
+        lo, hi = b * 1500, min((b + 1) * 1500, len(host["u"]))
+        want = ref.step(host["u"][lo:hi].tolist(), host["i"][lo:hi].tolist(), host["j"][lo:hi].tolist())
+        np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-9)
+    assert rel_err(tr.user_emb.cpu().numpy(), ref.user_emb.detach().numpy()) < 1e-4
+    assert rel_err(tr.item_emb.cpu().numpy(), ref.item_emb.detach().numpy()) < 1e-4
+    assert np.abs(tr.item_emb.cpu().numpy() - ref.item_emb.detach().numpy()).max() < 1e-5
