@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 9
+#define SRH_ABI_VERSION 10
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -307,6 +307,23 @@ srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_
                            const int32_t* row_offset, int32_t d,
                            int64_t* d_cursor_advance /* optional: {batch, step} += 1 */, void* stream);
 srh_status_t srh_cursor_advance(int64_t* d_cursor, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (f-1) Dataset files -> id arrays -- replaces the python loops of data/loader.py:22-33
+ * (FileIO.load_data_set: one "user item weight" line per interaction, single-space separated)
+ * and data/ui_graph.py:29-45 (ids in first-appearance order of the training file; test pairs kept
+ * only when both ends occur in training).  Host only.
+ * sizes5 = {n_users, n_items, n_train, n_test_kept, n_test_lines}; names are returned concatenated
+ * (offsets has n+1 entries).  which: 0 = users, 1 = items.
+ * ---------------------------------------------------------------------------------- */
+typedef struct srh_dataset srh_dataset_t;
+srh_status_t srh_dataset_load(srh_dataset_t** out, const char* train_path, const char* test_path /* or NULL */);
+void srh_dataset_destroy(srh_dataset_t* ds);
+srh_status_t srh_dataset_sizes(const srh_dataset_t* ds, int64_t* h_sizes5);
+srh_status_t srh_dataset_copy_ids(const srh_dataset_t* ds, int32_t* h_train_u, int32_t* h_train_i,
+                                  float* h_train_w, int32_t* h_test_u, int32_t* h_test_i);
+int64_t srh_dataset_names_bytes(const srh_dataset_t* ds, int32_t which);
+srh_status_t srh_dataset_copy_names(const srh_dataset_t* ds, int32_t which, char* h_buf, int64_t* h_offsets);
 
 #ifdef __cplusplus
 }

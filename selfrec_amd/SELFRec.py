@@ -10,8 +10,9 @@ class SELFRec:
     def __init__(self, config):
         self.config = config
         kind = config['model']['type']
-        self.training_data = FileIO.load_data_set(config['training.set'], kind)
-        self.test_data = FileIO.load_data_set(config['test.set'], kind)
+        # lazy, natively parsed triples: behave like the reference's lists for any model that touches them
+        self.training_data = FileIO.open_data_set(config['training.set'], kind)
+        self.test_data = FileIO.open_data_set(config['test.set'], kind)
         self.kwargs = {}
         print('Reading data and preprocessing...')
 

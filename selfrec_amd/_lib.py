@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -87,6 +87,12 @@ SIGNATURES = {
                                 _i32, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
+    "srh_dataset_load": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_char_p]),
+    "srh_dataset_destroy": (None, [_vp]),
+    "srh_dataset_sizes": (_i32, [_vp, _vp]),
+    "srh_dataset_copy_ids": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_dataset_names_bytes": (_i64, [_vp, _i32]),
+    "srh_dataset_copy_names": (_i32, [_vp, _i32, _vp, _vp]),
 }
 
 _lib = None

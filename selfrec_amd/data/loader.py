@@ -5,6 +5,39 @@ returned as ``[[user_str, item_str, float_weight], ...]`` in file order (the ord
 ids are assigned by first appearance, reference data/ui_graph.py:29-38).
 """
 import os
+from collections.abc import MutableSequence
+
+
+class TripleFile(MutableSequence):
+    """Lazy stand-in for the list ``FileIO.load_data_set(path, 'graph')`` returns.
+
+    ``Interaction`` recognises it and builds its id arrays with the native loader
+    (``srh_dataset_load``) without ever creating the python triples; any other consumer that
+    indexes, iterates or mutates it gets the ordinary list, materialised on first touch."""
+
+    def __init__(self, path):
+        self.path = path
+        self._rows = None
+
+    def _list(self):
+        if self._rows is None:
+            self._rows = FileIO.load_data_set(self.path, 'graph')
+        return self._rows
+
+    def __len__(self):
+        return len(self._list())
+
+    def __getitem__(self, k):
+        return self._list()[k]
+
+    def __setitem__(self, k, v):
+        self._list()[k] = v
+
+    def __delitem__(self, k):
+        del self._list()[k]
+
+    def insert(self, k, v):
+        self._list().insert(k, v)
 
 
 class FileIO:
@@ -25,6 +58,15 @@ class FileIO:
                     sequences[key] = tail.split()
             return sequences
         raise ValueError(f"unknown recommender type {rec_type!r}")
+
+    @staticmethod
+    def open_data_set(file, rec_type):
+        """Like load_data_set, but graph data is parsed natively and lazily (see TripleFile)."""
+        if rec_type == 'graph':
+            if not os.path.exists(file):
+                raise FileNotFoundError(file)
+            return TripleFile(file)
+        return FileIO.load_data_set(file, rec_type)
 
     @staticmethod
     def write_file(dir, file, content, op='w'):

@@ -17,12 +17,18 @@ import scipy.sparse as sp
 
 from .data import Data
 from .graph import Graph
+from .loader import TripleFile
 
 
 class Interaction(Data, Graph):
     def __init__(self, conf, training, test):
         Graph.__init__(self)
         Data.__init__(self, conf, training, test)
+        self._cache = {}
+        if isinstance(training, TripleFile) and training._rows is None and \
+                (isinstance(test, TripleFile) and test._rows is None or (not isinstance(test, TripleFile) and len(test) == 0)):
+            self._init_native(training.path, test.path if isinstance(test, TripleFile) else None)
+            return
         self.user, self.item = {}, {}
         n = len(self.training_data)
         self.train_u = np.empty(n, dtype=np.int32)
@@ -46,7 +52,43 @@ class Interaction(Data, Graph):
             if rec[0] in user and rec[1] in item:
                 self.test_set[rec[0]][rec[1]] = 1
                 self.test_set_item.add(rec[1])
-        self._cache = {}
+
+    def _init_native(self, train_path, test_path):
+        """Same products as the python loops above, parsed and id-mapped by srh_dataset_load."""
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.srh_dataset_load(C.byref(h), train_path.encode(), test_path.encode() if test_path else None),
+                   "srh_dataset_load")
+        try:
+            sizes = (C.c_int64 * 5)()
+            _lib.check(lib.srh_dataset_sizes(h, sizes))
+            n_users, n_items, n_train, n_test, self._n_test_lines = (int(x) for x in sizes)
+            self.train_u = np.empty(n_train, dtype=np.int32)
+            self.train_i = np.empty(n_train, dtype=np.int32)
+            test_u, test_i = np.empty(n_test, dtype=np.int32), np.empty(n_test, dtype=np.int32)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            _lib.check(lib.srh_dataset_copy_ids(h, vp(self.train_u), vp(self.train_i), None, vp(test_u), vp(test_i)))
+            names = []
+            for which, n in ((0, n_users), (1, n_items)):
+                buf = C.create_string_buffer(max(1, int(lib.srh_dataset_names_bytes(h, which))))
+                off = np.empty(n + 1, dtype=np.int64)
+                _lib.check(lib.srh_dataset_copy_names(h, which, buf, vp(off)))
+                raw = buf.raw
+                names.append([raw[off[k]:off[k + 1]].decode() for k in range(n)])
+        finally:
+            lib.srh_dataset_destroy(h)
+        user_names, item_names = names
+        self.user = dict(zip(user_names, range(n_users)))
+        self.item = dict(zip(item_names, range(n_items)))
+        self.id2user = dict(enumerate(user_names))
+        self.id2item = dict(enumerate(item_names))
+        self.user_num, self.item_num = n_users, n_items
+        self.test_set = defaultdict(dict)
+        for u, i in zip(test_u.tolist(), test_i.tolist()):
+            self.test_set[user_names[u]][item_names[i]] = 1
+        self.test_set_item = set(item_names[i] for i in np.unique(test_i).tolist())
 
     # ---- lazily built views ---------------------------------------------------------
     def _lazy(self, key, build):

@@ -113,3 +113,27 @@ def test_reference_model_files_import_against_the_mirrors():
         for k in [k for k in sys.modules if k.split(".")[0] in ("base", "data", "util", "model")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_native_loader_equals_python_path(tmp_path):
+    """srh_dataset_load + Interaction's native constructor == the reference-style python loops."""
+    import time
+    tu, ti, su, si, U, I = synth.make_dataset("small")
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    synth.write_text(str(tr), tu, ti)
+    with open(te, "w") as f:                                   # unseen user / item, CRLF, float weight
+        f.writelines(f"{a} {b} 1\n" for a, b in zip(su.tolist(), si.tolist()))
+        f.write("ghost 17 1\n17 phantom 4.5\r\n")
+    slow = Interaction({}, FileIO.load_data_set(str(tr), "graph"), FileIO.load_data_set(str(te), "graph"))
+    t0 = time.time()
+    fast = Interaction({}, FileIO.open_data_set(str(tr), "graph"), FileIO.open_data_set(str(te), "graph"))
+    assert fast.training_data._rows is None                     # no python triples were built
+    assert fast.user == slow.user and fast.item == slow.item and fast.id2item == slow.id2item
+    assert np.array_equal(fast.train_u, slow.train_u) and np.array_equal(fast.train_i, slow.train_i)
+    assert dict(fast.test_set) == dict(slow.test_set) and fast.test_set_item == slow.test_set_item
+    assert fast.test_size()[:2] == slow.test_size()[:2] and fast.training_size() == slow.training_size()
+    assert (fast.norm_adj != slow.norm_adj).nnz == 0
+    assert fast.training_data[0] == slow.training_data[0]       # materialises like the list on demand
+    with pytest.raises(Exception):
+        bad = tmp_path / "bad.txt"; bad.write_text("only_two tokens\n")
+        Interaction({}, FileIO.open_data_set(str(bad), "graph"), [])
