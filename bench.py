@@ -74,22 +74,35 @@ def step_alg_bytes(model, nnz, N, d, L, B):
 
 
 def time_spmm_kernel(trainer, iters=50):
-    """Mean duration of one propagation SpMM launch (perturb epilogue, as in the step), HIP events
-    on the launch stream."""
+    """Mean duration (s) of the propagation SpMM launch in the three flavours a step issues, HIP events on
+    the launch stream: dense (forward layers / inner backward layers: all rows, perturb epilogue),
+    row-masked (last forward layer: batch rows only) and column-masked (first backward layer: batch
+    columns only).  An XSimGCL step with L layers issues 2L launches: 2L-2 dense + 1 + 1."""
     from selfrec_amd import ops
     adj = trainer.graph.adj
     x, y = trainer.E0, trainer.Ha
-    ep = ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0)
-    for _ in range(5):
-        ops.spmm(adj, x, out=y, epilogue=ep)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    a.record()
-    for _ in range(iters):
-        ops.spmm(adj, x, out=y, epilogue=ep)
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters * 1e-3
+    stamp = (trainer.cursor[1:2] - 1).contiguous()            # the marks of the batch that just ran
+    flavours = {
+        "dense": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0),
+        "row_masked": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0, row_mark=trainer.mark,
+                                        mark_stamp=stamp),
+        "col_masked": ops.make_epilogue(col_mark=trainer.mark, mark_stamp=stamp),
+    }
+    out = {}
+    for name, ep in flavours.items():
+        for _ in range(5):
+            ops.spmm(adj, x, out=y, epilogue=ep)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            ops.spmm(adj, x, out=y, epilogue=ep)
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = a.elapsed_time(b) / iters * 1e-3
+    n = 2 * max(trainer.L, 1)
+    out["step_mix"] = ((n - 2) * out["dense"] + out["row_masked"] + out["col_masked"]) / n if n >= 2 else out["dense"]
+    return out
 
 
 def cpu_baseline(args, raw, seconds):
@@ -236,11 +249,16 @@ def main():
         t_spmm = time_spmm_kernel(trainer) if not sharded else None
         if t_spmm:
             alg = spmm_alg_bytes(g.adj.nnz, g.n_nodes, g.n_nodes, args.emb)
-            ach = alg / t_spmm / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "spmm_seg_kernel<16> (propagation SpMM + perturb epilogue)",
+            ach = alg / t_spmm["dense"] / 1e9
+            out["roofline"] = {"bound": "hbm",
+                               "kernel": f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over the whole graph, "
+                                         "perturb epilogue; split rows finished in-kernel)",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                               "alg_bytes_per_launch": alg, "launch_us": round(t_spmm * 1e6, 2),
+                               "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dense"] * 1e6, 2),
+                               "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
+                               "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
+                                       "launch_us_by_flavour.step_mix (profiles/)",
                                "step_alg_bytes": step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch),
                                "step_GBps": round(step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch)
                                                   / (elapsed / args.steps) / 1e9, 1)}

@@ -23,6 +23,10 @@ benchquick)
 eager)
   timeout 600 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OUT/bench_eager.log 2> $OUT/bench_eager.err; echo "eager exit $?"
   tail -3 $OUT/bench_eager.err; tail -2 $OUT/bench_eager.log;;
+profgraph)
+  rm -rf $OUT/profgraph; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profgraph -o trace -- python $OLDPWD/bench.py --steps 600 --warmup 50 --no-cpu-baseline --no-eval > $OLDPWD/$OUT/profgraph.log 2>&1); echo "profgraph exit $?"
+  f=$(find $OUT/profgraph -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/profgraph_kernel_stats.txt && head -16 $OUT/profgraph_kernel_stats.txt; tail -1 $OUT/profgraph.log | cut -c1-300
+  find $OUT/profgraph -name "*.db" -size +40M -delete;;
 prof)
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
   f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/prof_kernel_stats.txt && head -24 $OUT/prof_kernel_stats.txt
