@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 10
+#define SRH_ABI_VERSION 11
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -296,7 +296,9 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
                              int32_t* d_meta,
                              int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = step */,
-                             int32_t mark_item_offset, void* stream);
+                             int32_t mark_item_offset,
+                             double* d_zero4 /* optional: 4 loss accumulators cleared for the new step */,
+                             void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
  * d_counts[k] is NULL).  The sparse counterpart of a memset for gradient buffers that only

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -84,7 +84,7 @@ SIGNATURES = {
     "srh_topk_rows": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
     "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _i32, _vp]),
+                                _i32, _vp, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
     "srh_dataset_load": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_char_p]),

@@ -608,9 +608,8 @@ __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs 
   }
   if (valid) {
     const int dst = w.idx ? w.idx[i] : i;
-    float4* gp = reinterpret_cast<float4*>(PASS2 ? w.g2 : w.g1) + (size_t)dst * LPR + sub;
-    float4 cur = *gp;
-    *gp = f4_add(cur, dv);
+    // atomic: the BPR scatter may be adding to the same rows on another stream of the captured step
+    atomic_add_f4((PASS2 ? w.g2 : w.g1) + ((size_t)dst * LPR + sub) * 4, dv);
   }
 }
 
