@@ -20,6 +20,34 @@ from .graph import Graph
 from .loader import TripleFile
 
 
+class _LazyTriples(list):
+    """[[user, item, 1.0], ...] for id arrays, materialised on first element access; len() is free."""
+
+    def __init__(self, u, i):
+        super().__init__()
+        self._u, self._i, self._done = u, i, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            super().extend([str(a), str(b), 1.0] for a, b in zip(self._u.tolist(), self._i.tolist()))
+
+    def __len__(self):
+        return len(self._u) if not self._done else super().__len__()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __setitem__(self, k, v):
+        self._fill()
+        super().__setitem__(k, v)
+
+
 class Interaction(Data, Graph):
     def __init__(self, conf, training, test):
         Graph.__init__(self)
@@ -52,6 +80,31 @@ class Interaction(Data, Graph):
             if rec[0] in user and rec[1] in item:
                 self.test_set[rec[0]][rec[1]] = 1
                 self.test_set_item.add(rec[1])
+
+    @classmethod
+    def from_id_arrays(cls, conf, train_u, train_i, test_u, test_i, n_users, n_items):
+        """Build from dense integer ids (e.g. a generated graph) without creating python triples: the name
+        of node k is str(k).  Every user and item must occur in training (ids are then their own
+        first-appearance order only up to relabelling, which no kernel depends on)."""
+        self = cls.__new__(cls)
+        Graph.__init__(self)
+        self.config, self._cache = conf, {}
+        self.train_u = np.ascontiguousarray(train_u, dtype=np.int32)
+        self.train_i = np.ascontiguousarray(train_i, dtype=np.int32)
+        if np.unique(self.train_u).size != n_users or np.unique(self.train_i).size != n_items:
+            raise ValueError("from_id_arrays: every user and item needs at least one training interaction")
+        self.user_num, self.item_num = int(n_users), int(n_items)
+        self.user = {str(k): k for k in range(self.user_num)}
+        self.item = {str(k): k for k in range(self.item_num)}
+        self.id2user = {k: str(k) for k in range(self.user_num)}
+        self.id2item = {k: str(k) for k in range(self.item_num)}
+        self.test_set = defaultdict(dict)
+        for u, i in zip(np.asarray(test_u).tolist(), np.asarray(test_i).tolist()):
+            self.test_set[str(u)][str(i)] = 1
+        self.test_set_item = set(str(i) for i in np.unique(np.asarray(test_i)).tolist())
+        self.training_data = _LazyTriples(self.train_u, self.train_i)
+        self.test_data = _LazyTriples(np.asarray(test_u), np.asarray(test_i))
+        return self
 
     def _init_native(self, train_path, test_path):
         """Same products as the python loops above, parsed and id-mapped by srh_dataset_load."""

@@ -33,6 +33,11 @@ prof)
   find $OUT/prof -name "*.db" -size +40M -delete;;
 gather)
   mkdir -p $OUT; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_bw.hip -o /tmp/gather_bw && timeout 300 /tmp/gather_bw > $OUT/gather_bw.log 2>&1; echo "gather exit $?"; cat $OUT/gather_bw.log;;
+big)
+  timeout 1500 python tools/big_graph.py > $OUT/big_graph.log 2>&1; echo "big exit $?"; grep -v amdgpu.ids $OUT/big_graph.log | tail -8;;
+evalpmc)
+  rm -rf $OUT/evalpmc; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d $OLDPWD/$OUT/evalpmc -o pmc -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OLDPWD/$OUT/evalpmc.log 2>&1); echo "evalpmc exit $?"
+  f=$(find $OUT/evalpmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "gemm_nt|topk|mask_kernel|nce_tile" | tee $OUT/evalpmc_summary.txt;;
 sharded1)
   SRH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench_sharded1.log 2> $OUT/bench_sharded1.err; echo "sharded1 exit $?"; tail -3 $OUT/bench_sharded1.err; tail -1 $OUT/bench_sharded1.log | cut -c1-400;;
 zipf)
