@@ -632,10 +632,12 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   std::vector<Task> tasks[4];
   {
     const bool two_class = xcd_split_row > 0 && xcd_split_row < n_rows;
+    int short_max = kShortRow;                                   // A/B knob (non-DEEP kernels take any length)
+    if (const char* env = getenv("SRH_SPMM_SHORT")) short_max = std::max(1, atoi(env));
     std::vector<Seg> coop[2], shorts[2];
     for (const Seg& sgm : segs) {
       const int cls = (two_class && sgm.row >= xcd_split_row) ? 1 : 0;
-      (((sgm.end - sgm.start) > kShortRow || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
+      (((sgm.end - sgm.start) > short_max || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
     }
     auto longer2 = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
     int32_t off[4];

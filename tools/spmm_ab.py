@@ -30,10 +30,12 @@ def add(name, flags, split, slen, idx=None):
                                    xcd_split_row=split)
 
 
-for slen in (256, 512, 1024):
-    add(f"rows        f16 xcd split{slen}", 16, U, slen)
-    add(f"rows+finish f20 xcd split{slen}", 20, U, slen)
-add("rows+finish f20 xcd split128", 20, U, 128)
+for short in (16, 32, 64, 128, 256, 512):
+    os.environ["SRH_SPMM_SHORT"] = str(short)
+    add(f"rows+finish f20 xcd split512 short{short}", 20, U, 512)
+os.environ["SRH_SPMM_SHORT"] = "64"
+add("rows+finish f20 xcd split384 short64", 20, U, 384)
+add("rows+finish f20 xcd split768 short64", 20, U, 768)
 ref = None
 for k, csr in variants.items():
     if "cols%" in k:
@@ -44,7 +46,7 @@ for k, csr in variants.items():
     err = (out - ref).abs().max().item()
     assert err < 1e-4, (k, err)
 ep = ops.make_epilogue(perturb_eps=0.2, rng_seed=1)
-plain = {f"{k} [no epilogue]": v for k, v in variants.items() if "split512" in k and "cols" not in k}
+plain = {}
 times = {k: [] for k in list(variants) + list(plain)}
 for rnd in range(7):
     for k, csr in plain.items():
