@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 constexpr int kNceSplits = 16;      // workspace is sized for this many key splits; batch.splits <= it are used
 
 struct NceWs {
-  float *v1n, *v2n, *norm1, *norm2, *opart, *lpart, *invl;
+  float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
   double* losspart;     // one partial per finish wave
+  int32_t* ticket;      // finish waves still to arrive (zeroed by nce_prep, re-armed by the last arriver)
   // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
   // both stored FRAGMENT-LINEAR: the 64 lanes of one MFMA operand load read one contiguous 1 KB
   //   kq_*[view]  [row/16][k-slice s][lane][8]: lane (c16 = lane&15, g = lane>>4) holds row 16*tile + c16,
@@ -232,6 +233,7 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
   w.v1n = p; p += np * d;
   w.v2n = p; p += np * d;
   w.opart = p; p += (int64_t)kNceSplits * np * d;
+  w.opart2 = p; p += (int64_t)kNceSplits * np * d;
   w.norm1 = p; p += np;
   w.norm2 = p; p += np;
   w.lpart = p; p += (int64_t)kNceSplits * np;
@@ -244,6 +246,7 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
     w.vt_hi[v] = h; h += np * d;
     w.vt_lo[v] = h; h += np * d;
   }
+  w.ticket = reinterpret_cast<int32_t*>(h);
   return w;
 }
 
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
   const bool second = blockIdx.y == 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *w.ticket = 0;
   const float* V = second ? V2 : V1;
   float* out = second ? w.v2n : w.v1n;
   float* nrm = second ? w.norm2 : w.norm1;
@@ -547,6 +551,172 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
   }
 }
 
+
+// LDS-staged form of nce_tile_bf16 (the default).  The register version is latency-bound: a workgroup's
+// waves walk their key range 32 keys at a time and every step waits out an L2 round trip for 16 KB of
+// operands with one wave per SIMD to hide it.  Here the workgroup first copies its WHOLE key range --
+// the four fragment-linear images, <= 4 x 32 KB -- into LDS with direct global->LDS loads (the images
+// are lane-linear 1 KB fragments, exactly the layout global_load_lds writes), pays the latency once,
+// and then runs every step out of LDS with conflict-free ds_read_b128.  PASS2 also folds the softmax
+// denominators of its keys from pass 1's split partials while the copy is in flight, which retires
+// the separate finish launch between the passes.
+__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x8 lds_bf16x8(const unsigned char* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+
+template <int D, bool PASS2, int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float inv_tau) {
+  constexpr int NT = D / 16, KS = D / 32;
+  constexpr int CHUNK = 16384 / D;           // keys per LDS stage: 4 images x CHUNK x D x 2 B = 128 KB
+  constexpr int SPAN = CHUNK * D * 2;        // bytes of one image of one stage (32 KB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* invl_s = reinterpret_cast<float*>(smem + 4 * SPAN);
+  const NceWs& w = batch.w[blockIdx.z];
+  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+  const int np = (int)w.np;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x * WAVES + wv) * (16 * QT);
+  const int ks = blockIdx.y;
+  if (blockIdx.x * (16 * QT * WAVES) >= np) return;              // whole workgroup beyond this problem's rows
+  const int qv = PASS2 ? 1 : 0, kv = PASS2 ? 0 : 1;
+  const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
+  const int kb = ks * per, ke = min(np, kb + per);
+  const bool wave_live = q0 < np;
+
+  bf16x8 qh[QT][KS], ql[QT][KS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int tile = min((q0 >> 4) + t, (np >> 4) - 1);
+      const size_t at = (((size_t)tile * KS + s) * 64 + lane) * 8;
+      qh[t][s] = ld_bf16x8(w.kq_hi[qv] + at);
+      ql[t][s] = ld_bf16x8(w.kq_lo[qv] + at);
+    }
+  floatx4 O[QT][NT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) O[t][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float lsum[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) lsum[t] = 0.f;
+
+  for (int c0 = kb; c0 < ke; c0 += CHUNK) {
+    const int cn = min(CHUNK, ke - c0);                  // a multiple of 32
+    if (c0 != kb) __syncthreads();                       // the previous stage has been read by every wave
+    const int n_kb = cn * D * 2 / 1024;                  // 1 KB fragments per image in this stage
+    const unsigned char* src[4] = {
+        reinterpret_cast<const unsigned char*>(w.kq_hi[kv]) + (size_t)(c0 >> 4) * KS * 1024,
+        reinterpret_cast<const unsigned char*>(w.kq_lo[kv]) + (size_t)(c0 >> 4) * KS * 1024,
+        reinterpret_cast<const unsigned char*>(w.vt_hi[kv]) + (size_t)(c0 >> 5) * NT * 1024,
+        reinterpret_cast<const unsigned char*>(w.vt_lo[kv]) + (size_t)(c0 >> 5) * NT * 1024};
+#pragma unroll
+    for (int img = 0; img < 4; ++img)
+      for (int k = wv; k < n_kb; k += WAVES)
+        glds16(src[img] + (size_t)k * 1024 + lane * 16, smem + img * SPAN + k * 1024);
+    if (PASS2) {
+      // 1 / l(key) from pass 1's split partials, in split order (the order nce_finish uses)
+      for (int t = threadIdx.x; t < cn; t += 64 * WAVES) {
+        float l = 0.f;
+        for (int sp = 0; sp < batch.splits; ++sp) l += w.lpart[(size_t)sp * np + c0 + t];
+        invl_s[t] = 1.0f / l;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!wave_live) continue;
+
+    for (int j0 = 0; j0 < cn; j0 += 32) {
+      bf16x8 kh[2][KS], kl[2][KS];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int off = (((j0 >> 4) + h) * KS + s) * 1024 + lane * 16;
+          kh[h][s] = lds_bf16x8(smem + off);
+          kl[h][s] = lds_bf16x8(smem + SPAN + off);
+        }
+      bf16x8 vh[NT], vl[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int off = ((j0 >> 5) * NT + u) * 1024 + lane * 16;
+        vh[u] = lds_bf16x8(smem + 2 * SPAN + off);
+        vl[u] = lds_bf16x8(smem + 3 * SPAN + off);
+      }
+      float il[2][4];
+      if (PASS2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) il[h][r] = invl_s[j0 + 16 * h + 4 * g + r];
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        floatx4 a[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
+          }
+        }
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = c0 + j0 + 16 * h + 4 * g + r;
+            float e = __expf(a[h][r] * inv_tau - inv_tau);   // v_exp_f32: 1e-6 relative, inside the split-bf16 error
+            if (PASS2) e *= il[h][r];
+            const float wt = (key < n) ? e : 0.f;
+            lsum[t] += wt;
+            const __bf16 bh = (__bf16)wt;
+            ph[4 * h + r] = bh;
+            pl[4 * h + r] = (__bf16)(wt - (float)bh);
+          }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_live) return;
+
+  float* obase = PASS2 ? w.opart2 : w.opart;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qt0 = q0 + 16 * t;
+    if (qt0 >= np) break;
+    float* op = obase + ((size_t)ks * np + qt0) * D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+#pragma unroll
+      for (int u = 0; u < NT / 4; ++u)
+        reinterpret_cast<float4*>(rowp)[u] =
+            make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
+    }
+    if (!PASS2) {
+      float l = lsum[t];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (g == 0) w.lpart[(size_t)ks * np + qt0 + c16] = l;
+    }
+  }
+}
+
 struct NceFinishArgs {
   float inv_tau, loss_scale;
   double* loss;
@@ -613,6 +783,83 @@ __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs 
   }
 }
 
+
+// One finish for both passes (used with nce_tile_lds): folds the split partials, turns them into the
+// gradients of both views (through the normalisation) and scatters them; the loss partials are folded
+// in workgroup order by whichever workgroup of the problem arrives last (write-through partial ->
+// vmcnt(0) -> relaxed agent-scope ticket -> acquire), so the reported loss is bitwise reproducible.
+__device__ __forceinline__ void store_f64_sc1(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, float norm) {
+  const float proj = group_sum<LPR>(f4_dot(self, dn));
+  if (norm > 1e-12f)
+    return make_float4((dn.x - self.x * proj) / norm, (dn.y - self.y * proj) / norm,
+                       (dn.z - self.z * proj) / norm, (dn.w - self.w * proj) / norm);
+  return f4_scale(dn, 1e12f);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_finish_both(NceBatch batch, NceFinishArgs a) {
+  constexpr int G = 64 / LPR;
+  const NceWs& w = batch.w[blockIdx.z];
+  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  const int n_waves = (int)(w.np / G);
+  if (n <= 0 || wave >= n_waves) return;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int i = wave * G + g;
+  const bool valid = i < n;
+  const int ii = valid ? i : 0;
+  const size_t at = (size_t)ii * LPR + sub;
+  float4 O1 = f4_zero(), O2 = f4_zero();
+  float l = 0.f;
+  for (int ks = 0; ks < batch.splits; ++ks) {
+    O1 = f4_add(O1, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
+    O2 = f4_add(O2, reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at]);
+    l += w.lpart[(size_t)ks * w.np + ii];
+  }
+  const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
+  const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
+  const float coef = a.loss_scale * a.inv_tau / (float)n;
+  const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
+  const float lse = a.inv_tau + logf(l);
+  const double part = wave_sum_d((valid && sub == 0) ? (double)(lse - sii) : 0.0);
+  const float il = 1.0f / l;
+  const float4 dn1 = make_float4(coef * (O1.x * il - vb.x), coef * (O1.y * il - vb.y), coef * (O1.z * il - vb.z),
+                                 coef * (O1.w * il - vb.w));
+  const float4 dn2 = make_float4(coef * (O2.x - va.x), coef * (O2.y - va.y), coef * (O2.z - va.z), coef * (O2.w - va.w));
+  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, w.norm1[ii]);
+  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, w.norm2[ii]);
+  // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
+  __shared__ double wg_part[4];
+  if (lane == 0) wg_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const int n_wgs = n_waves / 4;                      // np is a multiple of 64: whole workgroups only
+  if (threadIdx.x < 64) {
+    if (lane == 0) store_f64_sc1(w.losspart + blockIdx.x, (wg_part[0] + wg_part[1]) + (wg_part[2] + wg_part[3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(w.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket == n_wgs - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (lane == 0) __hip_atomic_store(w.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double t = 0.0;
+      for (int k = lane; k < n_wgs; k += 64) t += w.losspart[k];
+      t = wave_sum_d(t);
+      if (lane == 0) atomicAdd(a.loss, (double)a.loss_scale * t / (double)n);   // one per problem
+    }
+  }
+  if (valid) {
+    const int dst = w.idx ? w.idx[i] : i;
+    atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
+    atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
+  }
+}
+
 template <int D>
 srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float tau, float loss_scale, double* loss,
                             void* ws, hipStream_t st) {
@@ -637,14 +884,43 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   SRH_LAUNCH_CHECK();
   dim3 gt(np_max / 64, batch.splits, count);
   static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
-  static const int qt = getenv("SRH_NCE_QT") ? atoi(getenv("SRH_NCE_QT")) : 2;      // query tiles per wave (A/B knob)
+  static const int qt = getenv("SRH_NCE_QT") ? atoi(getenv("SRH_NCE_QT")) : 1;      // query tiles per wave (A/B knob)
+  static const bool lds_path = !(getenv("SRH_NCE_LDS") && atoi(getenv("SRH_NCE_LDS")) == 0);   // A/B knob
   dim3 gt2((np_max + 127) / 128, batch.splits, count);
+  NceFinishArgs fa{inv_tau, loss_scale, loss};
+  dim3 fb((np_max / G + 3) / 4, 1, count);
+  if (!f32_path && lds_path) {
+    constexpr int kLds = 4 * (16384 / D) * D * 2 + (16384 / D) * 4;
+    static const int waves = getenv("SRH_NCE_WAVES") ? atoi(getenv("SRH_NCE_WAVES")) : 8;     // A/B knob
+#define SRH_NCE_LDS_LAUNCH(QTV, WV)                                                                            \
+  do {                                                                                                         \
+    static const bool attr_set = [] {                                                                          \
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, QTV, WV>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                             \
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, true, QTV, WV>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                             \
+      return true;                                                                                             \
+    }();                                                                                                       \
+    (void)attr_set;                                                                                            \
+    dim3 gl((np_max + 16 * QTV * WV - 1) / (16 * QTV * WV), batch.splits, count);                              \
+    nce_tile_lds<D, false, QTV, WV><<<gl, 64 * WV, kLds, st>>>(batch, inv_tau);                                \
+    SRH_LAUNCH_CHECK();                                                                                        \
+    nce_tile_lds<D, true, QTV, WV><<<gl, 64 * WV, kLds, st>>>(batch, inv_tau);                                 \
+    SRH_LAUNCH_CHECK();                                                                                        \
+  } while (0)
+    if (waves == 8 && qt == 1) SRH_NCE_LDS_LAUNCH(1, 8);
+    else if (waves == 8) SRH_NCE_LDS_LAUNCH(2, 8);
+    else if (qt == 1) SRH_NCE_LDS_LAUNCH(1, 4);
+    else SRH_NCE_LDS_LAUNCH(2, 4);
+#undef SRH_NCE_LDS_LAUNCH
+    nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
+    SRH_LAUNCH_CHECK();
+    return SRH_OK;
+  }
   if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   else if (qt == 2) nce_tile_bf16<D, false, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
   else nce_tile_bf16<D, false, 1><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
-  NceFinishArgs fa{inv_tau, loss_scale, loss};
-  dim3 fb((np_max / G + 3) / 4, 1, count);
   nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   if (f32_path) nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
@@ -753,7 +1029,7 @@ srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* st
 int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
-  return 4 * (2 * np * d + (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
+  return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
          16 * np * d + 256;
 }
 

@@ -17,10 +17,70 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ X, cons
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const long wave = (blockIdx.x * 256L + threadIdx.x) >> 6, n_waves = gridDim.x * 4L;
   float4 acc = make_float4(0, 0, 0, 0);
-  for (long base = wave * 8 * G; base + 8 * G <= n_idx; base += n_waves * 8 * G) {
+  // the index chunk of the NEXT iteration is in flight while this one's gathers are outstanding, so the
+  // loop measures gather throughput, not the idx -> gather latency chain
+  long base = wave * 8 * G;
+  int nxt[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) nxt[t] = (base + 8 * G <= n_idx) ? idx[base + t * G + g] : 0;
+  for (; base + 8 * G <= n_idx; base += n_waves * 8 * G) {
+    int cur[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+    const long nb = base + n_waves * 8 * G;
+    if (nb + 8 * G <= n_idx) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) nxt[t] = idx[nb + t * G + g];
+    }
     float4 x[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = X[(size_t)idx[base + t * G + g] * stride4 + sub];
+    for (int t = 0; t < 8; ++t) x[t] = X[(size_t)cur[t] * stride4 + sub];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc.x += x[t].x; acc.y += x[t].y; acc.z += x[t].z; acc.w += x[t].w; }
+  }
+  if (acc.x == 123.456f) out[0] = acc;
+}
+
+// variant 4: rows colder than a popularity rank are fetched with the non-temporal hint so they do not
+// evict the popular rows from L2 (sign bit of the index = cold).
+__global__ __launch_bounds__(256) void gather_nt(const float4* __restrict__ X, const int* __restrict__ enc, long n_idx,
+                                                 float4* out) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
+  const long wave = (blockIdx.x * 256L + threadIdx.x) >> 6, n_waves = gridDim.x * 4L;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (long base = wave * 32; base + 32 <= n_idx; base += n_waves * 32) {
+    float4 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = enc[base + t * 4 + g];
+      const float4* p = X + (size_t)(e & 0x7fffffff) * 16 + sub;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      if (e < 0) { const v4f q = __builtin_nontemporal_load((const v4f*)p); x[t] = make_float4(q.x, q.y, q.z, q.w); }
+      else x[t] = *p;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc.x += x[t].x; acc.y += x[t].y; acc.z += x[t].z; acc.w += x[t].w; }
+  }
+  if (acc.x == 123.456f) out[0] = acc;
+}
+
+// variant 3: the H most popular rows are staged in LDS by every (persistent) workgroup; the index stream
+// carries (0x80000000 | slot) for those.  Tests whether taking the hot lines off L2 pays.
+__global__ __launch_bounds__(1024) void gather_hot(const float4* __restrict__ X, const int* __restrict__ enc,
+                                                   const int* __restrict__ hot_rows, int H, long n_idx, float4* out) {
+  extern __shared__ float4 hot[];
+  for (int k = threadIdx.x; k < H * 16; k += 1024) hot[k] = X[(size_t)hot_rows[k >> 4] * 16 + (k & 15)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
+  const long wave = (blockIdx.x * 1024L + threadIdx.x) >> 6, n_waves = gridDim.x * 16L;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (long base = wave * 32; base + 32 <= n_idx; base += n_waves * 32) {
+    float4 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = enc[base + t * 4 + g];
+      x[t] = (e < 0) ? hot[(e & 0x7fffffff) * 16 + sub] : X[(size_t)e * 16 + sub];
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc.x += x[t].x; acc.y += x[t].y; acc.z += x[t].z; acc.w += x[t].w; }
   }
@@ -37,9 +97,12 @@ int main() {
   std::vector<int> perm(rows);
   for (int k = 0; k < rows; ++k) perm[k] = k;
   std::shuffle(perm.begin(), perm.end(), rng);
-  std::vector<int> h(n_idx);
+  std::vector<int> h(n_idx), rank(n_idx);
   std::uniform_real_distribution<double> U(0, s);
-  for (long i = 0; i < n_idx; ++i) h[i] = perm[std::lower_bound(cdf.begin(), cdf.end(), U(rng)) - cdf.begin()];
+  for (long i = 0; i < n_idx; ++i) {
+    rank[i] = (int)(std::lower_bound(cdf.begin(), cdf.end(), U(rng)) - cdf.begin());
+    h[i] = perm[rank[i]];
+  }
   float4 *X, *out; int* idx;
   CK(hipMalloc(&X, (size_t)rows * 256 * 2)); CK(hipMalloc(&out, 64)); CK(hipMalloc(&idx, n_idx * 4));
   CK(hipMemset(X, 0, (size_t)rows * 256 * 2));
@@ -48,7 +111,7 @@ int main() {
   for (int variant = 0; variant < 3; ++variant) {
     // 0: 256 B rows (stride 256)   1: 128 B half-rows inside 256 B rows (stride 256)   2: 128 B rows packed
     const int stride4 = (variant == 2) ? 8 : 16;
-    for (int blocks : {2048, 4096}) {
+    for (int blocks : {1024, 2048, 4096}) {
       float ms = 0;
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
@@ -61,6 +124,42 @@ int main() {
       printf("variant %d (%s) blocks %4d: %7.2f us  %6.2f TB/s   working set %.1f MB\n", variant,
              variant == 0 ? "256 B rows" : variant == 1 ? "128 B half of 256 B rows" : "128 B rows packed", blocks,
              ms * 1e3, bytes / (ms * 1e-3) / 1e12, rows * (variant == 0 ? 256.0 : 128.0) / 1e6);
+    }
+  }
+  int *enc, *hot_rows;
+  CK(hipMalloc(&enc, n_idx * 4)); CK(hipMalloc(&hot_rows, 1024 * 4));
+  CK(hipMemcpy(hot_rows, perm.data(), 1024 * 4, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute((const void*)gather_hot, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int T : {0, 4096, 8192, 12288, 16384, 24576, 38048}) {
+    std::vector<int> e(n_idx);
+    long cold = 0;
+    for (long i = 0; i < n_idx; ++i) { const bool c = rank[i] >= T; cold += c; e[i] = c ? (int)(0x80000000u | h[i]) : h[i]; }
+    CK(hipMemcpy(enc, e.data(), n_idx * 4, hipMemcpyHostToDevice));
+    float ms = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      CK(hipEventRecord(a));
+      gather_nt<<<2048, 256>>>(X, enc, n_idx, out);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms, a, b));
+    }
+    printf("variant 4 (256 B rows, ranks >= %5d non-temporal = %4.1f%% of fetches): %7.2f us\n", T, 100.0 * cold / n_idx, ms * 1e3);
+  }
+  for (int H : {0, 256}) {
+    std::vector<int> e(n_idx);
+    long hits = 0;
+    for (long i = 0; i < n_idx; ++i) { const bool hot = rank[i] < H; hits += hot; e[i] = hot ? (int)(0x80000000u | rank[i]) : h[i]; }
+    CK(hipMemcpy(enc, e.data(), n_idx * 4, hipMemcpyHostToDevice));
+    for (int blocks : {256, 512}) {
+      if ((size_t)H * 256 * (blocks / 256) > 160 * 1024) continue;
+      float ms = 0;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a));
+        gather_hot<<<blocks, 1024, (size_t)H * 256>>>(X, enc, hot_rows, H, n_idx, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        CK(hipEventElapsedTime(&ms, a, b));
+      }
+      printf("variant 3 (256 B rows, hot %3d rows in LDS = %4.1f%% of fetches) blocks %3d x 1024: %7.2f us\n", H,
+             100.0 * hits / n_idx, blocks, ms * 1e3);
     }
   }
   return 0;

@@ -29,8 +29,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(f"{a.elapsed_time(b) / 50 * 1e3:8.2f} us", flush=True)
 else:
     for n in (2048,):
-        for qt in (1, 2):
-            for splits in (4, 8, 16):
-                env = dict(os.environ, SRH_NCE_SPLITS=str(splits), SRH_NCE_QT=str(qt))
-                out = subprocess.run([sys.executable, __file__, "child", str(n)], env=env, capture_output=True, text=True)
-                print(f"n={n} bf16x3 qt={qt} splits={splits:2d}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
+        configs = [dict(SRH_NCE_LDS="0", SRH_NCE_QT="2", SRH_NCE_SPLITS="8")]
+        for waves, qt in ((4, 2), (4, 1), (8, 1), (8, 2)):
+            for splits in (8, 16):
+                configs.append(dict(SRH_NCE_LDS="1", SRH_NCE_WAVES=str(waves), SRH_NCE_QT=str(qt), SRH_NCE_SPLITS=str(splits)))
+        for cfg in configs:
+            out = subprocess.run([sys.executable, __file__, "child", str(n)], env=dict(os.environ, **cfg), capture_output=True, text=True)
+            tag = " ".join(f"{k[8:].lower()}={v}" for k, v in cfg.items())
+            print(f"n={n} bf16x3 {tag}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
