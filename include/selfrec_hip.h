@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 11
+#define SRH_ABI_VERSION 12
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -244,6 +244,35 @@ typedef struct srh_infonce_problem {
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems,
                                        int32_t d, float tau, float loss_scale, double* d_loss,
                                        void* d_ws, void* stream);
+
+/* The whole batch objective of XSimGCL.py:30-35 / SimGCL.py:33-36 / SGL.py:33-37 --
+ *   rec_loss + l2_reg_loss + cl_rate * cl_loss  and its gradients w.r.t. the gathered tables --
+ * in one call: exactly srh_bpr_l2_fwd_bwd(bpr...) followed by srh_infonce_fwd_bwd_multi(problems...),
+ * with the same outputs, but the two losses' O(batch) kernels share launches (4 instead of 6).
+ * `bpr` mirrors the argument list of srh_bpr_l2_fwd_bwd; both structs are HOST memory. */
+typedef struct srh_bpr_problem {
+  const float* d_user;
+  const float* d_item;
+  const float* d_reg_user;
+  const float* d_reg_item;
+  const int32_t* d_u_idx;
+  const int32_t* d_i_idx;
+  const int32_t* d_j_idx;
+  int64_t B;
+  const int32_t* d_n_rows;
+  float reg_coef;
+  int32_t reg_include_neg;
+  float loss_scale;
+  float* d_g_user;
+  float* d_g_item;
+  float* d_greg_user;
+  float* d_greg_item;
+  double* d_losses;
+  void* d_ws; /* srh_bpr_ws_bytes(B) */
+} srh_bpr_problem_t;
+srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* bpr, const srh_infonce_problem_t* problems,
+                                     int32_t n_problems, int32_t d, float tau, float cl_scale,
+                                     double* d_cl_loss, void* d_nce_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-9) Dense Adam -- replaces torch.optim.Adam(...).step() at XSimGCL.py:25,37

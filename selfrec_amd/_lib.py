@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
@@ -28,6 +28,15 @@ class InfonceProblem(C.Structure):
     """struct srh_infonce_problem (include/selfrec_hip.h)."""
     _fields_ = [("d_v1", C.c_void_p), ("d_v2", C.c_void_p), ("d_idx", C.c_void_p), ("n", C.c_int64),
                 ("d_n", C.c_void_p), ("d_g1", C.c_void_p), ("d_g2", C.c_void_p)]
+
+
+class BprProblem(C.Structure):
+    """struct srh_bpr_problem (include/selfrec_hip.h)."""
+    _fields_ = [("d_user", C.c_void_p), ("d_item", C.c_void_p), ("d_reg_user", C.c_void_p), ("d_reg_item", C.c_void_p),
+                ("d_u_idx", C.c_void_p), ("d_i_idx", C.c_void_p), ("d_j_idx", C.c_void_p), ("B", C.c_int64),
+                ("d_n_rows", C.c_void_p), ("reg_coef", C.c_float), ("reg_include_neg", C.c_int32),
+                ("loss_scale", C.c_float), ("d_g_user", C.c_void_p), ("d_g_item", C.c_void_p),
+                ("d_greg_user", C.c_void_p), ("d_greg_item", C.c_void_p), ("d_losses", C.c_void_p), ("d_ws", C.c_void_p)]
 
 
 class SpmmEpilogue(C.Structure):
@@ -78,6 +87,8 @@ SIGNATURES = {
     "srh_infonce_ws_bytes": (_i64, [_i64, _i32]),
     "srh_infonce_fwd_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "srh_infonce_fwd_bwd_multi": (_i32, [C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "srh_bpr_infonce_fwd_bwd": (_i32, [C.POINTER(BprProblem), C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp,
+                                       _vp]),
     "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
     "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),

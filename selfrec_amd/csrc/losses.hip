@@ -46,11 +46,11 @@ struct BprArgs {
 };
 
 template <int LPR>
-__global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) {
+__device__ __forceinline__ void bpr_phase1_body(const BprArgs& a, const unsigned block_id) {
   constexpr int G = 64 / LPR;
   const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const int b = (int)((block_id * 256u + threadIdx.x) >> 6) * G + g;
   const bool valid = b < rows;
   const int bu = valid ? a.u_idx[b] : 0, bi = valid ? a.i_idx[b] : 0, bj = valid ? a.j_idx[b] : 0;
   const float4 u = reinterpret_cast<const float4*>(a.user)[(size_t)bu * LPR + sub];
@@ -83,17 +83,17 @@ __global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) {
   if (lane == 0) { s_part[wv][0] = l_part; s_part[wv][1] = su; s_part[wv][2] = sp; s_part[wv][3] = sn; }
   __syncthreads();
   if (threadIdx.x < 4)
-    a.part[(size_t)blockIdx.x * 4 + threadIdx.x] =
+    a.part[(size_t)block_id * 4 + threadIdx.x] =
         s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) {
+__device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned block_id) {
   constexpr int G = 64 / LPR;
   const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
   if (rows <= 0) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const int b = (int)((block_id * 256u + threadIdx.x) >> 6) * G + g;
   __shared__ double s_tot[4];
   if (threadIdx.x < 64) {                 // wave 0 folds the per-workgroup partials (fixed order)
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) {
   }
   __syncthreads();
   const float nu = (float)sqrt(s_tot[1]), np = (float)sqrt(s_tot[2]), nn = (float)sqrt(s_tot[3]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (block_id == 0 && threadIdx.x == 0) {
     float r = nu / (float)rows + np / (float)rows;
     if (a.reg_include_neg) r += nn / (float)rows;
     a.losses[0] += (double)a.loss_scale * s_tot[0] / (double)rows;
@@ -146,6 +146,11 @@ __global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) {
   atomic_add_f4(a.g_item + ((size_t)bi * LPR + sub) * 4, gp);
   atomic_add_f4(a.g_item + ((size_t)bj * LPR + sub) * 4, gn);
 }
+
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) { bpr_phase1_body<LPR>(a, blockIdx.x); }
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) { bpr_phase2_body<LPR>(a, blockIdx.x); }
 
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_plain_fwd(const float4* __restrict__ U, const float4* __restrict__ P,
@@ -200,7 +205,7 @@ constexpr int kNceSplits = 16;      // workspace is sized for this many key spli
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
   double* losspart;     // one partial per finish wave
-  int32_t* ticket;      // finish waves still to arrive (zeroed by nce_prep, re-armed by the last arriver)
+  int32_t* ticket;      // np/16 + 1 arrival counters (zeroed by nce_prep, re-armed by the last arriver)
   // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
   // both stored FRAGMENT-LINEAR: the 64 lanes of one MFMA operand load read one contiguous 1 KB
   //   kq_*[view]  [row/16][k-slice s][lane][8]: lane (c16 = lane&15, g = lane>>4) holds row 16*tile + c16,
@@ -252,18 +257,20 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
 
 // normalise (and gather) the rows of both views; rows >= n are zero-filled
 template <int LPR>
-__global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
+__device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsigned bx, const unsigned by,
+                                              const unsigned bz) {
   constexpr int G = 64 / LPR;
-  const NceWs& w = batch.w[blockIdx.z];
+  const NceWs& w = batch.w[bz];
   const float* V1 = w.src1;
   const float* V2 = w.src2;
   const int32_t* idx = w.idx;
   const int n_max = w.n_max;
   const int n = w.d_n ? min(*w.d_n, n_max) : n_max;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
-  const bool second = blockIdx.y == 1;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *w.ticket = 0;
+  const int i = (int)((bx * 256u + threadIdx.x) >> 6) * G + g;
+  const bool second = by == 1;
+  if (bx == 0 && by == 0)
+    for (int k = threadIdx.x; k <= (int)(w.np / 16); k += 256) w.ticket[k] = 0;
   const float* V = second ? V2 : V1;
   float* out = second ? w.v2n : w.v1n;
   float* nrm = second ? w.norm2 : w.norm1;
@@ -310,6 +317,20 @@ __global__ __launch_bounds__(256) void nce_prep(NceBatch batch) {
       w.vt_lo[view][at] = lo[t];
     }
   }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_prep(NceBatch batch) { nce_prep_body<LPR>(batch, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Horizontal fusion for the engine's step: the BPR kernels and the InfoNCE prep / finish kernels are
+// all O(batch) and latency-bound with a wave or two per SIMD, and BPR phase 1 / the InfoNCE prep depend
+// only on the forward pass, BPR phase 2 / the InfoNCE finish only on their own earlier phases -- so each
+// pair shares one launch (workgroups [0, n_bpr) take the BPR role) and overlaps instead of queueing.
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_prep_bpr1(NceBatch batch, BprArgs bpr, int n_bpr, int gpx) {
+  if ((int)blockIdx.x < n_bpr) { bpr_phase1_body<LPR>(bpr, blockIdx.x); return; }
+  const unsigned k = blockIdx.x - n_bpr;
+  nce_prep_body<LPR>(batch, k % gpx, (k / gpx) & 1u, k / (2u * gpx));
 }
 
 
@@ -552,14 +573,72 @@ __global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_t
 }
 
 
+struct NceFinishArgs {
+  float inv_tau, loss_scale;
+  double* loss;
+};
+
+__device__ __forceinline__ void store_f64_sc1(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, float norm) {
+  const float proj = group_sum<LPR>(f4_dot(self, dn));
+  if (norm > 1e-12f)
+    return make_float4((dn.x - self.x * proj) / norm, (dn.y - self.y * proj) / norm,
+                       (dn.z - self.z * proj) / norm, (dn.w - self.w * proj) / norm);
+  return f4_scale(dn, 1e12f);
+}
+
+
+// Finish of one row (the LPR lanes of a row-group): fold both passes' split partials, form the
+// gradients of both views through the normalisation and scatter them.  Returns the row's loss term
+// (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
+template <int LPR>
+__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int splits, int n, int i,
+                                                 int sub) {
+  const bool valid = i < n;
+  const int ii = valid ? i : 0;
+  const size_t at = (size_t)ii * LPR + sub;
+  float4 O1 = f4_zero(), O2 = f4_zero();
+  float l = 0.f;
+  for (int ks = 0; ks < splits; ++ks) {
+    O1 = f4_add(O1, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
+    O2 = f4_add(O2, reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at]);
+    l += w.lpart[(size_t)ks * w.np + ii];
+  }
+  const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
+  const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
+  const float coef = a.loss_scale * a.inv_tau / (float)n;
+  const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
+  const float lse = a.inv_tau + logf(l);
+  const float il = 1.0f / l;
+  const float4 dn1 = make_float4(coef * (O1.x * il - vb.x), coef * (O1.y * il - vb.y), coef * (O1.z * il - vb.z),
+                                 coef * (O1.w * il - vb.w));
+  const float4 dn2 = make_float4(coef * (O2.x - va.x), coef * (O2.y - va.y), coef * (O2.z - va.z), coef * (O2.w - va.w));
+  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, w.norm1[ii]);
+  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, w.norm2[ii]);
+  if (valid) {
+    const int dst = w.idx ? w.idx[i] : i;
+    // atomic: BPR phase 2 shares this launch and adds to the same rows (a plain read-modify-write of
+    // the rows nobody else touches was measured: 2 us of 330)
+    atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
+    atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
+  }
+  return (valid && sub == 0) ? (double)(lse - sii) : 0.0;
+}
+
 // LDS-staged form of nce_tile_bf16 (the default).  The register version is latency-bound: a workgroup's
 // waves walk their key range 32 keys at a time and every step waits out an L2 round trip for 16 KB of
 // operands with one wave per SIMD to hide it.  Here the workgroup first copies its WHOLE key range --
 // the four fragment-linear images, <= 4 x 32 KB -- into LDS with direct global->LDS loads (the images
 // are lane-linear 1 KB fragments, exactly the layout global_load_lds writes), pays the latency once,
-// and then runs every step out of LDS with conflict-free ds_read_b128.  PASS2 also folds the softmax
-// denominators of its keys from pass 1's split partials while the copy is in flight, which retires
-// the separate finish launch between the passes.
+// and then runs every step out of LDS with conflict-free ds_read_b128; WAVES = 8 waves (two per SIMD)
+// share the stage so one wave's exp/convert VALU work overlaps the other's MFMAs.  PASS2 also folds the
+// softmax denominators of its keys from pass 1's split partials while the copy is in flight, which
+// retires the separate finish launch between the passes.  (Finishing a query block inside PASS2 by its
+// last-arriving split was measured and lost: 37 us against 12.6 + 13.2 us -- write-through partials.)
 __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
@@ -695,32 +774,30 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
   if (!wave_live) return;
 
   float* obase = PASS2 ? w.opart2 : w.opart;
+  if (wave_live) {
 #pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int qt0 = q0 + 16 * t;
-    if (qt0 >= np) break;
-    float* op = obase + ((size_t)ks * np + qt0) * D;
+    for (int t = 0; t < QT; ++t) {
+      const int qt0 = q0 + 16 * t;
+      if (qt0 >= np) break;
+      float* op = obase + ((size_t)ks * np + qt0) * D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
+      for (int r = 0; r < 4; ++r) {
+        float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
 #pragma unroll
-      for (int u = 0; u < NT / 4; ++u)
-        reinterpret_cast<float4*>(rowp)[u] =
-            make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
-    }
-    if (!PASS2) {
-      float l = lsum[t];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      if (g == 0) w.lpart[(size_t)ks * np + qt0 + c16] = l;
+        for (int u = 0; u < NT / 4; ++u) {
+          const float4 v = make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
+          reinterpret_cast<float4*>(rowp)[u] = v;
+        }
+      }
+      if (!PASS2) {
+        float l = lsum[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (g == 0) w.lpart[(size_t)ks * np + qt0 + c16] = l;
+      }
     }
   }
 }
-
-struct NceFinishArgs {
-  float inv_tau, loss_scale;
-  double* loss;
-};
 
 template <int LPR, bool PASS2>
 __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs a) {
@@ -788,58 +865,24 @@ __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs 
 // gradients of both views (through the normalisation) and scatters them; the loss partials are folded
 // in workgroup order by whichever workgroup of the problem arrives last (write-through partial ->
 // vmcnt(0) -> relaxed agent-scope ticket -> acquire), so the reported loss is bitwise reproducible.
-__device__ __forceinline__ void store_f64_sc1(double* p, double v) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
 template <int LPR>
-__device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, float norm) {
-  const float proj = group_sum<LPR>(f4_dot(self, dn));
-  if (norm > 1e-12f)
-    return make_float4((dn.x - self.x * proj) / norm, (dn.y - self.y * proj) / norm,
-                       (dn.z - self.z * proj) / norm, (dn.w - self.w * proj) / norm);
-  return f4_scale(dn, 1e12f);
-}
-
-template <int LPR>
-__global__ __launch_bounds__(256) void nce_finish_both(NceBatch batch, NceFinishArgs a) {
+__device__ __forceinline__ void nce_finish_both_body(const NceBatch& batch, const NceFinishArgs& a, const unsigned bx,
+                                                     const unsigned bz) {
   constexpr int G = 64 / LPR;
-  const NceWs& w = batch.w[blockIdx.z];
+  const NceWs& w = batch.w[bz];
   const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  const int wave = (int)((bx * 256u + threadIdx.x) >> 6);
   const int n_waves = (int)(w.np / G);
   if (n <= 0 || wave >= n_waves) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const int i = wave * G + g;
-  const bool valid = i < n;
-  const int ii = valid ? i : 0;
-  const size_t at = (size_t)ii * LPR + sub;
-  float4 O1 = f4_zero(), O2 = f4_zero();
-  float l = 0.f;
-  for (int ks = 0; ks < batch.splits; ++ks) {
-    O1 = f4_add(O1, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
-    O2 = f4_add(O2, reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at]);
-    l += w.lpart[(size_t)ks * w.np + ii];
-  }
-  const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
-  const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
-  const float coef = a.loss_scale * a.inv_tau / (float)n;
-  const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
-  const float lse = a.inv_tau + logf(l);
-  const double part = wave_sum_d((valid && sub == 0) ? (double)(lse - sii) : 0.0);
-  const float il = 1.0f / l;
-  const float4 dn1 = make_float4(coef * (O1.x * il - vb.x), coef * (O1.y * il - vb.y), coef * (O1.z * il - vb.z),
-                                 coef * (O1.w * il - vb.w));
-  const float4 dn2 = make_float4(coef * (O2.x - va.x), coef * (O2.y - va.y), coef * (O2.z - va.z), coef * (O2.w - va.w));
-  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, w.norm1[ii]);
-  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, w.norm2[ii]);
+  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, batch.splits, n, wave * G + g, sub));
   // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
   __shared__ double wg_part[4];
   if (lane == 0) wg_part[threadIdx.x >> 6] = part;
   __syncthreads();
   const int n_wgs = n_waves / 4;                      // np is a multiple of 64: whole workgroups only
   if (threadIdx.x < 64) {
-    if (lane == 0) store_f64_sc1(w.losspart + blockIdx.x, (wg_part[0] + wg_part[1]) + (wg_part[2] + wg_part[3]));
+    if (lane == 0) store_f64_sc1(w.losspart + bx, (wg_part[0] + wg_part[1]) + (wg_part[2] + wg_part[3]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(w.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -853,16 +896,22 @@ __global__ __launch_bounds__(256) void nce_finish_both(NceBatch batch, NceFinish
       if (lane == 0) atomicAdd(a.loss, (double)a.loss_scale * t / (double)n);   // one per problem
     }
   }
-  if (valid) {
-    const int dst = w.idx ? w.idx[i] : i;
-    atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
-    atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
-  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_finish_both(NceBatch batch, NceFinishArgs a) {
+  nce_finish_both_body<LPR>(batch, a, blockIdx.x, blockIdx.z);
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void nce_finish_bpr2(NceBatch batch, NceFinishArgs a, BprArgs bpr, int n_bpr, int fbx) {
+  if ((int)blockIdx.x < n_bpr) { bpr_phase2_body<LPR>(bpr, blockIdx.x); return; }
+  const unsigned k = blockIdx.x - n_bpr;
+  nce_finish_both_body<LPR>(batch, a, k % fbx, k / fbx);
 }
 
 template <int D>
 srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float tau, float loss_scale, double* loss,
-                            void* ws, hipStream_t st) {
+                            void* ws, hipStream_t st, const BprArgs* bpr = nullptr) {
   constexpr int LPR = D / 4, G = 64 / LPR;
   NceBatch batch{};
   batch.count = count;
@@ -880,7 +929,15 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   }
   const float inv_tau = 1.0f / tau;
   dim3 gp((np_max / G + 3) / 4, 2, count);
-  nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
+  BprArgs bp{};
+  int n_bpr = 0;
+  if (bpr) {
+    bp = *bpr;
+    n_bpr = bp.n_blocks = ((bp.B + G - 1) / G + 3) / 4;
+    nce_prep_bpr1<LPR><<<n_bpr + (int)(gp.x * 2 * count), 256, 0, st>>>(batch, bp, n_bpr, (int)gp.x);
+  } else {
+    nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
+  }
   SRH_LAUNCH_CHECK();
   dim3 gt(np_max / 64, batch.splits, count);
   static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
@@ -913,9 +970,14 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     else if (qt == 1) SRH_NCE_LDS_LAUNCH(1, 4);
     else SRH_NCE_LDS_LAUNCH(2, 4);
 #undef SRH_NCE_LDS_LAUNCH
-    nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
+    if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
+    else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
     SRH_LAUNCH_CHECK();
     return SRH_OK;
+  }
+  if (bpr) {            // the A/B paths below keep BPR as its own launch
+    bpr_phase2<LPR><<<n_bpr, 256, 0, st>>>(bp);
+    SRH_LAUNCH_CHECK();
   }
   if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   else if (qt == 2) nce_tile_bf16<D, false, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
@@ -1030,11 +1092,11 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
   return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
-         16 * np * d + 256;
+         16 * np * d + 4 * (np / 16) + 256;
 }
 
-srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,
-                                       float tau, float loss_scale, double* d_loss, void* d_ws, void* stream) {
+static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d, float tau,
+                                  float loss_scale, double* d_loss, void* d_ws, void* stream, const BprArgs* bpr) {
   SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
   SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);
   SRH_REQUIRE(d == 64 || d == 128, "infonce_fwd_bwd: d=%d unsupported (need 64 or 128)", d);
@@ -1048,8 +1110,29 @@ srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, in
     return SRH_ERR_UNSUPPORTED;
   }
   hipStream_t st = srh::as_stream(stream);
-  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st);
-  return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st);
+  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
+  return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
+}
+
+srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,
+                                       float tau, float loss_scale, double* d_loss, void* d_ws, void* stream) {
+  return infonce_entry(problems, n_problems, d, tau, loss_scale, d_loss, d_ws, stream, nullptr);
+}
+
+srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* b, const srh_infonce_problem_t* problems,
+                                     int32_t n_problems, int32_t d, float tau, float cl_scale, double* d_cl_loss,
+                                     void* d_nce_ws, void* stream) {
+  SRH_REQUIRE(b, "bpr_infonce_fwd_bwd: null bpr problem");
+  SRH_REQUIRE(b->d_user && b->d_item && b->d_reg_user && b->d_reg_item && b->d_u_idx && b->d_i_idx && b->d_j_idx,
+              "bpr_infonce_fwd_bwd: null input");
+  SRH_REQUIRE(b->d_g_user && b->d_g_item && b->d_greg_user && b->d_greg_item && b->d_losses && b->d_ws,
+              "bpr_infonce_fwd_bwd: null output");
+  SRH_REQUIRE(b->B > 0 && b->B < (int64_t(1) << 30), "bpr_infonce_fwd_bwd: bad batch size");
+  BprArgs a{b->d_user, b->d_item, b->d_reg_user, b->d_reg_item, b->d_u_idx, b->d_i_idx, b->d_j_idx, b->d_n_rows,
+            (int)b->B, b->reg_coef, b->loss_scale, b->reg_include_neg, b->d_g_user, b->d_g_item, b->d_greg_user,
+            b->d_greg_item, b->d_losses, reinterpret_cast<double*>(b->d_ws),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(b->d_ws) + bpr_part_bytes(b->B)), 0};
+  return infonce_entry(problems, n_problems, d, tau, cl_scale, d_cl_loss, d_nce_ws, stream, &a);
 }
 
 srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,

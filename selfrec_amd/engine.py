@@ -303,17 +303,19 @@ class FusedTrainer:
             reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
             reg_coef, inc_neg = self.reg, (m == "SGL")                      # XSimGCL.py:33, SGL.py:36
         # (forking BPR onto a second stream beside InfoNCE was measured: 0.367 vs 0.353 ms/step -- the
-        # extra graph edges cost more than the 15 us of overlap buy, so the step stays single-stream)
-        ops.bpr_l2_fwd_bwd(self._u(F), self._i(F), reg_u, reg_i, st["u"], st["i"], st["j"], batch=self.B,
-                           n_rows_dev=rows_dev, reg_coef=reg_coef, reg_include_neg=inc_neg, loss_scale=1.0,
-                           g_user=self._u(self.gF), g_item=self._i(self.gF), greg_user=greg_u, greg_item=greg_i,
-                           losses=self.losses[0:2], ws=self.bpr_ws)
-        # ---- contrastive loss (a-8)
+        # extra graph edges cost more than the overlap buys; instead the two losses' O(batch) kernels
+        # share launches inside srh_bpr_infonce_fwd_bwd)
+        bpr = dict(batch=self.B, n_rows_dev=rows_dev, reg_coef=reg_coef, reg_include_neg=inc_neg, loss_scale=1.0,
+                   g_user=self._u(self.gF), g_item=self._i(self.gF), greg_user=greg_u, greg_item=greg_i,
+                   losses=self.losses[0:2])
+        bpr_in = (self._u(F), self._i(F), reg_u, reg_i, st["u"], st["i"], st["j"])
+        nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws)
+        # ---- recommendation + contrastive loss (a-5..a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
-            ops.infonce_multi([(F[:U], CL[:U], st["uniq_u"], self.B, nuu_dev, self.gF[:U], self.gCL[:U]),
-                               (F[U:], CL[U:], st["uniq_i"], self.B, nui_dev, self.gF[U:], self.gCL[U:])],
-                              d=self.d, tau=self.tau, loss_scale=self.cl_rate, loss=self.losses[2:3], ws=self.nce_ws)
+            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=[
+                (F[:U], CL[:U], st["uniq_u"], self.B, nuu_dev, self.gF[:U], self.gCL[:U]),
+                (F[U:], CL[U:], st["uniq_i"], self.B, nui_dev, self.gF[U:], self.gCL[U:])])
         elif m in ("SimGCL", "SGL"):
             for vi, v in enumerate(self.views):
                 adj = g.adj if m == "SimGCL" else self.view_adj[vi]
@@ -321,15 +323,14 @@ class FusedTrainer:
                                    batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
-                ops.infonce_multi([(a["F"][:U], b["F"][:U], st["uniq_u"], self.B, nuu_dev, a["gF"][:U], b["gF"][:U]),
-                                   (a["F"][U:], b["F"][U:], st["uniq_i"], self.B, nui_dev, a["gF"][U:], b["gF"][U:])],
-                                  d=self.d, tau=self.tau, loss_scale=self.cl_rate, loss=self.losses[2:3],
-                                  ws=self.nce_ws)
+                problems = [(a["F"][:U], b["F"][:U], st["uniq_u"], self.B, nuu_dev, a["gF"][:U], b["gF"][:U]),
+                            (a["F"][U:], b["F"][U:], st["uniq_i"], self.B, nui_dev, a["gF"][U:], b["gF"][U:])]
             else:
                 self._build_cat_index()
-                ops.infonce_fwd_bwd(a["F"], b["F"], self.stage_cat, 2 * self.B, n_dev=self.n_cat, tau=self.tau,
-                                    loss_scale=self.cl_rate, loss=self.losses[2:3], g1=a["gF"], g2=b["gF"],
-                                    ws=self.nce_ws)
+                problems = [(a["F"], b["F"], self.stage_cat, 2 * self.B, self.n_cat, a["gF"], b["gF"])]
+            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems)
+        else:
+            ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=self.bpr_ws)
         # ---- backward through the encoder (a-4) and optimiser (a-9)
         if m == "MF":
             pass                                     # gF is gE0

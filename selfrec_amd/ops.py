@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "infonce_fwd_bwd", "infonce_multi", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
+           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
 
@@ -339,6 +339,34 @@ def infonce_multi(problems, *, d, tau, loss_scale, loss, ws):
         raise SelfrecHipError(f"infonce workspace too small: {ws.numel() * ws.element_size()} < {need}")
     check(lib.srh_infonce_fwd_bwd_multi(arr, len(problems), int(d), float(tau), float(loss_scale),
                                         _p(loss, torch.float64), _p(ws), _stream()), "srh_infonce_fwd_bwd_multi")
+
+
+def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
+                reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws,
+                problems, tau, cl_scale, cl_loss, nce_ws):
+    """bpr_l2_fwd_bwd + infonce_multi with their O(batch) kernels sharing launches (srh_bpr_infonce_fwd_bwd)."""
+    lib = _lib.load()
+    d = int(user.shape[1])
+    b = _lib.BprProblem()
+    b.d_user, b.d_item = _p(user, torch.float32), _p(item, torch.float32)
+    b.d_reg_user, b.d_reg_item = _p(reg_user, torch.float32), _p(reg_item, torch.float32)
+    b.d_u_idx, b.d_i_idx, b.d_j_idx = _p(u_idx, torch.int32), _p(i_idx, torch.int32), _p(j_idx, torch.int32)
+    b.B, b.d_n_rows = int(batch), _p(n_rows_dev, torch.int32)
+    b.reg_coef, b.reg_include_neg, b.loss_scale = float(reg_coef), int(bool(reg_include_neg)), float(loss_scale)
+    b.d_g_user, b.d_g_item = _p(g_user, torch.float32), _p(g_item, torch.float32)
+    b.d_greg_user, b.d_greg_item = _p(greg_user, torch.float32), _p(greg_item, torch.float32)
+    b.d_losses, b.d_ws = _p(losses, torch.float64), _p(bpr_ws)
+    arr = (_lib.InfonceProblem * len(problems))()
+    need = 0
+    for k, (v1, v2, idx, n, n_dev, g1, g2) in enumerate(problems):
+        arr[k].d_v1, arr[k].d_v2 = _p(v1, torch.float32), _p(v2, torch.float32)
+        arr[k].d_idx, arr[k].n, arr[k].d_n = _p(idx, torch.int32), int(n), _p(n_dev, torch.int32)
+        arr[k].d_g1, arr[k].d_g2 = _p(g1, torch.float32), _p(g2, torch.float32)
+        need += int(lib.srh_infonce_ws_bytes(n, d))
+    if nce_ws.numel() * nce_ws.element_size() < need:
+        raise SelfrecHipError(f"infonce workspace too small: {nce_ws.numel() * nce_ws.element_size()} < {need}")
+    check(lib.srh_bpr_infonce_fwd_bwd(C.byref(b), arr, len(problems), d, float(tau), float(cl_scale),
+                                      _p(cl_loss, torch.float64), _p(nce_ws), _stream()), "srh_bpr_infonce_fwd_bwd")
 
 
 # ----------------------------------------------------------------------------------------

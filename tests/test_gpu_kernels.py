@@ -237,6 +237,41 @@ def test_bpr_l2_fused_matches_oracle_with_duplicates():
             assert rel_err(gri.cpu().numpy(), eb.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("d,B", [(64, 2048), (128, 600)])
+def test_bpr_infonce_one_call_matches_oracle(d, B):
+    """srh_bpr_infonce_fwd_bwd = XSimGCL.py:30-35: rec + reg + cl_rate * (user InfoNCE + item InfoNCE), with
+    the gradients of the final and the contrast-layer tables, against torch autograd on the oracle losses."""
+    rng = np.random.default_rng(d + B)
+    U, I, tau, cl_rate, reg = 900, 1300, 0.2, 0.2, 1e-4
+    F = (rng.standard_normal((U + I, d)) * 0.3).astype(np.float32)
+    CL = (F + rng.standard_normal((U + I, d)) * 0.1).astype(np.float32)
+    ui, pi, ni = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    uu, up = np.unique(ui), np.unique(pi)
+    f = torch.tensor(F, requires_grad=True); c = torch.tensor(CL, requires_grad=True)
+    fu, fi, cu, ci = f[:U], f[U:], c[:U], c[U:]
+    rec = O.bpr_loss(fu[ui], fi[pi], fi[ni]); l2 = O.l2_reg_loss(reg, fu[ui], fi[pi])
+    cl = cl_rate * (O.info_nce(fu[uu], cu[uu], tau) + O.info_nce(fi[up], ci[up], tau))
+    (rec + l2 + cl).backward()
+
+    dF, dC = torch.from_numpy(F).to(DEV), torch.from_numpy(CL).to(DEV)
+    gF, gC = torch.zeros_like(dF), torch.zeros_like(dC)
+    losses = torch.zeros(3, dtype=torch.float64, device=DEV)
+    i32 = lambda a, n: torch.cat([torch.from_numpy(a.astype(np.int32)), torch.zeros(n - a.size, dtype=torch.int32)]).to(DEV)
+    cnt = lambda n: torch.tensor([n], dtype=torch.int32, device=DEV)
+    nce_ws = torch.empty(2 * ops.infonce_ws(B, d, DEV).numel(), dtype=torch.uint8, device=DEV)
+    for rep in range(2):                     # the workspaces re-arm themselves: a second call gives the same
+        gF.zero_(); gC.zero_(); losses.zero_()
+        ops.bpr_infonce(dF[:U], dF[U:], dF[:U], dF[U:], i32(ui, B), i32(pi, B), i32(ni, B), batch=B, n_rows_dev=cnt(B),
+                        reg_coef=reg, reg_include_neg=False, loss_scale=1.0, g_user=gF[:U], g_item=gF[U:],
+                        greg_user=gF[:U], greg_item=gF[U:], losses=losses[0:2], bpr_ws=ops.bpr_ws(B, DEV),
+                        problems=[(dF[:U], dC[:U], i32(uu, B), B, cnt(uu.size), gF[:U], gC[:U]),
+                                  (dF[U:], dC[U:], i32(up, B), B, cnt(up.size), gF[U:], gC[U:])],
+                        tau=tau, cl_scale=cl_rate, cl_loss=losses[2:3], nce_ws=nce_ws)
+        np.testing.assert_allclose(losses.cpu().numpy(), [rec.item(), l2.item(), cl.item()], rtol=1e-5)
+        assert rel_err(gF.cpu().numpy(), f.grad.numpy()) < 2e-5
+        assert rel_err(gC.cpu().numpy(), c.grad.numpy()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------
 # (a-9) Adam
 # ------------------------------------------------------------------------------------------

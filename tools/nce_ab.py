@@ -30,9 +30,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     for n in (2048,):
         configs = [dict(SRH_NCE_LDS="0", SRH_NCE_QT="2", SRH_NCE_SPLITS="8")]
-        for waves, qt in ((4, 2), (4, 1), (8, 1), (8, 2)):
-            for splits in (8, 16):
-                configs.append(dict(SRH_NCE_LDS="1", SRH_NCE_WAVES=str(waves), SRH_NCE_QT=str(qt), SRH_NCE_SPLITS=str(splits)))
+        for fin in (0, 1):
+            for waves, qt, splits in ((8, 1, 8), (8, 1, 16), (4, 2, 8), (8, 2, 8), (8, 2, 16)):
+                configs.append(dict(SRH_NCE_LDS="1", SRH_NCE_FINISH=str(fin), SRH_NCE_WAVES=str(waves), SRH_NCE_QT=str(qt),
+                                    SRH_NCE_SPLITS=str(splits)))
         for cfg in configs:
             out = subprocess.run([sys.executable, __file__, "child", str(n)], env=dict(os.environ, **cfg), capture_output=True, text=True)
             tag = " ".join(f"{k[8:].lower()}={v}" for k, v in cfg.items())
