@@ -306,6 +306,13 @@ srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int
 srh_status_t srh_topk_rows(const float* d_scores, int64_t rows, int64_t n, int32_t k,
                            int32_t* d_out_ids, float* d_out_scores, void* stream);
 
+/* (f-3) Metric tail: d_flags[q*k + r] = 1 iff d_ids[q*k + r] is a test item of user d_user_ids[q]
+ * (rows 0..n_query-1 when NULL), the membership test of util/evaluation.py:7-16 (hits) and :66-78
+ * (NDCG).  d_t_indptr / d_t_indices: the test set as a (users x items) CSR with sorted columns. */
+srh_status_t srh_topk_hit_flags(const int32_t* d_ids, int64_t n_query, int32_t k,
+                                const int32_t* d_user_ids, const int32_t* d_t_indptr,
+                                const int32_t* d_t_indices, uint8_t* d_flags, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Small device utilities used by the fused engine.
  * ---------------------------------------------------------------------------------- */

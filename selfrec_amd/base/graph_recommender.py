@@ -19,7 +19,7 @@ from .. import ops
 from ..data.loader import FileIO
 from ..data.ui_graph import Interaction
 from ..util.algorithm import find_k_largest
-from ..util.evaluation import ranking_evaluation
+from ..util.evaluation import RankedLists, ranking_evaluation
 from .recommender import Recommender
 
 MASKED_SCORE = -10e8
@@ -50,8 +50,22 @@ class GraphRecommender(Recommender):
             return ue.detach().float().contiguous(), ie.detach().float().contiguous()
         return None
 
-    def rank_on_device(self, user_ids, k=None):
-        """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids."""
+    def _test_csr(self, device):
+        """The test set as a (users x items) CSR with sorted columns on the device (built once)."""
+        cached = getattr(self, '_test_csr_cache', None)
+        if cached is None or cached[0].device != torch.device(device):
+            data = self.data
+            rows = [sorted(data.item[i] for i in data.test_set.get(data.id2user[u], ())) for u in range(data.user_num)]
+            indptr = np.zeros(data.user_num + 1, dtype=np.int32)
+            np.cumsum([len(r) for r in rows], out=indptr[1:])
+            indices = np.fromiter((i for r in rows for i in r), dtype=np.int32, count=int(indptr[-1]))
+            cached = (torch.from_numpy(indptr).to(device), torch.from_numpy(indices).to(device), indptr)
+            self._test_csr_cache = cached
+        return cached
+
+    def rank_on_device(self, user_ids, k=None, with_hits=False):
+        """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids; with_hits adds the uint8
+        flags 'this ranked item is in the user's test set' (srh_topk_hit_flags)."""
         k = self.max_N if k is None else k
         ue, ie = self._device_embeddings()
         g = self.data.device_graph(ie.device)
@@ -64,15 +78,26 @@ class GraphRecommender(Recommender):
             ids, sc = ops.score_mask_topk(ue, part, ie, g.r_indptr, g.r_indices, k, scores_ws=slab[:part.numel()])
             ids_parts.append(ids)
             sc_parts.append(sc)
-        return torch.cat(ids_parts).cpu().numpy(), torch.cat(sc_parts).cpu().numpy()
+        ids_dev = torch.cat(ids_parts)
+        if with_hits:
+            t_indptr, t_indices, _ = self._test_csr(ie.device)
+            flags = ops.topk_hit_flags(ids_dev, uid, t_indptr, t_indices)
+            return ids_dev.cpu().numpy(), torch.cat(sc_parts).cpu().numpy(), flags.cpu().numpy()
+        return ids_dev.cpu().numpy(), torch.cat(sc_parts).cpu().numpy()
 
     def test(self):
         users = list(self.data.test_set)
         if self._device_embeddings() is not None and users:
-            ids, scores = self.rank_on_device([self.data.user[u] for u in users])
-            id2item = self.data.id2item
-            names = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)[ids]
-            return {u: list(zip(names[r].tolist(), scores[r].tolist())) for r, u in enumerate(users)}
+            uid = np.fromiter((self.data.user[u] for u in users), dtype=np.int32, count=len(users))
+            ids, scores, flags = self.rank_on_device(uid, with_hits=True)
+            names = getattr(self, '_item_name_array', None)
+            if names is None:
+                id2item = self.data.id2item
+                names = self._item_name_array = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)
+            sizes = np.diff(self._test_csr(self.item_emb.device)[2])[uid]
+            # reads like the reference's {user: [(item, score), ...]}; rows are built on access and
+            # ranking_evaluation works on the arrays (same strings)
+            return RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=self.data.test_set)
         rec_list = {}
         for user in users:                                   # models with a custom predict()
             candidates = self.predict(user)

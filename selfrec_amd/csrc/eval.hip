@@ -208,6 +208,27 @@ srh_status_t gemm_dispatch(const float* a, const int32_t* a_rows, const float* b
   }
 }
 
+
+// (f-3) hit flags for the metric tail: flag[q][r] = 1 iff ranked id ids[q][r] is a test item of the
+// query's user (binary search in that user's sorted test row) -- what Metric.hits / Metric.NDCG
+// (reference util/evaluation.py:7-16,66-78) find by python set membership.
+__global__ __launch_bounds__(256) void hit_flags_kernel(const int32_t* __restrict__ ids, int64_t total, int k,
+                                                        const int32_t* __restrict__ user_ids,
+                                                        const int32_t* __restrict__ t_indptr,
+                                                        const int32_t* __restrict__ t_indices,
+                                                        uint8_t* __restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t q = t / k;
+  const int u = user_ids ? user_ids[q] : (int)q;
+  const int item = ids[t];
+  int lo = t_indptr[u], hi = t_indptr[u + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (t_indices[mid] < item) lo = mid + 1; else hi = mid;
+  }
+  flags[t] = (lo < t_indptr[u + 1] && t_indices[lo] == item) ? 1 : 0;
+}
 }  // namespace
 
 extern "C" {
@@ -243,6 +264,18 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
     SRH_LAUNCH_CHECK();
   }
   return srh_topk_rows(d_scores_ws, n_query, n_items, k, d_out_ids, d_out_scores, stream);
+}
+
+srh_status_t srh_topk_hit_flags(const int32_t* d_ids, int64_t n_query, int32_t k, const int32_t* d_user_ids,
+                                const int32_t* d_t_indptr, const int32_t* d_t_indices, uint8_t* d_flags,
+                                void* stream) {
+  SRH_REQUIRE(d_ids && d_t_indptr && d_t_indices && d_flags, "topk_hit_flags: null argument");
+  SRH_REQUIRE(n_query > 0 && k >= 1 && n_query * k < (int64_t(1) << 40), "topk_hit_flags: bad shape");
+  const int64_t total = n_query * k;
+  hit_flags_kernel<<<(unsigned)((total + 255) / 256), 256, 0, srh::as_stream(stream)>>>(d_ids, total, k, d_user_ids,
+                                                                                         d_t_indptr, d_t_indices, d_flags);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
 }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows",
+           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
 
@@ -411,6 +411,16 @@ def topk_rows(scores, k):
     check(_lib.load().srh_topk_rows(_p(scores, torch.float32), rows, n, int(k), _p(ids, torch.int32),
                                     _p(sc, torch.float32), _stream()), "srh_topk_rows")
     return ids, sc
+
+
+def topk_hit_flags(ids, user_ids, t_indptr, t_indices):
+    """uint8 (n_query, k): 1 where the ranked id is one of the user's test items."""
+    flags = torch.empty(ids.shape, dtype=torch.uint8, device=ids.device)
+    check(_lib.load().srh_topk_hit_flags(_p(ids, torch.int32), int(ids.shape[0]), int(ids.shape[1]),
+                                         _p(user_ids, torch.int32), _p(t_indptr, torch.int32),
+                                         _p(t_indices, torch.int32), _p(flags, torch.uint8), _stream()),
+          "srh_topk_hit_flags")
+    return flags
 
 
 def axpby(a, x, b, y):

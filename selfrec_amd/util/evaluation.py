@@ -4,6 +4,67 @@
 ``origin``: {user: {item: 1}}; ``res``: {user: [(item, score), ...]} best first.
 """
 import math
+from collections.abc import Mapping
+
+import numpy as np
+
+
+class RankedLists(Mapping):
+    """The ``{user: [(item, score), ...]}`` result of ``GraphRecommender.test()`` held as the arrays the
+    device ranking returned: (users x K) item ids and scores plus, when the ranking also produced them,
+    the per-position hit flags and the users' test-set sizes.  It reads like the reference's dict (same
+    keys in test-set order, rows materialised as lists of (item name, score) on access) so
+    ``evaluate()`` and any user code keep working, while ``ranking_evaluation`` takes the arrays.
+    """
+
+    def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None):
+        self.users = list(users)
+        self._row = {u: r for r, u in enumerate(self.users)}
+        self.item_names, self.ids, self.scores = item_names, ids, scores
+        self.hit_flags, self.truth_sizes, self.origin = hit_flags, truth_sizes, origin
+
+    def __len__(self):
+        return len(self.users)
+
+    def __iter__(self):
+        return iter(self.users)
+
+    def __getitem__(self, user):
+        r = self._row[user]
+        return list(zip(self.item_names[self.ids[r]].tolist(), self.scores[r].tolist()))
+
+
+def _fast_report(res, N):
+    """ranking_evaluation on a RankedLists carrying hit flags.  Every figure is accumulated in the
+    order and precision of the python loops below (left-to-right float adds over users in test-set
+    order, positions best-first), so the strings are identical, not just close."""
+    flags = res.hit_flags.astype(np.float64)                 # (users, K) 0/1
+    sizes = res.truth_sizes.astype(np.int64)
+    n_users = flags.shape[0]
+    relevant = int(sizes.sum())
+    report = []
+    for n in N:
+        n_eff = min(n, flags.shape[1])
+        hit_n = flags[:, :n_eff]
+        hits = hit_n.sum(axis=1)                               # small integers: exact in any order
+        total_hits = int(hits.sum())
+        gains = np.array([1.0 / math.log(pos + 2, 2) for pos in range(n_eff)])
+        ideal_prefix = [0.0]
+        for pos in range(n):
+            ideal_prefix.append(ideal_prefix[-1] + 1.0 / math.log(pos + 2, 2))
+        ideal = np.asarray(ideal_prefix)[np.minimum(sizes, n)]
+        dcg = np.zeros(n_users)
+        for pos in range(n_eff):                              # same order of adds as the generator sum
+            dcg = dcg + hit_n[:, pos] * gains[pos]
+        report.append('Top ' + str(n) + '\n')
+        report.append('Hit Ratio:' + str(round(total_hits / relevant, 5)) + '\n')
+        report.append('Precision:' + str(round(total_hits / (n_users * n), 5)) + '\n')
+        report.append('Recall:' + str(round(sum((hits / sizes).tolist()) / n_users, 5)) + '\n')
+        total = 0
+        for x in (dcg / ideal).tolist():                      # `sum_NDCG += DCG / IDCG`, user by user
+            total += x
+        report.append('NDCG:' + str(round(total / n_users, 5)) + '\n')
+    return report
 
 
 class Metric:
@@ -40,6 +101,8 @@ def ranking_evaluation(origin, res, N):
     if len(origin) != len(res):
         print('The Lengths of test set and predicted set do not match!')
         raise SystemExit(-1)
+    if isinstance(res, RankedLists) and res.hit_flags is not None and res.origin is origin:
+        return _fast_report(res, N)
     report = []
     for n in N:
         cut = {user: ranked[:n] for user, ranked in res.items()}

@@ -137,3 +137,30 @@ def test_native_loader_equals_python_path(tmp_path):
     with pytest.raises(Exception):
         bad = tmp_path / "bad.txt"; bad.write_text("only_two tokens\n")
         Interaction({}, FileIO.open_data_set(str(bad), "graph"), [])
+
+
+def test_ranked_lists_reads_like_the_dict_and_reports_the_same_strings():
+    """RankedLists (the array form of test()'s result) against the reference-shaped dict: same keys in the
+    same order, same rows, and ranking_evaluation's vectorised branch prints exactly what the per-user
+    loops print (util/evaluation.py:135-162), top-N cut shorter than K included."""
+    rng = np.random.default_rng(12)
+    n_users, n_items, K = 400, 300, 20
+    users = [f"u{k}" for k in rng.permutation(n_users)]
+    names = np.array([f"i{k}" for k in range(n_items)], dtype=object)
+    origin = {}
+    for u in users:
+        truth = rng.choice(n_items, size=int(rng.integers(1, 40)), replace=False)
+        origin[u] = {names[t]: 1 for t in truth}
+    ids = np.stack([rng.choice(n_items, size=K, replace=False) for _ in users]).astype(np.int32)
+    scores = np.sort(rng.standard_normal((n_users, K)).astype(np.float32))[:, ::-1].copy()
+    flags = np.array([[names[i] in origin[u] for i in ids[r]] for r, u in enumerate(users)], dtype=np.uint8)
+    sizes = np.array([len(origin[u]) for u in users])
+    ranked = evaluation.RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=origin)
+    as_dict = {u: [(names[i], float(s)) for i, s in zip(ids[r], scores[r])] for r, u in enumerate(users)}
+    assert list(ranked) == users and len(ranked) == n_users
+    assert dict(ranked) == as_dict and ranked[users[7]] == as_dict[users[7]]
+    for N in ([20], [10, 20], [1, 5, 20]):
+        assert evaluation.ranking_evaluation(origin, ranked, N) == evaluation.ranking_evaluation(origin, as_dict, N)
+    # without flags (or against another test set) it goes through the loops like any mapping
+    plain = evaluation.RankedLists(users, names, ids, scores)
+    assert evaluation.ranking_evaluation(origin, plain, [10, 20]) == evaluation.ranking_evaluation(origin, as_dict, [10, 20])
