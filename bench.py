@@ -246,7 +246,7 @@ def main():
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; sampling on a host thread inside the timed region",
                    "global_batch": args.batch, "parallelism": f"row-sharded x{world}" if sharded else "single",
-                   "launch": "eager" if (args.no_graph or sharded) else "hipGraph replay"},
+                   "launch": "hipGraph replay" if trainer.use_graph else "eager"},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     if rank == 0:

@@ -33,10 +33,12 @@ captured once in a hipGraph and replayed.
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import numpy as np
 import torch
+import torch.distributed as _dist
 
 from . import ops
 from ._lib import SelfrecHipError
@@ -44,13 +46,38 @@ from ._lib import SelfrecHipError
 MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
 
 
+def shard_adjacency(norm_adj_csr, rank, world):
+    """CSR rows of the nodes owned by `rank` (nodes rank, rank + world, ...), columns rewritten to the
+    all-gather layout (owner * n_pad + local row).  Returns (indptr, indices, data, n_pad)."""
+    n = norm_adj_csr.shape[0]
+    n_pad = (n + world - 1) // world
+    own = np.arange(rank, n, world)
+    sub = norm_adj_csr[own].tocsr()
+    sub.sort_indices()
+    cols = sub.indices.astype(np.int64)
+    new_cols = (cols % world) * n_pad + cols // world
+    indptr = np.zeros(n_pad + 1, dtype=np.int32)
+    indptr[1:len(own) + 1] = sub.indptr[1:]
+    indptr[len(own) + 1:] = sub.indptr[-1]                 # padding rows are empty
+    return indptr, new_cols.astype(np.int32), sub.data.astype(np.float32), n_pad
+
+
+class _GraphInfo:
+    """What bench.py reads from ``trainer.graph`` when the graph itself is sharded."""
+
+    def __init__(self, n_users, n_items, n_edges, adj):
+        self.n_users, self.n_items, self.n_edges = n_users, n_items, n_edges
+        self.n_nodes = n_users + n_items
+        self.adj = adj
+
+
 class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
-                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None):
+                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False):
         if model not in MODELS:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
-        ops._lib.require_gpu()
+        ops.require_gpu()
         self.model, self.data = model, data
         self.d, self.L = int(emb_size), (0 if model == "MF" else int(n_layers))
         self.lr, self.reg, self.cl_rate, self.eps, self.tau = float(lr), float(reg), float(cl_rate), float(eps), float(tau)
@@ -64,15 +91,43 @@ class FusedTrainer:
             raise SelfrecHipError("n_layers must be >= 1")
         if model == "XSimGCL" and not (0 <= self.layer_cl <= self.L):
             raise SelfrecHipError("l_star must be in [0, n_layer]")
-        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dev = dev
-        self.graph = data.device_graph(dev)
+        self.U, self.I = data.user_num, data.item_num
+        self.N = self.U + self.I
+        # ---- table layout.  Every (.., d) table has P rows; node p lives at row pos[p].  One GPU:
+        # pos = identity.  G ranks (shard=True): nodes are dealt round-robin, node p is owned by rank
+        # p % G as its local row p // G, and the tables are kept in all-gather order
+        # (row = owner * n_pad + local row), so `all_gather_into_tensor` of the owners' slices IS the
+        # table.  Each rank owns the rows self.loc of the parameters, the Adam state and every
+        # layer output; batch-level work (losses, their gradients) is O(batch) and replicated.
+        self.G, self.rank, self.sharded = 1, 0, bool(shard)
+        if shard:
+            if model not in ("MF", "LightGCN", "XSimGCL"):
+                raise SelfrecHipError(f"sharded training: model {model!r} is single-GPU for now (MF, LightGCN, XSimGCL shard)")
+            if not _dist.is_initialized():
+                raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
+            self.G, self.rank = _dist.get_world_size(), _dist.get_rank()
+        G, N, d, B = self.G, self.N, self.d, self.B
+        self.n_pad = (N + G - 1) // G
+        self.P = G * self.n_pad
+        nodes = np.arange(N, dtype=np.int64)
+        self._pos = ((nodes % G) * self.n_pad + nodes // G).astype(np.int32)
+        self._pos_dev = torch.from_numpy(self._pos.astype(np.int64)).to(dev)
+        self.loc = slice(self.rank * self.n_pad, (self.rank + 1) * self.n_pad)
+        if not self.sharded:
+            self.graph = data.device_graph(dev)
+            self.adj = self.graph.adj
+        else:
+            indptr, indices, vals, _ = shard_adjacency(data.norm_adj.tocsr(), self.rank, G)
+            self.adj = ops.DeviceCSR(indptr, indices, vals, (self.n_pad, self.P), device=dev,
+                                     xcd_split_row=len(range(self.rank, self.U, G)))
+            self.graph = _GraphInfo(self.U, self.I, len(data.train_u), self.adj)
         g = self.graph
-        self.U, self.I, self.N = g.n_users, g.n_items, g.n_nodes
-        N, d, B = self.N, self.d, self.B
+        P = self.P
 
-        def buf():
-            return torch.zeros((N, d), dtype=torch.float32, device=dev)
+        def buf(rows=P):
+            return torch.zeros((rows, d), dtype=torch.float32, device=dev)
 
         self.E0 = buf()
         if user_emb is None or item_emb is None:
@@ -80,9 +135,8 @@ class FusedTrainer:
             ie = torch.nn.init.xavier_uniform_(torch.empty(self.I, d))
         else:
             ue, ie = torch.as_tensor(user_emb, dtype=torch.float32), torch.as_tensor(item_emb, dtype=torch.float32)
-        self.E0[:self.U].copy_(ue)
-        self.E0[self.U:].copy_(ie)
-        self.m, self.v = buf(), buf()
+        self.E0[self._pos_dev] = torch.cat([ue, ie]).to(dev)
+        self.m, self.v = buf(self.n_pad), buf(self.n_pad)       # Adam state: owned rows only
         self.gE0 = buf()
         self.F = self.E0 if model == "MF" else buf()
         self.gF = self.gE0 if model == "MF" else buf()
@@ -91,7 +145,7 @@ class FusedTrainer:
         self.gCL = buf() if model == "XSimGCL" else None
         self.gReg = buf() if model == "LightGCN" else None    # ego-row regulariser gradient (sparse rows)
         # activity marks: mark[node] == optimiser step  <=>  the node is a row of the current batch
-        self.mark = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.mark = torch.zeros(P, dtype=torch.int32, device=dev)
         self.use_marks = True
         # models whose gradient buffers only ever hold O(batch) non-zero rows are reset row-wise
         self.sparse_reset = model in ("MF", "LightGCN", "XSimGCL")
@@ -100,7 +154,7 @@ class FusedTrainer:
             for _ in range(2):
                 self.views.append({"F": buf(), "Y": [buf() for _ in range(self.L)], "gF": buf()})
         self.view_adj = [None, None]              # SGL: dropped adjacencies (DeviceCSR)
-        self._view_vals = [torch.empty_like(g.adj.vals), torch.empty_like(g.adj.vals)] if model == "SGL" else None
+        self._view_vals = [torch.empty_like(self.adj.vals), torch.empty_like(self.adj.vals)] if model == "SGL" else None
         self.losses = torch.zeros(4, dtype=torch.float64, device=dev)      # bpr, reg, cl
         self.stage = {k: torch.zeros(B, dtype=torch.int32, device=dev) for k in ("u", "i", "j", "uniq_u", "uniq_i")}
         self.stage_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev)  # SGL: [uniq users ; uniq items + U]
@@ -121,7 +175,9 @@ class FusedTrainer:
         self._epoch_dev = {k: torch.zeros(n, dtype=torch.int32, device=dev) for k, n in sizes.items()}
         self._epoch_ready = False
         self.step_count = 0
-        self.use_graph = bool(use_graph)
+        # (a sharded step is captured only on request: RCCL collectives inside a hipGraph could not be
+        # exercised beyond one rank on the development box)
+        self.use_graph = bool(use_graph) and (not self.sharded or os.environ.get("SRH_SHARDED_GRAPH") == "1")
         self._graph = None
         self._noise_call = 0
 
@@ -130,17 +186,21 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------
     @property
     def user_emb(self):
-        return self.E0[:self.U]
+        return self.E0[:self.U] if not self.sharded else self.E0[self._pos_dev[:self.U]]
 
     @property
     def item_emb(self):
-        return self.E0[self.U:]
+        return self.E0[self.U:] if not self.sharded else self.E0[self._pos_dev[self.U:]]
 
-    def _u(self, t):
-        return t[:self.U]
+    def _loc(self, t):
+        """The rows of a table this rank owns (the whole table on one GPU)."""
+        return t if not self.sharded or t is None else t[self.loc]
 
-    def _i(self, t):
-        return t[self.U:]
+    def _allgather(self, t):
+        """Make a table whose owned rows were just written whole again on every rank."""
+        if self.sharded:
+            mine = t[self.loc]
+            _dist.all_gather_into_tensor(t, mine if self.dev.type == "cuda" else mine.clone())
 
     # ------------------------------------------------------------------------------------
     # sampling
@@ -164,8 +224,26 @@ class FusedTrainer:
                 mk[keep] = 1
                 masks.append(mk)
             out["masks"] = masks
-        out.update(self.sampler.epoch(self.B, 1, with_unique=True))
+        ep = self.sampler.epoch(self.B, 1, with_unique=True)
+        # node ids -> table rows (items follow the users; all-gather order when sharded)
+        if not self.sharded:
+            for k in ("i", "j", "uniq_i"):
+                ep[k] += self.U
+        else:
+            pos_u, pos_i = self._pos[:self.U], self._pos[self.U:]
+            for k, table in (("u", pos_u), ("i", pos_i), ("j", pos_i), ("uniq_u", pos_u), ("uniq_i", pos_i)):
+                ep[k] = table[ep[k]]
+        out.update(ep)
         return out
+
+    def epoch_node_ids(self, host=None):
+        """(u, i, j) of an epoch as the reference's user / item ids (the staged arrays hold table rows)."""
+        host = self._epoch_host if host is None else host
+        if not self.sharded:
+            return host["u"], host["i"] - self.U, host["j"] - self.U
+        node_of_row = np.full(self.P, -1, dtype=np.int64)
+        node_of_row[self._pos] = np.arange(self.N)
+        return node_of_row[host["u"]], node_of_row[host["i"]] - self.U, node_of_row[host["j"]] - self.U
 
     def upload_epoch(self, host):
         dev = self.dev
@@ -188,10 +266,14 @@ class FusedTrainer:
     def _noise(self):
         if self.noise_fn is None:
             return None
-        t = self.noise_fn((self.N, self.d))
-        return torch.as_tensor(t, dtype=torch.float32).to(self.dev).contiguous()
+        t = torch.as_tensor(self.noise_fn((self.N, self.d)), dtype=torch.float32).to(self.dev)
+        if not self.sharded:
+            return t.contiguous()
+        full = torch.zeros((self.P, self.d), dtype=torch.float32, device=self.dev)
+        full[self._pos_dev] = t
+        return full[self.loc].contiguous()
 
-    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False):
+    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False, need_last=False):
         """L SpMMs; layer k's epilogue perturbs (optional) and the last one also writes the
         layer mean into F.  Returns nothing; the CL view of XSimGCL is Ys[l*-1] (or E0).
         batch_rows_only: the last layer's output (and F) feed nothing but the batch losses, so
@@ -204,17 +286,21 @@ class FusedTrainer:
             if perturbed:
                 noise = self._noise()
                 kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed,
-                          rng_offset=(self._noise_call * self.N) & ((1 << 62) - 1),
+                          rng_offset=(self._noise_call * self.P + self.rank * self.n_pad) & ((1 << 62) - 1),
                           rng_step=self.cursor[1:2] if noise is None else None,
-                          rng_stride=self.N * 16)
+                          rng_stride=self.P * 16)
                 self._noise_call += 1
             if k == L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
-                kw.update(prev=prev, mean_div=float(L + 1 if include_ego else L), mean_out=F)
+                kw.update(prev=[self._loc(t) for t in prev], mean_div=float(L + 1 if include_ego else L),
+                          mean_out=self._loc(F))
                 if batch_rows_only and self.use_marks:
-                    kw.update(row_mark=self.mark, mark_stamp=self.cursor[1:2])
-            ops.spmm(adj, x, out=Ys[k], epilogue=ops.make_epilogue(**kw) if kw else None)
+                    kw.update(row_mark=self._loc(self.mark), mark_stamp=self.cursor[1:2])
+            ops.spmm(adj, x, out=self._loc(Ys[k]), epilogue=ops.make_epilogue(**kw) if kw else None)
+            if k < L - 1 or need_last:
+                self._allgather(Ys[k])          # the next layer (or the contrast view) reads every row
             x = Ys[k]
+        self._allgather(F)
 
     def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None, accumulate=False):
         """gE0 (+)= d loss / d E0 through one encoder pass (accumulate=False overwrites gE0).
@@ -235,13 +321,14 @@ class FusedTrainer:
         # the incoming gradient is non-zero only on this step's batch rows: the first product
         # skips every other column
         sparse_src = dict(col_mark=self.mark, mark_stamp=self.cursor[1:2]) if self.use_marks else {}
+        loc = self._loc
         # gF, gCL and the regulariser gradient are zero outside the batch rows: read them only there
         batch_sparse = {id(gF), id(gCL), id(extra)} - {id(None)} if self.use_marks else set()
 
         def sparse_add(add):
             if not batch_sparse:
                 return {}
-            return dict(add_mark=self.mark, mark_stamp=self.cursor[1:2], add_sparse=[id(a) in batch_sparse for a in add])
+            return dict(add_mark=loc(self.mark), mark_stamp=self.cursor[1:2], add_sparse=[id(a) in batch_sparse for a in add])
         bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
         for k in range(L - 1, 0, -1):              # produce H_k
             add, sc = [gF], [s]
@@ -249,8 +336,10 @@ class FusedTrainer:
                 add.append(gCL)
                 sc.append(1.0)
             dst = bufs[0]
-            ops.spmm(adj, src, out=dst,
-                     epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **{**sparse_add(add), **sparse_src}))
+            ops.spmm(adj, src, out=loc(dst),
+                     epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
+                                                **{**sparse_add(add), **sparse_src}))
+            self._allgather(dst)
             src, alpha, sparse_src = dst, 1.0, {}
             bufs.reverse()
         add, sc = ([self.gE0], [1.0]) if accumulate else ([], [])   # (aliasing y is allowed)
@@ -267,18 +356,20 @@ class FusedTrainer:
             if not accumulate:
                 raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
-        ops.spmm(adj, src, out=self.gE0,
-                 epilogue=ops.make_epilogue(add=add, add_scale=sc, alpha=alpha, **{**sparse_add(add), **sparse_src}))
+        ops.spmm(adj, src, out=loc(self.gE0),
+                 epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
+                                            **{**sparse_add(add), **sparse_src}))
 
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch
     # ------------------------------------------------------------------------------------
     def _step_kernels(self):
-        m, st, U = self.model, self.stage, self.U
-        g = self.graph
+        m, st = self.model, self.stage
+        adj = self.adj
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
+        # the staged ids are table rows (items already offset / permuted): one table, one index space
         ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
-                        row_mark=self.mark, mark_item_offset=U, zero4=self.losses)
+                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses)
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
         if not self.sparse_reset:     # SimGCL / SGL: dense gradient buffers, dense memsets
             self.gE0.zero_()
@@ -288,43 +379,42 @@ class FusedTrainer:
 
         include_ego = m in ("LightGCN", "SGL")
         if m != "MF":
-            self._forward_pass(g.adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
-                               batch_rows_only=True)
+            self._forward_pass(adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
+                               batch_rows_only=True, need_last=(m == "XSimGCL" and self.layer_cl == self.L))
         F = self.F
         # ---- recommendation loss + regulariser (a-5..a-7)
         if m == "LightGCN":
             # regulariser on the EGO rows (LightGCN.py:25); its gradient joins gE0 in the last product
-            reg_u, reg_i, greg_u, greg_i = self._u(self.E0), self._i(self.E0), self._u(self.gReg), self._i(self.gReg)
+            reg_t, greg_t = self.E0, self.gReg
             reg_coef, inc_neg = self.reg / self.B, True
         elif m == "MF":
-            reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
+            reg_t, greg_t = F, self.gF
             reg_coef, inc_neg = self.reg / self.B, True                     # MF.py:21
         else:
-            reg_u, reg_i, greg_u, greg_i = self._u(F), self._i(F), self._u(self.gF), self._i(self.gF)
+            reg_t, greg_t = F, self.gF
             reg_coef, inc_neg = self.reg, (m == "SGL")                      # XSimGCL.py:33, SGL.py:36
         # (forking BPR onto a second stream beside InfoNCE was measured: 0.367 vs 0.353 ms/step -- the
         # extra graph edges cost more than the overlap buys; instead the two losses' O(batch) kernels
         # share launches inside srh_bpr_infonce_fwd_bwd)
         bpr = dict(batch=self.B, n_rows_dev=rows_dev, reg_coef=reg_coef, reg_include_neg=inc_neg, loss_scale=1.0,
-                   g_user=self._u(self.gF), g_item=self._i(self.gF), greg_user=greg_u, greg_item=greg_i,
-                   losses=self.losses[0:2])
-        bpr_in = (self._u(F), self._i(F), reg_u, reg_i, st["u"], st["i"], st["j"])
+                   g_user=self.gF, g_item=self.gF, greg_user=greg_t, greg_item=greg_t, losses=self.losses[0:2])
+        bpr_in = (F, F, reg_t, reg_t, st["u"], st["i"], st["j"])
         nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws)
         # ---- recommendation + contrastive loss (a-5..a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=[
-                (F[:U], CL[:U], st["uniq_u"], self.B, nuu_dev, self.gF[:U], self.gCL[:U]),
-                (F[U:], CL[U:], st["uniq_i"], self.B, nui_dev, self.gF[U:], self.gCL[U:])])
+                (F, CL, st["uniq_u"], self.B, nuu_dev, self.gF, self.gCL),
+                (F, CL, st["uniq_i"], self.B, nui_dev, self.gF, self.gCL)])
         elif m in ("SimGCL", "SGL"):
             for vi, v in enumerate(self.views):
-                adj = g.adj if m == "SimGCL" else self.view_adj[vi]
-                self._forward_pass(adj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego,
+                vadj = adj if m == "SimGCL" else self.view_adj[vi]
+                self._forward_pass(vadj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego,
                                    batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
-                problems = [(a["F"][:U], b["F"][:U], st["uniq_u"], self.B, nuu_dev, a["gF"][:U], b["gF"][:U]),
-                            (a["F"][U:], b["F"][U:], st["uniq_i"], self.B, nui_dev, a["gF"][U:], b["gF"][U:])]
+                problems = [(a["F"], b["F"], st["uniq_u"], self.B, nuu_dev, a["gF"], b["gF"]),
+                            (a["F"], b["F"], st["uniq_i"], self.B, nui_dev, a["gF"], b["gF"])]
             else:
                 self._build_cat_index()
                 problems = [(a["F"], b["F"], self.stage_cat, 2 * self.B, self.n_cat, a["gF"], b["gF"])]
@@ -335,28 +425,29 @@ class FusedTrainer:
         if m == "MF":
             pass                                     # gF is gE0
         elif m == "XSimGCL":
-            self._backward_chain(g.adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl)
+            self._backward_chain(adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl)
         elif m == "LightGCN":
-            self._backward_chain(g.adj, self.gF, include_ego=True, extra=self.gReg)
+            self._backward_chain(adj, self.gF, include_ego=True, extra=self.gReg)
         elif m == "SimGCL":
             ops.axpby(1.0, self.views[0]["gF"], 1.0, self.gF)     # same linear operator for all passes
             ops.axpby(1.0, self.views[1]["gF"], 1.0, self.gF)
-            self._backward_chain(g.adj, self.gF, include_ego=False)
+            self._backward_chain(adj, self.gF, include_ego=False)
         else:                                        # SGL: three operators, three chains
-            self._backward_chain(g.adj, self.gF, include_ego=True)
+            self._backward_chain(adj, self.gF, include_ego=True)
             for vi, v in enumerate(self.views):
                 self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True)
-        ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.cursor[1:2], lr=self.lr)
+        ops.adam_step(self._loc(self.E0), self._loc(self.gE0), self.m, self.v, step_dev=self.cursor[1:2], lr=self.lr)
+        self._allgather(self.E0)                     # every rank's next forward pass reads the whole table
         if self.sparse_reset:
             # the gradient buffers hold non-zeros only on this batch's rows: clear just those
             B = self.B
-            lists = [(self.gF, st["u"], rows_dev, B, 0), (self.gF, st["i"], rows_dev, B, U),
-                     (self.gF, st["j"], rows_dev, B, U)]
+            lists = [(self.gF, st["u"], rows_dev, B, 0), (self.gF, st["i"], rows_dev, B, 0),
+                     (self.gF, st["j"], rows_dev, B, 0)]
             if self.gCL is not None:
-                lists += [(self.gCL, st["uniq_u"], nuu_dev, B, 0), (self.gCL, st["uniq_i"], nui_dev, B, U)]
+                lists += [(self.gCL, st["uniq_u"], nuu_dev, B, 0), (self.gCL, st["uniq_i"], nui_dev, B, 0)]
             if self.gReg is not None:
-                lists += [(self.gReg, st["u"], rows_dev, B, 0), (self.gReg, st["i"], rows_dev, B, U),
-                          (self.gReg, st["j"], rows_dev, B, U)]
+                lists += [(self.gReg, st["u"], rows_dev, B, 0), (self.gReg, st["i"], rows_dev, B, 0),
+                          (self.gReg, st["j"], rows_dev, B, 0)]
             ops.zero_rows(lists, self.d, cursor_advance=self.cursor)      # last kernel of the step
         else:
             ops.cursor_advance(self.cursor)
@@ -369,7 +460,7 @@ class FusedTrainer:
         nu, ni = self.meta[1], self.meta[2]
         from_u = self.stage["uniq_u"][pos.clamp(max=B - 1).long()]
         item_pos = (pos - nu).clamp(min=0, max=B - 1).long()
-        from_i = self.stage["uniq_i"][item_pos] + U
+        from_i = self.stage["uniq_i"][item_pos]               # already a table row (items follow the users)
         self.stage_cat.copy_(torch.where(pos < nu, from_u, from_i))
         self.n_cat.copy_((nu + ni).reshape(1))
 
@@ -414,10 +505,12 @@ class FusedTrainer:
     def embeddings(self):
         if self.model == "MF":
             return self.user_emb, self.item_emb
-        out = torch.empty_like(self.E0)
-        Ys = [torch.empty_like(self.E0) for _ in range(self.L)]
-        self._forward_pass(self.graph.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
-        return out[:self.U], out[self.U:]
+        out = torch.zeros_like(self.E0)
+        Ys = [torch.zeros_like(self.E0) for _ in range(self.L)]
+        self._forward_pass(self.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
+        if not self.sharded:
+            return out[:self.U], out[self.U:]
+        return out[self._pos_dev[:self.U]], out[self._pos_dev[self.U:]]
 
 
 class EpochPrefetcher:

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from ._lib import SelfrecHipError, SpmmEpilogue, check
 
+require_gpu = _lib.require_gpu
+
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]

@@ -1,0 +1,173 @@
+"""Torch-CPU stand-in for the part of ``selfrec_amd.ops`` that ``engine.FusedTrainer`` calls -- TEST
+INFRASTRUCTURE ONLY (tests/test_dist_cpu.py swaps it in for ``engine.ops``).
+
+It lets the world_size-2/3 gloo tests run the *product's* step code -- table layout, id -> row mapping,
+local slices, epilogue wiring, activity marks, all-gathers, cursor handling -- on a machine without a
+GPU.  The arithmetic of each op is the CPU oracle's; the product never imports this module."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from oracle import selfrec_oracle as O
+from selfrec_amd import ops as _real_ops
+
+SelfrecHipError = _real_ops.SelfrecHipError
+Sampler = _real_ops.Sampler          # host-only C++ (MT19937 replay): needs no GPU
+
+
+def require_gpu():
+    pass
+
+
+class DeviceCSR:
+    def __init__(self, indptr, indices, vals, shape, device=None, split_len=0, structure_of=None, xcd_split_row=0):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.vals = torch.as_tensor(np.asarray(vals), dtype=torch.float32)
+        m = sp.csr_matrix((self.vals.numpy(), np.asarray(indices), np.asarray(indptr)), shape=self.shape)
+        self._m = O.to_torch_sparse(m)
+        self.nnz = m.nnz
+        self._plan = object()
+
+
+def make_epilogue(**kw):
+    return kw
+
+
+def _live(mark, stamp):
+    return mark == int(stamp.item())
+
+
+def spmm(csr, x, out=None, epilogue=None):
+    ep = epilogue or {}
+    assert x.shape[0] == csr.shape[1]
+    if ep.get("col_mark") is not None:          # columns that are not live hold zeros by contract
+        x = x * _live(ep["col_mark"], ep["mark_stamp"]).unsqueeze(1)
+    y = torch.sparse.mm(csr._m, x)
+    if ep.get("add") or ep.get("alpha", 1.0) != 1.0:
+        y = y * ep.get("alpha", 1.0)
+        for a, s in zip(ep.get("add") or [], ep.get("add_scale") or []):
+            y = y + s * a                       # (batch-sparse addends are zero off the live rows)
+    if ep.get("perturb_eps") is not None:
+        assert ep.get("noise") is not None, "the CPU stand-in needs injected noise"
+        y = O.perturb_(y, ep["noise"], ep["perturb_eps"])
+    rows = slice(None) if ep.get("row_mark") is None else _live(ep["row_mark"], ep["mark_stamp"])
+    out[rows] = y[rows]
+    if ep.get("mean_out") is not None:
+        mean = torch.stack(list(ep.get("prev") or []) + [y], dim=1).sum(1) / ep["mean_div"]
+        ep["mean_out"][rows] = mean[rows]
+    return out
+
+
+def axpby(a, x, b, y):
+    y.copy_(a * x + (b * y if b != 0.0 else 0.0))
+
+
+def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None):
+    b, stamp = int(cursor[0]), int(cursor[1])
+    lo = b * batch_size
+    rows = max(0, min(batch_size, n_edges - lo))
+    for k in ("u", "i", "j"):
+        stage[k][:rows] = ep[k][lo:lo + rows]
+    if row_mark is not None and rows:
+        row_mark[stage["u"][:rows].long()] = stamp
+        row_mark[stage["i"][:rows].long() + mark_item_offset] = stamp
+        row_mark[stage["j"][:rows].long() + mark_item_offset] = stamp
+    a = c = 0
+    if ep.get("uniq_u") is not None and rows:
+        a, c = int(ep["n_uniq_u"][b]), int(ep["n_uniq_i"][b])
+        stage["uniq_u"][:a] = ep["uniq_u"][b * batch_size:b * batch_size + a]
+        stage["uniq_i"][:c] = ep["uniq_i"][b * batch_size:b * batch_size + c]
+    if zero4 is not None:
+        zero4.zero_()
+    meta.copy_(torch.tensor([rows, a, c, b], dtype=torch.int32))
+
+
+def cursor_advance(cursor):
+    cursor += 1
+
+
+def zero_rows(lists, d, cursor_advance=None):
+    for table, idx, n_dev, n_max, off in lists:
+        n = min(int(n_dev), n_max) if n_dev is not None else n_max
+        table[idx[:n].long() + off] = 0.0
+    if cursor_advance is not None:
+        cursor_advance += 1
+
+
+def bpr_ws(B, device):
+    return torch.empty(0)
+
+
+def infonce_ws(n, d, device):
+    return torch.empty(1, dtype=torch.uint8)
+
+
+def bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
+                   reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, ws=None):
+    rows = min(int(n_rows_dev), batch) if n_rows_dev is not None else batch
+    if rows == 0:
+        return
+    ui, pi, ni = (t[:rows].long() for t in (u_idx, i_idx, j_idx))
+    leaves = {}
+
+    def leaf(t):
+        if t.data_ptr() not in leaves:
+            leaves[t.data_ptr()] = t.detach().clone().requires_grad_()
+        return leaves[t.data_ptr()]
+    U, I, RU, RI = leaf(user), leaf(item), leaf(reg_user), leaf(reg_item)
+    bpr = O.bpr_loss(U[ui], I[pi], I[ni])
+    regs = [RU[ui], RI[pi]] + ([RI[ni]] if reg_include_neg else [])
+    reg = O.l2_reg_loss(reg_coef, *regs)
+    (loss_scale * (bpr + reg)).backward()
+    losses[0] += loss_scale * bpr.item()
+    losses[1] += loss_scale * reg.item()
+    # d/d table goes to the matching gradient table (BPR part -> g_*, regulariser part -> greg_*); when the
+    # regularised table IS the scored table the two gradients arrive summed, as in the kernel
+    same_u, same_i = reg_user.data_ptr() == user.data_ptr(), reg_item.data_ptr() == item.data_ptr()
+    done = set()
+    for src, dst in ((user, g_user), (item, g_item), (reg_user, greg_user if not same_u else g_user),
+                     (reg_item, greg_item if not same_i else g_item)):
+        if src.data_ptr() in done:
+            continue
+        done.add(src.data_ptr())
+        g = leaves[src.data_ptr()].grad
+        if g is not None:
+            dst += g
+
+
+def _infonce(problems, tau, scale, loss):
+    for v1, v2, idx, n_max, n_dev, g1, g2 in problems:
+        n = min(int(n_dev), n_max) if n_dev is not None else n_max
+        if n <= 0:
+            continue
+        rows = idx[:n].long() if idx is not None else torch.arange(n)
+        same = v1.data_ptr() == v2.data_ptr()
+        a = v1.detach().clone().requires_grad_()
+        b = a if same else v2.detach().clone().requires_grad_()
+        l = scale * O.info_nce(a[rows], b[rows], tau)
+        l.backward()
+        loss += l.item()
+        g1 += a.grad
+        if not same:
+            g2 += b.grad
+
+
+def infonce_multi(problems, *, d, tau, loss_scale, loss, ws=None):
+    _infonce(problems, tau, loss_scale, loss)
+
+
+def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
+                reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws=None, problems,
+                tau, cl_scale, cl_loss, nce_ws=None):
+    bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, batch=batch, n_rows_dev=n_rows_dev,
+                   reg_coef=reg_coef, reg_include_neg=reg_include_neg, loss_scale=loss_scale, g_user=g_user,
+                   g_item=g_item, greg_user=greg_user, greg_item=greg_item, losses=losses)
+    _infonce(problems, tau, cl_scale, cl_loss)
+
+
+def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    t = int(step_dev) if step_dev is not None else int(step)
+    p, g, mm, vv = (x.contiguous() for x in (param, grad, m, v))
+    pn, mn, vn = p.numpy().copy(), mm.numpy().copy(), vv.numpy().copy()
+    O.adam_step(pn, g.numpy(), mn, vn, t, lr)
+    param.copy_(torch.from_numpy(pn)); m.copy_(torch.from_numpy(mn)); v.copy_(torch.from_numpy(vn))

@@ -1,5 +1,6 @@
-"""world_size-2 (and 3) gloo runs of the row-sharded trainer on CPU: same result as the
-single-process oracle on the same batches and injected noise."""
+"""world_size-2 (and 3) gloo runs of the row-sharded trainer on CPU: the product's step code
+(engine.FusedTrainer with shard=True, via dist.ShardedTrainer) over CPU stand-ins of the kernels
+(tests/cpu_ops.py) gives the single-process oracle's result on the same batches and injected noise."""
 import os
 import socket
 
@@ -24,17 +25,19 @@ def _worker(rank, world, port, model, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from selfrec_amd import synth
+    from selfrec_amd import engine, synth
     from selfrec_amd.data.ui_graph import Interaction
     from selfrec_amd.dist import ShardedTrainer
-    from tests.cpu_backend import CpuBackend
+    from tests import cpu_ops
+    engine.ops = cpu_ops                      # the product's step code over CPU stand-ins of the kernels
     tu, ti, su, si, U, I = synth.make_dataset("tiny")
     data = Interaction({}, synth.as_triples(tu, ti), [])
     torch.manual_seed(0)
     ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
     gen = torch.Generator().manual_seed(7)
     tr = ShardedTrainer(data, 64, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
-                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), backend=CpuBackend())
+                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu")
+    assert tr.G == world and tr.P == world * tr.n_pad
     tr.sampler.seed(11)
     tr.begin_epoch()
     losses = []
@@ -44,10 +47,9 @@ def _worker(rank, world, port, model, out_path):
     pu, pi = tr.parameters_full()
     fu, fi = tr.embeddings()
     if rank == 0:
-        host = tr._host
+        eu, ei, ej = tr.epoch_node_ids()      # staged as table rows: back to node ids for the oracle
         np.savez(out_path, pu=pu.numpy(), pi=pi.numpy(), fu=fu.numpy(), fi=fi.numpy(), losses=np.asarray(losses),
-                 u=host["u"], i=host["i"], j=host["j"], train_u=data.train_u, train_i=data.train_i,
-                 ue=ue.numpy(), ie=ie.numpy())
+                 u=eu, i=ei, j=ej, train_u=data.train_u, train_i=data.train_i, ue=ue.numpy(), ie=ie.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

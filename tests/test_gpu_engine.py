@@ -42,8 +42,8 @@ def test_three_steps_match_reference_run(golden_models, golden_meta, tiny_data, 
     tr.seed_sampler_from_python()
     nb = tr.begin_epoch()
     assert nb == meta[name]["n_batches"]
-    host = tr._epoch_host
-    assert np.array_equal(host["u"], gm[f"{name}_batch_u"]) and np.array_equal(host["j"], gm[f"{name}_batch_j"])
+    eu, _, ej = tr.epoch_node_ids()
+    assert np.array_equal(eu, gm[f"{name}_batch_u"]) and np.array_equal(ej, gm[f"{name}_batch_j"])
     bpr, cl = [], []
     for _ in range(nb):
         tr.step()
@@ -209,6 +209,42 @@ def test_sharded_trainer_on_hip_backend_single_rank(golden_models, golden_meta, 
             dist.destroy_process_group()
 
 
+def test_sharded_step_in_a_hipgraph_equals_the_single_gpu_step(golden_models, golden_meta, tiny_data, monkeypatch):
+    """The sharded layout with its RCCL all-gathers captured in a hipGraph (opt-in, SRH_SHARDED_GRAPH=1),
+    world size 1: same in-kernel RNG stream and batches as the unsharded eager step => same parameters."""
+    import os
+    import torch.distributed as dist
+    from selfrec_amd.dist import ShardedTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        outs = []
+        for sharded in (False, True):
+            monkeypatch.setenv("SRH_SHARDED_GRAPH", "1")
+            m = golden_meta["XSimGCL"]; c = m["conf"]
+            kw = dict(model="XSimGCL", n_layers=int(c["n_layer"]), lr=m["lr"], reg=m["reg"], cl_rate=float(c["lambda"]),
+                      eps=float(c["eps"]), tau=float(c["tau"]), layer_cl=int(c["l_star"]), batch_size=m["batch"],
+                      user_emb=golden_models["XSimGCL_init_user"], item_emb=golden_models["XSimGCL_init_item"])
+            tr = ShardedTrainer(tiny_data, m["emb"], use_graph=True, **kw) if sharded else \
+                FusedTrainer(tiny_data, m["emb"], use_graph=False, **kw)
+            assert tr.use_graph == sharded
+            tr.sampler.seed(5)
+            for _ in range(2):
+                for _ in range(tr.begin_epoch()):
+                    tr.step()
+            torch.cuda.synchronize()
+            outs.append((torch.cat([tr.user_emb, tr.item_emb]).cpu().numpy(), tr.read_losses()))
+        assert np.isfinite(outs[0][0]).all()
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-5
+        np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("name,d", [("XSimGCL", 128), ("SGL", 128), ("LightGCN", 32), ("LightGCN", 256), ("MF", 128)])
 def test_other_embedding_sizes_match_oracle(name, d):
     """d = 128 is BASELINE.json config 4's size (two rows per wave, D=128 InfoNCE tiles); d = 32 / 256 use the
@@ -225,15 +261,15 @@ def test_other_embedding_sizes_match_oracle(name, d):
     random.seed(17)
     tr.seed_sampler_from_python()
     nb = tr.begin_epoch()
-    host = tr._epoch_host
+    eu, ei, ej = tr.epoch_node_ids()
     if name == "SGL":                       # the oracle draws its two dropped views from the same stream
         random.seed(17)
         ref.resample_views()
     for b in range(min(nb, 3)):
         tr.step()
         got = tr.read_losses()
-        lo, hi = b * 1500, min((b + 1) * 1500, len(host["u"]))
-        want = ref.step(host["u"][lo:hi].tolist(), host["i"][lo:hi].tolist(), host["j"][lo:hi].tolist())
+        lo, hi = b * 1500, min((b + 1) * 1500, len(eu))
+        want = ref.step(eu[lo:hi].tolist(), ei[lo:hi].tolist(), ej[lo:hi].tolist())
         np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-9)
     # Gradients agree to ~3e-6 relative (|diff| ~ 1e-9).  Adam turns that into lr * g / (|g| + 1e-8): on the
     # handful of elements whose gradient is itself ~1e-9..1e-8 the first update differs by up to ~2e-5
