@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1300)     # > 2 epochs of 616 batches
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def build_data(shape, seed):
@@ -71,6 +71,18 @@ def step_alg_bytes(model, nnz, N, d, L, B):
     bwd = {"MF": 0, "LightGCN": 1, "XSimGCL": 1, "SimGCL": 1, "SGL": 3}[model]
     spmm = (passes + bwd) * L * spmm_alg_bytes(nnz, N, N, d)
     return spmm + 7 * N * d * 4 + N * d * 4 + 2 * 3 * B * d * 4 + 4 * 2 * B * d * 4
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per dense SpMM launch from the committed PMC passes (bench.py cannot run under
+    rocprofv3 --pmc itself): profiles/spmm_dense_traffic.json, valid for the default workload only."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "spmm_dense_traffic.json")
+    default = args.shape == "yelp2018" and args.emb == 64
+    if not default or not os.path.exists(path):
+        return None, "no PMC pass committed for this workload"
+    with open(path) as f:
+        rec = json.load(f)
+    return rec["traffic_bytes_per_launch"], f"{rec['summary']}: {rec['how']}"
 
 
 def time_spmm_kernel(trainer, iters=50):
@@ -254,11 +266,14 @@ def main():
         if t_spmm:
             alg = spmm_alg_bytes(g.adj.nnz, g.n_nodes, g.n_nodes, args.emb)
             ach = alg / t_spmm["dense"] / 1e9
+            traffic, traffic_note = pmc_traffic(args)
             out["roofline"] = {"bound": "hbm",
                                "kernel": f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over the whole graph, "
                                          "perturb epilogue; split rows finished in-kernel)",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_source": traffic_note,
+                               "traffic_GBps": round(traffic / t_spmm["dense"] / 1e9, 1) if traffic else None,
                                "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dense"] * 1e6, 2),
                                "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
                                "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "

@@ -54,6 +54,15 @@ ncepmc)
   done;;
 ab)
   timeout 600 python tools/spmm_ab.py > $OUT/spmm_ab.log 2>&1; echo "ab exit $?"; tail -45 $OUT/spmm_ab.log;;
+pmcdense)
+  # dense-flavour SpMM only: FETCH_SIZE / WRITE_SIZE (KB per dispatch) in separate passes, then the json bench.py reads
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmcdense_$tag
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmcdense_$tag -o pmc -- python $OLDPWD/tools/spmm_pmc.py > $OLDPWD/$OUT/pmcdense_$tag.log 2>&1); echo "pmcdense $c exit $?"
+    f=$(find $OUT/pmcdense_$tag -name "*.db" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" --tail 40 | grep spmm_rows > $OUT/pmcdense_$tag.summary.txt; cat $OUT/pmcdense_$tag.summary.txt
+    find $OUT/pmcdense_$tag -name "*.db" -size +40M -delete
+  done;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmc_$tag

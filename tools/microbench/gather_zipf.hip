@@ -41,6 +41,28 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ X, cons
   if (acc.x == 123.456f) out[0] = acc;
 }
 
+// variant 5: does giving each XCD a FRACTION of the table pay?  Workgroup b runs on XCD b % 8; XCD x reads
+// only the index stream of column class (x / (8 / K)) % K -- rows whose popularity rank is congruent to
+// that class mod K -- so its L2 working set is 1/K of the table while the popularity law inside it is the
+// same.  Same total number of 256-byte gathers as variant 0.
+__global__ __launch_bounds__(256) void gather_split(const float4* __restrict__ X, const int* __restrict__ idx,
+                                                    long per_class, int K, float4* out) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
+  const int xcd = blockIdx.x & 7, cls = (xcd / (8 / K)) % K, peers = 8 / K;     // XCDs sharing this class
+  const long wave_in_class = ((long)(blockIdx.x >> 3) * peers + (xcd % peers)) * 4 + (threadIdx.x >> 6);
+  const long waves_in_class = (long)(gridDim.x >> 3) * peers * 4;
+  const int* my = idx + (long)cls * per_class;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (long base = wave_in_class * 32; base + 32 <= per_class; base += waves_in_class * 32) {
+    float4 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = X[(size_t)my[base + t * 4 + g] * 16 + sub];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc.x += x[t].x; acc.y += x[t].y; acc.z += x[t].z; acc.w += x[t].w; }
+  }
+  if (acc.x == 123.456f) out[0] = acc;
+}
+
 // variant 4: rows colder than a popularity rank are fetched with the non-temporal hint so they do not
 // evict the popular rows from L2 (sign bit of the index = cold).
 __global__ __launch_bounds__(256) void gather_nt(const float4* __restrict__ X, const int* __restrict__ enc, long n_idx,
@@ -130,7 +152,33 @@ int main() {
   CK(hipMalloc(&enc, n_idx * 4)); CK(hipMalloc(&hot_rows, 1024 * 4));
   CK(hipMemcpy(hot_rows, perm.data(), 1024 * 4, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)gather_hot, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  for (int T : {0, 4096, 8192, 12288, 16384, 24576, 38048}) {
+  for (int K : {1, 2, 4, 8}) {
+    // class c = the fetches whose popularity rank is congruent to c mod K, padded to equal length
+    std::vector<std::vector<int>> cls(K);
+    for (long i = 0; i < n_idx; ++i) cls[rank[i] % K].push_back(h[i]);
+    long per_class = 0;
+    for (auto& c : cls) per_class = std::max<long>(per_class, (long)c.size());
+    std::vector<int> flat((size_t)per_class * K);
+    for (int c = 0; c < K; ++c)
+      for (long i = 0; i < per_class; ++i) flat[(size_t)c * per_class + i] = cls[c][i % cls[c].size()];
+    int* d_flat;
+    CK(hipMalloc(&d_flat, flat.size() * 4));
+    CK(hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    for (int blocks : {2048, 4096}) {
+      float ms = 0;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a));
+        gather_split<<<blocks, 256>>>(X, d_flat, per_class, K, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        CK(hipEventElapsedTime(&ms, a, b));
+      }
+      const double bytes = (double)per_class * K * 256;
+      printf("variant 5 (256 B rows, each XCD reads 1/%d of the table = %.1f MB) blocks %4d: %7.2f us  %6.2f TB/s\n", K,
+             rows * 256.0 / K / 1e6, blocks, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+    }
+    CK(hipFree(d_flat));
+  }
+  for (int T : {38048}) {
     std::vector<int> e(n_idx);
     long cold = 0;
     for (long i = 0; i < n_idx; ++i) { const bool c = rank[i] >= T; cold += c; e[i] = c ? (int)(0x80000000u | h[i]) : h[i]; }
