@@ -121,6 +121,9 @@ srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
  *   PERTURB : y += sign(y) * normalize(noise_row) * eps        XSimGCL.py:90-91
  *   MEAN    : mean_out = (sum_t prev[t] + y) / mean_div         XSimGCL.py:95-96, LightGCN.py:74-75
  *   AXPY    : y = alpha * y + sum_t add_scale[t] * add[t]       (backward accumulation; add[t] may alias y)
+ *   FANOUT  : with PERTURB, the SAME product also leaves differently-perturbed copies     SimGCL.py:81-93
+ *             (SimGCL's clean pass and its two perturbed views multiply the same A by the same
+ *             ego table in their first layer: one gather pass, three outputs)
  *
  * The plan is the row schedule (degree-sorted rows, heavy rows split into segments); it
  * depends only on indptr and is shared by every value array over the same structure.
@@ -137,6 +140,7 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
 enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };
 #define SRH_MAX_PREV 8
 #define SRH_MAX_ADD 2
+#define SRH_MAX_EXTRA 2
 
 typedef struct srh_spmm_epilogue {
   int32_t flags;               /* OR of SRH_EPI_* ; 0 = plain y = A x                      */
@@ -165,6 +169,14 @@ typedef struct srh_spmm_epilogue {
    * live, so it is only read on live rows (the batch-row gradients gF / gCL of the backward chain). */
   const int32_t* d_add_mark;
   int32_t add_sparse_mask;
+  /* FANOUT (PERTURB only, no MEAN): n_extra further outputs extra_out[k] = perturb_k(product), each
+   * with its own injected noise (or NULL) / counter offset; main_clean != 0 leaves the main output y
+   * unperturbed. */
+  int32_t n_extra;
+  int32_t main_clean;
+  float* d_extra_out[SRH_MAX_EXTRA];
+  const float* d_extra_noise[SRH_MAX_EXTRA];
+  uint64_t extra_rng_offset[SRH_MAX_EXTRA];
 } srh_spmm_epilogue_t;
 
 /* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {32,64,128,256}.

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
 ABI_VERSION = 12
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
-SRH_MAX_PREV, SRH_MAX_ADD = 8, 2
+SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
 
 
 class SelfrecHipError(RuntimeError):
@@ -53,6 +53,8 @@ class SpmmEpilogue(C.Structure):
         ("add_scale", C.c_float * SRH_MAX_ADD),
         ("d_row_mark", C.c_void_p), ("d_col_mark", C.c_void_p), ("d_mark_stamp", C.c_void_p),
         ("d_add_mark", C.c_void_p), ("add_sparse_mask", C.c_int32),
+        ("n_extra", C.c_int32), ("main_clean", C.c_int32), ("d_extra_out", C.c_void_p * SRH_MAX_EXTRA),
+        ("d_extra_noise", C.c_void_p * SRH_MAX_EXTRA), ("extra_rng_offset", C.c_uint64 * SRH_MAX_EXTRA),
     ]
 
 

@@ -70,6 +70,11 @@ struct DevEpilogue {
   const int64_t* mark_stamp;
   const int32_t* add_mark;       // AXPY: addends flagged in add_sparse are zero outside marked rows
   int32_t add_sparse;
+  // FANOUT: further perturbed copies of the same product
+  int32_t n_extra, main_clean;
+  float* extra_out[SRH_MAX_EXTRA];
+  const float* extra_noise[SRH_MAX_EXTRA];
+  uint32_t extra_off_lo[SRH_MAX_EXTRA], extra_off_hi[SRH_MAX_EXTRA];
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -93,6 +98,29 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 // Epilogue on one full row held as float4 per lane of an LPR-lane group.  Executed by all
 // groups of the wave with identical data (they all hold the reduced row); `store` selects
 // the group that writes.
+// y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
+template <int LPR>
+__device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
+                                              uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep) {
+  float4 nu;
+  if (noise) {
+    nu = reinterpret_cast<const float4*>(noise)[at];
+  } else {
+    uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
+    if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+    uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
+    nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+  }
+  float ss = group_sum<LPR>(f4_dot(nu, nu));
+  // F.normalize: v / max(||v||, 1e-12); one reciprocal instead of four divisions (<= 1 ulp apart)
+  const float scale = ep.eps / fmaxf(sqrtf(ss), 1e-12f);
+  y.x += sgnf(y.x) * (nu.x * scale);
+  y.y += sgnf(y.y) * (nu.y * scale);
+  y.z += sgnf(y.z) * (nu.z * scale);
+  y.w += sgnf(y.w) * (nu.w * scale);
+  return y;
+}
+
 template <int LPR>
 __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
                                              const DevEpilogue& ep) {
@@ -108,22 +136,12 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
     }
   }
   if (ep.flags & SRH_EPI_PERTURB) {
-    float4 nu;
-    if (ep.noise) {
-      nu = reinterpret_cast<const float4*>(ep.noise)[at];
-    } else {
-      uint64_t ctr = (((uint64_t)ep.off_hi << 32) | ep.off_lo) + (uint64_t)row;
-      if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
-      uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
-      nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    const float4 raw = y;
+    if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep);
+    for (int k = 0; k < ep.n_extra; ++k) {
+      const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
+      if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = yk;
     }
-    float ss = group_sum<LPR>(f4_dot(nu, nu));
-    // F.normalize: v / max(||v||, 1e-12); one reciprocal instead of four divisions (<= 1 ulp apart)
-    const float scale = ep.eps / fmaxf(sqrtf(ss), 1e-12f);
-    y.x += sgnf(y.x) * (nu.x * scale);
-    y.y += sgnf(y.y) * (nu.y * scale);
-    y.z += sgnf(y.z) * (nu.z * scale);
-    y.w += sgnf(y.w) * (nu.w * scale);
   }
   if (store) Y[at] = y;
   if (ep.flags & SRH_EPI_MEAN) {
@@ -840,6 +858,21 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.mark_stamp = epi->d_mark_stamp;
     ep.add_mark = epi->d_add_mark;
     ep.add_sparse = epi->add_sparse_mask;
+    if (epi->n_extra || epi->main_clean) {
+      SRH_REQUIRE((epi->flags & SRH_EPI_PERTURB) && !(epi->flags & SRH_EPI_MEAN) && epi->n_extra >= 0 &&
+                      epi->n_extra <= SRH_MAX_EXTRA,
+                  "spmm_f32: extra perturbed outputs need PERTURB without MEAN and at most %d of them", SRH_MAX_EXTRA);
+      ep.n_extra = epi->n_extra;
+      ep.main_clean = epi->main_clean != 0;
+      for (int k = 0; k < epi->n_extra; ++k) {
+        SRH_REQUIRE(epi->d_extra_out[k] && epi->d_extra_out[k] != d_y && epi->d_extra_out[k] != d_x,
+                    "spmm_f32: bad extra output %d", k);
+        ep.extra_out[k] = epi->d_extra_out[k];
+        ep.extra_noise[k] = epi->d_extra_noise[k];
+        ep.extra_off_lo[k] = (uint32_t)epi->extra_rng_offset[k];
+        ep.extra_off_hi[k] = (uint32_t)(epi->extra_rng_offset[k] >> 32);
+      }
+    }
     SRH_REQUIRE(!(ep.row_mark || ep.col_mark || ep.add_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
     if (epi->flags & SRH_EPI_MEAN) {
       SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,

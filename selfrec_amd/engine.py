@@ -273,20 +273,26 @@ class FusedTrainer:
         full[self._pos_dev] = t
         return full[self.loc].contiguous()
 
-    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False, need_last=False):
+    def _rng_offset(self, call):
+        """Counter offset of perturbed-layer call number `call` of this step (rows of all ranks)."""
+        return (call * self.P + self.rank * self.n_pad) & ((1 << 62) - 1)
+
+    def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False, need_last=False,
+                      start_layer=0, noises=None, call_base=None):
         """L SpMMs; layer k's epilogue perturbs (optional) and the last one also writes the
         layer mean into F.  Returns nothing; the CL view of XSimGCL is Ys[l*-1] (or E0).
         batch_rows_only: the last layer's output (and F) feed nothing but the batch losses, so
         only the rows marked for this step are computed (the others keep stale values that are
-        never read)."""
+        never read).  start_layer > 0: Ys[:start_layer] are already there (SimGCL's shared first
+        product); noises / call_base: injected noise per layer and the RNG call number of layer 0."""
         L = self.L
-        x = self.E0
-        for k in range(L):
+        x = self.E0 if start_layer == 0 else Ys[start_layer - 1]
+        for k in range(start_layer, L):
             kw = {}
             if perturbed:
-                noise = self._noise()
-                kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed,
-                          rng_offset=(self._noise_call * self.P + self.rank * self.n_pad) & ((1 << 62) - 1),
+                noise = noises[k] if noises is not None else self._noise()
+                call = self._noise_call if call_base is None else call_base + k
+                kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed, rng_offset=self._rng_offset(call),
                           rng_step=self.cursor[1:2] if noise is None else None,
                           rng_stride=self.P * 16)
                 self._noise_call += 1
@@ -301,6 +307,32 @@ class FusedTrainer:
                 self._allgather(Ys[k])          # the next layer (or the contrast view) reads every row
             x = Ys[k]
         self._allgather(F)
+
+    def _simgcl_forward(self, adj):
+        """SimGCL.py:81-93 three times (clean pass for the recommendation loss, two perturbed views): the
+        first layer of all three is the SAME product A.E0, so it is gathered once and leaves three
+        outputs (clean, +noise_a, +noise_b); the remaining layers differ in their inputs."""
+        L, a, b = self.L, self.views[0], self.views[1]
+        if L < 2:                               # the only layer also carries the mean: three plain passes
+            self._forward_pass(adj, self.Y, self.F, perturbed=False, include_ego=False, batch_rows_only=True)
+            for v in (a, b):
+                self._forward_pass(adj, v["Y"], v["F"], perturbed=True, include_ego=False, batch_rows_only=True)
+            return
+        # injected noise is drawn in the reference's order: view a layers 1..L, then view b
+        na = [self._noise() for _ in range(L)] if self.noise_fn is not None else [None] * L
+        nb = [self._noise() for _ in range(L)] if self.noise_fn is not None else [None] * L
+        ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), epilogue=ops.make_epilogue(
+            perturb_eps=self.eps, noise=None, rng_seed=self.rng_seed, rng_offset=0,
+            rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * 16, main_clean=True,
+            extra_out=[self._loc(a["Y"][0]), self._loc(b["Y"][0])], extra_noise=[na[0], nb[0]],
+            extra_rng_offset=[self._rng_offset(0), self._rng_offset(L)]))
+        for t in (self.Y[0], a["Y"][0], b["Y"][0]):
+            self._allgather(t)
+        self._forward_pass(adj, self.Y, self.F, perturbed=False, include_ego=False, batch_rows_only=True, start_layer=1)
+        self._forward_pass(adj, a["Y"], a["F"], perturbed=True, include_ego=False, batch_rows_only=True,
+                           start_layer=1, noises=na, call_base=0)
+        self._forward_pass(adj, b["Y"], b["F"], perturbed=True, include_ego=False, batch_rows_only=True,
+                           start_layer=1, noises=nb, call_base=L)
 
     def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None, accumulate=False):
         """gE0 (+)= d loss / d E0 through one encoder pass (accumulate=False overwrites gE0).
@@ -378,7 +410,9 @@ class FusedTrainer:
                 v["gF"].zero_()
 
         include_ego = m in ("LightGCN", "SGL")
-        if m != "MF":
+        if m == "SimGCL":
+            self._simgcl_forward(adj)
+        elif m != "MF":
             self._forward_pass(adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
                                batch_rows_only=True, need_last=(m == "XSimGCL" and self.layer_cl == self.L))
         F = self.F
@@ -407,10 +441,10 @@ class FusedTrainer:
                 (F, CL, st["uniq_u"], self.B, nuu_dev, self.gF, self.gCL),
                 (F, CL, st["uniq_i"], self.B, nui_dev, self.gF, self.gCL)])
         elif m in ("SimGCL", "SGL"):
-            for vi, v in enumerate(self.views):
-                vadj = adj if m == "SimGCL" else self.view_adj[vi]
-                self._forward_pass(vadj, v["Y"], v["F"], perturbed=(m == "SimGCL"), include_ego=include_ego,
-                                   batch_rows_only=True)
+            if m == "SGL":
+                for vi, v in enumerate(self.views):
+                    self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=include_ego,
+                                       batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
                 problems = [(a["F"], b["F"], st["uniq_u"], self.B, nuu_dev, a["gF"], b["gF"]),

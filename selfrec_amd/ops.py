@@ -201,7 +201,8 @@ class DeviceCSR:
 
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
-                  row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None):
+                  row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
+                  extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False):
     ep = SpmmEpilogue()
     keep = []
     flags = 0
@@ -213,6 +214,16 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
         ep.d_rng_step = _p(rng_step, torch.int64, "rng_step")
         ep.rng_stride = int(rng_stride)
         keep += [noise, rng_step]
+        extra_out = list(extra_out or [])
+        if extra_out or main_clean:        # further perturbed copies of the same product (SimGCL layer 1)
+            if len(extra_out) > _lib.SRH_MAX_EXTRA:
+                raise SelfrecHipError(f"at most {_lib.SRH_MAX_EXTRA} extra perturbed outputs")
+            ep.n_extra, ep.main_clean = len(extra_out), int(bool(main_clean))
+            for k, t in enumerate(extra_out):
+                ep.d_extra_out[k] = _p(t, torch.float32, "extra_out")
+                ep.d_extra_noise[k] = _p((extra_noise or [None] * len(extra_out))[k], torch.float32, "extra_noise")
+                ep.extra_rng_offset[k] = int((extra_rng_offset or [0] * len(extra_out))[k])
+            keep += extra_out + list(extra_noise or [])
     if mean_out is not None:
         flags |= _lib.SRH_EPI_MEAN
         prev = list(prev or [])

@@ -94,6 +94,30 @@ def test_spmm_epilogues_match_oracle():
     assert rel_err(out.cpu().numpy(), want) < 2e-6
 
 
+def test_spmm_fanout_equals_separate_launches():
+    """One product, three outputs (SimGCL's clean pass + two perturbed views share A.E0 in layer 1): each
+    output is bit-identical to a launch of its own, with injected noise and with the counter RNG."""
+    d, n = 64, 900
+    m = powerlaw_csr(n, n, 15000, seed=21, heavy_rows=2, heavy_len=800, empty_rows=4)
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    na, nb = (torch.from_numpy(rng.random((n, d)).astype(np.float32)).to(DEV) for _ in range(2))
+    csr = ops.DeviceCSR.from_scipy(m)
+    clean = ops.spmm(csr, x)
+    for injected in (True, False):
+        kw = dict(perturb_eps=0.2, rng_seed=77, rng_stride=n * 16)
+        if injected:
+            sep = [ops.spmm(csr, x, epilogue=ops.make_epilogue(noise=t, **kw)) for t in (na, nb)]
+            extra = dict(extra_noise=[na, nb])
+        else:
+            sep = [ops.spmm(csr, x, epilogue=ops.make_epilogue(rng_offset=off, **kw)) for off in (5 * n, 9 * n)]
+            extra = dict(extra_rng_offset=[5 * n, 9 * n])
+        ya, yb, y = torch.empty_like(clean), torch.empty_like(clean), torch.empty_like(clean)
+        ops.spmm(csr, x, out=y, epilogue=ops.make_epilogue(main_clean=True, extra_out=[ya, yb], **extra, **kw))
+        assert torch.equal(y, clean) and torch.equal(ya, sep[0]) and torch.equal(yb, sep[1])
+        assert not torch.equal(ya, yb)
+
+
 def test_spmm_rng_perturbation_properties():
     d, n = 64, 500
     m = powerlaw_csr(n, n, 6000, seed=9)
