@@ -303,13 +303,13 @@ srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, floa
  *   scores[r, :] = item_emb @ user_emb[user_ids[r]]       fp32 MFMA (exact-f32 fma chain)
  *   scores[r, i] = -1e9 for i in training items of that user (CSR d_r_indptr/d_r_indices)
  *   top-K by (score desc, id asc), written best-first.
- * d_scores_ws: (n_query, n_items) fp32 scratch (the caller chunks users so it stays
- * cache-resident).  d_user_ids may be NULL (rows 0..n_query-1 of d_user_emb).
+ * d_scores_ws: (ws_rows, n_items) fp32 scratch; the queries pass through it ws_rows at a time (size
+ * it to stay cache-resident: <= ~96 MB).  d_user_ids may be NULL (rows 0..n_query-1 of d_user_emb).
  * ---------------------------------------------------------------------------------- */
 srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_ids,
                                  int64_t n_query, const float* d_item_emb, int64_t n_items,
                                  int32_t d, const int32_t* d_r_indptr, const int32_t* d_r_indices,
-                                 int32_t k, float* d_scores_ws, int32_t* d_out_ids,
+                                 int32_t k, float* d_scores_ws, int64_t ws_rows, int32_t* d_out_ids,
                                  float* d_out_scores, void* stream);
 /* The scoring GEMM alone: C (m, n) = A (m, d) B (n, d)^T, fp32 MFMA. */
 srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int64_t m,

@@ -71,19 +71,16 @@ class GraphRecommender(Recommender):
         g = self.data.device_graph(ie.device)
         uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=ie.device)
         chunk = max(32, min(len(user_ids), SCORE_SLAB_BYTES // (4 * ie.shape[0])))
-        slab = torch.empty((chunk, ie.shape[0]), dtype=torch.float32, device=ie.device)
-        ids_parts, sc_parts = [], []
-        for lo in range(0, uid.numel(), chunk):
-            part = uid[lo:lo + chunk]
-            ids, sc = ops.score_mask_topk(ue, part, ie, g.r_indptr, g.r_indices, k, scores_ws=slab[:part.numel()])
-            ids_parts.append(ids)
-            sc_parts.append(sc)
-        ids_dev = torch.cat(ids_parts)
+        slab = getattr(self, '_score_slab', None)
+        if slab is None or slab.shape != (chunk, ie.shape[0]) or slab.device != ie.device:
+            slab = self._score_slab = torch.empty((chunk, ie.shape[0]), dtype=torch.float32, device=ie.device)
+        # one call: the users pass through the cache-sized slab `chunk` at a time inside the library
+        ids_dev, sc_dev = ops.score_mask_topk(ue, uid, ie, g.r_indptr, g.r_indices, k, scores_ws=slab)
         if with_hits:
             t_indptr, t_indices, _ = self._test_csr(ie.device)
             flags = ops.topk_hit_flags(ids_dev, uid, t_indptr, t_indices)
-            return ids_dev.cpu().numpy(), torch.cat(sc_parts).cpu().numpy(), flags.cpu().numpy()
-        return ids_dev.cpu().numpy(), torch.cat(sc_parts).cpu().numpy()
+            return ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy()
+        return ids_dev.cpu().numpy(), sc_dev.cpu().numpy()
 
     def test(self):
         users = list(self.data.test_set)

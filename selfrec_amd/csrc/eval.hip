@@ -74,11 +74,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t* __restrict__ user_ids, int m,
                                                    const int32_t* __restrict__ indptr,
                                                    const int32_t* __restrict__ indices, float* __restrict__ scores,
-                                                   int n) {
+                                                   int n, int user_base) {
   const int q = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
   if (q >= m) return;
   const int lane = threadIdx.x & 63;
-  const int u = user_ids ? user_ids[q] : q;
+  const int u = user_ids ? user_ids[q] : user_base + q;
   const int s = indptr[u], e = indptr[u + 1];
   for (int p = s + lane; p < e; p += 64) scores[(size_t)q * n + indices[p]] = -10e8f;
 }
@@ -252,18 +252,28 @@ srh_status_t srh_topk_rows(const float* d_scores, int64_t rows, int64_t n, int32
 srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
                                  const float* d_item_emb, int64_t n_items, int32_t d,
                                  const int32_t* d_r_indptr, const int32_t* d_r_indices, int32_t k,
-                                 float* d_scores_ws, int32_t* d_out_ids, float* d_out_scores, void* stream) {
+                                 float* d_scores_ws, int64_t ws_rows, int32_t* d_out_ids, float* d_out_scores,
+                                 void* stream) {
   SRH_REQUIRE(d_user_emb && d_item_emb && d_scores_ws && d_out_ids && d_out_scores, "score_mask_topk: null argument");
   SRH_REQUIRE((d_r_indptr == nullptr) == (d_r_indices == nullptr), "score_mask_topk: mask CSR must be given whole");
+  SRH_REQUIRE(ws_rows > 0, "score_mask_topk: the score slab must hold at least one row");
   hipStream_t st = srh::as_stream(stream);
-  srh_status_t rc = gemm_dispatch(d_user_emb, d_user_ids, d_item_emb, d_scores_ws, n_query, n_items, d, st);
-  if (rc) return rc;
-  if (d_r_indptr) {
-    mask_kernel<<<(int)((n_query + 3) / 4), 256, 0, st>>>(d_user_ids, (int)n_query, d_r_indptr, d_r_indices,
-                                                          d_scores_ws, (int)n_items);
-    SRH_LAUNCH_CHECK();
+  // the queries go through the slab ws_rows at a time (it is sized to stay in the Infinity Cache)
+  for (int64_t lo = 0; lo < n_query; lo += ws_rows) {
+    const int64_t m = std::min(ws_rows, n_query - lo);
+    const float* emb = d_user_ids ? d_user_emb : d_user_emb + lo * d;
+    const int32_t* ids = d_user_ids ? d_user_ids + lo : nullptr;
+    srh_status_t rc = gemm_dispatch(emb, ids, d_item_emb, d_scores_ws, m, n_items, d, st);
+    if (rc) return rc;
+    if (d_r_indptr) {
+      mask_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(ids, (int)m, d_r_indptr, d_r_indices, d_scores_ws, (int)n_items,
+                                                      (int)lo);
+      SRH_LAUNCH_CHECK();
+    }
+    rc = srh_topk_rows(d_scores_ws, m, n_items, k, d_out_ids + lo * k, d_out_scores + lo * k, stream);
+    if (rc) return rc;
   }
-  return srh_topk_rows(d_scores_ws, n_query, n_items, k, d_out_ids, d_out_scores, stream);
+  return SRH_OK;
 }
 
 srh_status_t srh_topk_hit_flags(const int32_t* d_ids, int64_t n_query, int32_t k, const int32_t* d_user_ids,

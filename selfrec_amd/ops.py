@@ -392,6 +392,8 @@ def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=
 
 
 def score_mask_topk(user_emb, user_ids, item_emb, r_indptr, r_indices, k, scores_ws=None):
+    """ids, scores (device, (n_query, k)).  scores_ws: (rows, n_items) slab the queries pass through
+    `rows` at a time inside the call (default: one slab for all queries)."""
     nq = int(user_ids.numel()) if user_ids is not None else int(user_emb.shape[0])
     n_items, d = int(item_emb.shape[0]), int(item_emb.shape[1])
     dev = item_emb.device
@@ -402,8 +404,8 @@ def score_mask_topk(user_emb, user_ids, item_emb, r_indptr, r_indices, k, scores
     check(_lib.load().srh_score_mask_topk(_p(user_emb, torch.float32), _p(user_ids, torch.int32), nq,
                                           _p(item_emb, torch.float32), n_items, d, _p(r_indptr, torch.int32),
                                           _p(r_indices, torch.int32), int(k), _p(scores_ws, torch.float32),
-                                          _p(ids, torch.int32), _p(sc, torch.float32), _stream()),
-          "srh_score_mask_topk")
+                                          int(scores_ws.shape[0]), _p(ids, torch.int32), _p(sc, torch.float32),
+                                          _stream()), "srh_score_mask_topk")
     return ids, sc
 
 
