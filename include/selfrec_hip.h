@@ -311,6 +311,24 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
                                  int32_t d, const int32_t* d_r_indptr, const int32_t* d_r_indices,
                                  int32_t k, float* d_scores_ws, int64_t ws_rows, int32_t* d_out_ids,
                                  float* d_out_scores, void* stream);
+/* The same ranking without ever storing the (users x items) scores.  Per chunk of chunk_rows users:
+ *   1. the exact pipeline above on the first `sample_items` items only; its K-th score t_u is a lower
+ *      bound of user u's overall K-th score;
+ *   2. the scoring GEMM over the whole catalogue with a filter epilogue: a score is kept iff it is
+ *      >= t_u -- a few hundred (item, score) pairs per user, appended to a list of `cap` slots;
+ *   3. training items of u are dropped from its list (binary search in the mask CSR) and the rest is
+ *      put in exact (score desc, id asc) order.
+ * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
+ * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
+ * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with
+ * srh_score_mask_topk.  d_ws: srh_score_mask_topk_filtered_ws_bytes(chunk_rows, ...) bytes. */
+int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap);
+srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
+                                          const float* d_item_emb, int64_t n_items, int32_t d,
+                                          const int32_t* d_r_indptr, const int32_t* d_r_indices, int32_t k,
+                                          int64_t sample_items, int32_t cap, int64_t chunk_rows, void* d_ws,
+                                          int32_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
+                                          void* stream);
 /* The scoring GEMM alone: C (m, n) = A (m, d) B (n, d)^T, fp32 MFMA. */
 srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int64_t m,
                              int64_t n, int32_t d, void* stream);

@@ -93,6 +93,9 @@ SIGNATURES = {
                                        _vp]),
     "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
     "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "srh_score_mask_topk_filtered_ws_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "srh_score_mask_topk_filtered": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp,
+                                            _vp, _vp, _vp]),
     "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "srh_topk_rows": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "srh_topk_hit_flags": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),

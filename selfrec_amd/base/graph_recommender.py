@@ -25,6 +25,8 @@ from .recommender import Recommender
 MASKED_SCORE = -10e8
 # users per scoring call: chunk * n_items * 4 B stays well inside the 256 MiB Infinity Cache
 SCORE_SLAB_BYTES = 96 << 20
+# filtered ranking: items scored exactly to bound each user's K-th score, survivor slots per user, users per chunk
+FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 4096
 
 
 class GraphRecommender(Recommender):
@@ -63,6 +65,30 @@ class GraphRecommender(Recommender):
             self._test_csr_cache = cached
         return cached
 
+    def _rank_exact(self, ue, uid, ie, g, k):
+        """Scores through a cache-sized slab, masked, exact top-K (srh_score_mask_topk): one call, the
+        users pass through the slab `chunk` at a time inside the library."""
+        chunk = max(32, min(int(uid.numel()), SCORE_SLAB_BYTES // (4 * ie.shape[0])))
+        slab = getattr(self, '_score_slab', None)
+        if slab is None or slab.shape != (chunk, ie.shape[0]) or slab.device != ie.device:
+            slab = self._score_slab = torch.empty((chunk, ie.shape[0]), dtype=torch.float32, device=ie.device)
+        return ops.score_mask_topk(ue, uid, ie, g.r_indptr, g.r_indices, k, scores_ws=slab)
+
+    def _rank(self, ue, uid, ie, g, k):
+        """Large catalogues: the score matrix is never stored (srh_score_mask_topk_filtered: a bound from a
+        slice of the catalogue, then a filtering pass); the few rows whose survivor list overflowed
+        (tie-heavy scores) are re-ranked by the exact path.  Same ids and scores either way."""
+        if ie.shape[0] < 4 * FILTER_SAMPLE_ITEMS:
+            return self._rank_exact(ue, uid, ie, g, k)
+        ids, sc, counts, self._filter_ws = ops.score_mask_topk_filtered(
+            ue, uid, ie, g.r_indptr, g.r_indices, k, sample_items=FILTER_SAMPLE_ITEMS, cap=FILTER_CAP,
+            chunk_rows=FILTER_CHUNK_ROWS, ws=getattr(self, '_filter_ws', None))
+        redo = torch.nonzero(counts > FILTER_CAP).flatten()
+        if redo.numel():
+            ids_r, sc_r = self._rank_exact(ue, uid[redo].contiguous(), ie, g, k)
+            ids[redo], sc[redo] = ids_r, sc_r
+        return ids, sc
+
     def rank_on_device(self, user_ids, k=None, with_hits=False):
         """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids; with_hits adds the uint8
         flags 'this ranked item is in the user's test set' (srh_topk_hit_flags)."""
@@ -70,27 +96,28 @@ class GraphRecommender(Recommender):
         ue, ie = self._device_embeddings()
         g = self.data.device_graph(ie.device)
         uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=ie.device)
-        chunk = max(32, min(len(user_ids), SCORE_SLAB_BYTES // (4 * ie.shape[0])))
-        slab = getattr(self, '_score_slab', None)
-        if slab is None or slab.shape != (chunk, ie.shape[0]) or slab.device != ie.device:
-            slab = self._score_slab = torch.empty((chunk, ie.shape[0]), dtype=torch.float32, device=ie.device)
-        # one call: the users pass through the cache-sized slab `chunk` at a time inside the library
-        ids_dev, sc_dev = ops.score_mask_topk(ue, uid, ie, g.r_indptr, g.r_indices, k, scores_ws=slab)
+        ids_dev, sc_dev = self._rank(ue, uid, ie, g, k)
         if with_hits:
             t_indptr, t_indices, _ = self._test_csr(ie.device)
             flags = ops.topk_hit_flags(ids_dev, uid, t_indptr, t_indices)
             return ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy()
         return ids_dev.cpu().numpy(), sc_dev.cpu().numpy()
 
-    def test(self):
-        users = list(self.data.test_set)
-        if self._device_embeddings() is not None and users:
+    def _test_users(self):
+        """Test users in test-set order with their ids, test-set sizes and the item-name table (built once)."""
+        cached = getattr(self, '_test_users_cache', None)
+        if cached is None or cached[0] is not self.data.test_set:
+            users = list(self.data.test_set)
             uid = np.fromiter((self.data.user[u] for u in users), dtype=np.int32, count=len(users))
+            id2item = self.data.id2item
+            names = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)
+            cached = self._test_users_cache = (self.data.test_set, users, uid, names)
+        return cached[1:]
+
+    def test(self):
+        users, uid, names = self._test_users()
+        if self._device_embeddings() is not None and users:
             ids, scores, flags = self.rank_on_device(uid, with_hits=True)
-            names = getattr(self, '_item_name_array', None)
-            if names is None:
-                id2item = self.data.id2item
-                names = self._item_name_array = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)
             sizes = np.diff(self._test_csr(self.item_emb.device)[2])[uid]
             # reads like the reference's {user: [(item, score), ...]}; rows are built on access and
             # ranking_evaluation works on the arrays (same strings)

@@ -18,10 +18,38 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // walks TILES_PER_WAVE column tiles.  Operand layout of v_mfma_f32_32x32x2_f32: lane l gives
 // A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; the k index is a free summation index, so lane
 // half h takes dimensions [h*D/2, (h+1)*D/2) of its row -- every load is a contiguous float4.
-template <int D, int TILES_PER_WAVE>
+// FILTER: instead of writing the 32x32 score tile, keep only the scores that reach the row's threshold --
+// appended to the row's candidate list (see srh_score_mask_topk_filtered); C is not touched.  (Training
+// items are dropped from the lists afterwards, by cand_topk_kernel: a binary search per score in this
+// epilogue stalled the MFMA loop.)
+struct FilterArgs {
+  const float* thr;            // row r's threshold = thr[r * thr_stride]
+  int thr_stride;
+  int32_t* cnt;                // per row: candidates seen (may exceed cap: the row is then incomplete)
+  int32_t* cand_id;
+  float* cand_sc;
+  int cap;
+};
+constexpr int kStageCap = 192;   // survivors a wave stages in LDS before it appends them to the rows' lists
+
+// append the wave's staged survivors to their rows' candidate lists: each lane takes one entry, one
+// vector atomic reserves the slots
+__device__ __forceinline__ void filter_flush(const FilterArgs& f, int m0, const short* stage_row, const int* stage_col,
+                                             const float* stage_sc, int staged, int lane) {
+  for (int e = lane; e < staged; e += 64) {
+    const int row = m0 + stage_row[e];
+    const int slot = atomicAdd(f.cnt + row, 1);
+    if (slot < f.cap) {
+      f.cand_id[(size_t)row * f.cap + slot] = stage_col[e];
+      f.cand_sc[(size_t)row * f.cap + slot] = stage_sc[e];
+    }
+  }
+}
+
+template <int D, int TILES_PER_WAVE, bool FILTER>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_rows,
                                                       const float* __restrict__ B, float* __restrict__ C,
-                                                      int m, int n) {
+                                                      int m, int n, FilterArgs f) {
   constexpr int DH = D / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
@@ -41,20 +69,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
       a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
     }
   }
+  __shared__ short s_stage_row[FILTER ? 4 * kStageCap : 1];
+  __shared__ int s_stage_col[FILTER ? 4 * kStageCap : 1];
+  __shared__ float s_stage_sc[FILTER ? 4 * kStageCap : 1];
+  short* stage_row = s_stage_row + (FILTER ? wv * kStageCap : 0);
+  int* stage_col = s_stage_col + (FILTER ? wv * kStageCap : 0);
+  float* stage_sc = s_stage_sc + (FILTER ? wv * kStageCap : 0);
+  int staged = 0;                // wave-uniform
+  float thr[16];                 // FILTER: thresholds of the 16 rows this lane holds results for
+  if (FILTER) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = m0 + (t & 3) + 8 * (t >> 2) + 4 * h;
+      thr[t] = (row < m) ? f.thr[(size_t)row * f.thr_stride] : INFINITY;
+    }
+  }
+  // the B tile of step tt+1 is in flight while the 32 MFMAs of step tt run (one wave cannot hide an L2 /
+  // Infinity-Cache round trip per tile behind anything else)
+  float bn[DH];
+  auto load_b = [&](int tile, float* dst) {
+    const int br = min(tile * 32 + r32, n - 1);
+    const float4* bp = reinterpret_cast<const float4*>(B + (size_t)br * D + h * DH);
+#pragma unroll
+    for (int t = 0; t < DH / 4; ++t) {
+      float4 v = bp[t];
+      dst[4 * t] = v.x; dst[4 * t + 1] = v.y; dst[4 * t + 2] = v.z; dst[4 * t + 3] = v.w;
+    }
+  };
+  load_b(tile0, bn);
   for (int tt = 0; tt < TILES_PER_WAVE; ++tt) {
     const int tile = tile0 + tt;
     if (tile >= n_tiles) break;
     const int n0 = tile * 32;
     float b[DH];
-    {
-      const int br = min(n0 + r32, n - 1);
-      const float4* bp = reinterpret_cast<const float4*>(B + (size_t)br * D + h * DH);
 #pragma unroll
-      for (int t = 0; t < DH / 4; ++t) {
-        float4 v = bp[t];
-        b[4 * t] = v.x; b[4 * t + 1] = v.y; b[4 * t + 2] = v.z; b[4 * t + 3] = v.w;
-      }
-    }
+    for (int t = 0; t < DH; ++t) b[t] = bn[t];
+    if (tt + 1 < TILES_PER_WAVE && tile + 1 < n_tiles) load_b(tile + 1, bn);
     floatx16 acc;
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = 0.f;
@@ -62,12 +112,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     for (int s = 0; s < DH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = n0 + r32;
+    if (FILTER) {
+      // survivors of this tile go to the wave's LDS staging list (ballot prefix: no atomics); the list is
+      // flushed -- one vector atomic for up to 64 survivors -- only when it could overflow or at the end
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int row = m0 + (t & 3) + 8 * (t >> 2) + 4 * h;
-      if (row < m && col < n) C[(size_t)row * n + col] = acc[t];
+      for (int t = 0; t < 16; ++t) {
+        const bool pass = (col < n) && (acc[t] >= thr[t]);             // (rows >= m carry +inf)
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+        if (bal == 0) continue;                                         // wave-uniform
+        if (pass) {
+          const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+          stage_row[at] = (short)((t & 3) + 8 * (t >> 2) + 4 * h);
+          stage_col[at] = col;
+          stage_sc[at] = acc[t];
+        }
+        staged += __builtin_popcountll(bal);
+        if (staged > kStageCap - 64) { filter_flush(f, m0, stage_row, stage_col, stage_sc, staged, lane); staged = 0; }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = m0 + (t & 3) + 8 * (t >> 2) + 4 * h;
+        if (row < m && col < n) C[(size_t)row * n + col] = acc[t];
+      }
     }
   }
+  if (FILTER && staged > 0) filter_flush(f, m0, stage_row, stage_col, stage_sc, staged, lane);
 }
 
 // scores[q][item] = -1e9 for every training item of query user q (graph_recommender.py:49-50)
@@ -80,7 +150,56 @@ __global__ __launch_bounds__(256) void mask_kernel(const int32_t* __restrict__ u
   const int lane = threadIdx.x & 63;
   const int u = user_ids ? user_ids[q] : user_base + q;
   const int s = indptr[u], e = indptr[u + 1];
-  for (int p = s + lane; p < e; p += 64) scores[(size_t)q * n + indices[p]] = -10e8f;
+  for (int p = s + lane; p < e; p += 64) {
+    const int item = indices[p];
+    if (item < n) scores[(size_t)q * n + item] = -10e8f;      // (n < catalogue size: a leading slice of the items)
+  }
+}
+
+// Exact top-K of each row's candidate list (score desc, id asc) -- the ranking stage of topk_kernel on a
+// few hundred survivors instead of the whole catalogue.  Rows whose list overflowed are left alone.
+__global__ __launch_bounds__(256) void cand_topk_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ cand_id,
+                                                        const float* __restrict__ cand_sc, int cap, int k,
+                                                        const int32_t* __restrict__ user_ids, int user_base,
+                                                        const int32_t* __restrict__ r_indptr,
+                                                        const int32_t* __restrict__ r_indices,
+                                                        int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  extern __shared__ unsigned char cand_smem[];
+  float* s_val = reinterpret_cast<float*>(cand_smem);
+  int* s_idx = reinterpret_cast<int*>(cand_smem) + cap;
+  __shared__ int s_n;
+  const int row = blockIdx.x;
+  const int c = cnt[row];
+  if (c > cap) return;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  // training items of the user are dropped here (graph_recommender.py:49-50 masks them to -10e8)
+  const int u = user_ids ? user_ids[row] : user_base + row;
+  const int rs = r_indptr ? r_indptr[u] : 0, re = r_indptr ? r_indptr[u + 1] : 0;
+  for (int t = threadIdx.x; t < c; t += 256) {
+    const int id = cand_id[(size_t)row * cap + t];
+    int lo = rs, hi = re;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (r_indices[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (lo < re && r_indices[lo] == id) continue;
+    const int at = atomicAdd(&s_n, 1);
+    s_val[at] = cand_sc[(size_t)row * cap + t];
+    s_idx[at] = id;
+  }
+  __syncthreads();
+  const int nv = s_n;
+  for (int t = threadIdx.x; t < nv; t += 256) {
+    const float v = s_val[t];
+    const int id = s_idx[t];
+    int rank = 0;
+    for (int j = 0; j < nv; ++j) rank += (s_val[j] > v) || (s_val[j] == v && s_idx[j] < id);
+    if (rank < k) {
+      out_ids[(size_t)row * k + rank] = id;
+      out_scores[(size_t)row * k + rank] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -185,23 +304,25 @@ __global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restr
 }
 
 template <int D>
-srh_status_t launch_gemm(const float* a, const int32_t* a_rows, const float* b, float* c, int m, int n, hipStream_t st) {
+srh_status_t launch_gemm(const float* a, const int32_t* a_rows, const float* b, float* c, int m, int n, hipStream_t st,
+                         const FilterArgs* filter) {
   constexpr int TPW = 8;
   const int n_tiles = (n + 31) / 32;
   dim3 grid((n_tiles + 4 * TPW - 1) / (4 * TPW), (m + 31) / 32);
-  gemm_nt_kernel<D, TPW><<<grid, 256, 0, st>>>(a, a_rows, b, c, m, n);
+  if (filter) gemm_nt_kernel<D, TPW, true><<<grid, 256, 0, st>>>(a, a_rows, b, c, m, n, *filter);
+  else gemm_nt_kernel<D, TPW, false><<<grid, 256, 0, st>>>(a, a_rows, b, c, m, n, FilterArgs{});
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }
 
 srh_status_t gemm_dispatch(const float* a, const int32_t* a_rows, const float* b, float* c, int64_t m, int64_t n,
-                           int d, hipStream_t st) {
+                           int d, hipStream_t st, const FilterArgs* filter = nullptr) {
   SRH_REQUIRE(m > 0 && n > 0 && m < (int64_t(1) << 31) && n < (int64_t(1) << 31), "gemm_nt: bad shape");
   SRH_REQUIRE((m + 31) / 32 <= 65535, "gemm_nt: at most 2,097,120 query rows per call");
   switch (d) {
-    case 32: return launch_gemm<32>(a, a_rows, b, c, (int)m, (int)n, st);
-    case 64: return launch_gemm<64>(a, a_rows, b, c, (int)m, (int)n, st);
-    case 128: return launch_gemm<128>(a, a_rows, b, c, (int)m, (int)n, st);
+    case 32: return launch_gemm<32>(a, a_rows, b, c, (int)m, (int)n, st, filter);
+    case 64: return launch_gemm<64>(a, a_rows, b, c, (int)m, (int)n, st, filter);
+    case 128: return launch_gemm<128>(a, a_rows, b, c, (int)m, (int)n, st, filter);
     default:
       srh::set_error("gemm_nt: d=%d unsupported (need 32, 64 or 128)", d);
       return SRH_ERR_UNSUPPORTED;
@@ -272,6 +393,63 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
     }
     rc = srh_topk_rows(d_scores_ws, m, n_items, k, d_out_ids + lo * k, d_out_scores + lo * k, stream);
     if (rc) return rc;
+  }
+  return SRH_OK;
+}
+
+// Layout of one user chunk in the workspace of the filtered ranking
+static inline int64_t filt_align(int64_t b) { return (b + 255) / 256 * 256; }
+static int64_t filt_chunk_bytes(int64_t rows, int64_t sample, int32_t k, int32_t cap) {
+  return filt_align(rows * sample * 4) + 2 * filt_align(rows * k * 4) + filt_align(rows * 4) + 2 * filt_align(rows * (int64_t)cap * 4);
+}
+
+int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap) {
+  if (chunk_rows <= 0 || sample_items <= 0 || k <= 0 || cap <= 0) return 0;
+  return filt_chunk_bytes(chunk_rows, sample_items, k, cap);
+}
+
+srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
+                                          const float* d_item_emb, int64_t n_items, int32_t d,
+                                          const int32_t* d_r_indptr, const int32_t* d_r_indices, int32_t k,
+                                          int64_t sample_items, int32_t cap, int64_t chunk_rows, void* d_ws,
+                                          int32_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts, void* stream) {
+  SRH_REQUIRE(d_user_emb && d_item_emb && d_ws && d_out_ids && d_out_scores && d_out_counts, "score_mask_topk_filtered: null argument");
+  SRH_REQUIRE((d_r_indptr == nullptr) == (d_r_indices == nullptr), "score_mask_topk_filtered: mask CSR must be given whole");
+  SRH_REQUIRE(n_query > 0 && n_items > 0 && chunk_rows > 0, "score_mask_topk_filtered: bad shape");
+  SRH_REQUIRE(k >= 1 && k <= 128 && sample_items >= k && sample_items <= n_items && cap >= k && cap <= 4096,
+              "score_mask_topk_filtered: need k <= sample_items <= n_items and k <= cap <= 4096");
+  hipStream_t st = srh::as_stream(stream);
+  char* ws = reinterpret_cast<char*>(d_ws);
+  float* slab = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * sample_items * 4);
+  int32_t* s_ids = reinterpret_cast<int32_t*>(ws); ws += filt_align(chunk_rows * k * 4);
+  float* s_sc = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * k * 4);
+  int32_t* cand_id = reinterpret_cast<int32_t*>(ws); ws += filt_align(chunk_rows * (int64_t)cap * 4);
+  float* cand_sc = reinterpret_cast<float*>(ws);
+  for (int64_t lo = 0; lo < n_query; lo += chunk_rows) {
+    const int64_t m = std::min(chunk_rows, n_query - lo);
+    const float* emb = d_user_ids ? d_user_emb : d_user_emb + lo * d;
+    const int32_t* ids = d_user_ids ? d_user_ids + lo : nullptr;
+    int32_t* cnt = d_out_counts + lo;
+    // 1. exact top-K over a leading slice of the catalogue: its K-th score is a lower bound of the
+    //    row's overall K-th score (a subset's K-th best cannot beat the whole set's)
+    srh_status_t rc = gemm_dispatch(emb, ids, d_item_emb, slab, m, sample_items, d, st);
+    if (rc) return rc;
+    if (d_r_indptr) {
+      mask_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(ids, (int)m, d_r_indptr, d_r_indices, slab, (int)sample_items, (int)lo);
+      SRH_LAUNCH_CHECK();
+    }
+    rc = srh_topk_rows(slab, m, sample_items, k, s_ids, s_sc, stream);
+    if (rc) return rc;
+    // 2. all scores again, never stored: only those reaching the bound and not masked are kept
+    hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int32_t) * m, st);
+    if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+    FilterArgs fa{s_sc + (k - 1), k, cnt, cand_id, cand_sc, cap};
+    rc = gemm_dispatch(emb, ids, d_item_emb, nullptr, m, n_items, d, st, &fa);
+    if (rc) return rc;
+    // 3. exact order of the survivors
+    cand_topk_kernel<<<(int)m, 256, (size_t)cap * 8, st>>>(cnt, cand_id, cand_sc, cap, k, ids, (int)lo, d_r_indptr, d_r_indices,
+                                                           d_out_ids + lo * k, d_out_scores + lo * k);
+    SRH_LAUNCH_CHECK();
   }
   return SRH_OK;
 }

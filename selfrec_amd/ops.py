@@ -17,7 +17,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 require_gpu = _lib.require_gpu
 
 __all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "gemm_nt", "topk_rows", "topk_hit_flags",
+           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
 
@@ -407,6 +407,30 @@ def score_mask_topk(user_emb, user_ids, item_emb, r_indptr, r_indices, k, scores
                                           int(scores_ws.shape[0]), _p(ids, torch.int32), _p(sc, torch.float32),
                                           _stream()), "srh_score_mask_topk")
     return ids, sc
+
+
+def score_mask_topk_filtered(user_emb, user_ids, item_emb, r_indptr, r_indices, k, *, sample_items=4096, cap=1024,
+                             chunk_rows=4096, ws=None):
+    """ids, scores, counts (device).  Rows with counts > cap are not valid (see include/selfrec_hip.h):
+    rank those with score_mask_topk."""
+    lib = _lib.load()
+    nq = int(user_ids.numel()) if user_ids is not None else int(user_emb.shape[0])
+    n_items, d = int(item_emb.shape[0]), int(item_emb.shape[1])
+    dev = item_emb.device
+    sample_items = max(int(k), min(int(sample_items), n_items))
+    chunk_rows = max(1, min(int(chunk_rows), nq))
+    need = int(lib.srh_score_mask_topk_filtered_ws_bytes(chunk_rows, sample_items, int(k), int(cap)))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    check(lib.srh_score_mask_topk_filtered(_p(user_emb, torch.float32), _p(user_ids, torch.int32), nq,
+                                           _p(item_emb, torch.float32), n_items, d, _p(r_indptr, torch.int32),
+                                           _p(r_indices, torch.int32), int(k), sample_items, int(cap), chunk_rows,
+                                           _p(ws), _p(ids, torch.int32), _p(sc, torch.float32),
+                                           _p(counts, torch.int32), _stream()), "srh_score_mask_topk_filtered")
+    return ids, sc, counts, ws
 
 
 def gemm_nt(a, b, out=None):

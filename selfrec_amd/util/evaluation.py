@@ -18,8 +18,8 @@ class RankedLists(Mapping):
     """
 
     def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None):
-        self.users = list(users)
-        self._row = {u: r for r, u in enumerate(self.users)}
+        self.users = users if isinstance(users, list) else list(users)
+        self._row = None                       # user -> row, built on first lookup
         self.item_names, self.ids, self.scores = item_names, ids, scores
         self.hit_flags, self.truth_sizes, self.origin = hit_flags, truth_sizes, origin
 
@@ -30,6 +30,8 @@ class RankedLists(Mapping):
         return iter(self.users)
 
     def __getitem__(self, user):
+        if self._row is None:
+            self._row = {u: r for r, u in enumerate(self.users)}
         r = self._row[user]
         return list(zip(self.item_names[self.ids[r]].tolist(), self.scores[r].tolist()))
 

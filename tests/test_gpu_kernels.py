@@ -296,6 +296,32 @@ def test_bpr_infonce_one_call_matches_oracle(d, B):
         assert rel_err(gC.cpu().numpy(), c.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_filtered_ranking_equals_exact_ranking(d):
+    """srh_score_mask_topk_filtered (scores never stored) against srh_score_mask_topk: identical ids and scores
+    on every row whose survivor list fits; tie-heavy rows (all-zero user vectors) report an overflow instead."""
+    rng = np.random.default_rng(31 + d)
+    U, I, K = 1500, 20000, 20
+    ue = torch.from_numpy((rng.standard_normal((U, d)) * 0.3).astype(np.float32)).to(DEV)
+    ie = torch.from_numpy((rng.standard_normal((I, d)) * 0.3).astype(np.float32)).to(DEV)
+    ue[7] = 0.0; ue[900] = 0.0                          # every score equal: thousands of survivors
+    ie[100:140] = ie[100]                                # a block of tied items inside the sample slice
+    lens = rng.integers(0, 60, U); lens[3] = 5000        # one user with a huge training row
+    indptr = np.zeros(U + 1, dtype=np.int32); np.cumsum(lens, out=indptr[1:])
+    indices = np.concatenate([np.sort(rng.choice(I, size=n, replace=False)) for n in lens]).astype(np.int32)
+    r_indptr, r_indices = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    users = torch.from_numpy(rng.permutation(U).astype(np.int32)).to(DEV)
+    want_ids, want_sc = ops.score_mask_topk(ue, users, ie, r_indptr, r_indices, K)
+    for chunk in (4096, 700):                            # one chunk / several chunks with a ragged tail
+        ids, sc, counts, _ = ops.score_mask_topk_filtered(ue, users, ie, r_indptr, r_indices, K, sample_items=2048,
+                                                          cap=512, chunk_rows=chunk)
+        ok = (counts <= 512)
+        bad_users = set(users[~ok].tolist())
+        assert bad_users == {7, 900}
+        assert (counts[ok] >= K).all()
+        assert torch.equal(ids[ok], want_ids[ok]) and torch.equal(sc[ok], want_sc[ok])
+
+
 # ------------------------------------------------------------------------------------------
 # (a-9) Adam
 # ------------------------------------------------------------------------------------------

@@ -27,6 +27,10 @@ profgraph)
   rm -rf $OUT/profgraph; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profgraph -o trace -- python $OLDPWD/bench.py --steps 600 --warmup 50 --no-cpu-baseline --no-eval > $OLDPWD/$OUT/profgraph.log 2>&1); echo "profgraph exit $?"
   f=$(find $OUT/profgraph -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/profgraph_kernel_stats.txt && head -16 $OUT/profgraph_kernel_stats.txt; tail -1 $OUT/profgraph.log | cut -c1-300
   find $OUT/profgraph -name "*.db" -size +40M -delete;;
+profeval)
+  rm -rf $OUT/profeval; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profeval -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/profeval.log 2>&1); echo "profeval exit $?"
+  f=$(find $OUT/profeval -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" | grep -E "kernel  |gemm_nt|topk|mask_kernel|cand_|hit_flags|Memset|fill" > $OUT/profeval_kernel_stats.txt; cat $OUT/profeval_kernel_stats.txt
+  find $OUT/profeval -name "*.db" -size +40M -delete;;
 prof)
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-eval --no-graph > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"
   f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/prof_kernel_stats.txt && head -24 $OUT/prof_kernel_stats.txt
