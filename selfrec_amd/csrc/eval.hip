@@ -234,8 +234,16 @@ __global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restr
   const float* x = scores + (size_t)row * n;
   const int tid = threadIdx.x;
 
+  // 16-byte loads over the aligned body of the row (any partition of the row into 256 disjoint sets
+  // keeps the bound below valid), scalar tail
+  const int n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
   float mx = -INFINITY;
-  for (int i = tid; i < n; i += kTopkThreads) mx = fmaxf(mx, x[i]);
+  for (int i = tid; i < n4; i += kTopkThreads) {
+    const float4 v = x4[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  for (int i = 4 * n4 + tid; i < n; i += kTopkThreads) mx = fmaxf(mx, x[i]);
   s_max[tid] = mx;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
@@ -249,13 +257,19 @@ __global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restr
   }
   __syncthreads();
   const float thr = s_thr;
-  for (int i = tid; i < n; i += kTopkThreads) {
-    const float v = x[i];
+  auto keep = [&](float v, int i) {
     if (v >= thr) {
       const int slot = atomicAdd(&s_cnt, 1);
       if (slot < kTopkCap) { s_val[slot] = v; s_idx[slot] = i; }
     }
+  };
+  for (int i = tid; i < n4; i += kTopkThreads) {
+    const float4 v = x4[i];
+    if (fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) >= thr) {
+      keep(v.x, 4 * i); keep(v.y, 4 * i + 1); keep(v.z, 4 * i + 2); keep(v.w, 4 * i + 3);
+    }
   }
+  for (int i = 4 * n4 + tid; i < n; i += kTopkThreads) keep(x[i], i);
   __syncthreads();
   const int cnt = s_cnt;
   if (cnt <= kTopkCap) {
