@@ -337,8 +337,9 @@ srh_status_t gemm_dispatch(const float* a, const int32_t* a_rows, const float* b
     case 32: return launch_gemm<32>(a, a_rows, b, c, (int)m, (int)n, st, filter);
     case 64: return launch_gemm<64>(a, a_rows, b, c, (int)m, (int)n, st, filter);
     case 128: return launch_gemm<128>(a, a_rows, b, c, (int)m, (int)n, st, filter);
+    case 256: return launch_gemm<256>(a, a_rows, b, c, (int)m, (int)n, st, filter);
     default:
-      srh::set_error("gemm_nt: d=%d unsupported (need 32, 64 or 128)", d);
+      srh::set_error("gemm_nt: d=%d unsupported (need 32, 64, 128 or 256)", d);
       return SRH_ERR_UNSUPPORTED;
   }
 }

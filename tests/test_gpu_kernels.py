@@ -296,7 +296,7 @@ def test_bpr_infonce_one_call_matches_oracle(d, B):
         assert rel_err(gC.cpu().numpy(), c.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [64, 128, 256])
 def test_filtered_ranking_equals_exact_ranking(d):
     """srh_score_mask_topk_filtered (scores never stored) against srh_score_mask_topk: identical ids and scores
     on every row whose survivor list fits; tie-heavy rows (all-zero user vectors) report an overflow instead."""
@@ -348,7 +348,7 @@ def test_adam_matches_torch_optim():
 # ------------------------------------------------------------------------------------------
 # (a-10/a-11) scoring GEMM, mask, top-K
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,n,d", [(1, 33, 64), (70, 1000, 64), (257, 4099, 128), (64, 96, 32)])
+@pytest.mark.parametrize("m,n,d", [(1, 33, 64), (70, 1000, 64), (257, 4099, 128), (64, 96, 32), (100, 777, 256)])
 def test_gemm_nt_is_exact_f32(m, n, d):
     rng = np.random.default_rng(m + n)
     a = rng.standard_normal((m, d)).astype(np.float32)
