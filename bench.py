@@ -91,13 +91,13 @@ def time_spmm_kernel(trainer, iters=50):
     row-masked (last forward layer: batch rows only) and column-masked (first backward layer: batch
     columns only).  An XSimGCL step with L layers issues 2L launches: 2L-2 dense + 1 + 1."""
     from selfrec_amd import ops
-    adj = trainer.graph.adj
-    x, y = trainer.E0, trainer.Ha
+    adj = trainer.adj                                         # (this rank's rows when the graph is sharded)
+    x, y = trainer.E0, trainer._loc(trainer.Ha)
     stamp = (trainer.cursor[1:2] - 1).contiguous()            # the marks of the batch that just ran
     flavours = {
         "dense": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0),
-        "row_masked": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0, row_mark=trainer.mark,
-                                        mark_stamp=stamp),
+        "row_masked": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0,
+                                        row_mark=trainer._loc(trainer.mark), mark_stamp=stamp),
         "col_masked": ops.make_epilogue(col_mark=trainer.mark, mark_stamp=stamp),
     }
     out = {}
@@ -262,13 +262,14 @@ def main():
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     if rank == 0:
-        t_spmm = time_spmm_kernel(trainer) if not sharded else None
+        t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
         if t_spmm:
-            alg = spmm_alg_bytes(g.adj.nnz, g.n_nodes, g.n_nodes, args.emb)
+            alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], args.emb)
             ach = alg / t_spmm["dense"] / 1e9
-            traffic, traffic_note = pmc_traffic(args)
+            traffic, traffic_note = pmc_traffic(args) if not sharded else (None, "PMC pass exists for the unsharded launch only")
             out["roofline"] = {"bound": "hbm",
-                               "kernel": f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over the whole graph, "
+                               "kernel": f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
+                                         f"{'the rows of one rank of the' if sharded else 'the whole'} graph, "
                                          "perturb epilogue; split rows finished in-kernel)",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -278,8 +279,8 @@ def main():
                                "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
                                "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
                                        "launch_us_by_flavour.step_mix (profiles/)",
-                               "step_alg_bytes": step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch),
-                               "step_GBps": round(step_alg_bytes(args.model, g.adj.nnz, g.n_nodes, args.emb, args.layers, args.batch)
+                               "step_alg_bytes": step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch),
+                               "step_GBps": round(step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch)
                                                   / (elapsed / args.steps) / 1e9, 1)}
         if not args.no_eval and not sharded:
             out["eval"] = eval_throughput(trainer, data)
