@@ -364,6 +364,8 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = step */,
                              int32_t mark_item_offset,
                              double* d_zero4 /* optional: 4 loss accumulators cleared for the new step */,
+                             int32_t* d_stage_cat /* optional (2*batch_size): [uniq users ; uniq items + cat_item_offset] */,
+                             int32_t cat_item_offset, int32_t* d_n_cat /* optional: n_uniq_u + n_uniq_i */,
                              void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when

@@ -101,7 +101,7 @@ SIGNATURES = {
     "srh_topk_hit_flags": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
     "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _i32, _vp, _vp]),
+                                _i32, _vp, _vp, _i32, _vp, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
     "srh_dataset_load": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_char_p]),

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void batch_fetch_kernel(
     const int32_t* __restrict__ uu, const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
     const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, const int64_t* __restrict__ cursor, int32_t* su,
     int32_t* si, int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta, int32_t* __restrict__ mark,
-    int32_t item_offset, double* __restrict__ zero4) {
+    int32_t item_offset, double* __restrict__ zero4, int32_t* __restrict__ cat, int32_t cat_item_offset,
+    int32_t* __restrict__ n_cat) {
   const int64_t b = cursor[0];
   const int32_t stamp = (int32_t)cursor[1];
   const int64_t ptr = b * bs;
@@ -77,7 +78,12 @@ __global__ __launch_bounds__(256) void batch_fetch_kernel(
     c = nui[b];
     for (int64_t i = tid; i < a; i += nth) suu[i] = uu[b * bs + i];
     for (int64_t i = tid; i < c; i += nth) sui[i] = ui[b * bs + i];
+    if (cat) {       // [unique users ; unique items] as one index list (SGL.py:120-125 concatenates the two sides)
+      for (int64_t i = tid; i < a; i += nth) cat[i] = uu[b * bs + i];
+      for (int64_t i = tid; i < c; i += nth) cat[a + i] = ui[b * bs + i] + cat_item_offset;
+    }
   }
+  if (n_cat && tid == 0) *n_cat = a + c;
   if (zero4 && tid < 4) zero4[tid] = 0.0;        // the step's loss accumulators
   if (tid == 0) {
     meta[0] = (int32_t)rows;
@@ -150,7 +156,7 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              int64_t batch_size, const int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
                              int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
                              int32_t* d_meta, int32_t* d_row_mark, int32_t mark_item_offset, double* d_zero4,
-                             void* stream) {
+                             int32_t* d_stage_cat, int32_t cat_item_offset, int32_t* d_n_cat, void* stream) {
   SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
               "batch_fetch: null argument");
   const bool uq = d_epoch_uniq_u != nullptr;
@@ -160,7 +166,7 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
   batch_fetch_kernel<<<kFetchBlocks, 256, 0, srh::as_stream(stream)>>>(
       d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u, d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges, batch_size,
       d_cursor, d_stage_u, d_stage_i, d_stage_j, d_stage_uniq_u, d_stage_uniq_i, d_meta, d_row_mark,
-      mark_item_offset, d_zero4);
+      mark_item_offset, d_zero4, uq ? d_stage_cat : nullptr, cat_item_offset, uq ? d_n_cat : nullptr);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

@@ -148,7 +148,7 @@ class FusedTrainer:
         self.mark = torch.zeros(P, dtype=torch.int32, device=dev)
         self.use_marks = True
         # models whose gradient buffers only ever hold O(batch) non-zero rows are reset row-wise
-        self.sparse_reset = model in ("MF", "LightGCN", "XSimGCL")
+        self.sparse_reset = True
         self.views = []                           # SimGCL / SGL: extra passes [(F_v, Y_v list, gF_v)]
         if model in ("SimGCL", "SGL"):
             for _ in range(2):
@@ -400,14 +400,10 @@ class FusedTrainer:
         adj = self.adj
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         # the staged ids are table rows (items already offset / permuted): one table, one index space
+        cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
         ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
-                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses)
+                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses, **cat)
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
-        if not self.sparse_reset:     # SimGCL / SGL: dense gradient buffers, dense memsets
-            self.gE0.zero_()
-            self.gF.zero_()
-            for v in self.views:
-                v["gF"].zero_()
 
         include_ego = m in ("LightGCN", "SGL")
         if m == "SimGCL":
@@ -447,10 +443,11 @@ class FusedTrainer:
                                        batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
-                problems = [(a["F"], b["F"], st["uniq_u"], self.B, nuu_dev, a["gF"], b["gF"]),
-                            (a["F"], b["F"], st["uniq_i"], self.B, nui_dev, a["gF"], b["gF"])]
+                # the three passes share one backward chain (same linear operator), so the views'
+                # gradients go straight into gF
+                problems = [(a["F"], b["F"], st["uniq_u"], self.B, nuu_dev, self.gF, self.gF),
+                            (a["F"], b["F"], st["uniq_i"], self.B, nui_dev, self.gF, self.gF)]
             else:
-                self._build_cat_index()
                 problems = [(a["F"], b["F"], self.stage_cat, 2 * self.B, self.n_cat, a["gF"], b["gF"])]
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems)
         else:
@@ -463,8 +460,6 @@ class FusedTrainer:
         elif m == "LightGCN":
             self._backward_chain(adj, self.gF, include_ego=True, extra=self.gReg)
         elif m == "SimGCL":
-            ops.axpby(1.0, self.views[0]["gF"], 1.0, self.gF)     # same linear operator for all passes
-            ops.axpby(1.0, self.views[1]["gF"], 1.0, self.gF)
             self._backward_chain(adj, self.gF, include_ego=False)
         else:                                        # SGL: three operators, three chains
             self._backward_chain(adj, self.gF, include_ego=True)
@@ -482,21 +477,11 @@ class FusedTrainer:
             if self.gReg is not None:
                 lists += [(self.gReg, st["u"], rows_dev, B, 0), (self.gReg, st["i"], rows_dev, B, 0),
                           (self.gReg, st["j"], rows_dev, B, 0)]
+            if m == "SGL":                       # the views' gradients live on the contrast rows
+                lists += [(v["gF"], self.stage_cat, self.n_cat, 2 * B, 0) for v in self.views]
             ops.zero_rows(lists, self.d, cursor_advance=self.cursor)      # last kernel of the step
         else:
             ops.cursor_advance(self.cursor)
-
-    def _build_cat_index(self):
-        """SGL: InfoNCE over [unique users ; unique items] of the batch (SGL.py:120-125), as one
-        index list into the (N, d) tables.  Sizes stay on the device."""
-        B, U = self.B, self.U
-        pos = torch.arange(2 * B, device=self.dev, dtype=torch.int32)
-        nu, ni = self.meta[1], self.meta[2]
-        from_u = self.stage["uniq_u"][pos.clamp(max=B - 1).long()]
-        item_pos = (pos - nu).clamp(min=0, max=B - 1).long()
-        from_i = self.stage["uniq_i"][item_pos]               # already a table row (items follow the users)
-        self.stage_cat.copy_(torch.where(pos < nu, from_u, from_i))
-        self.n_cat.copy_((nu + ni).reshape(1))
 
     def step(self):
         """Run one training step on the next batch of the current epoch."""

@@ -485,7 +485,8 @@ def zero_rows(lists, d, cursor_advance=None):
                                     _stream()), "srh_zero_rows")
 
 
-def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None):
+def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
+                stage_cat=None, cat_item_offset=0, n_cat=None):
     """ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
     check(_lib.load().srh_batch_fetch(
         _p(ep["u"], torch.int32), _p(ep["i"], torch.int32), _p(ep["j"], torch.int32),
@@ -494,4 +495,4 @@ def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mar
         _p(cursor, torch.int64), _p(stage["u"], torch.int32), _p(stage["i"], torch.int32),
         _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
         _p(meta, torch.int32), _p(row_mark, torch.int32), int(mark_item_offset), _p(zero4, torch.float64),
-        _stream()), "srh_batch_fetch")
+        _p(stage_cat, torch.int32), int(cat_item_offset), _p(n_cat, torch.int32), _stream()), "srh_batch_fetch")

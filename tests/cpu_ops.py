@@ -62,7 +62,8 @@ def axpby(a, x, b, y):
     y.copy_(a * x + (b * y if b != 0.0 else 0.0))
 
 
-def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None):
+def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
+                stage_cat=None, cat_item_offset=0, n_cat=None):
     b, stamp = int(cursor[0]), int(cursor[1])
     lo = b * batch_size
     rows = max(0, min(batch_size, n_edges - lo))
@@ -77,6 +78,11 @@ def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mar
         a, c = int(ep["n_uniq_u"][b]), int(ep["n_uniq_i"][b])
         stage["uniq_u"][:a] = ep["uniq_u"][b * batch_size:b * batch_size + a]
         stage["uniq_i"][:c] = ep["uniq_i"][b * batch_size:b * batch_size + c]
+    if stage_cat is not None and ep.get("uniq_u") is not None and rows:
+        stage_cat[:a] = stage["uniq_u"][:a]
+        stage_cat[a:a + c] = stage["uniq_i"][:c] + cat_item_offset
+    if n_cat is not None:
+        n_cat.fill_(a + c)
     if zero4 is not None:
         zero4.zero_()
     meta.copy_(torch.tensor([rows, a, c, b], dtype=torch.int32))
