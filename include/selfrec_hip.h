@@ -185,6 +185,14 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                           const int32_t* d_indices, const float* d_vals, const float* d_x,
                           float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream);
 
+/* y_v = A_v x for three value arrays over ONE structure in one traversal (the x rows are gathered once):
+ * the first layer of SGL.py:104-108, where the full adjacency and its two edge-dropped views
+ * (data/augmentor.py:29-40: same indptr / indices, dropped entries = 0) multiply the same ego table.
+ * Bit-identical to three srh_spmm_f32 calls.  d = 64 only (SRH_ERR_UNSUPPORTED otherwise). */
+srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals0,
+                           const float* d_vals1, const float* d_vals2, const float* d_x, float* d_y0,
+                           float* d_y1, float* d_y2, int32_t d, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * (a-5, a-6, a-7) Row gather + BPR + L2 regulariser, forward and backward in one call --
  * replaces  emb[idx]  (XSimGCL.py:30), util/loss_torch.py:6-10 bpr_loss and :18-22

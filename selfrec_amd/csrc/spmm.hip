@@ -445,6 +445,133 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
   row_epilogue<LPR>(acc, row, sub, live, Y, ep);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Three value arrays over one structure, one input: y_v = A_v x for v = 0..2 in ONE traversal.  SGL's
+// first layer multiplies the full adjacency and its two edge-dropped views (same indptr / indices,
+// dropped entries are zeros: data/augmentor.py:29-40) by the same ego table, so the x rows -- the
+// traffic that bounds this kernel -- are gathered once for all three.  Same schedule, DPP broadcasts
+// and in-kernel finish of split rows as spmm_rows_kernel; no epilogue (the layer has none).
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int T0>
+__device__ __forceinline__ void gather8x3(int c, float v0, float v1, float v2, const float4* __restrict__ X, int sub,
+                                          float4 (&acc)[3]) {
+  int cc[8];
+  float a0[8], a1[8], a2[8];
+  float4 xx[8];
+#define SRH_BC(T) cc[T] = row_bcast_i<T0 + T>(c); a0[T] = row_bcast_f<T0 + T>(v0); a1[T] = row_bcast_f<T0 + T>(v1); \
+  a2[T] = row_bcast_f<T0 + T>(v2);
+  SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3) SRH_BC(4) SRH_BC(5) SRH_BC(6) SRH_BC(7)
+#undef SRH_BC
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    xx[t] = f4_zero();
+    if (a0[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];     // (views are sub-graphs: a0 == 0 only for padding)
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc[0] = f4_fma(a0[t], xx[t], acc[0]);
+    acc[1] = f4_fma(a1[t], xx[t], acc[1]);
+    acc[2] = f4_fma(a2[t], xx[t], acc[2]);
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                         const Seg* __restrict__ segs,
+                                                         const int32_t* __restrict__ indices,
+                                                         const float* __restrict__ vals0, const float* __restrict__ vals1,
+                                                         const float* __restrict__ vals2, const float4* __restrict__ X,
+                                                         float4* __restrict__ Y0, float4* __restrict__ Y1,
+                                                         float4* __restrict__ Y2, float4* __restrict__ partial,
+                                                         const Heavy* __restrict__ heavy,
+                                                         const int32_t* __restrict__ slot_owner,
+                                                         int32_t* __restrict__ tickets) {
+  static_assert(3 * LPR <= 64, "three partial rows must fit one 256-float partial slot");
+  constexpr int G = 64 / LPR;
+  constexpr int CH = 16 * G;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
+  const Task tk = tasks[wave];
+  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
+  const int first = __builtin_amdgcn_readfirstlane(tk.first);
+  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  float4 acc[3] = {f4_zero(), f4_zero(), f4_zero()};
+  float4* const Y[3] = {Y0, Y1, Y2};
+
+  if (kind == 0) {
+    const Seg sg = segs[first];
+    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
+    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    for (int base = s; base < e; base += CH) {
+      const int j = base + 16 * g + e16;
+      int c = 0;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (j < e) { c = indices[j]; v0 = vals0[j]; v1 = vals1[j]; v2 = vals2[j]; }
+      gather8x3<LPR, 0>(c, v0, v1, v2, X, sub, acc);
+      if (e - base > 8) gather8x3<LPR, 8>(c, v0, v1, v2, X, sub, acc);
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], m));
+    if (slot < 0) {
+      if (g == 0) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) Y[v][(size_t)row * LPR + sub] = acc[v];
+      }
+      return;
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int v = 0; v < 3; ++v) store_f4_sc1(partial + (size_t)slot * 64 + v * LPR + sub, acc[v]);
+    }
+    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+    const Heavy h = heavy[hid];
+    const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
+    const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != hn - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      float4 sum = f4_zero();
+      for (int t = g; t < hn; t += G) sum = f4_add(sum, partial[(size_t)(hfirst + t) * 64 + v * LPR + sub]);
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
+      if (g == 0) Y[v][(size_t)row * LPR + sub] = sum;
+    }
+    return;
+  }
+
+  // ---- one short row per row-group ----
+  const bool have = g < count;
+  const Seg sg = segs[first + (have ? g : 0)];
+  const int row = sg.row, s = sg.start;
+  const int e = have ? sg.end : s;
+  int maxlen = e - s;
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  for (int q = 0; q * 16 < maxlen; ++q) {
+    const int j = s + 16 * q + e16;
+    int c = 0;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (j < e) { c = indices[j]; v0 = vals0[j]; v1 = vals1[j]; v2 = vals2[j]; }
+    gather8x3<LPR, 0>(c, v0, v1, v2, X, sub, acc);
+    if (maxlen - 16 * q > 8) gather8x3<LPR, 8>(c, v0, v1, v2, X, sub, acc);
+  }
+  if (have) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) Y[v][(size_t)row * LPR + sub] = acc[v];
+  }
+}
+
 // Persistent, software-pipelined variant (the default).  Profiling the one-wave-per-segment kernel
 // showed it is latency-bound, not bandwidth-bound: with x folded into an L2-resident 1 MB it ran
 // exactly as fast (tools/spmm_ab.py, profiles/r01_b_spmm_ab.txt), because every wave serialises
@@ -835,6 +962,26 @@ srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const
 }
 
 }  // namespace
+
+extern "C" srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals0,
+                                      const float* d_vals1, const float* d_vals2, const float* d_x, float* d_y0,
+                                      float* d_y1, float* d_y2, int32_t d, void* stream) {
+  SRH_REQUIRE(plan && d_indices && d_vals0 && d_vals1 && d_vals2 && d_x && d_y0 && d_y1 && d_y2, "spmm3_f32: null argument");
+  SRH_REQUIRE(d_x != d_y0 && d_x != d_y1 && d_x != d_y2 && d_y0 != d_y1 && d_y0 != d_y2 && d_y1 != d_y2,
+              "spmm3_f32: x and the three outputs must be distinct");
+  if (d != 64 || (plan->flags & 20) != 20) {
+    srh::set_error("spmm3_f32: d=%d / kernel flags %d unsupported (d = 64 with the default kernel only)", d, plan->flags);
+    return SRH_ERR_UNSUPPORTED;
+  }
+  constexpr int gi = 1;                      // LPR = 16
+  spmm_rows3_kernel<16><<<(plan->n_tasks[gi] + 3) / 4, 256, 0, srh::as_stream(stream)>>>(
+      plan->d_tasks[gi], plan->n_tasks[gi], plan->d_tsegs, d_indices, d_vals0, d_vals1, d_vals2,
+      reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y0), reinterpret_cast<float4*>(d_y1),
+      reinterpret_cast<float4*>(d_y2), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
+      plan->d_tickets);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
 
 extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                                      const int32_t* d_indices, const float* d_vals, const float* d_x,

@@ -406,8 +406,18 @@ class FusedTrainer:
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
 
         include_ego = m in ("LightGCN", "SGL")
+        sgl_shared_first = m == "SGL" and self.L >= 2 and self.d == 64
         if m == "SimGCL":
             self._simgcl_forward(adj)
+        elif sgl_shared_first:
+            # SGL.py:104-108 on the full graph and on both dropped views: the first layer of all three
+            # multiplies the same ego table -- one traversal of the shared structure, three value arrays
+            a, b = self.views
+            ops.spmm3([adj, self.view_adj[0], self.view_adj[1]], self.E0, [self.Y[0], a["Y"][0], b["Y"][0]])
+            self._forward_pass(adj, self.Y, self.F, perturbed=False, include_ego=True, batch_rows_only=True, start_layer=1)
+            for vi, v in enumerate(self.views):
+                self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=True,
+                                   batch_rows_only=True, start_layer=1)
         elif m != "MF":
             self._forward_pass(adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
                                batch_rows_only=True, need_last=(m == "XSimGCL" and self.layer_cl == self.L))
@@ -437,7 +447,7 @@ class FusedTrainer:
                 (F, CL, st["uniq_u"], self.B, nuu_dev, self.gF, self.gCL),
                 (F, CL, st["uniq_i"], self.B, nui_dev, self.gF, self.gCL)])
         elif m in ("SimGCL", "SGL"):
-            if m == "SGL":
+            if m == "SGL" and not sgl_shared_first:
                 for vi, v in enumerate(self.views):
                     self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=include_ego,
                                        batch_rows_only=True)

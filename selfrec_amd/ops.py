@@ -16,7 +16,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 require_gpu = _lib.require_gpu
 
-__all__ = ["Sampler", "DeviceCSR", "spmm", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
+__all__ = ["Sampler", "DeviceCSR", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
@@ -286,6 +286,18 @@ def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, 
                                             _p(deg_ws, torch.float32),
                                             _p(out, torch.float32), _stream()), "srh_adj_sym_normalize")
     return out
+
+
+def spmm3(csrs, x, outs):
+    """outs[v] = csrs[v] @ x for three DeviceCSRs over ONE structure (srh_spmm3_f32: x rows gathered once).
+    Raises SelfrecHipError (unsupported) unless d == 64."""
+    base = csrs[0]
+    if any(c._plan is not base._plan for c in csrs) or len(csrs) != 3 or len(outs) != 3:
+        raise SelfrecHipError("spmm3: needs three value arrays over one structure and three outputs")
+    check(_lib.load().srh_spmm3_f32(base._plan, _p(base.indices, torch.int32), _p(csrs[0].vals, torch.float32),
+                                    _p(csrs[1].vals, torch.float32), _p(csrs[2].vals, torch.float32),
+                                    _p(x, torch.float32, "x"), _p(outs[0], torch.float32), _p(outs[1], torch.float32),
+                                    _p(outs[2], torch.float32), int(x.shape[1]), _stream()), "srh_spmm3_f32")
 
 
 # ----------------------------------------------------------------------------------------

@@ -118,6 +118,28 @@ def test_spmm_fanout_equals_separate_launches():
         assert not torch.equal(ya, yb)
 
 
+def test_spmm3_equals_three_launches():
+    """Three value arrays over one structure, one traversal (SGL's first layer): bit-identical to three
+    launches, split rows and dropped (zero) entries included; other widths are refused."""
+    d, n = 64, 1100
+    m = powerlaw_csr(n, n, 18000, seed=23, heavy_rows=3, heavy_len=900, empty_rows=6)
+    rng = np.random.default_rng(6)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    base = ops.DeviceCSR.from_scipy(m)
+    views = [base]
+    for _ in range(2):
+        keep = torch.from_numpy((rng.random(m.nnz) > 0.3).astype(np.float32)).to(DEV)
+        views.append(base.with_values(base.vals * keep * float(rng.uniform(0.5, 2.0))))
+    want = [ops.spmm(v, x) for v in views]
+    outs = [torch.full((n, d), 3.0, device=DEV) for _ in range(3)]
+    ops.spmm3(views, x, outs)
+    for got, ref in zip(outs, want):
+        assert torch.equal(got, ref)
+    with pytest.raises(ops.SelfrecHipError):
+        x128 = torch.zeros((n, 128), device=DEV)
+        ops.spmm3(views, x128, [torch.empty((n, 128), device=DEV) for _ in range(3)])
+
+
 def test_spmm_rng_perturbation_properties():
     d, n = 64, 500
     m = powerlaw_csr(n, n, 6000, seed=9)
