@@ -131,10 +131,14 @@ srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
 typedef struct srh_spmm_plan srh_spmm_plan_t;
 
 /* xcd_split_row: 0, or the first row of the second node class of a bipartite adjacency (= number
- * of users): rows below it are issued to XCDs 0-3, the rest to XCDs 4-7 (L2 locality only). */
+ * of users): rows below it are issued to XCDs 0-3, the rest to XCDs 4-7 (L2 locality only).
+ * h_row_mid: NULL, or per row: m >= 0 -- the caller ordered the row's entries [column class 0 | column
+ * class 1] and class 1 starts at entry m: the two parts are scheduled as separate segments on different
+ * XCDs (each L2 then caches one column class of one row class) and summed in-kernel; -1 - c -- the row
+ * stays whole and runs with column class c.  Locality only: the product is the same. */
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
                                   const int32_t* h_indptr, int32_t split_len /* 0 = default */,
-                                  int64_t xcd_split_row);
+                                  int64_t xcd_split_row, const int32_t* h_row_mid);
 void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
 
 enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };

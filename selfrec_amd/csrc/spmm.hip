@@ -98,6 +98,19 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 // Epilogue on one full row held as float4 per lane of an LPR-lane group.  Executed by all
 // groups of the wave with identical data (they all hold the reduced row); `store` selects
 // the group that writes.
+// Agent-scope (sc1) load of a partial another XCD published with a write-through store: coherence per
+// access.  An acquire FENCE here (buffer_inv sc1) drops the whole XCD L2 -- thousands of them per launch
+// were costing the x rows their hit rate.
+__device__ __forceinline__ float4 load_f4_agent(const float4* p) {
+  const float* q = reinterpret_cast<const float*>(p);
+  float4 v;
+  v.x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
 // y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
 template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
@@ -242,10 +255,9 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ s
   if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
   if (ticket != n - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   float4 sum = f4_zero();
-  for (int t = g; t < n; t += G) sum = f4_add(sum, partial[(size_t)(first + t) * LPR + sub]);
+  for (int t = g; t < n; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(first + t) * LPR + sub));
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
   row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
@@ -277,6 +289,14 @@ __device__ __forceinline__ int row_bcast_i(int x) { return __builtin_amdgcn_upda
 template <int K>
 __device__ __forceinline__ float row_bcast_f(float x) { return __int_as_float(row_bcast_i<K>(__float_as_int(x))); }
 
+// x row `c`, this lane's 16 bytes: uniform 64-bit base + 32-bit byte offset (one VALU op instead of a
+// sign-extend, a 64-bit shift and a 64-bit add per gather; srh_spmm_f32 checks the table is < 4 GiB)
+template <int LPR>
+__device__ __forceinline__ float4 ld_x(const float4* __restrict__ X, int c, int sub) {
+  const unsigned off = (unsigned)c * (unsigned)(LPR * 16) + (unsigned)(sub * 16);
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + off);
+}
+
 // entries T0 .. T0+7 of the 16 that this lane's DPP row holds: 8 gathers in flight, then 8 FMAs
 template <int LPR, int T0>
 __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
@@ -289,7 +309,7 @@ __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     xx[t] = f4_zero();
-    if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];     // padding / dropped / dead columns: no gather
+    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // padding / dropped / dead columns: no gather
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
@@ -308,7 +328,7 @@ __device__ __forceinline__ void gather16(int c, float v, const float4* __restric
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     xx[t] = f4_zero();
-    if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];
+    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);
   }
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc = f4_fma(vv[t], xx[t], acc);
@@ -322,9 +342,9 @@ __device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
 }
 
 // FINISH: split rows are completed inside this launch by whichever of their segments arrives last
-// (write-through partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver takes one agent
-// acquire, adds the partials in slot order -- bitwise reproducible -- runs the epilogue and re-arms the
-// ticket).  Otherwise spmm_heavy_kernel does it in a second launch.
+// (write-through partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver reads the partials
+// with agent-scope loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms
+// the ticket).  Otherwise spmm_heavy_kernel does it in a second launch.
 template <int LPR, bool NT, bool DEEP, bool FINISH>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
                                                         const Seg* __restrict__ segs,
@@ -389,10 +409,9 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
     if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != hn - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's L1 before reading the others' partials
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     float4 sum = f4_zero();
-    for (int t = g; t < hn; t += G) sum = f4_add(sum, partial[(size_t)(hfirst + t) * LPR + sub]);
+    for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
     row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
@@ -465,7 +484,7 @@ __device__ __forceinline__ void gather8x3(int c, float v0, float v1, float v2, c
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     xx[t] = f4_zero();
-    if (a0[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];     // (views are sub-graphs: a0 == 0 only for padding)
+    if (a0[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // (views are sub-graphs: a0 == 0 only for padding)
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -536,12 +555,11 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
     if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != hn - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
       float4 sum = f4_zero();
-      for (int t = g; t < hn; t += G) sum = f4_add(sum, partial[(size_t)(hfirst + t) * 64 + v * LPR + sub]);
+      for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * 64 + v * LPR + sub));
 #pragma unroll
       for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
       if (g == 0) Y[v][(size_t)row * LPR + sub] = sum;
@@ -711,7 +729,8 @@ struct srh_spmm_plan {
 extern "C" {
 
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
-                                  const int32_t* h_indptr, int32_t split_len, int64_t xcd_split_row) {
+                                  const int32_t* h_indptr, int32_t split_len, int64_t xcd_split_row,
+                                  const int32_t* h_row_mid) {
   SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
@@ -722,24 +741,49 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   std::vector<Seg> segs;
   std::vector<Heavy> heavy;
   std::vector<int32_t> slot_owner;
+  std::vector<int8_t> seg_half;            // column class of a segment's entries (0 when the plan has none)
   segs.reserve((size_t)n_rows + 1024);
   int32_t n_slots = 0;
   for (int64_t r = 0; r < n_rows; ++r) {
     const int32_t s = h_indptr[r], e = h_indptr[r + 1];
     if (e < s) { srh::set_error("spmm_plan_create: indptr not monotone at row %lld", (long long)r); return SRH_ERR_INVALID_ARG; }
-    const int32_t len = e - s;
-    if (len <= split_len) {
-      segs.push_back({(int32_t)r, s, e, -1});
+    // h_row_mid[r] >= 0: the row's entries are ordered [column class 0 | column class 1] and the second
+    // part starts at s + h_row_mid[r]; the two parts become separate segments (run on different XCDs).
+    // h_row_mid[r] = -1 - c: the row stays whole and goes with column class c.
+    const int32_t mid_rel = h_row_mid ? h_row_mid[r] : -1;
+    if (mid_rel > e - s) { srh::set_error("spmm_plan_create: row_mid out of range at row %lld", (long long)r); return SRH_ERR_INVALID_ARG; }
+    const int8_t whole_half = (mid_rel < 0) ? (int8_t)((-1 - mid_rel) & 1) : 0;
+    struct Part { int32_t s, e; int8_t half; };
+    Part parts[2];
+    int n_parts = 0;
+    if (mid_rel < 0) {
+      parts[n_parts++] = {s, e, whole_half};
     } else {
-      const int32_t pieces = (len + split_len - 1) / split_len;
-      heavy.push_back({(int32_t)r, n_slots, pieces, 0});
-      for (int32_t p = 0; p < pieces; ++p) {
-        segs.push_back({(int32_t)r, s + p * split_len, std::min(e, s + (p + 1) * split_len), n_slots + p});
+      if (mid_rel > 0) parts[n_parts++] = {s, s + mid_rel, 0};
+      if (s + mid_rel < e) parts[n_parts++] = {s + mid_rel, e, 1};
+      if (n_parts == 0) parts[n_parts++] = {s, e, 0};
+    }
+    int32_t pieces = 0;
+    for (int k = 0; k < n_parts; ++k) pieces += std::max(1, (parts[k].e - parts[k].s + split_len - 1) / split_len);
+    if (pieces == 1) {
+      segs.push_back({(int32_t)r, parts[0].s, parts[0].e, -1});
+      seg_half.push_back(parts[0].half);
+      continue;
+    }
+    heavy.push_back({(int32_t)r, n_slots, pieces, 0});
+    for (int k = 0; k < n_parts; ++k) {
+      const int32_t np_k = std::max(1, (parts[k].e - parts[k].s + split_len - 1) / split_len);
+      for (int32_t q = 0; q < np_k; ++q) {
+        segs.push_back({(int32_t)r, parts[k].s + q * split_len, std::min(parts[k].e, parts[k].s + (q + 1) * split_len), n_slots++});
+        seg_half.push_back(parts[k].half);
         slot_owner.push_back((int32_t)heavy.size() - 1);
       }
-      n_slots += pieces;
     }
   }
+  const int n_col_classes = h_row_mid ? 2 : 1;
+  // segment -> class: (row class) * n_col_classes + column class; used by the default kernel's task order
+  std::vector<std::pair<Seg, int8_t>> seg_cls(segs.size());
+  for (size_t i = 0; i < segs.size(); ++i) seg_cls[i] = {segs[i], seg_half[i]};
   // longest first; ties keep row order (stable) so neighbouring waves touch neighbouring y rows
   auto longer = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
   if (xcd_split_row > 0 && xcd_split_row < n_rows) {
@@ -776,44 +820,52 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   std::vector<Seg> tsegs;
   std::vector<Task> tasks[4];
   {
-    const bool two_class = xcd_split_row > 0 && xcd_split_row < n_rows;
+    // task classes: row class (user rows / item rows of a bipartite adjacency) x column class.  Workgroup b
+    // = 4 consecutive tasks runs on XCD b % 8; the 8 XCDs are dealt to the classes in equal groups, so each
+    // L2 caches only the x rows of one row class AND one column class.
+    const bool two_row = xcd_split_row > 0 && xcd_split_row < n_rows;
+    const int NC = (two_row ? 2 : 1) * n_col_classes;             // 1, 2 or 4
     int short_max = kShortRow;                                   // A/B knob (non-DEEP kernels take any length)
     if (const char* env = getenv("SRH_SPMM_SHORT")) short_max = std::max(1, atoi(env));
-    std::vector<Seg> coop[2], shorts[2];
-    for (const Seg& sgm : segs) {
-      const int cls = (two_class && sgm.row >= xcd_split_row) ? 1 : 0;
+    std::vector<Seg> coop[4], shorts[4];
+    for (const auto& sc : seg_cls) {
+      const Seg& sgm = sc.first;
+      const int cls = ((two_row && sgm.row >= xcd_split_row) ? n_col_classes : 0) + (n_col_classes > 1 ? sc.second : 0);
       (((sgm.end - sgm.start) > short_max || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
     }
     auto longer2 = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
-    int32_t off[4];
-    for (int c = 0; c < 2; ++c) { std::stable_sort(coop[c].begin(), coop[c].end(), longer2); }
-    for (int c = 0; c < 2; ++c) { std::stable_sort(shorts[c].begin(), shorts[c].end(), longer2); }
-    off[0] = 0; off[1] = (int32_t)coop[0].size(); off[2] = off[1] + (int32_t)coop[1].size();
-    off[3] = off[2] + (int32_t)shorts[0].size();
-    for (int c = 0; c < 2; ++c) tsegs.insert(tsegs.end(), coop[c].begin(), coop[c].end());
-    for (int c = 0; c < 2; ++c) tsegs.insert(tsegs.end(), shorts[c].begin(), shorts[c].end());
+    int32_t coop_off[4], short_off[4];
+    for (int c = 0; c < NC; ++c) { std::stable_sort(coop[c].begin(), coop[c].end(), longer2); }
+    for (int c = 0; c < NC; ++c) { std::stable_sort(shorts[c].begin(), shorts[c].end(), longer2); }
+    for (int c = 0; c < NC; ++c) { coop_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), coop[c].begin(), coop[c].end()); }
+    for (int c = 0; c < NC; ++c) { short_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), shorts[c].begin(), shorts[c].end()); }
     for (int gi = 0; gi < 4; ++gi) {
       const int Gr = 8 >> gi;                            // rows per wave for LPR = 8, 16, 32, 64
       std::vector<Task>& out_t = tasks[gi];
       size_t blk = 0;
-      // workgroup b = 4 consecutive tasks runs on XCD b % 8: class 0 -> XCDs 0-3, class 1 -> XCDs 4-7
-      auto emit = [&](size_t n0, size_t n1, int kind, int32_t base0, int32_t base1, int unit) {
-        size_t i0 = 0, i1 = 0;
-        while (i0 < n0 || i1 < n1) {
-          const bool want0 = (blk % 8) < 4;
-          for (int w = 0; w < 4 && (i0 < n0 || i1 < n1); ++w) {
-            const bool take0 = (want0 && i0 < n0) || i1 >= n1;
-            size_t& i = take0 ? i0 : i1;
-            const size_t n = take0 ? n0 : n1;
-            const int32_t cnt = (int32_t)std::min<size_t>(unit, n - i);
-            out_t.push_back({kind, (take0 ? base0 : base1) + (int32_t)i, cnt, 0});
-            i += cnt;
+      auto emit = [&](const std::vector<Seg>* lists, int kind, const int32_t* base, int unit) {
+        size_t pos[4] = {0, 0, 0, 0};
+        auto left = [&](int c) { return lists[c].size() - pos[c]; };
+        for (;;) {
+          size_t total = 0;
+          for (int c = 0; c < NC; ++c) total += left(c);
+          if (total == 0) break;
+          int want = (int)((blk % 8) / (8 / NC));        // the class this workgroup's XCD belongs to
+          for (int w = 0; w < 4; ++w) {
+            int c = want;
+            if (left(c) == 0) {                          // its list ran dry: help the fullest one
+              for (int k = 0; k < NC; ++k) if (left(k) > left(c)) c = k;
+              if (left(c) == 0) break;
+            }
+            const int32_t cnt = (int32_t)std::min<size_t>(unit, left(c));
+            out_t.push_back({kind, base[c] + (int32_t)pos[c], cnt, 0});
+            pos[c] += cnt;
           }
           ++blk;
         }
       };
-      emit(coop[0].size(), coop[1].size(), 0, off[0], off[1], 1);
-      emit(shorts[0].size(), shorts[1].size(), 1, off[2], off[3], Gr);
+      emit(coop, 0, coop_off, 1);
+      emit(shorts, 1, short_off, Gr);
     }
   }
   // ---- streaming kernel: balance the segments over a fixed set of resident waves (LPT greedy) ----
@@ -990,6 +1042,8 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
   SRH_REQUIRE(plan && d_indices && d_vals && d_x && d_y, "spmm_f32: null argument");
   SRH_REQUIRE(srh::dim_supported(d), "spmm_f32: d=%d unsupported (need 32, 64, 128 or 256)", d);
   SRH_REQUIRE(d_x != d_y, "spmm_f32: x and y must not alias");
+  SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 32), "spmm_f32: x (%lld rows x %d) must be smaller than 4 GiB",
+              (long long)plan->n_cols, d);
   DevEpilogue ep{};
   if (epi) {
     SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY)) == 0, "spmm_f32: unknown epilogue flag");

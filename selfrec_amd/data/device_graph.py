@@ -13,6 +13,8 @@ Layout (all int32 structure / fp32 values, sized for one MI355X's 288 GB):
   adj.vals                     D^-1/2 A D^-1/2 computed on device by srh_adj_sym_normalize
 Edge-dropped views share the structure and own only a value array (``dropped_view``).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -37,13 +39,19 @@ class DeviceGraph:
         indptr = np.concatenate([r.indptr, r.indptr[-1] + rt.indptr[1:]]).astype(np.int32)
         indices = np.concatenate([r.indices.astype(np.int64) + self.n_users, rt.indices]).astype(np.int32)
         edge_id = np.concatenate([eid, rt.data - 1]).astype(np.int32)
+        w_full = None if np.all(r.data == 1.0) else np.concatenate([r.data, r.data[rt.data - 1]]).astype(np.float32)
+        # long rows are stored [even columns | odd columns] so the SpMM plan can give each half to its own
+        # XCDs (each 4 MiB L2 then caches a quarter of the table instead of a half; ops.column_class_order)
+        row_mid = None
+        min_len = int(os.environ.get("SRH_SPMM_COLSPLIT", "64"))
+        if min_len > 0:
+            perm, row_mid = ops.column_class_order(indptr, indices, min_len)
+            indices, edge_id = indices[perm], edge_id[perm]
+            w_full = None if w_full is None else w_full[perm]
         self.r_indptr = torch.from_numpy(r.indptr.astype(np.int32)).to(dev)
         self.r_indices = torch.from_numpy(r.indices.astype(np.int32)).to(dev)
         self.edge_id = torch.from_numpy(edge_id).to(dev)
-        w = r.data.astype(np.float32)
-        self.weight = None
-        if not np.all(w == 1.0):
-            self.weight = torch.from_numpy(np.concatenate([w, w[rt.data - 1]])).to(dev)
+        self.weight = None if w_full is None else torch.from_numpy(w_full).to(dev)
         self.h_r_indptr, self.h_r_indices = r.indptr.astype(np.int32), r.indices.astype(np.int32)
         self._deg_ws = torch.empty(self.n_nodes, dtype=torch.float32, device=dev)
         # k^-1/2 exactly as the host's numpy evaluates np.power(float32(k), -0.5) (graph.py:14)
@@ -53,7 +61,7 @@ class DeviceGraph:
         table[0] = 0.0
         self._inv_sqrt = torch.from_numpy(table.astype(np.float32)).to(dev)
         self.adj = ops.DeviceCSR(indptr, indices, torch.zeros(indices.size, dtype=torch.float32, device=dev),
-                                 (self.n_nodes, self.n_nodes), device=dev, xcd_split_row=self.n_users)
+                                 (self.n_nodes, self.n_nodes), device=dev, xcd_split_row=self.n_users, row_mid=row_mid)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, None, self.n_nodes,
                               weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws,
                               inv_sqrt_table=self._inv_sqrt)

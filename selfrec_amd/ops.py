@@ -16,7 +16,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 require_gpu = _lib.require_gpu
 
-__all__ = ["Sampler", "DeviceCSR", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
+__all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
 
@@ -154,7 +154,7 @@ class DeviceCSR:
     """
 
     def __init__(self, indptr, indices, vals, shape, device=None, split_len: int = 0, structure_of=None,
-                 xcd_split_row: int = 0):
+                 xcd_split_row: int = 0, row_mid=None):
         self._lib = _lib.load()
         _lib.require_gpu()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -171,8 +171,12 @@ class DeviceCSR:
             self.indptr = torch.from_numpy(h_indptr).to(device)
             self.indices = torch.as_tensor(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
             h = C.c_void_p()
+            h_mid = None if row_mid is None else np.ascontiguousarray(row_mid, dtype=np.int32)
+            if h_mid is not None and h_mid.size != self.shape[0]:
+                raise SelfrecHipError("DeviceCSR: row_mid needs one entry per row")
             check(self._lib.srh_spmm_plan_create(C.byref(h), self.shape[0], self.shape[1],
-                                                 h_indptr.ctypes.data_as(C.c_void_p), split_len, int(xcd_split_row)),
+                                                 h_indptr.ctypes.data_as(C.c_void_p), split_len, int(xcd_split_row),
+                                                 None if h_mid is None else h_mid.ctypes.data_as(C.c_void_p)),
                   "srh_spmm_plan_create")
             self._plan = h
             self._plan_owner = None
@@ -197,6 +201,26 @@ class DeviceCSR:
 
     def with_values(self, vals):
         return DeviceCSR(None, None, vals, self.shape, device=self.vals.device, structure_of=self)
+
+
+def column_class_order(indptr, indices, min_len: int):
+    """Host helper for DeviceCSR(row_mid=...): reorder the entries of every row with >= min_len non-zeros
+    as [even columns | odd columns] (stable), leave the others alone.  Returns (perm, row_mid): apply
+    perm to indices / values / anything aligned with them; row_mid[r] = number of even-column entries of
+    a reordered row, or -1 - c for a row left whole whose columns are mostly of parity c."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices)
+    n = indptr.size - 1
+    lens = np.diff(indptr)
+    row_of = np.repeat(np.arange(n, dtype=np.int64), lens)
+    odd = (indices & 1).astype(np.int64)
+    split = lens >= int(min_len)
+    key = row_of * 2 + np.where(split[row_of], odd, 0)
+    perm = np.argsort(key, kind="stable")
+    n_odd = np.bincount(row_of, weights=odd, minlength=n).astype(np.int64)
+    n_even = lens - n_odd
+    row_mid = np.where(split, n_even, -1 - (n_odd > n_even).astype(np.int64)).astype(np.int32)
+    return perm, row_mid
 
 
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,

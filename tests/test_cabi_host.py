@@ -118,3 +118,25 @@ def test_seed_matches_cpython_for_wide_seeds():
         want = [random.getrandbits(32) for _ in range(3)]
         s.seed(seed)
         assert [s.next_u32() for _ in range(3)] == want
+
+
+def test_column_class_order_is_a_stable_partition_of_long_rows():
+    """ops.column_class_order (host side of srh_spmm_plan_create's h_row_mid): a permutation that leaves
+    short rows alone and stores long rows [even columns | odd columns], each part in its old order."""
+    import numpy as np
+    from selfrec_amd import ops
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 40, 200)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(5000, size=n, replace=False)) for n in lens]).astype(np.int32)
+    perm, row_mid = ops.column_class_order(indptr, indices, 12)
+    assert sorted(perm.tolist()) == list(range(indices.size)) and row_mid.dtype == np.int32
+    new = indices[perm]
+    for r, n in enumerate(lens):
+        old_row, new_row = indices[indptr[r]:indptr[r + 1]], new[indptr[r]:indptr[r + 1]]
+        if n >= 12:
+            even, odd = old_row[old_row % 2 == 0], old_row[old_row % 2 == 1]
+            assert row_mid[r] == even.size and np.array_equal(new_row, np.concatenate([even, odd]))
+        else:
+            assert np.array_equal(new_row, old_row)
+            assert row_mid[r] == (-2 if (old_row % 2 == 1).sum() > (old_row % 2 == 0).sum() else -1)

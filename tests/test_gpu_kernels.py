@@ -140,6 +140,32 @@ def test_spmm3_equals_three_launches():
         ops.spmm3(views, x128, [torch.empty((n, 128), device=DEV) for _ in range(3)])
 
 
+@pytest.mark.parametrize("d,min_len", [(64, 64), (64, 8), (128, 16), (32, 16)])
+def test_spmm_with_column_class_schedule_matches_scipy(d, min_len):
+    """Rows of >= min_len non-zeros stored [even columns | odd columns] and scheduled as two segments on
+    different XCDs (srh_spmm_plan_create h_row_mid): same product, split heavy rows and masks included."""
+    n, U = 1300, 500
+    m = powerlaw_csr(n, n, 26000, seed=17, heavy_rows=3, heavy_len=1100, empty_rows=7)
+    perm, row_mid = ops.column_class_order(m.indptr, m.indices, min_len)
+    assert sorted(perm.tolist()) == list(range(m.nnz)) and (row_mid >= 0).sum() == (np.diff(m.indptr) >= min_len).sum()
+    csr = ops.DeviceCSR(m.indptr, m.indices[perm], m.data[perm], m.shape, xcd_split_row=U, row_mid=row_mid)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    tx = torch.from_numpy(x).to(DEV)
+    want = m.astype(np.float64) @ x.astype(np.float64)
+    got = ops.spmm(csr, tx)
+    assert rel_err(got.cpu().numpy(), want) < 2e-6
+    assert torch.equal(ops.spmm(csr, tx), got)                      # reproducible bit for bit
+    # column marks: only the live columns contribute
+    live = rng.random(n) < 0.3
+    mark = torch.from_numpy(np.where(live, 5, 0).astype(np.int32)).to(DEV)
+    stamp = torch.tensor([5], dtype=torch.int64, device=DEV)
+    xm = tx * torch.from_numpy(live.astype(np.float32)).to(DEV).unsqueeze(1)
+    got_m = ops.spmm(csr, xm, epilogue=ops.make_epilogue(col_mark=mark, mark_stamp=stamp))
+    want_m = m.astype(np.float64) @ (x * live[:, None]).astype(np.float64)
+    assert rel_err(got_m.cpu().numpy(), want_m) < 2e-6
+
+
 def test_spmm_rng_perturbation_properties():
     d, n = 64, 500
     m = powerlaw_csr(n, n, 6000, seed=9)
@@ -169,9 +195,12 @@ def test_spmm_rng_perturbation_properties():
 def test_device_normalisation_matches_reference(golden_ops, tiny_data):
     g = tiny_data.device_graph()
     assert np.array_equal(g.adj.indptr.cpu().numpy(), golden_ops["norm_adj_indptr"])
-    assert np.array_equal(g.adj.indices.cpu().numpy(), golden_ops["norm_adj_indices"])
-    got = g.adj.vals.cpu().numpy()
-    assert np.array_equal(got, golden_ops["norm_adj_data"])          # bit-exact (host pow table)
+    # (long rows are stored [even columns | odd columns] for the SpMM schedule: compare in sorted order)
+    mine = sp.csr_matrix((g.adj.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()),
+                         shape=(g.n_nodes, g.n_nodes))
+    mine.sort_indices()
+    assert np.array_equal(mine.indices, golden_ops["norm_adj_indices"])
+    assert np.array_equal(mine.data, golden_ops["norm_adj_data"])    # bit-exact (host pow table)
     # edge-dropped, re-normalised view (SGL.py:89-96) from the reference keep-set
     keep = np.zeros(g.n_edges, dtype=np.uint8)
     keep[golden_ops["edge_dropout_keep"]] = 1
