@@ -27,7 +27,7 @@ from .engine import FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacenc
 
 
 class ShardedTrainer(FusedTrainer):
-    """``FusedTrainer`` over the default process group (MF, LightGCN, XSimGCL).  Same constructor, same
+    """``FusedTrainer`` over the default process group (MF, LightGCN, XSimGCL, SimGCL).  Same constructor, same
     ``begin_epoch / step / read_losses / embeddings``; every rank must be seeded identically."""
 
     def __init__(self, data, emb_size, **kw):

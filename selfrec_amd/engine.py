@@ -103,8 +103,9 @@ class FusedTrainer:
         # layer output; batch-level work (losses, their gradients) is O(batch) and replicated.
         self.G, self.rank, self.sharded = 1, 0, bool(shard)
         if shard:
-            if model not in ("MF", "LightGCN", "XSimGCL"):
-                raise SelfrecHipError(f"sharded training: model {model!r} is single-GPU for now (MF, LightGCN, XSimGCL shard)")
+            if model not in ("MF", "LightGCN", "XSimGCL", "SimGCL"):
+                raise SelfrecHipError(f"sharded training: model {model!r} is single-GPU for now (SGL's dropped views are "
+                                      "normalised on the whole graph)")
             if not _dist.is_initialized():
                 raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
             self.G, self.rank = _dist.get_world_size(), _dist.get_rank()

@@ -47,10 +47,15 @@ def spmm(csr, x, out=None, epilogue=None):
         y = y * ep.get("alpha", 1.0)
         for a, s in zip(ep.get("add") or [], ep.get("add_scale") or []):
             y = y + s * a                       # (batch-sparse addends are zero off the live rows)
-    if ep.get("perturb_eps") is not None:
-        assert ep.get("noise") is not None, "the CPU stand-in needs injected noise"
-        y = O.perturb_(y, ep["noise"], ep["perturb_eps"])
     rows = slice(None) if ep.get("row_mark") is None else _live(ep["row_mark"], ep["mark_stamp"])
+    if ep.get("perturb_eps") is not None:
+        raw = y
+        for k, extra in enumerate(ep.get("extra_out") or []):           # FANOUT: more perturbed copies of the product
+            assert ep["extra_noise"][k] is not None, "the CPU stand-in needs injected noise"
+            extra[rows] = O.perturb_(raw.clone(), ep["extra_noise"][k], ep["perturb_eps"])[rows]
+        if not ep.get("main_clean"):
+            assert ep.get("noise") is not None, "the CPU stand-in needs injected noise"
+            y = O.perturb_(raw.clone(), ep["noise"], ep["perturb_eps"])
     out[rows] = y[rows]
     if ep.get("mean_out") is not None:
         mean = torch.stack(list(ep.get("prev") or []) + [y], dim=1).sum(1) / ep["mean_div"]

@@ -54,7 +54,7 @@ def _worker(rank, world, port, model, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3)])
+@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3), ("SimGCL", 2)])
 def test_sharded_equals_single_process_oracle(tmp_path, model, world):
     out = str(tmp_path / "res.npz")
     mp.spawn(_worker, args=(world, _free_port(), model, out), nprocs=world, join=True)
