@@ -279,3 +279,40 @@ def test_other_embedding_sizes_match_oracle(name, d):
     diff = np.abs(got - want)
     assert diff.max() < 5e-5 and (diff > 3e-6).mean() < 1e-3
     assert rel_err(got, want) < 5e-4
+
+
+@pytest.mark.parametrize("name,L,l_star", [("XSimGCL", 1, 0), ("XSimGCL", 1, 1), ("XSimGCL", 4, 0), ("XSimGCL", 4, 4),
+                                           ("LightGCN", 1, 0), ("LightGCN", 4, 0), ("SimGCL", 1, 0), ("SimGCL", 4, 0),
+                                           ("SGL", 1, 0), ("SGL", 4, 0)])
+def test_layer_count_and_contrast_layer_edge_cases(name, L, l_star):
+    """One layer (the only product also carries the mean; SimGCL / SGL cannot share a first layer), four layers,
+    the contrast view at the ego table (l* = 0) and at the last layer (l* = L): two steps against the CPU oracle."""
+    d = 64
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    torch.manual_seed(5)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, d)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, d))
+    g1, g2 = torch.Generator().manual_seed(4), torch.Generator().manual_seed(4)
+    kw = dict(n_layers=L, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=l_star, drop_rate=0.1, batch_size=1500)
+    tr = FusedTrainer(data, d, model=name, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=g1), **kw)
+    ref = O.OracleTrainer(name, data.train_u, data.train_i, U, I, d, user_emb=ue, item_emb=ie,
+                          noise_fn=lambda s: torch.rand(s, generator=g2), **kw)
+    random.seed(23)
+    tr.seed_sampler_from_python()
+    tr.begin_epoch()
+    eu, ei, ej = tr.epoch_node_ids()
+    if name == "SGL":
+        random.seed(23)
+        ref.resample_views()
+    for b in range(2):
+        tr.step()
+        lo, hi = b * 1500, (b + 1) * 1500
+        want = ref.step(eu[lo:hi].tolist(), ei[lo:hi].tolist(), ej[lo:hi].tolist())
+        np.testing.assert_allclose(tr.read_losses(), want, rtol=3e-5, atol=1e-9)
+    got = np.concatenate([tr.user_emb.cpu().numpy(), tr.item_emb.cpu().numpy()])
+    want = np.concatenate([ref.user_emb.detach().numpy(), ref.item_emb.detach().numpy()])
+    diff = np.abs(got - want)
+    assert diff.max() < 5e-5 and (diff > 3e-6).mean() < 1e-3
+    fu, fi = tr.embeddings()
+    ru, ri = ref.embeddings()
+    assert rel_err(fu.cpu().numpy(), ru) < 1e-4 and rel_err(fi.cpu().numpy(), ri) < 1e-4
