@@ -150,6 +150,51 @@ def cpu_baseline(args, raw, seconds):
                       f"shuffle {t_first:.2f} s amortised over the epoch"}
 
 
+def eval_cpu_baseline(trainer, data, k=20, n_users=300):
+    """The reference's evaluation loop (graph_recommender.py:46-53: one mat-vec, a python mask loop over the
+    user's training items and a heap top-K per user) as the CPU oracle restates it, on a bounded sample of the
+    test users; numba is not in this image, so `find_k_largest` runs as python ("as shipped here") -- the
+    second figure leaves the top-K out so the comparison is not inflated by that."""
+    from oracle import selfrec_oracle as O
+    ue, ie = (t.float().cpu().numpy() for t in trainer.embeddings())
+    users = [data.user[u] for u in list(data.test_set)[:n_users]]
+    rated = {u: [data.item[i] for i in data.training_set_u[data.id2user[u]]] for u in users}
+    t0 = time.time()
+    O.full_rank_topk(ue, ie, users, lambda u: rated[u], k)
+    t_full = time.time() - t0
+    t0 = time.time()
+    for u in users:                                      # scores + mask only
+        cand = (ie @ ue[u]).astype(np.float32)
+        for i in rated[u]:
+            cand[i] = -10e8
+    t_nok = time.time() - t0
+    return {"as_shipped_users_per_s": round(len(users) / t_full, 1), "topk_excluded_users_per_s": round(len(users) / t_nok, 1),
+            "kind": "port", "cores": torch.get_num_threads(),
+            "sample": f"{len(users)} test users through the oracle's per-user loop (python heap top-{k}; numba absent)"}
+
+
+def stream_bandwidth(dev):
+    """Measured streaming rates of this GPU with the library's own elementwise kernel, y = a*x + b*y
+    (srh_axpby: 2 reads + 1 write per element): arrays that stay in the 256 MiB Infinity Cache (the regime
+    of the engine's 17.8 MB tables) and arrays far beyond it (HBM proper) -- the achievable counterparts
+    of the 8 TB/s spec (tools/stream_bw.py prints the same for Adam's 7-stream pattern)."""
+    from selfrec_amd import ops
+    out = {}
+    for label, mib in (("infinity_cache_64MiB_arrays", 64), ("hbm_1GiB_arrays", 1024)):
+        n = mib * (1 << 20) // 4
+        x, y = torch.ones(n, device=dev), torch.ones(n, device=dev)
+        for _ in range(3):
+            ops.axpby(0.5, x, 0.5, y)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record()
+        for _ in range(10):
+            ops.axpby(0.5, x, 0.5, y)
+        b.record(); torch.cuda.synchronize()
+        out[label] = round(3.0 * n * 4 * 10 / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+        del x, y
+    return out
+
+
 def eval_throughput(trainer, data, k=20):
     from selfrec_amd.base.graph_recommender import GraphRecommender
     users = list(data.test_set)
@@ -273,6 +318,7 @@ def main():
                                          "perturb epilogue; split rows finished in-kernel)",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "measured_stream_GBps": stream_bandwidth(trainer.dev),
                                "traffic_source": traffic_note,
                                "traffic_GBps": round(traffic / t_spmm["dense"] / 1e9, 1) if traffic else None,
                                "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dense"] * 1e6, 2),
@@ -286,6 +332,8 @@ def main():
             out["eval"] = eval_throughput(trainer, data)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
+            if out.get("eval"):
+                out["eval"]["cpu_baseline"] = eval_cpu_baseline(trainer, data)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
