@@ -103,6 +103,10 @@ srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out);
  * Output: d_vals[p] = keep ? (dinv[row] * w) * dinv[col] : 0 with
  * dinv[r] = (sum of kept weights in row r)^-1/2, 0 for an empty row -- the reference's
  * inf -> 0 rule (graph.py:15).  d_deg_ws: workspace of n_rows floats.
+ * Row-sharded graphs (the CSR holds the rows [row_offset, row_offset + n_rows) of the node table and
+ * its columns index the whole table): d_deg_ws covers the whole table, phase 1 only fills this
+ * shard's dinv entries, the caller all-gathers d_deg_ws, phase 2 only writes the values.
+ * phase 0 = both in one call (row_offset 0 for a whole graph).
  * d_inv_sqrt_table (optional, table_len entries): table[k] = float32(k)^-1/2 as the HOST's
  * numpy computes it; integral degrees below table_len are looked up there, which makes the
  * values bit-identical to the reference's np.power(rowsum, -0.5) (numpy's fp32 pow is not
@@ -112,7 +116,8 @@ srh_status_t srh_adj_sym_normalize(int64_t n_rows, const int32_t* d_indptr,
                                    const int32_t* d_indices, const int32_t* d_edge_id,
                                    const float* d_weight, const uint8_t* d_keep,
                                    const float* d_inv_sqrt_table, int32_t table_len,
-                                   float* d_deg_ws, float* d_vals, void* stream);
+                                   float* d_deg_ws, float* d_vals, int64_t row_offset, int32_t phase,
+                                   void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-3, a-4) Sparse propagation -- replaces torch.sparse.mm(adj, dense) at

@@ -76,7 +76,7 @@ SIGNATURES = {
     "srh_sampler_epoch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
     "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
-    "srh_adj_sym_normalize": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "srh_adj_sym_normalize": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp]),
     "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32, _i64, _vp]),
     "srh_spmm_plan_destroy": (None, [_vp]),
     "srh_spmm3_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -75,3 +75,62 @@ class DeviceGraph:
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep_mask, self.n_nodes,
                               weight=self.weight, out=out, deg_ws=self._deg_ws, inv_sqrt_table=self._inv_sqrt)
         return self.adj.with_values(out)
+
+
+class ShardedDeviceGraph:
+    """One rank's rows of the same (N x N) adjacency for the row-sharded engine (engine.FusedTrainer with
+    shard=True): nodes rank, rank + G, ... as local rows 0.., columns rewritten to all-gather order
+    (owner * n_pad + local row), edge ids and weights riding along, normalised on the device in two
+    phases with one all-gather of the D^-1/2 vector in between (srh_adj_sym_normalize phase 1 / 2) --
+    so edge-dropped views (SGL) work exactly as on one GPU: a keep mask over interactions, the degrees
+    of the dropped graph, a new value array over the shared structure."""
+
+    def __init__(self, interaction_mat, rank, world, device, all_gather):
+        r = interaction_mat.tocsr()
+        r.sum_duplicates()
+        r.sort_indices()
+        self.n_users, self.n_items = r.shape
+        self.n_nodes = N = self.n_users + self.n_items
+        self.n_edges = r.nnz
+        self.device, self._all_gather = device, all_gather
+        eid = np.arange(r.nnz, dtype=np.int64)
+        rt = sp.csr_matrix((eid + 1, r.indices, r.indptr), shape=r.shape).tocsc()
+        rt.sort_indices()
+        indptr = np.concatenate([r.indptr, r.indptr[-1] + rt.indptr[1:]]).astype(np.int64)
+        indices = np.concatenate([r.indices.astype(np.int64) + self.n_users, rt.indices])
+        edge_id = np.concatenate([eid, rt.data - 1]).astype(np.int32)
+        w_full = None if np.all(r.data == 1.0) else np.concatenate([r.data, r.data[rt.data - 1]]).astype(np.float32)
+        self.n_pad = n_pad = (N + world - 1) // world
+        self.P = world * n_pad
+        own = np.arange(rank, N, world)
+        lens = (indptr[1:] - indptr[:-1])[own]
+        l_indptr = np.zeros(n_pad + 1, dtype=np.int32)
+        l_indptr[1:own.size + 1] = np.cumsum(lens)
+        l_indptr[own.size + 1:] = l_indptr[own.size]                      # padding rows are empty
+        entry = np.repeat(indptr[own] - l_indptr[:own.size], lens) + np.arange(int(l_indptr[own.size]), dtype=np.int64)
+        cols = indices[entry]
+        l_cols = ((cols % world) * n_pad + cols // world).astype(np.int32)
+        self.edge_id = torch.from_numpy(edge_id[entry]).to(device)
+        self.weight = None if w_full is None else torch.from_numpy(w_full[entry]).to(device)
+        max_deg = int(max(np.diff(r.indptr).max(initial=0), np.diff(rt.indptr).max(initial=0)))
+        with np.errstate(divide='ignore'):
+            table = np.power(np.arange(max_deg + 1, dtype=np.float32), -0.5)
+        table[0] = 0.0
+        self._inv_sqrt = torch.from_numpy(table.astype(np.float32)).to(device)
+        self._dinv = torch.zeros(self.P, dtype=torch.float32, device=device)
+        self.row_offset = rank * n_pad
+        self.adj = ops.DeviceCSR(l_indptr, l_cols, torch.zeros(l_cols.size, dtype=torch.float32, device=device),
+                                 (n_pad, self.P), device=device, xcd_split_row=len(range(rank, self.n_users, world)))
+        self._normalize(None, self.adj.vals)
+
+    def _normalize(self, keep, out):
+        kw = dict(weight=self.weight, out=out, deg_ws=self._dinv, inv_sqrt_table=self._inv_sqrt, row_offset=self.row_offset)
+        ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep, self.n_pad, phase=1, **kw)
+        self._all_gather(self._dinv)                 # every rank needs D^-1/2 of the columns it references
+        ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep, self.n_pad, phase=2, **kw)
+
+    def dropped_view(self, keep_mask, out=None):
+        if out is None:
+            out = torch.empty_like(self.adj.vals)
+        self._normalize(keep_mask, out)
+        return self.adj.with_values(out)

@@ -16,6 +16,9 @@ its CSR rows:
                        gradients are simply recomputed everywhere -- no collective, and the step keeps
                        its device-side cursor, so it is captured in a hipGraph like the 1-GPU step
     optimiser          Adam on the owned rows only
+    graph              each rank normalises its own CSR rows on the device (degrees of its rows, one all-gather of
+                       the D^-1/2 vector, then the values: data/device_graph.ShardedDeviceGraph), which is also
+                       how SGL's edge-dropped views are rebuilt every epoch
 
 On the xGMI mesh an all-gather of (N/G).d.4-byte slices moves each slice over its own link; at the
 Yelp2018 shape (17.8 MB tables) the step is latency-bound and does not beat one GPU -- the layout is
@@ -27,7 +30,7 @@ from .engine import FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacenc
 
 
 class ShardedTrainer(FusedTrainer):
-    """``FusedTrainer`` over the default process group (MF, LightGCN, XSimGCL, SimGCL).  Same constructor, same
+    """``FusedTrainer`` over the default process group (all five models).  Same constructor, same
     ``begin_epoch / step / read_losses / embeddings``; every rank must be seeded identically."""
 
     def __init__(self, data, emb_size, **kw):

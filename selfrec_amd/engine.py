@@ -62,15 +62,6 @@ def shard_adjacency(norm_adj_csr, rank, world):
     return indptr, new_cols.astype(np.int32), sub.data.astype(np.float32), n_pad
 
 
-class _GraphInfo:
-    """What bench.py reads from ``trainer.graph`` when the graph itself is sharded."""
-
-    def __init__(self, n_users, n_items, n_edges, adj):
-        self.n_users, self.n_items, self.n_edges = n_users, n_items, n_edges
-        self.n_nodes = n_users + n_items
-        self.adj = adj
-
-
 class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
@@ -103,9 +94,6 @@ class FusedTrainer:
         # layer output; batch-level work (losses, their gradients) is O(batch) and replicated.
         self.G, self.rank, self.sharded = 1, 0, bool(shard)
         if shard:
-            if model not in ("MF", "LightGCN", "XSimGCL", "SimGCL"):
-                raise SelfrecHipError(f"sharded training: model {model!r} is single-GPU for now (SGL's dropped views are "
-                                      "normalised on the whole graph)")
             if not _dist.is_initialized():
                 raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
             self.G, self.rank = _dist.get_world_size(), _dist.get_rank()
@@ -120,10 +108,9 @@ class FusedTrainer:
             self.graph = data.device_graph(dev)
             self.adj = self.graph.adj
         else:
-            indptr, indices, vals, _ = shard_adjacency(data.norm_adj.tocsr(), self.rank, G)
-            self.adj = ops.DeviceCSR(indptr, indices, vals, (self.n_pad, self.P), device=dev,
-                                     xcd_split_row=len(range(self.rank, self.U, G)))
-            self.graph = _GraphInfo(self.U, self.I, len(data.train_u), self.adj)
+            from .data import device_graph as _dg
+            self.graph = _dg.ShardedDeviceGraph(data.interaction_mat, self.rank, G, dev, self._allgather)
+            self.adj = self.graph.adj
         g = self.graph
         P = self.P
 
@@ -414,7 +401,10 @@ class FusedTrainer:
             # SGL.py:104-108 on the full graph and on both dropped views: the first layer of all three
             # multiplies the same ego table -- one traversal of the shared structure, three value arrays
             a, b = self.views
-            ops.spmm3([adj, self.view_adj[0], self.view_adj[1]], self.E0, [self.Y[0], a["Y"][0], b["Y"][0]])
+            firsts = [self.Y[0], a["Y"][0], b["Y"][0]]
+            ops.spmm3([adj, self.view_adj[0], self.view_adj[1]], self.E0, [self._loc(t) for t in firsts])
+            for t in firsts:
+                self._allgather(t)
             self._forward_pass(adj, self.Y, self.F, perturbed=False, include_ego=True, batch_rows_only=True, start_layer=1)
             for vi, v in enumerate(self.views):
                 self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=True,

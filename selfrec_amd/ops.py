@@ -297,7 +297,7 @@ def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilo
 
 
 def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None,
-                      inv_sqrt_table=None):
+                      inv_sqrt_table=None, row_offset: int = 0, phase: int = 0):
     dev = indices.device
     if out is None:
         out = torch.empty(indices.numel(), dtype=torch.float32, device=dev)
@@ -308,7 +308,8 @@ def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, 
                                             _p(keep, torch.uint8), _p(inv_sqrt_table, torch.float32),
                                             0 if inv_sqrt_table is None else int(inv_sqrt_table.numel()),
                                             _p(deg_ws, torch.float32),
-                                            _p(out, torch.float32), _stream()), "srh_adj_sym_normalize")
+                                            _p(out, torch.float32), int(row_offset), int(phase), _stream()),
+          "srh_adj_sym_normalize")
     return out
 
 

@@ -20,13 +20,49 @@ def require_gpu():
 
 
 class DeviceCSR:
-    def __init__(self, indptr, indices, vals, shape, device=None, split_len=0, structure_of=None, xcd_split_row=0):
+    def __init__(self, indptr, indices, vals, shape, device=None, split_len=0, structure_of=None, xcd_split_row=0,
+                 row_mid=None):
         self.shape = (int(shape[0]), int(shape[1]))
-        self.vals = torch.as_tensor(np.asarray(vals), dtype=torch.float32)
-        m = sp.csr_matrix((self.vals.numpy(), np.asarray(indices), np.asarray(indptr)), shape=self.shape)
-        self._m = O.to_torch_sparse(m)
-        self.nnz = m.nnz
-        self._plan = object()
+        if structure_of is not None:
+            self.indptr, self.indices, self._plan = structure_of.indptr, structure_of.indices, structure_of._plan
+        else:
+            self.indptr = torch.as_tensor(np.asarray(indptr), dtype=torch.int32)
+            self.indices = torch.as_tensor(np.asarray(indices), dtype=torch.int32)
+            self._plan = object()
+        self.vals = vals if isinstance(vals, torch.Tensor) else torch.as_tensor(np.asarray(vals), dtype=torch.float32)
+        self.nnz = int(self.indices.numel())
+
+    @property
+    def _m(self):        # (values may be rewritten in place by adj_sym_normalize: build on use)
+        m = sp.csr_matrix((self.vals.numpy(), self.indices.numpy(), self.indptr.numpy()), shape=self.shape)
+        return O.to_torch_sparse(m)
+
+    def with_values(self, vals):
+        return DeviceCSR(None, None, vals, self.shape, structure_of=self)
+
+
+def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows, weight=None, out=None, deg_ws=None, inv_sqrt_table=None,
+                      row_offset=0, phase=0):
+    ip, ix = indptr.numpy().astype(np.int64), indices.numpy().astype(np.int64)
+    rows = np.repeat(np.arange(n_rows), np.diff(ip))
+    w = np.ones(ix.size, dtype=np.float32) if weight is None else weight.numpy()
+    kept = np.ones(ix.size, dtype=bool) if keep is None else keep.numpy()[edge_id.numpy().astype(np.int64)] != 0
+    if phase != 2:
+        deg = np.bincount(rows, weights=np.where(kept, w, 0.0), minlength=n_rows).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            dinv = np.power(deg, -0.5).astype(np.float32)            # graph.py:14-15
+        dinv[np.isinf(dinv)] = 0.0
+        deg_ws[row_offset:row_offset + n_rows] = torch.from_numpy(dinv)
+    if phase != 1:
+        d = deg_ws.numpy()
+        vals = np.where(kept, (d[row_offset + rows] * w) * d[ix], 0.0).astype(np.float32)
+        out.copy_(torch.from_numpy(vals))
+    return out
+
+
+def spmm3(csrs, x, outs):
+    for c, o in zip(csrs, outs):
+        o.copy_(torch.sparse.mm(c._m, x))
 
 
 def make_epilogue(**kw):

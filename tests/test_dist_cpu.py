@@ -26,19 +26,22 @@ def _worker(rank, world, port, model, out_path):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from selfrec_amd import engine, synth
+    from selfrec_amd.data import device_graph
     from selfrec_amd.data.ui_graph import Interaction
     from selfrec_amd.dist import ShardedTrainer
     from tests import cpu_ops
-    engine.ops = cpu_ops                      # the product's step code over CPU stand-ins of the kernels
+    engine.ops = device_graph.ops = cpu_ops   # the product's step code over CPU stand-ins of the kernels
     tu, ti, su, si, U, I = synth.make_dataset("tiny")
     data = Interaction({}, synth.as_triples(tu, ti), [])
     torch.manual_seed(0)
     ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
     gen = torch.Generator().manual_seed(7)
     tr = ShardedTrainer(data, 64, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
-                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu")
+                        drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu")
     assert tr.G == world and tr.P == world * tr.n_pad
-    tr.sampler.seed(11)
+    import random
+    random.seed(11)
+    tr.seed_sampler_from_python()             # (SGL: the two dropped views come out of this stream first)
     tr.begin_epoch()
     losses = []
     for _ in range(3):
@@ -54,15 +57,19 @@ def _worker(rank, world, port, model, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3), ("SimGCL", 2)])
+@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3), ("SimGCL", 2), ("SGL", 2)])
 def test_sharded_equals_single_process_oracle(tmp_path, model, world):
     out = str(tmp_path / "res.npz")
     mp.spawn(_worker, args=(world, _free_port(), model, out), nprocs=world, join=True)
     r = np.load(out)
     gen = torch.Generator().manual_seed(7)
     ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, 64, n_layers=3, batch_size=1000, layer_cl=2,
-                          tau=0.2, eps=0.2, cl_rate=0.2, user_emb=r["ue"], item_emb=r["ie"],
+                          tau=0.2, eps=0.2, cl_rate=0.2, drop_rate=0.1, user_emb=r["ue"], item_emb=r["ie"],
                           noise_fn=lambda s: torch.rand(s, generator=gen))
+    if model == "SGL":                       # the oracle draws its two dropped views from the same stream
+        import random
+        random.seed(11)
+        ref.resample_views()
     want = []
     for b in range(3):
         lo, hi = b * 1000, (b + 1) * 1000

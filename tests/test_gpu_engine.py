@@ -171,7 +171,7 @@ def test_full_size_properties_yelp_shape():
     assert torch.isfinite(tr.E0).all() and (tr.E0 != before).float().mean() > 0.99
 
 
-@pytest.mark.parametrize("name", ["XSimGCL", "LightGCN"])
+@pytest.mark.parametrize("name", ["XSimGCL", "LightGCN", "SimGCL", "SGL"])
 def test_sharded_trainer_on_hip_backend_single_rank(golden_models, golden_meta, tiny_data, name):
     """The row-sharded trainer through RCCL ("nccl") with the real HIP kernels, world size 1 (one GPU box):
     same reference run as the fused engine.  World sizes 2 and 3 are covered on CPU (tests/test_dist_cpu.py)."""
@@ -189,7 +189,8 @@ def test_sharded_trainer_on_hip_backend_single_rank(golden_models, golden_meta, 
         gen = torch.Generator().manual_seed(m["noise_seed"])
         tr = ShardedTrainer(tiny_data, m["emb"], model=name, n_layers=int(c["n_layer"]), lr=m["lr"], reg=m["reg"],
                             cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)),
-                            tau=float(c.get("tau", 0.2)), layer_cl=int(c.get("l_star", 1)), batch_size=m["batch"],
+                            tau=float(c.get("tau", c.get("temp", 0.2))), layer_cl=int(c.get("l_star", 1)),
+                            drop_rate=float(c.get("drop_rate", 0.1)), batch_size=m["batch"],
                             user_emb=gm[f"{name}_init_user"], item_emb=gm[f"{name}_init_item"],
                             noise_fn=lambda shape: torch.rand(shape, generator=gen))
         random.seed(m["sampler_seed"])
