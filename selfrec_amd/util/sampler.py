@@ -7,8 +7,6 @@ the reference would leave it (after every batch, so interleaved ``random`` calls
 caller see the same stream), and shuffles ``data.training_data`` in place into the same
 order.
 """
-import random
-
 from .. import ops
 
 
