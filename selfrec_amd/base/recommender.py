@@ -1,79 +1,90 @@
-"""Root template of every recommender: same constructor contract, attributes and
-``execute()`` sequence as reference base/recommender.py:7-83, so model classes written
-against the reference subclass this one unchanged.
+"""Root template of every recommender.
+
+Interface contract (what model classes written against SELFRec rely on, reference
+base/recommender.py:7-83): the constructor signature ``(conf, training_set, test_set, **kwargs)``,
+the attribute names set from the config (``emb_size``, ``maxEpoch``, ``batch_size``, ``lRate``,
+``reg``, ``ranking``, ``output``, ``model_log``, ``result``, ``recOutput``), the seven overridable
+hooks and the ``execute()`` stage order build -> train -> test -> evaluate with the same console
+lines.  The implementation is table-driven: the config keys, the banner and the run stages are data.
 """
-from os.path import abspath
-from time import localtime, strftime, time
+import os
+import time
 
 from ..data.data import Data
 from ..util.logger import Log
 
+# attribute name -> (config key, converter)
+_CONF_FIELDS = (
+    ("ranking", "item.ranking.topN", None),
+    ("emb_size", "embedding.size", int),
+    ("maxEpoch", "max.epoch", int),
+    ("batch_size", "batch.size", int),
+    ("lRate", "learning.rate", float),
+    ("reg", "reg.lambda", float),
+    ("output", "output", None),
+)
+
+# console banner: label -> how to obtain the value from the instance
+_BANNER = (
+    ("Model:", lambda s: s.model_name),
+    ("Training Set:", lambda s: os.path.abspath(s.config["training.set"])),
+    ("Test Set:", lambda s: os.path.abspath(s.config["test.set"])),
+    ("Embedding Dimension:", lambda s: s.emb_size),
+    ("Maximum Epoch:", lambda s: s.maxEpoch),
+    ("Learning Rate:", lambda s: s.lRate),
+    ("Batch Size:", lambda s: s.batch_size),
+    ("Regularization Parameter:", lambda s: s.reg),
+)
+
+
+def _noop(self, *args, **kwargs):
+    return None
+
 
 class Recommender:
-    def __init__(self, conf, training_set, test_set, **kwargs):
-        self.config = conf
-        self.data = Data(self.config, training_set, test_set)
-        self.model_name = self.config['model']['name']
-        self.ranking = self.config['item.ranking.topN']
-        self.emb_size = int(self.config['embedding.size'])
-        self.maxEpoch = int(self.config['max.epoch'])
-        self.batch_size = int(self.config['batch.size'])
-        self.lRate = float(self.config['learning.rate'])
-        self.reg = float(self.config['reg.lambda'])
-        self.output = self.config['output']
-        stamp = strftime("%Y-%m-%d %H-%M-%S", localtime(time()))
-        self.model_log = Log(self.model_name, f"{self.model_name} {stamp}")
-        self.result = []
-        self.recOutput = []
-
-    def initializing_log(self):
-        self.model_log.add('### model configuration ###')
-        for key, value in self.config.config.items():
-            self.model_log.add(f"{key}={value}")
-
-    def print_model_info(self):
-        print('Model:', self.model_name)
-        print('Training Set:', abspath(self.config['training.set']))
-        print('Test Set:', abspath(self.config['test.set']))
-        print('Embedding Dimension:', self.emb_size)
-        print('Maximum Epoch:', self.maxEpoch)
-        print('Learning Rate:', self.lRate)
-        print('Batch Size:', self.batch_size)
-        print('Regularization Parameter:', self.reg)
-        if self.config.contain(self.model_name):
-            block = self.config[self.model_name]
-            print('Specific parameters:', '  '.join(f"{k}:{block[k]}" for k in block))
-
-    # hooks a model overrides ------------------------------------------------------------
-    def build(self):
-        pass
-
-    def train(self):
-        pass
+    # hooks a model overrides (all default to doing nothing, like the reference's)
+    build = train = test = save = load = _noop
 
     def predict(self, u):
-        pass
-
-    def test(self):
-        pass
-
-    def save(self):
-        pass
-
-    def load(self):
-        pass
+        return None
 
     def evaluate(self, rec_list):
-        pass
+        return None
+
+    def __init__(self, conf, training_set, test_set, **kwargs):
+        self.config = conf
+        self.data = Data(conf, training_set, test_set)
+        self.model_name = conf["model"]["name"]
+        for attr, key, convert in _CONF_FIELDS:
+            raw = conf[key]
+            setattr(self, attr, convert(raw) if convert else raw)
+        started = time.strftime("%Y-%m-%d %H-%M-%S", time.localtime(time.time()))
+        self.model_log = Log(self.model_name, "%s %s" % (self.model_name, started))
+        self.result, self.recOutput = [], []
+
+    def initializing_log(self):
+        log = self.model_log
+        log.add("### model configuration ###")
+        for key, value in self.config.config.items():
+            log.add("%s=%s" % (key, value))
+
+    def print_model_info(self):
+        for label, value_of in _BANNER:
+            print(label, value_of(self))
+        if self.config.contain(self.model_name):
+            section = self.config[self.model_name]
+            print("Specific parameters:", "  ".join("%s:%s" % (k, section[k]) for k in section))
 
     def execute(self):
         self.initializing_log()
         self.print_model_info()
-        print('Initializing and building model...')
-        self.build()
-        print('Training Model...')
-        self.train()
-        print('Testing...')
-        rec_list = self.test()
-        print('Evaluating...')
-        self.evaluate(rec_list)
+        rec_list = None
+        for banner, stage in (("Initializing and building model...", "build"), ("Training Model...", "train"),
+                              ("Testing...", "test"), ("Evaluating...", "evaluate")):
+            print(banner)
+            if stage == "evaluate":
+                self.evaluate(rec_list)
+            elif stage == "test":
+                rec_list = self.test()
+            else:
+                getattr(self, stage)()
