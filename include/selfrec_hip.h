@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 12
+#define SRH_ABI_VERSION 13
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -186,9 +186,17 @@ typedef struct srh_spmm_epilogue {
   float* d_extra_out[SRH_MAX_EXTRA];
   const float* d_extra_noise[SRH_MAX_EXTRA];
   uint64_t extra_rng_offset[SRH_MAX_EXTRA];
+  /* Column-sharded tables (multi-GPU): y / x / every epilogue tensor hold columns
+   * [noise_col0, noise_col0 + d) of rows that are noise_d_full wide on the whole job (d in {8, 16, 32}).
+   * Only PERTURB cares: its unit vector is normalised over the WHOLE row (XSimGCL.py:90), so d_noise /
+   * d_extra_noise are (n_rows, noise_d_full) and the counter RNG regenerates the other ranks' columns.
+   * 0 = the rows are d wide (everything above). */
+  int32_t noise_d_full;
+  int32_t noise_col0;
 } srh_spmm_epilogue_t;
 
-/* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {32,64,128,256}.
+/* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {8,16,32,64,128,256}
+ * (8 and 16: the thin-table kernel of the column-sharded layout).
  * x and y must not alias.  epi may be NULL. */
 srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                           const int32_t* d_indices, const float* d_vals, const float* d_x,
@@ -394,6 +402,37 @@ srh_status_t srh_zero_rows(int32_t n_lists, float* const* d_tables, const int32_
                            const int32_t* row_offset, int32_t d,
                            int64_t* d_cursor_advance /* optional: {batch, step} += 1 */, void* stream);
 srh_status_t srh_cursor_advance(int64_t* d_cursor, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (e) Column-sharded tables -- the multi-GPU layout for graphs that fit one GPU (DESIGN.md
+ * section 6).  Rank r keeps columns [r*dl, (r+1)*dl) of every (N, d) table, dl = d / G.  Propagation
+ * (LightGCN.py:72, XSimGCL.py:88) is independent per column: no exchange.  The losses
+ * (XSimGCL.py:30-33,45-50; loss_torch.py:6-10,18-22,35-50) read whole rows, but only O(batch) of
+ * them: the rows the staged batch lists name.  Those are exchanged by ONE all-gather per step:
+ *   srh_batch_pack -> all-gather (host: RCCL) -> srh_batch_unpack -> the loss kernels above on the
+ *   "compact" (5B, d) tables with the constant index lists slot -> slot -> srh_batch_scatter.
+ * Compact row k = slot k of [u | i | j | unique users | unique items] (B slots each; slots past a
+ * list's device-side count are dead: never written, never read).
+ * ------------------------------------------------------------------------------------ */
+#define SRH_MAX_EXCHANGE 4
+typedef struct srh_batch_lists {
+  const int32_t* d_idx[5];     /* staged lists of srh_batch_fetch: u, i, j, uniq_u, uniq_i (table rows)  */
+  const int32_t* d_count[5];   /* device-side live counts (d_meta[0] for u/i/j, [1], [2]); NULL = B      */
+  int32_t B;                   /* slots per list                                                         */
+} srh_batch_lists_t;
+/* d_send (n_tables, 5B, dl): the listed rows of each local (N, dl) table (dead slots: zeros).
+ * d_cat_idx / d_n_cat (optional, 2B / 1): compact slots of [unique users ; unique items] as one list
+ * (SGL.py:120-125 concatenates the two sides). */
+srh_status_t srh_batch_pack(const srh_batch_lists_t* lists, int32_t n_tables, const float* const* d_tables,
+                            int32_t dl, float* d_send, int32_t* d_cat_idx, int32_t* d_n_cat, void* stream);
+/* d_recv (world, n_tables, 5B, dl) = all-gather of every rank's d_send -> d_compact[t] (5B, world*dl);
+ * the live rows of the n_grads compact gradient tables are zeroed. */
+srh_status_t srh_batch_unpack(const srh_batch_lists_t* lists, int32_t n_tables, int32_t world, int32_t dl,
+                              const float* d_recv, float* const* d_compact, int32_t n_grads,
+                              float* const* d_compact_grads, void* stream);
+/* d_local_grads[p][node, :] += d_compact_grads[p][slot, col0 : col0 + dl] for every live slot. */
+srh_status_t srh_batch_scatter(const srh_batch_lists_t* lists, int32_t n_pairs, const float* const* d_compact_grads,
+                               float* const* d_local_grads, int32_t d_full, int32_t col0, int32_t dl, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (f-1) Dataset files -> id arrays -- replaces the python loops of data/loader.py:22-33

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
@@ -55,7 +55,16 @@ class SpmmEpilogue(C.Structure):
         ("d_add_mark", C.c_void_p), ("add_sparse_mask", C.c_int32),
         ("n_extra", C.c_int32), ("main_clean", C.c_int32), ("d_extra_out", C.c_void_p * SRH_MAX_EXTRA),
         ("d_extra_noise", C.c_void_p * SRH_MAX_EXTRA), ("extra_rng_offset", C.c_uint64 * SRH_MAX_EXTRA),
+        ("noise_d_full", C.c_int32), ("noise_col0", C.c_int32),
     ]
+
+
+SRH_MAX_EXCHANGE = 4
+
+
+class BatchLists(C.Structure):
+    """struct srh_batch_lists (include/selfrec_hip.h)."""
+    _fields_ = [("d_idx", C.c_void_p * 5), ("d_count", C.c_void_p * 5), ("B", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
@@ -105,6 +114,9 @@ SIGNATURES = {
                                 _i32, _vp, _vp, _i32, _vp, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
+    "srh_batch_pack": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "srh_batch_unpack": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "srh_batch_scatter": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "srh_dataset_load": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_char_p]),
     "srh_dataset_destroy": (None, [_vp]),
     "srh_dataset_sizes": (_i32, [_vp, _vp]),

@@ -75,6 +75,9 @@ struct DevEpilogue {
   float* extra_out[SRH_MAX_EXTRA];
   const float* extra_noise[SRH_MAX_EXTRA];
   uint32_t extra_off_lo[SRH_MAX_EXTRA], extra_off_hi[SRH_MAX_EXTRA];
+  // column-sharded tables (thin kernel): y holds columns [noise_col0, noise_col0 + d) of rows that are
+  // noise_d_full wide -- the perturbation's unit vector is normalised over the WHOLE row
+  int32_t noise_d_full, noise_col0;
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -706,6 +709,316 @@ __global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict
   row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Thin tables: the column-sharded multi-GPU layout keeps DL = d / G columns of
+// every (N, d) table on each rank, so a propagation layer needs no exchange at all -- the product is
+// independent per column -- and a gathered x row is only DL * 4 = 32 .. 128 bytes.  A 16-lane float4
+// row-group would leave most lanes idle there, so the mapping is turned round:
+//   * one LANE owns a whole (DL-float) x row per entry: DL/4 dwordx4 gathers, DL FMAs into DL private
+//     accumulators; eight float4 gathers are in flight per lane before the first FMA;
+//   * 8 lanes share a short row (<= 64 non-zeros: the plan's 8-rows-per-wave task list), taking entries
+//     e8, e8 + 8, ...; all 64 lanes share a long row / split segment (entries lane, lane + 64, ...);
+//   * the 8 partial vectors of a group meet in a 3-step butterfly reduce-scatter (xor 4, 2, 1: each
+//     step halves the values a lane keeps), which leaves lane e8 with columns [e8 * DL/8, (e8+1) * DL/8)
+//     of the finished row -- the epilogue then runs on DL/8 values per lane and a row is stored as one
+//     contiguous DL * 4-byte piece per group; coop tasks add the 8 groups with xor 8 / 16 / 32;
+//   * split rows use the same write-through partials + ticket hand-off as spmm_rows_kernel (a slot holds
+//     DL floats), summed in slot order: bitwise reproducible.
+// The PERTURB unit vector is normalised over the whole d-wide row (XSimGCL.py:90): with the counter RNG
+// every rank regenerates the row's other columns (hash only, no memory), with injected noise it reads
+// the full noise row; its own columns use exactly the counters of the one-GPU kernel, so a sharded
+// run sees the same perturbation as an unsharded one.
+// ---------------------------------------------------------------------------------------------
+template <int EPL> struct ThinVec;
+template <> struct ThinVec<1> { using type = float; };
+template <> struct ThinVec<2> { using type = float2; };
+template <> struct ThinVec<4> { using type = float4; };
+
+template <int EPL>
+__device__ __forceinline__ void ld_epl(const float* p, float (&v)[EPL]) {
+  using V = typename ThinVec<EPL>::type;
+  union { V vec; float f[EPL]; } u;
+  u.vec = *reinterpret_cast<const V*>(p);
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) v[i] = u.f[i];
+}
+template <int EPL>
+__device__ __forceinline__ void st_epl(float* p, const float (&v)[EPL]) {
+  using V = typename ThinVec<EPL>::type;
+  union { V vec; float f[EPL]; } u;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) u.f[i] = v[i];
+  *reinterpret_cast<V*>(p) = u.vec;
+}
+// write-through (sc1) store of a partial: not left dirty in this XCD's L2 (see store_f4_sc1)
+template <int EPL>
+__device__ __forceinline__ void st_epl_sc1(float* p, const float (&v)[EPL]) {
+  if constexpr (EPL == 1) {
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v[0]) : "memory");
+  } else if constexpr (EPL == 2) {
+    typedef float floatx2_t __attribute__((ext_vector_type(2)));
+    floatx2_t x = {v[0], v[1]};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  } else {
+    floatx4_t x = {v[0], v[1], v[2], v[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void ld_epl_agent(const float* p, float (&v)[EPL]) {
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) v[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ float pick4(uint4 r, int comp) {
+  const uint32_t w = (comp == 0) ? r.x : (comp == 1) ? r.y : (comp == 2) ? r.z : r.w;
+  return u01(w);
+}
+
+// up to 8 entries of this lane (j, j + stride, ...; all below e): acc += val * x[col, 0:DL]
+template <int DL>
+__device__ __forceinline__ void thin_accumulate(const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                                const float* __restrict__ X, int j, int stride, int e,
+                                                const int32_t* __restrict__ col_mark, int stamp, float (&acc)[DL]) {
+  constexpr int NV = DL / 4;                       // float4 per x row
+  constexpr int U = (DL >= 32) ? 1 : 32 / DL;      // entries whose gathers fly together (8 float4)
+  int c[8];
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int jj = j + k * stride;
+    c[k] = 0;
+    v[k] = 0.f;
+    if (jj < e) { c[k] = indices[jj]; v[k] = vals[jj]; }
+  }
+  if (col_mark) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (v[k] != 0.f && col_mark[c[k]] != stamp) v[k] = 0.f;      // x row known to be zero
+  }
+#pragma unroll
+  for (int k0 = 0; k0 < 8; k0 += U) {
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < U; ++k) mine |= (v[k0 + k] != 0.f);
+    if (!__any(mine)) continue;                    // the whole wave is past its entries
+    float4 x[U][NV];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float4* xr = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) +
+                                                         (unsigned)c[k0 + k] * (unsigned)(DL * 4));
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        x[k][q] = f4_zero();
+        if (v[k0 + k] != 0.f) x[k][q] = xr[q];      // padding / dropped edges / dead columns: no gather
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float w = v[k0 + k];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        acc[4 * q + 0] = fmaf(w, x[k][q].x, acc[4 * q + 0]);
+        acc[4 * q + 1] = fmaf(w, x[k][q].y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(w, x[k][q].z, acc[4 * q + 2]);
+        acc[4 * q + 3] = fmaf(w, x[k][q].w, acc[4 * q + 3]);
+      }
+    }
+  }
+}
+
+// butterfly reduce-scatter over the 8 lanes of a group: lane e8 ends with columns [e8*DL/8, (e8+1)*DL/8)
+template <int DL>
+__device__ __forceinline__ void thin_reduce8(const float (&acc)[DL], float (&out)[DL / 8], int e8) {
+  const bool b2 = (e8 & 4) != 0, b1 = (e8 & 2) != 0, b0 = (e8 & 1) != 0;
+  float a1[DL / 2], a2[DL / 4];
+#pragma unroll
+  for (int i = 0; i < DL / 2; ++i) {
+    const float keep = b2 ? acc[i + DL / 2] : acc[i];
+    const float send = b2 ? acc[i] : acc[i + DL / 2];
+    a1[i] = keep + __shfl_xor(send, 4);
+  }
+#pragma unroll
+  for (int i = 0; i < DL / 4; ++i) {
+    const float keep = b1 ? a1[i + DL / 4] : a1[i];
+    const float send = b1 ? a1[i] : a1[i + DL / 4];
+    a2[i] = keep + __shfl_xor(send, 2);
+  }
+#pragma unroll
+  for (int i = 0; i < DL / 8; ++i) {
+    const float keep = b0 ? a2[i + DL / 8] : a2[i];
+    const float send = b0 ? a2[i] : a2[i + DL / 8];
+    out[i] = keep + __shfl_xor(send, 1);
+  }
+}
+
+template <int DL>
+__device__ __forceinline__ void thin_perturb(float (&y)[DL / 8], const float (&raw)[DL / 8], int row, int e8,
+                                             const float* noise, uint32_t off_lo, uint32_t off_hi,
+                                             const DevEpilogue& ep) {
+  constexpr int EPL = DL / 8;
+  const int dfull = ep.noise_d_full;
+  const int e0 = ep.noise_col0 + e8 * EPL;          // first of this lane's columns in the whole row
+  float nu[EPL];
+  float ss = 0.f;
+  if (noise) {
+    const float* nr = noise + (size_t)row * dfull;
+    const int per = dfull / 8;                      // this lane's share of the row for the norm
+    for (int t = 0; t < per; t += 4) {
+      const float4 z = *reinterpret_cast<const float4*>(nr + e8 * per + t);
+      ss += f4_dot(z, z);
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) nu[i] = nr[e0 + i];
+  } else {
+    uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
+    if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+    for (int sub = e8; sub < dfull / 4; sub += 8) {
+      const uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
+      const float4 z = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+      ss += f4_dot(z, z);
+    }
+    const uint4 r = counter_rng4(ctr, (uint32_t)(e0 >> 2), ep.seed_lo, ep.seed_hi);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) nu[i] = pick4(r, (e0 & 3) + i);
+  }
+  ss = group_sum<8>(ss);
+  const float scale = ep.eps / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) y[i] = raw[i] + sgnf(raw[i]) * (nu[i] * scale);
+}
+
+template <int DL>
+__device__ __forceinline__ void thin_epilogue(float (&y)[DL / 8], int row, int e8, bool store, float* __restrict__ Y,
+                                              const DevEpilogue& ep) {
+  constexpr int EPL = DL / 8;
+  const size_t at = (size_t)row * DL + e8 * EPL;
+  if (ep.flags & SRH_EPI_AXPY) {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) y[i] *= ep.alpha;
+    const bool marked = !ep.add_mark || ep.add_mark[row] == (int)(*ep.mark_stamp);
+    for (int t = 0; t < ep.n_add; ++t) {
+      if (((ep.add_sparse >> t) & 1) && !marked) continue;
+      float a[EPL];
+      ld_epl<EPL>(ep.add[t] + at, a);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) y[i] = fmaf(ep.add_scale[t], a[i], y[i]);
+    }
+  }
+  if (ep.flags & SRH_EPI_PERTURB) {
+    float raw[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) raw[i] = y[i];
+    if (!ep.main_clean) thin_perturb<DL>(y, raw, row, e8, ep.noise, ep.off_lo, ep.off_hi, ep);
+    for (int k = 0; k < ep.n_extra; ++k) {
+      float yk[EPL];
+      thin_perturb<DL>(yk, raw, row, e8, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
+      if (store) st_epl<EPL>(ep.extra_out[k] + at, yk);
+    }
+  }
+  if (store) st_epl<EPL>(Y + at, y);
+  if (ep.flags & SRH_EPI_MEAN) {
+    float m[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) m[i] = 0.f;
+    for (int t = 0; t < ep.n_prev; ++t) {
+      float a[EPL];
+      ld_epl<EPL>(ep.prev[t] + at, a);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) m[i] = (t == 0) ? a[i] : m[i] + a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) m[i] = (ep.n_prev > 0 ? m[i] + y[i] : y[i]) * ep.mean_rcp;
+    if (store) st_epl<EPL>(ep.mean_out + at, m);
+  }
+}
+
+template <int DL>
+__global__ __launch_bounds__(256) void spmm_thin_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                        const Seg* __restrict__ segs,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals, const float* __restrict__ X,
+                                                        float* __restrict__ Y, float* __restrict__ partial,
+                                                        const Heavy* __restrict__ heavy,
+                                                        const int32_t* __restrict__ slot_owner,
+                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
+  constexpr int EPL = DL / 8;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, e8 = lane & 7;
+  const Task tk = tasks[wave];
+  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
+  const int first = __builtin_amdgcn_readfirstlane(tk.first);
+  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  float acc[DL];
+#pragma unroll
+  for (int i = 0; i < DL; ++i) acc[i] = 0.f;
+  float out[EPL];
+
+  if (kind == 0) {
+    // ---- the whole wave on one long row / split segment ----
+    const Seg sg = segs[first];
+    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
+    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    for (int base = s; base < e; base += 512)
+      thin_accumulate<DL>(indices, vals, X, base + lane, 64, e, ep.col_mark, stamp, acc);
+    thin_reduce8<DL>(acc, out, e8);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      out[i] += __shfl_xor(out[i], 8);
+      out[i] += __shfl_xor(out[i], 16);
+      out[i] += __shfl_xor(out[i], 32);
+    }
+    if (slot < 0) {
+      thin_epilogue<DL>(out, row, e8, g == 0, Y, ep);
+      return;
+    }
+    if (g == 0) st_epl_sc1<EPL>(partial + (size_t)slot * DL + e8 * EPL, out);
+    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+    const Heavy h = heavy[hid];
+    const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
+    const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != hn - 1) return;
+    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    float sum[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) sum[i] = 0.f;
+    for (int t = g; t < hn; t += 8) {
+      float pz[EPL];
+      ld_epl_agent<EPL>(partial + (size_t)(hfirst + t) * DL + e8 * EPL, pz);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) sum[i] += pz[i];
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      sum[i] += __shfl_xor(sum[i], 8);
+      sum[i] += __shfl_xor(sum[i], 16);
+      sum[i] += __shfl_xor(sum[i], 32);
+    }
+    thin_epilogue<DL>(sum, row, e8, g == 0, Y, ep);
+    return;
+  }
+
+  // ---- one short row (<= 64 non-zeros) per 8-lane group ----
+  const bool have = g < count;
+  const Seg sg = segs[first + (have ? g : 0)];
+  const int row = sg.row, s = sg.start;
+  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
+  const int e = live ? sg.end : s;
+  for (int base = s; __any(base < e); base += 64)
+    thin_accumulate<DL>(indices, vals, X, base + e8, 8, e, ep.col_mark, stamp, acc);
+  thin_reduce8<DL>(acc, out, e8);
+  thin_epilogue<DL>(out, row, e8, live, Y, ep);
+}
+
 }  // namespace
 
 struct srh_spmm_plan {
@@ -814,6 +1127,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->split_len = split_len;
   p->flags = 16 | 4;
   if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 31;  // A/B knob for tools/spmm_ab.py
+  if (const char* env = getenv("SRH_SPMM_THIN32")) p->flags |= atoi(env) ? 32 : 0;   // d = 32 through the thin kernel
   // ---- default kernel: coop tasks (long rows / split pieces) then G short rows per task ----
   // tsegs = coop(class 0) ++ coop(class 1) ++ short(class 0) ++ short(class 1), each longest first;
   // one task list per row-group count G = 64/LPR in {8, 4, 2, 1}
@@ -1040,7 +1354,7 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
                                      float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
   (void)d_indptr;  // the schedule in `plan` already encodes the row extents
   SRH_REQUIRE(plan && d_indices && d_vals && d_x && d_y, "spmm_f32: null argument");
-  SRH_REQUIRE(srh::dim_supported(d), "spmm_f32: d=%d unsupported (need 32, 64, 128 or 256)", d);
+  SRH_REQUIRE(srh::dim_supported(d) || d == 8 || d == 16, "spmm_f32: d=%d unsupported (need 8, 16, 32, 64, 128 or 256)", d);
   SRH_REQUIRE(d_x != d_y, "spmm_f32: x and y must not alias");
   SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 32), "spmm_f32: x (%lld rows x %d) must be smaller than 4 GiB",
               (long long)plan->n_cols, d);
@@ -1059,6 +1373,14 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.mark_stamp = epi->d_mark_stamp;
     ep.add_mark = epi->d_add_mark;
     ep.add_sparse = epi->add_sparse_mask;
+    if (epi->noise_d_full) {       // y is a column slice of noise_d_full-wide rows (column-sharded tables)
+      SRH_REQUIRE(d <= 32 && epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
+                      epi->noise_col0 + d <= epi->noise_d_full,
+                  "spmm_f32: column slice [%d, %d) of %d-wide rows is not supported (slices of 8, 16 or 32 columns)",
+                  epi->noise_col0, epi->noise_col0 + d, epi->noise_d_full);
+      ep.noise_d_full = epi->noise_d_full;
+      ep.noise_col0 = epi->noise_col0;
+    }
     if (epi->n_extra || epi->main_clean) {
       SRH_REQUIRE((epi->flags & SRH_EPI_PERTURB) && !(epi->flags & SRH_EPI_MEAN) && epi->n_extra >= 0 &&
                       epi->n_extra <= SRH_MAX_EXTRA,
@@ -1098,6 +1420,21 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     }
   }
   hipStream_t st = srh::as_stream(stream);
+  // thin tables (8 / 16 columns, or a 32-column slice of wider rows): one lane per gathered x row
+  const bool slice = ep.noise_d_full != 0;
+  if (!slice) { ep.noise_d_full = d; ep.noise_col0 = 0; }
+  if (d < 32 || (d == 32 && (slice || (plan->flags & 32)))) {
+    SRH_REQUIRE(ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
+                "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
+#define SRH_THIN(DLV)                                                                                              \
+  spmm_thin_kernel<DLV><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(                                              \
+      plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, d_x, d_y, plan->d_partial, plan->d_heavy, \
+      plan->d_slot_owner, plan->d_tickets, ep)
+    if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
+#undef SRH_THIN
+    SRH_LAUNCH_CHECK();
+    return SRH_OK;
+  }
   switch (d) {
     case 32: return launch_spmm<8>(plan, d_indices, d_vals, d_x, d_y, ep, st);
     case 64: return launch_spmm<16>(plan, d_indices, d_vals, d_x, d_y, ep, st);

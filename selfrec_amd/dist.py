@@ -1,8 +1,28 @@
-"""(e) Multi-GPU: the fused step with the graph and the tables row-sharded over the ranks of one node.
+"""(e) Multi-GPU: the fused step over the GPUs of one node -- one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI).  Two LAYOUTS of ``engine.FusedTrainer`` (not second engines):
 
-One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).  The partition SURVEY.md
-8(e) describes -- graph rows = embedding rows -- is a LAYOUT of ``engine.FusedTrainer``, not a second
-engine: nodes are dealt round-robin (node p -> rank p % G, local row p // G: power-law rows balance
+**"cols" -- column-sharded tables (the default whenever d / G is 8, 16 or 32).**  Rank r keeps columns
+[r.w, (r+1).w), w = d / G, of every (N, d) table -- parameters, Adam moments, layer outputs, gradient
+buffers -- and the whole graph (Yelp2018 shape: 26 MB; the 1 M x 500 k graph: 1 GB of 288 GB).
+
+    forward / backward layers   Y[:, own] = A . X[:, own]: a sparse product is independent per column, so
+                                the 2L + 1 products of a step need NO exchange (thin kernel, csrc/spmm.hip)
+    perturbation                the unit vector is normalised over the whole row (XSimGCL.py:90): the
+                                counter RNG regenerates the other ranks' columns -- hash only, no memory
+    losses                      read whole rows, but only the O(batch) rows the staged lists name:
+                                pack -> ONE all-gather per step (a few hundred KB per rank) -> compact
+                                (5B, d) tables -> the unchanged BPR / InfoNCE kernels (replicated, O(batch))
+                                -> each rank scatters its columns of the batch-row gradients (csrc/exchange.hip)
+    optimiser                   Adam on the rank's columns
+    hipGraph                    two captured graphs per step with the all-gather between them
+
+xGMI is point-to-point (7 links per GPU): a per-layer exchange of (N, d) tables costs 2L + 1 all-gathers of
+N.d.4 bytes per step (17.8 MB each at the Yelp2018 shape against a 0.32 ms step); the column layout moves
+< 1 MB per step instead, and every rank still streams the (col, val) arrays -- the price: the index stream
+is read G times in total, and gathered x rows are 32 .. 128 bytes.
+
+**"rows" -- row-sharded graph and tables (for d / G outside the thin kernel's widths).**
+Nodes are dealt round-robin (node p -> rank p % G, local row p // G: power-law rows balance
 without a partitioner), every (.., d) table is kept in all-gather order, each rank owns one slice of
 the parameters, the Adam moments and every layer output, and computes it with the same kernels from
 its CSR rows:
@@ -11,31 +31,44 @@ its CSR rows:
     backward layer k   H_k[own] = A[own, :] . H_(k+1) + ...      then all-gather H_k   (A is symmetric:
                        the transpose product is the same local row product, so there is no
                        reduce-scatter -- 2L all-gathers of N.d.4 bytes per step, plus one for E0)
-    batch level        the sampler is replicated (same seed, same MT19937 stream => identical batches on
-                       every rank); with whole tables on every rank the O(batch) losses and their
-                       gradients are simply recomputed everywhere -- no collective, and the step keeps
-                       its device-side cursor, so it is captured in a hipGraph like the 1-GPU step
+    batch level        with whole tables on every rank the O(batch) losses and their gradients are simply
+                       recomputed everywhere -- no collective
     optimiser          Adam on the owned rows only
     graph              each rank normalises its own CSR rows on the device (degrees of its rows, one all-gather of
                        the D^-1/2 vector, then the values: data/device_graph.ShardedDeviceGraph), which is also
                        how SGL's edge-dropped views are rebuilt every epoch
 
-On the xGMI mesh an all-gather of (N/G).d.4-byte slices moves each slice over its own link; at the
-Yelp2018 shape (17.8 MB tables) the step is latency-bound and does not beat one GPU -- the layout is
-for graphs whose tables do not fit or whose SpMM dominates (the 1 M x 500 k configuration).
+Both: the sampler is replicated (same seed, same MT19937 stream => identical batches on every rank) and the
+step keeps its device-side cursor.
 """
 from __future__ import annotations
 
-from .engine import FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacency: public helper)
+import os
+
+import torch.distributed as _dist
+
+from .engine import THIN_WIDTHS, FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacency: public helper)
+
+
+def pick_layout(emb_size: int, world: int, layout: str | None = None) -> str:
+    """"cols" whenever the column slice d / world is a width the thin SpMM kernel serves, else "rows".
+    ``layout`` / ``SRH_SHARD_LAYOUT`` = rows | cols | auto overrides."""
+    layout = (layout or os.environ.get("SRH_SHARD_LAYOUT") or "auto").lower()
+    if layout in ("rows", "cols"):
+        return layout
+    if layout != "auto":
+        raise ValueError(f"shard layout {layout!r}: rows, cols or auto")
+    return "cols" if emb_size % world == 0 and emb_size // world in THIN_WIDTHS else "rows"
 
 
 class ShardedTrainer(FusedTrainer):
     """``FusedTrainer`` over the default process group (all five models).  Same constructor, same
     ``begin_epoch / step / read_losses / embeddings``; every rank must be seeded identically."""
 
-    def __init__(self, data, emb_size, **kw):
+    def __init__(self, data, emb_size, layout=None, **kw):
         kw.pop("backend", None)
-        super().__init__(data, emb_size, shard=True, **kw)
+        world = kw["comm"].world if kw.get("comm") is not None else _dist.get_world_size()
+        super().__init__(data, emb_size, shard=pick_layout(int(emb_size), int(world), layout), **kw)
 
     def parameters_full(self):
         return self.user_emb, self.item_emb

@@ -44,6 +44,20 @@ from . import ops
 from ._lib import SelfrecHipError
 
 MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
+THIN_WIDTHS = (8, 16, 32)        # column slices the thin SpMM kernel serves (csrc/spmm.hip)
+
+
+class TorchComm:
+    """The default process group as the two things the trainer needs from it."""
+
+    def __init__(self):
+        if not _dist.is_initialized():
+            raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
+        self.world, self.rank = _dist.get_world_size(), _dist.get_rank()
+
+    def all_gather(self, out, inp):
+        # (flat views: rank r's contribution is the r-th equal piece of `out`, whatever the shapes)
+        _dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
 
 
 def shard_adjacency(norm_adj_csr, rank, world):
@@ -65,7 +79,7 @@ def shard_adjacency(norm_adj_csr, rank, world):
 class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
-                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False):
+                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False, comm=None):
         if model not in MODELS:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
         ops.require_gpu()
@@ -92,18 +106,35 @@ class FusedTrainer:
         # (row = owner * n_pad + local row), so `all_gather_into_tensor` of the owners' slices IS the
         # table.  Each rank owns the rows self.loc of the parameters, the Adam state and every
         # layer output; batch-level work (losses, their gradients) is O(batch) and replicated.
-        self.G, self.rank, self.sharded = 1, 0, bool(shard)
-        if shard:
-            if not _dist.is_initialized():
-                raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
-            self.G, self.rank = _dist.get_world_size(), _dist.get_rank()
-        G, N, d, B = self.G, self.N, self.d, self.B
+        #
+        # shard="cols": the tables are split by COLUMNS instead -- rank r keeps columns [r*w, (r+1)*w),
+        # w = d / G, of every table, the graph is replicated, pos = identity.  A sparse product is
+        # independent per column, so the 2L + 1 products of a step need NO exchange; the losses read
+        # whole rows, but only the O(batch) rows the staged lists name: those are all-gathered once per
+        # step into compact (5B, d) tables (csrc/exchange.hip) on which the unchanged loss kernels run.
+        if shard not in (False, True, None, "rows", "cols"):
+            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows' or 'cols')")
+        self.G, self.rank = 1, 0
+        self.sharded = shard in (True, "rows")          # row-sharded layout
+        self.cols = shard == "cols"                      # column-sharded layout
+        self.comm = None
+        if self.sharded or self.cols:
+            self.comm = comm if comm is not None else TorchComm()
+            self.G, self.rank = int(self.comm.world), int(self.comm.rank)
+        N, d, B = self.N, self.d, self.B
+        self.w = d                                       # width of this rank's tables
+        if self.cols:
+            if d % self.G or (d // self.G) not in THIN_WIDTHS:
+                raise SelfrecHipError(f"column-sharded layout: d / world = {d}/{self.G} must be one of {THIN_WIDTHS}")
+            self.w = d // self.G
+        self.col0 = self.rank * self.w if self.cols else 0
+        G = self.G if self.sharded else 1                # ranks the ROWS are dealt over
         self.n_pad = (N + G - 1) // G
         self.P = G * self.n_pad
         nodes = np.arange(N, dtype=np.int64)
         self._pos = ((nodes % G) * self.n_pad + nodes // G).astype(np.int32)
         self._pos_dev = torch.from_numpy(self._pos.astype(np.int64)).to(dev)
-        self.loc = slice(self.rank * self.n_pad, (self.rank + 1) * self.n_pad)
+        self.loc = slice(self.rank * self.n_pad, (self.rank + 1) * self.n_pad) if self.sharded else slice(0, self.P)
         if not self.sharded:
             self.graph = data.device_graph(dev)
             self.adj = self.graph.adj
@@ -114,8 +145,10 @@ class FusedTrainer:
         g = self.graph
         P = self.P
 
+        w = self.w
+
         def buf(rows=P):
-            return torch.zeros((rows, d), dtype=torch.float32, device=dev)
+            return torch.zeros((rows, w), dtype=torch.float32, device=dev)
 
         self.E0 = buf()
         if user_emb is None or item_emb is None:
@@ -123,7 +156,7 @@ class FusedTrainer:
             ie = torch.nn.init.xavier_uniform_(torch.empty(self.I, d))
         else:
             ue, ie = torch.as_tensor(user_emb, dtype=torch.float32), torch.as_tensor(item_emb, dtype=torch.float32)
-        self.E0[self._pos_dev] = torch.cat([ue, ie]).to(dev)
+        self.E0[self._pos_dev] = torch.cat([ue, ie])[:, self.col0:self.col0 + w].contiguous().to(dev)
         self.m, self.v = buf(self.n_pad), buf(self.n_pad)       # Adam state: owned rows only
         self.gE0 = buf()
         self.F = self.E0 if model == "MF" else buf()
@@ -165,19 +198,77 @@ class FusedTrainer:
         self.step_count = 0
         # (a sharded step is captured only on request: RCCL collectives inside a hipGraph could not be
         # exercised beyond one rank on the development box)
+        # (the column-sharded step is captured as two graphs with the one all-gather issued between them)
         self.use_graph = bool(use_graph) and (not self.sharded or os.environ.get("SRH_SHARDED_GRAPH") == "1")
         self._graph = None
         self._noise_call = 0
+        if self.cols:
+            self._init_exchange()
+
+    # ------------------------------------------------------------------------------------
+    # column-sharded layout: the batch-row exchange (csrc/exchange.hip)
+    # ------------------------------------------------------------------------------------
+    def _init_exchange(self):
+        m, B, d, dev = self.model, self.B, self.d, self.dev
+        a, b = (self.views + [None, None])[:2]
+        if m == "MF":
+            tables, grads = [self.E0], [self.gF]
+        elif m == "LightGCN":
+            tables, grads = [self.F, self.E0], [self.gF, self.gReg]
+        elif m == "XSimGCL":
+            cl = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
+            tables, grads = [self.F, cl], [self.gF, self.gCL]
+        elif m == "SimGCL":
+            tables, grads = [self.F, a["F"], b["F"]], [self.gF]       # (the views' gradients join gF: one chain)
+        else:
+            tables, grads = [self.F, a["F"], b["F"]], [self.gF, a["gF"], b["gF"]]
+        rows = 5 * B
+
+        def compact():
+            return torch.zeros((rows, d), dtype=torch.float32, device=dev)
+        self._x_tables = tables
+        self._x_compact = {id(t): compact() for t in tables}
+        self._x_cgrad = {id(g): compact() for g in grads}
+        self._x_pairs = [(self._x_cgrad[id(g)], g) for g in grads]
+        self._x_send = torch.zeros((len(tables), rows, self.w), dtype=torch.float32, device=dev)
+        self._x_recv = torch.zeros((self.G, len(tables), rows, self.w), dtype=torch.float32, device=dev)
+        slots = torch.arange(rows, dtype=torch.int32, device=dev)
+        self._x_idx = {k: slots[s * B:(s + 1) * B] for s, k in enumerate(("u", "i", "j", "uniq_u", "uniq_i"))}
+        self._x_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev) if m == "SGL" else None
+        self._x_lists = ops.batch_lists(self.stage, self.meta, B)
+
+    def _pack(self):
+        ops.batch_pack(self._x_lists, self._x_tables, self._x_send, cat_idx=self._x_cat)
+
+    def _exchange(self):
+        """The step's one collective: every rank's slices of the batch rows."""
+        self.comm.all_gather(self._x_recv, self._x_send)
+
+    def _unpack(self):
+        ops.batch_unpack(self._x_lists, self._x_recv, self.G, self.w, [self._x_compact[id(t)] for t in self._x_tables],
+                         [c for c, _ in self._x_pairs])
+
+    def _full(self, t):
+        """(rows, w) slice on every rank -> the whole (rows, d) table (a collective; plumbing, not per step)."""
+        if not self.cols:
+            return t
+        recv = torch.empty((self.G,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.comm.all_gather(recv, t.contiguous())
+        return recv.permute(1, 0, 2).reshape(t.shape[0], self.d).contiguous()
 
     # ------------------------------------------------------------------------------------
     # views of the tables
     # ------------------------------------------------------------------------------------
     @property
     def user_emb(self):
+        if self.cols:
+            return self._full(self.E0)[:self.U]         # (a collective: every rank must ask)
         return self.E0[:self.U] if not self.sharded else self.E0[self._pos_dev[:self.U]]
 
     @property
     def item_emb(self):
+        if self.cols:
+            return self._full(self.E0)[self.U:]
         return self.E0[self.U:] if not self.sharded else self.E0[self._pos_dev[self.U:]]
 
     def _loc(self, t):
@@ -188,7 +279,7 @@ class FusedTrainer:
         """Make a table whose owned rows were just written whole again on every rank."""
         if self.sharded:
             mine = t[self.loc]
-            _dist.all_gather_into_tensor(t, mine if self.dev.type == "cuda" else mine.clone())
+            self.comm.all_gather(t, mine if self.dev.type == "cuda" else mine.clone())
 
     # ------------------------------------------------------------------------------------
     # sampling
@@ -256,14 +347,18 @@ class FusedTrainer:
             return None
         t = torch.as_tensor(self.noise_fn((self.N, self.d)), dtype=torch.float32).to(self.dev)
         if not self.sharded:
-            return t.contiguous()
+            return t.contiguous()          # (column-sharded: whole rows too -- the unit vector spans the row)
         full = torch.zeros((self.P, self.d), dtype=torch.float32, device=self.dev)
         full[self._pos_dev] = t
         return full[self.loc].contiguous()
 
     def _rng_offset(self, call):
         """Counter offset of perturbed-layer call number `call` of this step (rows of all ranks)."""
-        return (call * self.P + self.rank * self.n_pad) & ((1 << 62) - 1)
+        return (call * self.P + (self.rank * self.n_pad if self.sharded else 0)) & ((1 << 62) - 1)
+
+    def _slice_kw(self):
+        """PERTURB on a column slice: tell the kernel where the slice sits in the whole row."""
+        return dict(d_full=self.d, col0=self.col0) if self.cols else {}
 
     def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False, need_last=False,
                       start_layer=0, noises=None, call_base=None):
@@ -282,7 +377,7 @@ class FusedTrainer:
                 call = self._noise_call if call_base is None else call_base + k
                 kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed, rng_offset=self._rng_offset(call),
                           rng_step=self.cursor[1:2] if noise is None else None,
-                          rng_stride=self.P * 16)
+                          rng_stride=self.P * 16, **self._slice_kw())
                 self._noise_call += 1
             if k == L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
@@ -312,6 +407,7 @@ class FusedTrainer:
         ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), epilogue=ops.make_epilogue(
             perturb_eps=self.eps, noise=None, rng_seed=self.rng_seed, rng_offset=0,
             rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * 16, main_clean=True,
+            **self._slice_kw(),
             extra_out=[self._loc(a["Y"][0]), self._loc(b["Y"][0])], extra_noise=[na[0], nb[0]],
             extra_rng_offset=[self._rng_offset(0), self._rng_offset(L)]))
         for t in (self.Y[0], a["Y"][0], b["Y"][0]):
@@ -384,9 +480,18 @@ class FusedTrainer:
     # one training step on the staged batch
     # ------------------------------------------------------------------------------------
     def _step_kernels(self):
+        self._step_front()
+        if self.cols:
+            self._exchange()
+        self._step_back()
+
+    def _sgl_shared_first(self):
+        return self.model == "SGL" and self.L >= 2 and self.w == 64
+
+    def _step_front(self):
+        """batch_fetch + the encoder passes (+ packing the batch rows when the tables are column slices)."""
         m, st = self.model, self.stage
         adj = self.adj
-        rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         # the staged ids are table rows (items already offset / permuted): one table, one index space
         cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
         ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
@@ -394,7 +499,7 @@ class FusedTrainer:
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
 
         include_ego = m in ("LightGCN", "SGL")
-        sgl_shared_first = m == "SGL" and self.L >= 2 and self.d == 64
+        sgl_shared_first = self._sgl_shared_first()
         if m == "SimGCL":
             self._simgcl_forward(adj)
         elif sgl_shared_first:
@@ -412,7 +517,30 @@ class FusedTrainer:
         elif m != "MF":
             self._forward_pass(adj, self.Y, self.F, perturbed=(m == "XSimGCL"), include_ego=include_ego,
                                batch_rows_only=True, need_last=(m == "XSimGCL" and self.layer_cl == self.L))
+        if m == "SGL" and not sgl_shared_first:
+            for vi, v in enumerate(self.views):
+                self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=include_ego,
+                                   batch_rows_only=True)
+        if self.cols:
+            self._pack()
+
+    def _step_back(self):
+        """losses on the batch rows, backward through the encoder, optimiser, row-wise resets."""
+        m, st = self.model, self.stage
+        adj = self.adj
+        rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         F = self.F
+        if self.cols:
+            # whole rows exist only for the batch: compact (5B, d) tables, slot -> slot index lists
+            self._unpack()
+            T = lambda t: self._x_compact[id(t)]            # noqa: E731
+            GT = lambda g: self._x_cgrad[id(g)]             # noqa: E731
+            ix = self._x_idx
+            cat_idx = self._x_cat
+        else:
+            T = GT = lambda t: t                            # noqa: E731
+            ix = st
+            cat_idx = self.stage_cat
         # ---- recommendation loss + regulariser (a-5..a-7)
         if m == "LightGCN":
             # regulariser on the EGO rows (LightGCN.py:25); its gradient joins gE0 in the last product
@@ -428,31 +556,31 @@ class FusedTrainer:
         # extra graph edges cost more than the overlap buys; instead the two losses' O(batch) kernels
         # share launches inside srh_bpr_infonce_fwd_bwd)
         bpr = dict(batch=self.B, n_rows_dev=rows_dev, reg_coef=reg_coef, reg_include_neg=inc_neg, loss_scale=1.0,
-                   g_user=self.gF, g_item=self.gF, greg_user=greg_t, greg_item=greg_t, losses=self.losses[0:2])
-        bpr_in = (F, F, reg_t, reg_t, st["u"], st["i"], st["j"])
+                   g_user=GT(self.gF), g_item=GT(self.gF), greg_user=GT(greg_t), greg_item=GT(greg_t),
+                   losses=self.losses[0:2])
+        bpr_in = (T(F), T(F), T(reg_t), T(reg_t), ix["u"], ix["i"], ix["j"])
         nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws)
         # ---- recommendation + contrastive loss (a-5..a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=[
-                (F, CL, st["uniq_u"], self.B, nuu_dev, self.gF, self.gCL),
-                (F, CL, st["uniq_i"], self.B, nui_dev, self.gF, self.gCL)])
+                (T(F), T(CL), ix["uniq_u"], self.B, nuu_dev, GT(self.gF), GT(self.gCL)),
+                (T(F), T(CL), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gCL))])
         elif m in ("SimGCL", "SGL"):
-            if m == "SGL" and not sgl_shared_first:
-                for vi, v in enumerate(self.views):
-                    self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=include_ego,
-                                       batch_rows_only=True)
             a, b = self.views
             if m == "SimGCL":
                 # the three passes share one backward chain (same linear operator), so the views'
                 # gradients go straight into gF
-                problems = [(a["F"], b["F"], st["uniq_u"], self.B, nuu_dev, self.gF, self.gF),
-                            (a["F"], b["F"], st["uniq_i"], self.B, nui_dev, self.gF, self.gF)]
+                problems = [(T(a["F"]), T(b["F"]), ix["uniq_u"], self.B, nuu_dev, GT(self.gF), GT(self.gF)),
+                            (T(a["F"]), T(b["F"]), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gF))]
             else:
-                problems = [(a["F"], b["F"], self.stage_cat, 2 * self.B, self.n_cat, a["gF"], b["gF"])]
+                problems = [(T(a["F"]), T(b["F"]), cat_idx, 2 * self.B, self.n_cat, GT(a["gF"]), GT(b["gF"]))]
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems)
         else:
             ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=self.bpr_ws)
+        if self.cols:
+            # this rank's columns of the batch-row gradients, added to the nodes' rows of the local tables
+            ops.batch_scatter(self._x_lists, self._x_pairs, self.d, self.col0, self.w)
         # ---- backward through the encoder (a-4) and optimiser (a-9)
         if m == "MF":
             pass                                     # gF is gE0
@@ -480,7 +608,7 @@ class FusedTrainer:
                           (self.gReg, st["j"], rows_dev, B, 0)]
             if m == "SGL":                       # the views' gradients live on the contrast rows
                 lists += [(v["gF"], self.stage_cat, self.n_cat, 2 * B, 0) for v in self.views]
-            ops.zero_rows(lists, self.d, cursor_advance=self.cursor)      # last kernel of the step
+            ops.zero_rows(lists, self.w, cursor_advance=self.cursor)      # last kernel of the step
         else:
             ops.cursor_advance(self.cursor)
 
@@ -492,7 +620,7 @@ class FusedTrainer:
             if self._graph is None:
                 self._capture()
             else:
-                self._graph.replay()
+                self._replay()
         else:
             self._step_kernels()
         self.step_count += 1
@@ -507,11 +635,28 @@ class FusedTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._step_kernels()
+        if self.cols:
+            # two graphs with the collective between them: RCCL stays outside the captured region
+            self._graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(self._graph[0], pool=pool, capture_error_mode="thread_local"):
+                self._step_front()
+            with torch.cuda.graph(self._graph[1], pool=pool, capture_error_mode="thread_local"):
+                self._step_back()
+        else:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._step_kernels()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        self._graph.replay()
+        self._replay()
+
+    def _replay(self):
+        if self.cols:
+            self._graph[0].replay()
+            self._exchange()
+            self._graph[1].replay()
+        else:
+            self._graph.replay()
 
     def read_losses(self):
         """(bpr, reg, cl) of the last step -- a device-to-host sync, call sparingly."""
@@ -528,6 +673,8 @@ class FusedTrainer:
         out = torch.zeros_like(self.E0)
         Ys = [torch.zeros_like(self.E0) for _ in range(self.L)]
         self._forward_pass(self.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
+        if self.cols:
+            out = self._full(out)                 # (a collective: every rank must ask)
         if not self.sharded:
             return out[:self.U], out[self.U:]
         return out[self._pos_dev[:self.U]], out[self._pos_dev[self.U:]]

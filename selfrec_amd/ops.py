@@ -18,7 +18,8 @@ require_gpu = _lib.require_gpu
 
 __all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
-           "axpby", "batch_fetch", "zero_rows", "cursor_advance", "SelfrecHipError"]
+           "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",
+           "SelfrecHipError"]
 
 
 def _stream() -> int:
@@ -226,8 +227,9 @@ def column_class_order(indptr, indices, min_len: int):
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
                   row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
-                  extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False):
+                  extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0):
     ep = SpmmEpilogue()
+    ep.noise_d_full, ep.noise_col0 = int(d_full), int(col0)      # column-sharded tables (0 = whole rows)
     keep = []
     flags = 0
     if perturb_eps is not None:
@@ -533,3 +535,49 @@ def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mar
         _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
         _p(meta, torch.int32), _p(row_mark, torch.int32), int(mark_item_offset), _p(zero4, torch.float64),
         _p(stage_cat, torch.int32), int(cat_item_offset), _p(n_cat, torch.int32), _stream()), "srh_batch_fetch")
+
+
+# ----------------------------------------------------------------------------------------
+# (e) column-sharded tables: the batch-row exchange around the loss section (csrc/exchange.hip)
+# ----------------------------------------------------------------------------------------
+def batch_lists(stage, meta, batch_size):
+    """struct srh_batch_lists over the staging buffers of batch_fetch: (u, i, j, uniq_u, uniq_i) with
+    their device-side counts (meta[0] for the pair lists, meta[1], meta[2])."""
+    bl = _lib.BatchLists()
+    keep = []
+    for s, (name, cnt) in enumerate((("u", 0), ("i", 0), ("j", 0), ("uniq_u", 1), ("uniq_i", 2))):
+        c = meta[cnt:cnt + 1]
+        bl.d_idx[s] = _p(stage[name], torch.int32, name)
+        bl.d_count[s] = _p(c, torch.int32, "count")
+        keep += [stage[name], c]
+    bl.B = int(batch_size)
+    bl._keepalive = keep
+    return bl
+
+
+def _ptr_array(tensors, name):
+    return (C.c_void_p * len(tensors))(*[_p(t, torch.float32, name) for t in tensors])
+
+
+def batch_pack(lists, tables, send, cat_idx=None, n_cat=None):
+    dl = int(tables[0].shape[1])
+    rows = 5 * lists.B
+    if send.numel() < len(tables) * rows * dl or any(int(t.shape[1]) != dl for t in tables):
+        raise SelfrecHipError("batch_pack: send buffer too small / tables of different widths")
+    check(_lib.load().srh_batch_pack(C.byref(lists), len(tables), _ptr_array(tables, "table"), dl,
+                                     _p(send, torch.float32, "send"), _p(cat_idx, torch.int32, "cat_idx"),
+                                     _p(n_cat, torch.int32, "n_cat"), _stream()), "srh_batch_pack")
+
+
+def batch_unpack(lists, recv, world, dl, compact, compact_grads):
+    check(_lib.load().srh_batch_unpack(C.byref(lists), len(compact), int(world), int(dl),
+                                       _p(recv, torch.float32, "recv"), _ptr_array(compact, "compact"),
+                                       len(compact_grads), _ptr_array(compact_grads, "compact_grad") if compact_grads else None,
+                                       _stream()), "srh_batch_unpack")
+
+
+def batch_scatter(lists, pairs, d_full, col0, dl):
+    """pairs: [(compact gradient (5B, d_full), local gradient (N, dl)), ...]"""
+    check(_lib.load().srh_batch_scatter(C.byref(lists), len(pairs), _ptr_array([c for c, _ in pairs], "compact_grad"),
+                                        _ptr_array([g for _, g in pairs], "local_grad"), int(d_full), int(col0), int(dl),
+                                        _stream()), "srh_batch_scatter")

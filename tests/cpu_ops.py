@@ -13,6 +13,7 @@ from selfrec_amd import ops as _real_ops
 
 SelfrecHipError = _real_ops.SelfrecHipError
 Sampler = _real_ops.Sampler          # host-only C++ (MT19937 replay): needs no GPU
+column_class_order = _real_ops.column_class_order    # host-only numpy
 
 
 def require_gpu():
@@ -86,12 +87,18 @@ def spmm(csr, x, out=None, epilogue=None):
     rows = slice(None) if ep.get("row_mark") is None else _live(ep["row_mark"], ep["mark_stamp"])
     if ep.get("perturb_eps") is not None:
         raw = y
+        c0, w = int(ep.get("col0") or 0), y.shape[1]
+
+        def perturbed(noise):
+            assert noise is not None, "the CPU stand-in needs injected noise"
+            if ep.get("d_full"):        # column slice: the unit vector is normalised over the whole row
+                unit = torch.nn.functional.normalize(noise, dim=-1)[:, c0:c0 + w]
+                return raw + torch.sign(raw) * unit * ep["perturb_eps"]
+            return O.perturb_(raw.clone(), noise, ep["perturb_eps"])
         for k, extra in enumerate(ep.get("extra_out") or []):           # FANOUT: more perturbed copies of the product
-            assert ep["extra_noise"][k] is not None, "the CPU stand-in needs injected noise"
-            extra[rows] = O.perturb_(raw.clone(), ep["extra_noise"][k], ep["perturb_eps"])[rows]
+            extra[rows] = perturbed(ep["extra_noise"][k])[rows]
         if not ep.get("main_clean"):
-            assert ep.get("noise") is not None, "the CPU stand-in needs injected noise"
-            y = O.perturb_(raw.clone(), ep["noise"], ep["perturb_eps"])
+            y = perturbed(ep.get("noise"))
     out[rows] = y[rows]
     if ep.get("mean_out") is not None:
         mean = torch.stack(list(ep.get("prev") or []) + [y], dim=1).sum(1) / ep["mean_div"]
@@ -218,3 +225,51 @@ def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=
     pn, mn, vn = p.numpy().copy(), mm.numpy().copy(), vv.numpy().copy()
     O.adam_step(pn, g.numpy(), mn, vn, t, lr)
     param.copy_(torch.from_numpy(pn)); m.copy_(torch.from_numpy(mn)); v.copy_(torch.from_numpy(vn))
+
+
+# ---- column-sharded tables: the batch-row exchange (csrc/exchange.hip) ----
+def batch_lists(stage, meta, batch_size):
+    return {"stage": stage, "meta": meta, "B": int(batch_size)}
+
+
+def _live_slots(lists):
+    """[(compact slot, node)] of every live slot of [u | i | j | uniq_u | uniq_i]."""
+    B, meta, st = lists["B"], lists["meta"], lists["stage"]
+    out = []
+    for s, (name, cnt) in enumerate((("u", 0), ("i", 0), ("j", 0), ("uniq_u", 1), ("uniq_i", 2))):
+        n = min(int(meta[cnt]), B)
+        out += [(s * B + k, int(st[name][k])) for k in range(n)]
+    return out
+
+
+def batch_pack(lists, tables, send, cat_idx=None, n_cat=None):
+    send.zero_()
+    live = _live_slots(lists)
+    slots = torch.tensor([k for k, _ in live], dtype=torch.long)
+    nodes = torch.tensor([n for _, n in live], dtype=torch.long)
+    for t, table in enumerate(tables):
+        send[t][slots] = table[nodes]
+    if cat_idx is not None:
+        B, meta = lists["B"], lists["meta"]
+        a, c = min(int(meta[1]), B), min(int(meta[2]), B)
+        cat_idx[:a] = torch.arange(3 * B, 3 * B + a, dtype=torch.int32)
+        cat_idx[a:a + c] = torch.arange(4 * B, 4 * B + c, dtype=torch.int32)
+        if n_cat is not None:
+            n_cat.fill_(a + c)
+
+
+def batch_unpack(lists, recv, world, dl, compact, compact_grads):
+    slots = torch.tensor([k for k, _ in _live_slots(lists)], dtype=torch.long)
+    for t, table in enumerate(compact):
+        whole = recv[:, t].permute(1, 0, 2).reshape(recv.shape[2], world * dl)
+        table[slots] = whole[slots]
+    for g in compact_grads:
+        g[slots] = 0.0
+
+
+def batch_scatter(lists, pairs, d_full, col0, dl):
+    live = _live_slots(lists)
+    slots = torch.tensor([k for k, _ in live], dtype=torch.long)
+    nodes = torch.tensor([n for _, n in live], dtype=torch.long)
+    for cg, local in pairs:
+        local.index_add_(0, nodes, cg[slots, col0:col0 + dl])

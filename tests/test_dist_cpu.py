@@ -1,5 +1,6 @@
-"""world_size-2 (and 3) gloo runs of the row-sharded trainer on CPU: the product's step code
-(engine.FusedTrainer with shard=True, via dist.ShardedTrainer) over CPU stand-ins of the kernels
+"""world_size-2 (3, 4, 8) gloo runs of the sharded trainer on CPU, both layouts -- column-sharded tables
+(one all-gather of the batch rows per step) and row-sharded graph + tables (an all-gather per layer): the
+product's step code (engine.FusedTrainer via dist.ShardedTrainer) over CPU stand-ins of the kernels
 (tests/cpu_ops.py) gives the single-process oracle's result on the same batches and injected noise."""
 import os
 import socket
@@ -19,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, model, out_path):
+def _worker(rank, world, port, model, layout, out_path):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -37,8 +38,13 @@ def _worker(rank, world, port, model, out_path):
     ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
     gen = torch.Generator().manual_seed(7)
     tr = ShardedTrainer(data, 64, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
-                        drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu")
-    assert tr.G == world and tr.P == world * tr.n_pad
+                        drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu",
+                        layout=layout)
+    assert tr.G == world
+    if layout == "rows":
+        assert tr.sharded and tr.P == world * tr.n_pad
+    else:
+        assert tr.cols and tr.w == 64 // world and tr.E0.shape == (U + I, 64 // world)
     import random
     random.seed(11)
     tr.seed_sampler_from_python()             # (SGL: the two dropped views come out of this stream first)
@@ -57,10 +63,16 @@ def _worker(rank, world, port, model, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 2), ("MF", 2), ("XSimGCL", 3), ("SimGCL", 2), ("SGL", 2)])
-def test_sharded_equals_single_process_oracle(tmp_path, model, world):
+CASES = [("XSimGCL", 2, "rows"), ("LightGCN", 2, "rows"), ("MF", 2, "rows"), ("XSimGCL", 3, "rows"), ("SimGCL", 2, "rows"),
+         ("SGL", 2, "rows"),
+         ("XSimGCL", 2, "cols"), ("XSimGCL", 4, "cols"), ("XSimGCL", 8, "cols"), ("LightGCN", 2, "cols"), ("MF", 4, "cols"),
+         ("SimGCL", 2, "cols"), ("SGL", 2, "cols")]
+
+
+@pytest.mark.parametrize("model,world,layout", CASES)
+def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), model, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), model, layout, out), nprocs=world, join=True)
     r = np.load(out)
     gen = torch.Generator().manual_seed(7)
     ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, 64, n_layers=3, batch_size=1000, layer_cl=2,
@@ -101,3 +113,9 @@ def test_shard_adjacency_layout():
         own = np.arange(r, 23, world)
         np.testing.assert_allclose(loc[:len(own)], full[own], rtol=1e-6)
         assert not loc[len(own):].any()
+
+
+def test_layout_choice():
+    from selfrec_amd.dist import pick_layout
+    assert [pick_layout(64, w) for w in (1, 2, 3, 4, 8, 16)] == ["rows", "cols", "rows", "cols", "cols", "rows"]
+    assert pick_layout(128, 8) == "cols" and pick_layout(128, 2) == "rows" and pick_layout(64, 2, "rows") == "rows"
