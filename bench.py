@@ -94,11 +94,12 @@ def time_spmm_kernel(trainer, iters=50):
     adj = trainer.adj                                         # (this rank's rows when the graph is sharded)
     x, y = trainer.E0, trainer._loc(trainer.Ha)
     stamp = (trainer.cursor[1:2] - 1).contiguous()            # the marks of the batch that just ran
+    sl = trainer._slice_kw()                                  # (column-sharded: where the slice sits in the row)
     flavours = {
-        "dense": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0),
+        "dense": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0, **sl),
         "row_masked": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0,
-                                        row_mark=trainer._loc(trainer.mark), mark_stamp=stamp),
-        "col_masked": ops.make_epilogue(col_mark=trainer.mark, mark_stamp=stamp),
+                                        row_mark=trainer._loc(trainer.mark), mark_stamp=stamp, **sl),
+        "col_masked": ops.make_epilogue(col_mark=trainer.mark, mark_stamp=stamp, **sl),
     }
     out = {}
     for name, ep in flavours.items():
@@ -290,7 +291,8 @@ def main():
         elapsed = float(t.item())
     losses = trainer.read_losses()
 
-    # The graph is row-sharded: the global batch is fixed at B pairs per step for every N (strong scaling).
+    # Sharded or not, the global batch is fixed at B pairs per step for every N (strong scaling).
+    layout = "column-sharded tables" if getattr(trainer, "cols", False) else "row-sharded graph + tables"
     pairs = args.steps * args.batch
     value = pairs / elapsed
     g = trainer.graph
@@ -302,20 +304,23 @@ def main():
         "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; sampling on a host thread inside the timed region",
-                   "global_batch": args.batch, "parallelism": f"row-sharded x{world}" if sharded else "single",
+                   "global_batch": args.batch, "parallelism": f"{layout} x{world}" if sharded else "single",
                    "launch": "hipGraph replay" if trainer.use_graph else "eager"},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     if rank == 0:
         t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
         if t_spmm:
-            alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], args.emb)
+            alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
             ach = alg / t_spmm["dense"] / 1e9
             traffic, traffic_note = pmc_traffic(args) if not sharded else (None, "PMC pass exists for the unsharded launch only")
             out["roofline"] = {"bound": "hbm",
-                               "kernel": f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
-                                         f"{'the rows of one rank of the' if sharded else 'the whole'} graph, "
-                                         "perturb epilogue; split rows finished in-kernel)",
+                               "kernel": (f"{'spmm_thin_kernel<8>' if trainer.w == 8 else f'spmm_slice_kernel<{trainer.w // 4}>'} "
+                                          f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
+                                          f"{args.emb} columns, perturb epilogue)") if getattr(trainer, "cols", False) else
+                                         (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
+                                          f"{'the rows of one rank of the' if sharded else 'the whole'} graph, "
+                                          "perturb epilogue; split rows finished in-kernel)"),
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "measured_stream_GBps": stream_bandwidth(trainer.dev),

@@ -414,7 +414,7 @@ srh_status_t srh_cursor_advance(int64_t* d_cursor, void* stream);
  * Compact row k = slot k of [u | i | j | unique users | unique items] (B slots each; slots past a
  * list's device-side count are dead: never written, never read).
  * ------------------------------------------------------------------------------------ */
-#define SRH_MAX_EXCHANGE 4
+#define SRH_MAX_EXCHANGE 8
 typedef struct srh_batch_lists {
   const int32_t* d_idx[5];     /* staged lists of srh_batch_fetch: u, i, j, uniq_u, uniq_i (table rows)  */
   const int32_t* d_count[5];   /* device-side live counts (d_meta[0] for u/i/j, [1], [2]); NULL = B      */

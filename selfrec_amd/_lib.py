@@ -59,7 +59,7 @@ class SpmmEpilogue(C.Structure):
     ]
 
 
-SRH_MAX_EXCHANGE = 4
+SRH_MAX_EXCHANGE = 8
 
 
 class BatchLists(C.Structure):

@@ -119,15 +119,34 @@ template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
                                               uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep) {
   float4 nu;
-  if (noise) {
-    nu = reinterpret_cast<const float4*>(noise)[at];
-  } else {
+  float ss;
+  if (ep.noise_d_full != 4 * LPR) {
+    // y is a column slice of noise_d_full-wide rows: the unit vector is normalised over the WHOLE row, whose
+    // other columns are regenerated (counter RNG) or read (injected noise) by the group's lanes in turn
+    const int nq = ep.noise_d_full >> 2, own = (ep.noise_col0 >> 2) + sub;
     uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
-    if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
-    uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
-    nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    if (!noise && ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+    const float4* nr = reinterpret_cast<const float4*>(noise) + (size_t)row * nq;
+    auto draw = [&](int q) {
+      if (noise) return nr[q];
+      const uint4 r = counter_rng4(ctr, (uint32_t)q, ep.seed_lo, ep.seed_hi);
+      return make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    };
+    ss = 0.f;
+    for (int q = sub; q < nq; q += LPR) { const float4 z = draw(q); ss += f4_dot(z, z); }
+    ss = group_sum<LPR>(ss);
+    nu = draw(own);
+  } else {
+    if (noise) {
+      nu = reinterpret_cast<const float4*>(noise)[at];
+    } else {
+      uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
+      if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+      uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
+      nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    }
+    ss = group_sum<LPR>(f4_dot(nu, nu));
   }
-  float ss = group_sum<LPR>(f4_dot(nu, nu));
   // F.normalize: v / max(||v||, 1e-12); one reciprocal instead of four divisions (<= 1 ulp apart)
   const float scale = ep.eps / fmaxf(sqrtf(ss), 1e-12f);
   y.x += sgnf(y.x) * (nu.x * scale);
@@ -1019,6 +1038,178 @@ __global__ __launch_bounds__(256) void spmm_thin_kernel(const Task* __restrict__
   thin_epilogue<DL>(out, row, e8, live, Y, ep);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 16- and 32-column slices (column-sharded layout at G = 4 / 2 for d = 64): spmm_rows_kernel's
+// schedule with LPR = 4 / 8 lanes per row, so that ONE gather instruction fetches a whole 64 / 128-byte
+// x row per row-group -- one L1 lookup per entry (the lane-per-entry mapping of spmm_thin_kernel pays
+// one per 16 bytes: measured 39 / 67 us per Yelp-shape launch at 16 / 32 columns against 26 us at 8).
+//   * a row-group consumes 8 entries per iteration, held by its own lanes as 8 / LPR sub-blocks of LPR
+//     consecutive entries; entry t of a sub-block is broadcast inside the group with DPP -- quad_perm
+//     for LPR = 4 (a group is a quad), two row_newbcast + a select for LPR = 8 (two groups per DPP row);
+//   * 8 gathers are in flight per row-group before the first FMA; G = 64 / LPR = 16 / 8 short rows per
+//     wave (task lists of the plan), or all groups on one long row / split segment (8 G entries per
+//     iteration) summed with xor-shuffles; split rows finish in-kernel (write-through partials + ticket).
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int T>
+__device__ __forceinline__ int grp_bcast_i(int x, int lane) {
+  if constexpr (LPR == 4) {
+    return __builtin_amdgcn_update_dpp(0, x, T * 0x55, 0xf, 0xf, false);           // quad_perm [T,T,T,T]
+  } else {
+    const int lo = __builtin_amdgcn_update_dpp(0, x, 0x150 + T, 0xf, 0xf, false);      // row_newbcast:T
+    const int hi = __builtin_amdgcn_update_dpp(0, x, 0x150 + T + 8, 0xf, 0xf, false);  // row_newbcast:T+8
+    return (lane & 8) ? hi : lo;
+  }
+}
+template <int LPR, int T>
+__device__ __forceinline__ float grp_bcast_f(float x, int lane) {
+  return __int_as_float(grp_bcast_i<LPR, T>(__float_as_int(x), lane));
+}
+
+// 8 entries of this row-group: sub-block b holds entries b*LPR .. b*LPR+LPR-1 in (c[b], v[b]) of its lanes
+template <int LPR>
+__device__ __forceinline__ void slice_gather8(const int (&c)[8 / LPR], const float (&v)[8 / LPR],
+                                              const float4* __restrict__ X, int sub, int lane, float4& acc) {
+  int cc[8];
+  float vv[8];
+  float4 xx[8];
+  if constexpr (LPR == 8) {
+#define SRH_BC(T) cc[T] = grp_bcast_i<8, T>(c[0], lane); vv[T] = grp_bcast_f<8, T>(v[0], lane);
+    SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3) SRH_BC(4) SRH_BC(5) SRH_BC(6) SRH_BC(7)
+#undef SRH_BC
+  } else {
+#define SRH_BC(T) cc[T] = grp_bcast_i<4, T>(c[0], lane); vv[T] = grp_bcast_f<4, T>(v[0], lane); \
+                  cc[4 + T] = grp_bcast_i<4, T>(c[1], lane); vv[4 + T] = grp_bcast_f<4, T>(v[1], lane);
+    SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3)
+#undef SRH_BC
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    xx[t] = f4_zero();
+    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // padding / dropped / dead columns: no gather
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                         const Seg* __restrict__ segs,
+                                                         const int32_t* __restrict__ indices,
+                                                         const float* __restrict__ vals,
+                                                         const float4* __restrict__ X, float4* __restrict__ Y,
+                                                         float4* __restrict__ partial,
+                                                         const Heavy* __restrict__ heavy,
+                                                         const int32_t* __restrict__ slot_owner,
+                                                         int32_t* __restrict__ tickets, DevEpilogue ep) {
+  static_assert(LPR == 4 || LPR == 8, "16- and 32-column slices");
+  constexpr int G = 64 / LPR;          // row-groups per wave
+  constexpr int NB = 8 / LPR;          // sub-blocks of LPR entries a group holds per iteration
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  const Task tk = tasks[wave];
+  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
+  const int first = __builtin_amdgcn_readfirstlane(tk.first);
+  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  float4 acc = f4_zero();
+
+  if (kind == 0) {
+    const Seg sg = segs[first];
+    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
+    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    // the (col, val) pairs of 512 entries are loaded up front -- one index latency per segment instead of one
+    // per 8 G entries: with a few thousand waves per launch this kernel runs on its latency chain, not on bytes
+    constexpr int KCH = 512 / (8 * G);       // iterations per 512 entries: 8 (LPR = 8), 4 (LPR = 4)
+    for (int base = s; base < e; base += 512) {
+      int cq[KCH][NB];
+      float vq[KCH][NB];
+#pragma unroll
+      for (int k = 0; k < KCH; ++k) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int j = base + 8 * G * k + 8 * g + b * LPR + sub;
+          cq[k][b] = 0;
+          vq[k][b] = 0.f;
+          if (j < e) { cq[k][b] = indices[j]; vq[k][b] = vals[j]; }
+        }
+      }
+      if (ep.col_mark) {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if (vq[k][b] != 0.f && ep.col_mark[cq[k][b]] != stamp) vq[k][b] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KCH; ++k)
+        if (base + 8 * G * k < e) slice_gather8<LPR>(cq[k], vq[k], X, sub, lane, acc);
+    }
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    if (slot < 0) {
+      row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+      return;
+    }
+    if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, acc);
+    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+    const Heavy h = heavy[hid];
+    const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
+    const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != hn - 1) return;
+    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    float4 sum = f4_zero();
+    for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
+    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
+    return;
+  }
+
+  // ---- one short row per row-group ----
+  const bool have = g < count;
+  const Seg sg = segs[first + (have ? g : 0)];
+  const int row = sg.row, s = sg.start;
+  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
+  const int e = live ? sg.end : s;
+  int maxlen = e - s;
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  for (int q0 = 0; q0 * 8 < maxlen; q0 += 8) {        // (one pass: short rows have at most 64 entries)
+    int cq[8][NB];
+    float vq[8][NB];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = s + 8 * (q0 + k) + b * LPR + sub;
+        cq[k][b] = 0;
+        vq[k][b] = 0.f;
+        if (j < e) { cq[k][b] = indices[j]; vq[k][b] = vals[j]; }
+      }
+    }
+    if (ep.col_mark) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (vq[k][b] != 0.f && ep.col_mark[cq[k][b]] != stamp) vq[k][b] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((q0 + k) * 8 < maxlen) slice_gather8<LPR>(cq[k], vq[k], X, sub, lane, acc);
+  }
+  row_epilogue<LPR>(acc, row, sub, live, Y, ep);
+}
+
 }  // namespace
 
 struct srh_spmm_plan {
@@ -1026,8 +1217,8 @@ struct srh_spmm_plan {
   int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
   int32_t flags = 0;               // kernel variant, see spmm_seg_kernel; bit 8 = streaming kernel
   // default kernel: one task per wave; a task list per row-group count (index log2(LPR / 8))
-  int32_t n_tasks[4] = {0, 0, 0, 0};
-  Task* d_tasks[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t n_tasks[5] = {0, 0, 0, 0, 0};         // index 4: 16 rows per wave (LPR = 4: 16-column slices)
+  Task* d_tasks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Seg* d_tsegs = nullptr;          // segments in task order
   int32_t n_waves = 0;             // streaming kernel: resident waves, each with its own segment list
   Seg* d_wsegs = nullptr;          // segments grouped by wave
@@ -1127,12 +1318,12 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   p->split_len = split_len;
   p->flags = 16 | 4;
   if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 31;  // A/B knob for tools/spmm_ab.py
-  if (const char* env = getenv("SRH_SPMM_THIN32")) p->flags |= atoi(env) ? 32 : 0;   // d = 32 through the thin kernel
+  if (const char* env = getenv("SRH_SPMM_THIN")) p->flags |= atoi(env) ? 32 : 0;   // A/B: 16 / 32 columns lane-per-row too
   // ---- default kernel: coop tasks (long rows / split pieces) then G short rows per task ----
   // tsegs = coop(class 0) ++ coop(class 1) ++ short(class 0) ++ short(class 1), each longest first;
   // one task list per row-group count G = 64/LPR in {8, 4, 2, 1}
   std::vector<Seg> tsegs;
-  std::vector<Task> tasks[4];
+  std::vector<Task> tasks[5];
   {
     // task classes: row class (user rows / item rows of a bipartite adjacency) x column class.  Workgroup b
     // = 4 consecutive tasks runs on XCD b % 8; the 8 XCDs are dealt to the classes in equal groups, so each
@@ -1153,8 +1344,8 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     for (int c = 0; c < NC; ++c) { std::stable_sort(shorts[c].begin(), shorts[c].end(), longer2); }
     for (int c = 0; c < NC; ++c) { coop_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), coop[c].begin(), coop[c].end()); }
     for (int c = 0; c < NC; ++c) { short_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), shorts[c].begin(), shorts[c].end()); }
-    for (int gi = 0; gi < 4; ++gi) {
-      const int Gr = 8 >> gi;                            // rows per wave for LPR = 8, 16, 32, 64
+    for (int gi = 0; gi < 5; ++gi) {
+      const int Gr = (gi == 4) ? 16 : (8 >> gi);         // rows per wave for LPR = 8, 16, 32, 64; then LPR = 4
       std::vector<Task>& out_t = tasks[gi];
       size_t blk = 0;
       auto emit = [&](const std::vector<Seg>* lists, int kind, const int32_t* base, int unit) {
@@ -1215,7 +1406,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(&p->d_tsegs, sizeof(Seg) * tsegs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_tsegs, tsegs.data(), sizeof(Seg) * tsegs.size(), hipMemcpyHostToDevice);
-  for (int gi = 0; gi < 4 && err == hipSuccess; ++gi) {
+  for (int gi = 0; gi < 5 && err == hipSuccess; ++gi) {
     p->n_tasks[gi] = (int32_t)tasks[gi].size();
     err = hipMalloc(&p->d_tasks[gi], sizeof(Task) * tasks[gi].size());
     if (err == hipSuccess) err = hipMemcpy(p->d_tasks[gi], tasks[gi].data(), sizeof(Task) * tasks[gi].size(), hipMemcpyHostToDevice);
@@ -1250,7 +1441,7 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_slot_owner) (void)hipFree(p->d_slot_owner);
   if (p->d_tickets) (void)hipFree(p->d_tickets);
   if (p->d_tsegs) (void)hipFree(p->d_tsegs);
-  for (int gi = 0; gi < 4; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
+  for (int gi = 0; gi < 5; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
   if (p->d_wsegs) (void)hipFree(p->d_wsegs);
   if (p->d_wave_ptr) (void)hipFree(p->d_wave_ptr);
   delete p;
@@ -1423,9 +1614,23 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
   // thin tables (8 / 16 columns, or a 32-column slice of wider rows): one lane per gathered x row
   const bool slice = ep.noise_d_full != 0;
   if (!slice) { ep.noise_d_full = d; ep.noise_col0 = 0; }
-  if (d < 32 || (d == 32 && (slice || (plan->flags & 32)))) {
+  if (d <= 32) {
     SRH_REQUIRE(ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
                 "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
+    if (d >= 16 && !(plan->flags & 32)) {       // 16 / 32 columns: a row-group per gathered row (flag 32: A/B, lane per row)
+      if (d == 16)
+        spmm_slice_kernel<4><<<(plan->n_tasks[4] + 3) / 4, 256, 0, st>>>(
+            plan->d_tasks[4], plan->n_tasks[4], plan->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+            reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
+            plan->d_tickets, ep);
+      else
+        spmm_slice_kernel<8><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(
+            plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+            reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
+            plan->d_tickets, ep);
+      SRH_LAUNCH_CHECK();
+      return SRH_OK;
+    }
 #define SRH_THIN(DLV)                                                                                              \
   spmm_thin_kernel<DLV><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(                                              \
       plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, d_x, d_y, plan->d_partial, plan->d_heavy, \

@@ -206,10 +206,12 @@ class Interaction(Data, Graph):
         lifted = sp.csr_matrix((adj_mat.data, (rows, cols + nu)), shape=(nu + ni, nu + ni), dtype=np.float32)
         return self.normalize_graph_mat(lifted + lifted.T)
 
-    def device_graph(self, device=None):
-        """Device CSR mirrors (built once): see data/device_graph.py."""
+    def device_graph(self, device=None, column_classes=True):
+        """Device CSR mirrors (built once per flavour): see data/device_graph.py.  column_classes=False: the
+        plain row order, for tables narrow enough to sit in every L2 (the column-sharded layout)."""
         from .device_graph import DeviceGraph
-        return self._lazy('dev', lambda: DeviceGraph(self.interaction_mat, device=device))
+        key = 'dev' if column_classes else 'dev_plain'
+        return self._lazy(key, lambda: DeviceGraph(self.interaction_mat, device=device, column_classes=column_classes))
 
     # ---- accessors of the reference surface -----------------------------------------
     def get_user_id(self, u):

@@ -136,7 +136,7 @@ class FusedTrainer:
         self._pos_dev = torch.from_numpy(self._pos.astype(np.int64)).to(dev)
         self.loc = slice(self.rank * self.n_pad, (self.rank + 1) * self.n_pad) if self.sharded else slice(0, self.P)
         if not self.sharded:
-            self.graph = data.device_graph(dev)
+            self.graph = data.device_graph(dev, column_classes=not self.cols)
             self.adj = self.graph.adj
         else:
             from .data import device_graph as _dg
@@ -616,22 +616,37 @@ class FusedTrainer:
         """Run one training step on the next batch of the current epoch."""
         if not self._epoch_ready:
             raise SelfrecHipError("call begin_epoch() first")
-        if self.use_graph and self.noise_fn is None:
-            if self._graph is None:
-                self._capture()
-            else:
-                self._replay()
-        else:
-            self._step_kernels()
-        self.step_count += 1
+        for phase in self.step_phases():
+            phase()
+
+    def step_phases(self):
+        """The step as a sequence of calls.  One GPU / row-sharded: a single call.  Column-sharded: (local
+        kernels, the one all-gather, local kernels) -- so a test can drive several ranks in lock-step on one
+        GPU, and so the collective stays outside the two captured graphs."""
+        if not self._epoch_ready:
+            raise SelfrecHipError("call begin_epoch() first")
+        graphed = self.use_graph and self.noise_fn is None
+        if graphed and self._graph is None:
+            self._capture()
+
+        def done():
+            self.step_count += 1
+        if self.cols:
+            front = self._graph[0].replay if graphed else self._step_front
+            back = self._graph[1].replay if graphed else self._step_back
+            return (front, self._exchange, back, done)
+        return (self._graph.replay if graphed else self._step_kernels, done)
 
     def _capture(self):
-        # warm up once eagerly on a side stream (allocator + lazy module loads), then capture
+        # warm up once eagerly on a side stream (allocator + lazy module loads), then capture.  (Column-
+        # sharded: the warm-up skips the all-gather -- its numbers are thrown away with the snapshot -- so
+        # capturing is a purely local act.)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snapshot = (self.E0.clone(), self.m.clone(), self.v.clone(), self.cursor.clone())
         with torch.cuda.stream(side):
-            self._step_kernels()
+            self._step_front()
+            self._step_back()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
@@ -648,15 +663,6 @@ class FusedTrainer:
             with torch.cuda.graph(self._graph):
                 self._step_kernels()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        self._replay()
-
-    def _replay(self):
-        if self.cols:
-            self._graph[0].replay()
-            self._exchange()
-            self._graph[1].replay()
-        else:
-            self._graph.replay()
 
     def read_losses(self):
         """(bpr, reg, cl) of the last step -- a device-to-host sync, call sparingly."""

@@ -1,0 +1,279 @@
+"""The column-sharded multi-GPU layout on ONE GPU: the thin SpMM kernel against the wide kernel's column
+slices and scipy, the batch-row exchange kernels against torch indexing, and G "virtual ranks" -- G
+trainers with layout "cols" driven in lock-step, their all-gather done by the test -- against the
+unsharded trainer and the reference's own 3-step runs (tests/golden/models.npz)."""
+import random
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from selfrec_amd import ops
+from selfrec_amd.dist import ShardedTrainer
+from selfrec_amd.engine import FusedTrainer
+
+pytestmark = pytest.mark.gpu
+WIDTHS = (8, 16, 32)
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def power_law_csr(n=3000, seed=0):
+    """Square CSR with empty rows, short rows, rows of 65..512 non-zeros (coop) and split rows (> 512)."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum((rng.pareto(1.1, n) * 6).astype(np.int64), n - 1)
+    lens[:5] = [0, 1, 700, 1500, 64]
+    lens[n // 2] = 0
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([rng.choice(n, size=k, replace=False) for k in lens]) if lens.sum() else np.zeros(0, np.int64)
+    vals = rng.standard_normal(rows.size).astype(np.float32)
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    m.sort_indices()
+    return m
+
+
+@pytest.fixture(scope="module")
+def csr_case():
+    m = power_law_csr()
+    csr = ops.DeviceCSR.from_scipy(m)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((m.shape[0], 64), device="cuda", generator=gen)
+    return m, csr, x
+
+
+def slices(t, w):
+    return [t[:, c:c + w].contiguous() for c in range(0, t.shape[1], w)]
+
+
+@pytest.mark.parametrize("w", WIDTHS)
+def test_thin_spmm_plain_matches_scipy_and_wide_kernel(csr_case, w):
+    m, csr, x = csr_case
+    want64 = m.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+    wide = ops.spmm(csr, x)
+    for r, xs in enumerate(slices(x, w)):
+        ys = ops.spmm(csr, xs, epilogue=ops.make_epilogue(d_full=64, col0=r * w))       # (d = 32 too goes thin)
+        assert rel_err(ys.cpu().numpy(), want64[:, r * w:(r + 1) * w]) < 2e-6
+        assert rel_err(ys.cpu().numpy(), wide[:, r * w:(r + 1) * w].cpu().numpy()) < 2e-6
+    # bitwise repeatable (fixed-order reductions, slot-ordered split rows)
+    xs = slices(x, w)[0]
+    a = ops.spmm(csr, xs, epilogue=ops.make_epilogue(d_full=64, col0=0))
+    for _ in range(5):
+        assert torch.equal(a, ops.spmm(csr, xs, epilogue=ops.make_epilogue(d_full=64, col0=0)))
+
+
+@pytest.mark.parametrize("w", WIDTHS)
+def test_thin_spmm_epilogues_match_wide_kernel_slices(csr_case, w):
+    """PERTURB (injected noise and counter RNG: the unit vector spans the WHOLE row), MEAN, AXPY with sparse
+    addends, row / column marks, FANOUT -- every slice equals the same columns of the d = 64 launch."""
+    m, csr, x = csr_case
+    n = m.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    noise = torch.rand((n, 64), device="cuda", generator=gen)
+    noise2 = torch.rand((n, 64), device="cuda", generator=gen)
+    prev = [torch.randn((n, 64), device="cuda", generator=gen) for _ in range(2)]
+    add = [torch.randn((n, 64), device="cuda", generator=gen) for _ in range(2)]
+    stamp = torch.tensor([7], dtype=torch.int64, device="cuda")
+    mark = torch.where(torch.rand(n, device="cuda", generator=gen) < 0.3, 7, 3).to(torch.int32)
+    add[1][mark != 7] = 0.0                      # a batch-sparse addend is zero off the marked rows
+    xm = x * (mark == 7).unsqueeze(1)             # col_mark contract: x is zero on dead columns
+    step = torch.tensor([5], dtype=torch.int64, device="cuda")
+
+    def run(xin, width, col0, sl):
+        """All epilogue flavours on tables of `width` columns starting at col0; sl() slices a 64-wide tensor."""
+        kw = {} if width == 64 else dict(d_full=64, col0=col0)
+        out = {}
+        out["noise"] = ops.spmm(csr, xin, epilogue=ops.make_epilogue(perturb_eps=0.2, noise=noise, **kw))
+        out["rng"] = ops.spmm(csr, xin, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=11, rng_offset=3 * n,
+                                                                 rng_step=step, rng_stride=16 * n, **kw))
+        mean_out = torch.zeros((n, width), device="cuda")
+        out["mean_y"] = ops.spmm(csr, xin, epilogue=ops.make_epilogue(perturb_eps=0.1, noise=noise, prev=[sl(p) for p in prev],
+                                                                    mean_div=3.0, mean_out=mean_out, **kw))
+        out["mean"] = mean_out
+        out["axpy"] = ops.spmm(csr, sl(xm) if width != 64 else xm, epilogue=ops.make_epilogue(
+            add=[sl(a) for a in add], add_scale=[0.5, 2.0], alpha=0.25, add_mark=mark, add_sparse=[False, True],
+            col_mark=mark, mark_stamp=stamp, **kw))
+        rm = torch.full((n, width), -5.0, device="cuda")
+        ops.spmm(csr, xin, out=rm, epilogue=ops.make_epilogue(row_mark=mark, mark_stamp=stamp, **kw))
+        out["rowmark"] = rm
+        e1, e2 = torch.zeros((n, width), device="cuda"), torch.zeros((n, width), device="cuda")
+        out["fan_main"] = ops.spmm(csr, xin, epilogue=ops.make_epilogue(
+            perturb_eps=0.2, main_clean=True, extra_out=[e1, e2], extra_noise=[noise, noise2], **kw))
+        out["fan1"], out["fan2"] = e1, e2
+        return out
+
+    wide = run(x, 64, 0, lambda t: t)
+    for r in range(64 // w):
+        c0 = r * w
+        sl = lambda t, c0=c0: t[:, c0:c0 + w].contiguous()      # noqa: E731
+        thin = run(sl(x), w, c0, sl)
+        for k, v in thin.items():
+            assert rel_err(v.cpu().numpy(), wide[k][:, c0:c0 + w].cpu().numpy()) < 3e-6, (k, w, r)
+    assert (wide["rowmark"][mark != 7] == -5.0).all()
+
+
+def test_exchange_kernels_match_torch_indexing():
+    B, n, G, w = 96, 500, 4, 16
+    d = G * w
+    gen = torch.Generator().manual_seed(3)
+    stage = {k: torch.randint(0, n, (B,), generator=gen, dtype=torch.int32).cuda() for k in ("u", "i", "j", "uniq_u", "uniq_i")}
+    meta = torch.tensor([70, 33, 96, 0], dtype=torch.int32).cuda()
+    counts = {"u": 70, "i": 70, "j": 70, "uniq_u": 33, "uniq_i": 96}
+    lists = ops.batch_lists(stage, meta, B)
+    full = [torch.randn((n, d), generator=gen).cuda() for _ in range(2)]
+    sends = []
+    cat = torch.full((2 * B,), -1, dtype=torch.int32).cuda()
+    for r in range(G):
+        send = torch.full((2, 5 * B, w), 9.0).cuda()
+        ops.batch_pack(lists, [t[:, r * w:(r + 1) * w].contiguous() for t in full], send, cat_idx=cat)
+        sends.append(send)
+    recv = torch.stack(sends)
+    compact = [torch.full((5 * B, d), 7.0).cuda() for _ in range(2)]
+    cg = [torch.full((5 * B, d), 7.0).cuda() for _ in range(2)]
+    ops.batch_unpack(lists, recv, G, w, compact, cg)
+    assert cat[:33].tolist() == list(range(3 * B, 3 * B + 33)) and cat[33:33 + 96].tolist() == list(range(4 * B, 5 * B))
+    for s, k in enumerate(("u", "i", "j", "uniq_u", "uniq_i")):
+        live = slice(s * B, s * B + counts[k])
+        dead = slice(s * B + counts[k], (s + 1) * B)
+        for t in range(2):
+            assert torch.equal(compact[t][live], full[t][stage[k][:counts[k]].long()])
+            assert (compact[t][dead] == 7.0).all() and (cg[t][live] == 0.0).all() and (cg[t][dead] == 7.0).all()
+    # scatter: column slice of every live compact row, added to the node's row (duplicates sum)
+    grads = [torch.randn((5 * B, d), generator=gen).cuda() for _ in range(2)]
+    grads[1][: 3 * B] = 0.0
+    for r in range(G):
+        local = [torch.zeros((n, w)).cuda() for _ in range(2)]
+        ops.batch_scatter(lists, list(zip(grads, local)), d, r * w, w)
+        for t in range(2):
+            want = torch.zeros((n, w), dtype=torch.float64)
+            for s, k in enumerate(("u", "i", "j", "uniq_u", "uniq_i")):
+                rows = grads[t][s * B:s * B + counts[k], r * w:(r + 1) * w].double().cpu()
+                want.index_add_(0, stage[k][:counts[k]].long().cpu(), rows)
+            assert rel_err(local[t].cpu().numpy(), want.numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# virtual ranks: G column-sharded trainers on one GPU, their collective done by the driver
+# ---------------------------------------------------------------------------------------------------
+class LockstepGroup:
+    def __init__(self, world):
+        self.world, self.calls = world, []
+
+    def comm(self, rank):
+        group = self
+
+        class Comm:
+            world, rank_ = group.world, rank
+
+            def all_gather(self, out, inp):
+                group.calls.append((rank, out, inp))
+        c = Comm()
+        c.rank = rank
+        return c
+
+    def flush(self):
+        assert sorted(r for r, _, _ in self.calls) == list(range(self.world))
+        ins = [inp for _, _, inp in sorted(self.calls, key=lambda t: t[0])]
+        for _, out, _ in self.calls:
+            for r, inp in enumerate(ins):
+                out.view(self.world, -1)[r].copy_(inp.reshape(-1))
+        self.calls = []
+
+
+def lockstep_step(group, trainers):
+    phases = [tr.step_phases() for tr in trainers]
+    for k in range(len(phases[0])):
+        for ph in phases:
+            ph[k]()
+        if group.calls:
+            group.flush()
+
+
+def gathered(trainers, name):
+    return torch.cat([getattr(tr, name) for tr in trainers], dim=1)
+
+
+def make_kw(name, gm, meta, noise=True):
+    m = meta[name]; c = m["conf"]
+    kw = dict(model=name, n_layers=int(c.get("n_layer", 0)), lr=m["lr"], reg=m["reg"],
+              cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)),
+              tau=float(c.get("tau", c.get("temp", 0.2))), layer_cl=int(c.get("l_star", 1)),
+              drop_rate=float(c.get("drop_rate", 0.1)), batch_size=m["batch"],
+              user_emb=gm[f"{name}_init_user"], item_emb=gm[f"{name}_init_item"])
+    if noise:
+        kw["noise_seed"] = m["noise_seed"]
+    return kw
+
+
+@pytest.mark.parametrize("name,world", [("MF", 2), ("LightGCN", 4), ("XSimGCL", 2), ("XSimGCL", 4), ("XSimGCL", 8),
+                                        ("SimGCL", 4), ("SGL", 8)])
+def test_virtual_ranks_match_reference_run(golden_models, golden_meta, tiny_data, name, world):
+    """Column-sharded over `world` virtual ranks == the reference's own 3 training steps (noise injected)."""
+    gm, meta = golden_models, golden_meta
+    d = meta[name]["emb"]
+    if d % world or d // world not in WIDTHS:
+        pytest.skip(f"d / world = {d}/{world} is not a thin width")
+    group = LockstepGroup(world)
+    trainers = []
+    for r in range(world):
+        kw = make_kw(name, gm, meta)
+        gen = torch.Generator().manual_seed(kw.pop("noise_seed"))      # every rank draws the same noise stream
+        trainers.append(ShardedTrainer(tiny_data, d, layout="cols", comm=group.comm(r),
+                                       noise_fn=lambda shape, gen=gen: torch.rand(shape, generator=gen), **kw))
+    for tr in trainers:
+        assert tr.cols and tr.E0.shape[1] == d // world
+        random.seed(meta[name]["sampler_seed"])
+        tr.seed_sampler_from_python()
+        nb = tr.begin_epoch()
+    bpr, cl = [], []
+    for _ in range(nb):
+        lockstep_step(group, trainers)
+        per_rank = [tr.read_losses() for tr in trainers]
+        for other in per_rank[1:]:
+            np.testing.assert_allclose(other, per_rank[0], rtol=1e-6)     # replicated loss section
+        bpr.append(per_rank[0][0]); cl.append(per_rank[0][2])
+    np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+    if name in ("XSimGCL", "SimGCL"):
+        np.testing.assert_allclose(cl, gm[f"{name}_loss_nce"].reshape(nb, 2).sum(1) * trainers[0].cl_rate, rtol=2e-5)
+    elif name == "SGL":
+        np.testing.assert_allclose(cl, gm[f"{name}_loss_nce"] * trainers[0].cl_rate, rtol=2e-5)
+    U = trainers[0].U
+    E0 = gathered(trainers, "E0").cpu().numpy()
+    assert rel_err(E0[:U], gm[f"{name}_param_user"]) < 1e-4 and rel_err(E0[U:], gm[f"{name}_param_item"]) < 1e-4
+    du = E0[:U] - gm[f"{name}_init_user"]
+    assert np.abs(du - (gm[f"{name}_param_user"] - gm[f"{name}_init_user"])).max() < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, tiny_data, use_graph):
+    """In-kernel noise: the sharded run regenerates exactly the unsharded run's perturbation, eager and as two
+    captured graphs per step with the all-gather between them."""
+    gm, meta = golden_models, golden_meta
+    name, world = "XSimGCL", 4
+    d = meta[name]["emb"]
+    if d // world not in WIDTHS:
+        pytest.skip("thin width")
+    kw = make_kw(name, gm, meta, noise=False)
+    single = FusedTrainer(tiny_data, d, noise_fn=None, use_graph=False, **kw)
+    group = LockstepGroup(world)
+    trainers = [ShardedTrainer(tiny_data, d, layout="cols", comm=group.comm(r), noise_fn=None, use_graph=use_graph, **kw)
+                for r in range(world)]
+    for tr in [single] + trainers:
+        tr.sampler.seed(5)
+    for _ in range(2):
+        nb = single.begin_epoch()
+        for tr in trainers:
+            assert tr.begin_epoch() == nb
+        for _ in range(nb):
+            single.step()
+            lockstep_step(group, trainers)
+    torch.cuda.synchronize()
+    assert trainers[0].step_count == single.step_count == 2 * nb
+    want = single.E0.cpu().numpy()
+    assert np.isfinite(want).all()
+    # (different kernels, different summation orders, 2 epochs of Adam in between: the parity budget, not bitwise)
+    assert rel_err(gathered(trainers, "E0").cpu().numpy(), want) < 1e-4
+    np.testing.assert_allclose(trainers[0].read_losses(), single.read_losses(), rtol=1e-4)

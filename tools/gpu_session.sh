@@ -56,6 +56,12 @@ ncepmc)
     (cd /tmp && SRH_NCE_SPLITS=8 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/ncepmc_$tag -o pmc -- python $OLDPWD/tools/nce_ab.py child 2048 > $OLDPWD/$OUT/ncepmc_$tag.log 2>&1); echo "ncepmc exit $?"
     f=$(find $OUT/ncepmc_$tag -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -i "nce_" | head -8
   done;;
+cols)
+  timeout 600 python -m pytest tests/test_gpu_cols.py -q --tb=short -x -p no:cacheprovider > $OUT/tests_cols.log 2>&1; echo "cols tests exit $?"
+  tail -30 $OUT/tests_cols.log;;
+colsprobe)
+  timeout 600 python tools/cols_probe.py > $OUT/cols_probe.log 2>&1; echo "colsprobe exit $?"; grep -v amdgpu.ids $OUT/cols_probe.log
+  SRH_SPMM_THIN=1 COLS_PROBE_KERNELS_ONLY=1 timeout 600 python tools/cols_probe.py > $OUT/cols_probe_thin.log 2>&1; echo "colsprobe (lane-per-row A/B) exit $?"; grep spmm $OUT/cols_probe_thin.log;;
 ab)
   timeout 600 python tools/spmm_ab.py > $OUT/spmm_ab.log 2>&1; echo "ab exit $?"; tail -45 $OUT/spmm_ab.log;;
 pmcdense)
