@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict_
 
 struct srh_spmm_plan {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
-  int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0;
+  int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0, short_max = 64;
   int32_t flags = 0;               // kernel variant, see spmm_seg_kernel; bit 8 = streaming kernel
   // default kernel: one task per wave; a task list per row-group count (index log2(LPR / 8))
   int32_t n_tasks[5] = {0, 0, 0, 0, 0};         // index 4: 16 rows per wave (LPR = 4: 16-column slices)
@@ -1332,6 +1332,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     const int NC = (two_row ? 2 : 1) * n_col_classes;             // 1, 2 or 4
     int short_max = kShortRow;                                   // A/B knob (non-DEEP kernels take any length)
     if (const char* env = getenv("SRH_SPMM_SHORT")) short_max = std::max(1, atoi(env));
+    p->short_max = short_max;
     std::vector<Seg> coop[4], shorts[4];
     for (const auto& sc : seg_cls) {
       const Seg& sgm = sc.first;

@@ -248,7 +248,7 @@ def test_virtual_ranks_match_reference_run(golden_models, golden_meta, tiny_data
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, tiny_data, use_graph):
+def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, tiny_data, use_graph, monkeypatch):
     """In-kernel noise: the sharded run regenerates exactly the unsharded run's perturbation, eager and as two
     captured graphs per step with the all-gather between them."""
     gm, meta = golden_models, golden_meta
@@ -257,6 +257,8 @@ def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, t
     if d // world not in WIDTHS:
         pytest.skip("thin width")
     kw = make_kw(name, gm, meta, noise=False)
+    if use_graph:
+        monkeypatch.setenv("SRH_SHARDED_GRAPH", "1")          # (sharded steps launch eagerly unless asked)
     single = FusedTrainer(tiny_data, d, noise_fn=None, use_graph=False, **kw)
     group = LockstepGroup(world)
     trainers = [ShardedTrainer(tiny_data, d, layout="cols", comm=group.comm(r), noise_fn=None, use_graph=use_graph, **kw)
@@ -271,9 +273,44 @@ def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, t
             single.step()
             lockstep_step(group, trainers)
     torch.cuda.synchronize()
-    assert trainers[0].step_count == single.step_count == 2 * nb
+    assert trainers[0].step_count == single.step_count == 2 * nb and trainers[0].use_graph == use_graph
     want = single.E0.cpu().numpy()
     assert np.isfinite(want).all()
     # (different kernels, different summation orders, 2 epochs of Adam in between: the parity budget, not bitwise)
     assert rel_err(gathered(trainers, "E0").cpu().numpy(), want) < 1e-4
     np.testing.assert_allclose(trainers[0].read_losses(), single.read_losses(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["XSimGCL", "SGL"])
+def test_cols_layout_through_rccl_single_rank(golden_models, golden_meta, tiny_data, name):
+    """The column-sharded step with its batch-row all-gather going through RCCL ("nccl"), world size 1 (the
+    one rank keeps whole rows): pack -> all_gather_into_tensor -> unpack -> compact-table losses -> scatter
+    reproduce the reference's own 3-step run."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29579")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        gm, meta = golden_models, golden_meta
+        kw = make_kw(name, gm, meta)
+        gen = torch.Generator().manual_seed(kw.pop("noise_seed"))
+        tr = ShardedTrainer(tiny_data, meta[name]["emb"], layout="cols", noise_fn=lambda shape: torch.rand(shape, generator=gen), **kw)
+        assert tr.cols and tr.G == 1 and tr.w == tr.d
+        random.seed(meta[name]["sampler_seed"])
+        tr.seed_sampler_from_python()
+        bpr = []
+        for _ in range(tr.begin_epoch()):
+            tr.step()
+            bpr.append(tr.read_losses()[0])
+        np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+        pu, pi = tr.parameters_full()
+        assert rel_err(pu.cpu().numpy(), gm[f"{name}_param_user"]) < 1e-4
+        assert rel_err(pi.cpu().numpy(), gm[f"{name}_param_item"]) < 1e-4
+        fu, _ = tr.embeddings()
+        assert rel_err(fu.cpu().numpy(), gm[f"{name}_final_user"]) < 1e-4
+    finally:
+        if created:
+            dist.destroy_process_group()

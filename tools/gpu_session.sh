@@ -44,6 +44,8 @@ evalpmc)
   f=$(find $OUT/evalpmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "gemm_nt|topk|mask_kernel|nce_tile" | tee $OUT/evalpmc_summary.txt;;
 sharded1)
   SRH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench_sharded1.log 2> $OUT/bench_sharded1.err; echo "sharded1 exit $?"; tail -3 $OUT/bench_sharded1.err; tail -1 $OUT/bench_sharded1.log | cut -c1-400;;
+sharded1cols)
+  SRH_FORCE_SHARDED=1 SRH_SHARD_LAYOUT=cols timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_sharded1cols.log 2> $OUT/bench_sharded1cols.err; echo "sharded1cols exit $?"; tail -3 $OUT/bench_sharded1cols.err; tail -1 $OUT/bench_sharded1cols.log | cut -c1-700;;
 zipf)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_zipf.hip -o /tmp/gather_zipf 2>/dev/null && timeout 300 /tmp/gather_zipf > $OUT/gather_zipf.log 2>&1; echo "zipf exit $?"; cat $OUT/gather_zipf.log;;
 matrix)
