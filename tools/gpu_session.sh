@@ -44,6 +44,13 @@ evalpmc)
   f=$(find $OUT/evalpmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "gemm_nt|topk|mask_kernel|nce_tile" | tee $OUT/evalpmc_summary.txt;;
 sharded1)
   SRH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench_sharded1.log 2> $OUT/bench_sharded1.err; echo "sharded1 exit $?"; tail -3 $OUT/bench_sharded1.err; tail -1 $OUT/bench_sharded1.log | cut -c1-400;;
+colsprof)
+  # per-kernel times of one rank's share of a column-sharded step (virtual rank 0 of G, stand-in communicator)
+  for G in 2 4 8; do
+    rm -rf $OUT/prof_cols$G; (cd /tmp && COLS_PROBE_WORLDS=$G COLS_PROBE_MODES=eager timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof_cols$G -o trace -- python $OLDPWD/tools/cols_probe.py > $OLDPWD/$OUT/prof_cols$G.log 2>&1); echo "colsprof $G exit $?"
+    f=$(find $OUT/prof_cols$G -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" | grep -v "at::native\|rocclr\|normalize_kernel\|degree_kernel" > $OUT/prof_cols${G}_kernel_stats.txt && head -16 $OUT/prof_cols${G}_kernel_stats.txt
+    find $OUT/prof_cols$G -name "*.db" -size +30M -delete
+  done;;
 sharded1cols)
   SRH_FORCE_SHARDED=1 SRH_SHARD_LAYOUT=cols timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_sharded1cols.log 2> $OUT/bench_sharded1cols.err; echo "sharded1cols exit $?"; tail -3 $OUT/bench_sharded1cols.err; tail -1 $OUT/bench_sharded1cols.log | cut -c1-700;;
 zipf)
