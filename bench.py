@@ -315,7 +315,7 @@ def main():
             ach = alg / t_spmm["dense"] / 1e9
             traffic, traffic_note = pmc_traffic(args) if not sharded else (None, "PMC pass exists for the unsharded launch only")
             out["roofline"] = {"bound": "hbm",
-                               "kernel": (f"{'spmm_thin_kernel<8>' if trainer.w == 8 else f'spmm_slice_kernel<{trainer.w // 4}>'} "
+                               "kernel": (f"{'spmm_pair_kernel' if trainer.w == 8 else f'spmm_slice_kernel<{trainer.w // 4}>'} "
                                           f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
                                           f"{args.emb} columns, perturb epilogue)") if getattr(trainer, "cols", False) else
                                          (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "

@@ -873,19 +873,19 @@ __device__ __forceinline__ void thin_reduce8(const float (&acc)[DL], float (&out
 }
 
 template <int DL>
-__device__ __forceinline__ void thin_perturb(float (&y)[DL / 8], const float (&raw)[DL / 8], int row, int e8,
+__device__ __forceinline__ void thin_perturb(float (&y)[DL / 8], const float (&raw)[DL / 8], int row, int el,
                                              const float* noise, uint32_t off_lo, uint32_t off_hi,
                                              const DevEpilogue& ep) {
   constexpr int EPL = DL / 8;
   const int dfull = ep.noise_d_full;
-  const int e0 = ep.noise_col0 + e8 * EPL;          // first of this lane's columns in the whole row
+  const int e0 = ep.noise_col0 + el * EPL;          // first of this lane's columns in the whole row
   float nu[EPL];
   float ss = 0.f;
   if (noise) {
     const float* nr = noise + (size_t)row * dfull;
     const int per = dfull / 8;                      // this lane's share of the row for the norm
     for (int t = 0; t < per; t += 4) {
-      const float4 z = *reinterpret_cast<const float4*>(nr + e8 * per + t);
+      const float4 z = *reinterpret_cast<const float4*>(nr + el * per + t);
       ss += f4_dot(z, z);
     }
 #pragma unroll
@@ -893,7 +893,7 @@ __device__ __forceinline__ void thin_perturb(float (&y)[DL / 8], const float (&r
   } else {
     uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
     if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
-    for (int sub = e8; sub < dfull / 4; sub += 8) {
+    for (int sub = el; sub < dfull / 4; sub += 8) {
       const uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
       const float4 z = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
       ss += f4_dot(z, z);
@@ -909,10 +909,11 @@ __device__ __forceinline__ void thin_perturb(float (&y)[DL / 8], const float (&r
 }
 
 template <int DL>
-__device__ __forceinline__ void thin_epilogue(float (&y)[DL / 8], int row, int e8, bool store, float* __restrict__ Y,
+__device__ __forceinline__ void thin_epilogue(float (&y)[DL / 8], int row, int el, bool store, float* __restrict__ Y,
                                               const DevEpilogue& ep) {
+  // el: which EPL columns of the slice this lane holds -- any bijection of 0..7 over the 8 lanes of a group
   constexpr int EPL = DL / 8;
-  const size_t at = (size_t)row * DL + e8 * EPL;
+  const size_t at = (size_t)row * DL + el * EPL;
   if (ep.flags & SRH_EPI_AXPY) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) y[i] *= ep.alpha;
@@ -929,10 +930,10 @@ __device__ __forceinline__ void thin_epilogue(float (&y)[DL / 8], int row, int e
     float raw[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) raw[i] = y[i];
-    if (!ep.main_clean) thin_perturb<DL>(y, raw, row, e8, ep.noise, ep.off_lo, ep.off_hi, ep);
+    if (!ep.main_clean) thin_perturb<DL>(y, raw, row, el, ep.noise, ep.off_lo, ep.off_hi, ep);
     for (int k = 0; k < ep.n_extra; ++k) {
       float yk[EPL];
-      thin_perturb<DL>(yk, raw, row, e8, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
+      thin_perturb<DL>(yk, raw, row, el, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
       if (store) st_epl<EPL>(ep.extra_out[k] + at, yk);
     }
   }
@@ -1038,6 +1039,124 @@ __global__ __launch_bounds__(256) void spmm_thin_kernel(const Task* __restrict__
   thin_epilogue<DL>(out, row, e8, live, Y, ep);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 8-column slices, two lanes per x row.  Where the time of spmm_thin_kernel<8> goes was measured by
+// knocking parts out (Yelp2018 shape, 23.5 us): without the x gathers 11.0, without the (col, val) loads
+// 21.1, without both 10.2 -- the gathers cost 12.5 us, and they cost it per L1 LOOK-UP (a lane that owns
+// a 32-byte row issues two 16-byte loads = two look-ups of the same line), not per byte.  Here the two
+// lanes of a pair fetch the two halves of a row with ONE instruction -- one look-up per entry -- and
+// 4 pairs share a short row (entries p, p + 4, ...), 32 pairs a long one; a lane keeps 4 partial sums,
+// and a 2-step butterfly over the 4 pairs (xor 4, xor 2) leaves each lane one column of the row.
+// 60 VGPRs instead of 90: 8 waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                        const Seg* __restrict__ segs,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals, const float* __restrict__ X,
+                                                        float* __restrict__ Y, float* __restrict__ partial,
+                                                        const Heavy* __restrict__ heavy,
+                                                        const int32_t* __restrict__ slot_owner,
+                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
+  constexpr int DL = 8;
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, e8 = lane & 7, h = lane & 1, pg = e8 >> 1;     // group, lane in group, half, pair in group
+  const bool b2 = (e8 & 4) != 0, b1 = (e8 & 2) != 0;
+  const int el = h * 4 + (b2 ? 2 : 0) + (b1 ? 1 : 0);                      // the column this lane ends up with
+  const Task tk = tasks[wave];
+  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
+  const int first = __builtin_amdgcn_readfirstlane(tk.first);
+  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const float4* Xh = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + h * 16);
+  float4 acc = f4_zero();
+
+  // 8 entries of this pair: j, j + stride, ...
+  auto accumulate = [&](int j, int stride, int e) {
+    int c[8];
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int jj = j + k * stride;
+      c[k] = 0;
+      v[k] = 0.f;
+      if (jj < e) { c[k] = indices[jj]; v[k] = vals[jj]; }
+    }
+    if (ep.col_mark) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (v[k] != 0.f && ep.col_mark[c[k]] != stamp) v[k] = 0.f;
+    }
+    float4 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      x[k] = f4_zero();
+      if (v[k] != 0.f)
+        x[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Xh) + (unsigned)c[k] * 32u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = f4_fma(v[k], x[k], acc);
+  };
+  // sum over the 4 pairs of a group; afterwards lane (h, b2, b1) holds column h*4 + 2*b2 + b1
+  auto reduce4 = [&]() {
+    const float k0 = b2 ? acc.z : acc.x, k1 = b2 ? acc.w : acc.y;
+    const float s0 = b2 ? acc.x : acc.z, s1 = b2 ? acc.y : acc.w;
+    const float a0 = k0 + __shfl_xor(s0, 4), a1 = k1 + __shfl_xor(s1, 4);
+    const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
+    return keep + __shfl_xor(send, 2);
+  };
+  float out[1];
+
+  if (kind == 0) {
+    const Seg sg = segs[first];
+    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
+    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    for (int base = s; base < e; base += 256) accumulate(base + (lane >> 1), 32, e);
+    out[0] = reduce4();
+    out[0] += __shfl_xor(out[0], 8);
+    out[0] += __shfl_xor(out[0], 16);
+    out[0] += __shfl_xor(out[0], 32);
+    if (slot < 0) {
+      thin_epilogue<DL>(out, row, el, g == 0, Y, ep);
+      return;
+    }
+    if (g == 0) st_epl_sc1<1>(partial + (size_t)slot * DL + el, out);
+    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+    const Heavy hv = heavy[hid];
+    const int hfirst = __builtin_amdgcn_readfirstlane(hv.first_slot);
+    const int hn = __builtin_amdgcn_readfirstlane(hv.n_slots);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != hn - 1) return;
+    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    float sum[1] = {0.f};
+    for (int t = g; t < hn; t += 8) {
+      float pz[1];
+      ld_epl_agent<1>(partial + (size_t)(hfirst + t) * DL + el, pz);
+      sum[0] += pz[0];
+    }
+    sum[0] += __shfl_xor(sum[0], 8);
+    sum[0] += __shfl_xor(sum[0], 16);
+    sum[0] += __shfl_xor(sum[0], 32);
+    thin_epilogue<DL>(sum, row, el, g == 0, Y, ep);
+    return;
+  }
+
+  // ---- one short row per 8-lane group, 4 pairs striding over its entries ----
+  const bool have = g < count;
+  const Seg sg = segs[first + (have ? g : 0)];
+  const int row = sg.row, s = sg.start;
+  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
+  const int e = live ? sg.end : s;
+  for (int base = s; __any(base < e); base += 32) accumulate(base + pg, 4, e);
+  out[0] = reduce4();
+  thin_epilogue<DL>(out, row, el, live, Y, ep);
+}
 
 // ---------------------------------------------------------------------------------------------
 // 16- and 32-column slices (column-sharded layout at G = 4 / 2 for d = 64): spmm_rows_kernel's
@@ -1636,7 +1755,11 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
   spmm_thin_kernel<DLV><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(                                              \
       plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, d_x, d_y, plan->d_partial, plan->d_heavy, \
       plan->d_slot_owner, plan->d_tickets, ep)
-    if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
+    if (d == 8 && !(plan->flags & 32))
+      spmm_pair_kernel<<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices,
+                                                                 d_vals, d_x, d_y, plan->d_partial, plan->d_heavy,
+                                                                 plan->d_slot_owner, plan->d_tickets, ep);
+    else if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
 #undef SRH_THIN
     SRH_LAUNCH_CHECK();
     return SRH_OK;

@@ -200,11 +200,12 @@ class FusedTrainer:
         self.step_count = 0
         # (a sharded step is captured only on request: RCCL collectives inside a hipGraph could not be
         # exercised beyond one rank on the development box)
-        # Column-sharded steps capture as two graphs with the one all-gather issued between them (measured on
-        # one GPU with a stand-in communicator: 252 us captured against 239 us eager per step at 8 ranks --
-        # the kernels are long enough for the host to stay ahead), so both sharded layouts launch eagerly unless asked.
-        multi = self.sharded or self.cols
-        self.use_graph = bool(use_graph) and (not multi or os.environ.get("SRH_SHARDED_GRAPH") == "1")
+        # Column-sharded steps capture as TWO graphs with the one all-gather issued between them, so RCCL stays
+        # outside the captured region (one GPU, stand-in communicator, 8 ranks: 197 us captured, 211 us eager);
+        # SRH_SHARDED_GRAPH=0 launches eagerly.  The row-sharded step has a collective after every product: it
+        # launches eagerly unless SRH_SHARDED_GRAPH=1 asks for RCCL inside the capture.
+        env = os.environ.get("SRH_SHARDED_GRAPH")
+        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols) or env == "1" or (self.cols and env != "0"))
         self._graph = None
         self._noise_call = 0
         if self.cols:
@@ -632,7 +633,16 @@ class FusedTrainer:
             raise SelfrecHipError("call begin_epoch() first")
         graphed = self.use_graph and self.noise_fn is None
         if graphed and self._graph is None:
-            self._capture()
+            try:
+                self._capture()
+            except RuntimeError as e:
+                if not (self.sharded or self.cols):
+                    raise
+                # (a capture next to a live process group is the one thing that could not be exercised beyond one
+                # rank here: fall back to eager launches rather than lose the run -- the state is the snapshot's)
+                import sys
+                print(f"[selfrec_amd] hipGraph capture failed on rank {self.rank} ({e}); launching eagerly", file=sys.stderr)
+                self.use_graph, self._graph, graphed = False, None, False
 
         def done():
             self.step_count += 1

@@ -257,8 +257,7 @@ def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, t
     if d // world not in WIDTHS:
         pytest.skip("thin width")
     kw = make_kw(name, gm, meta, noise=False)
-    if use_graph:
-        monkeypatch.setenv("SRH_SHARDED_GRAPH", "1")          # (sharded steps launch eagerly unless asked)
+    monkeypatch.setenv("SRH_SHARDED_GRAPH", "1" if use_graph else "0")
     single = FusedTrainer(tiny_data, d, noise_fn=None, use_graph=False, **kw)
     group = LockstepGroup(world)
     trainers = [ShardedTrainer(tiny_data, d, layout="cols", comm=group.comm(r), noise_fn=None, use_graph=use_graph, **kw)

@@ -63,7 +63,6 @@ if False:
 
 if os.environ.get("COLS_PROBE_KERNELS_ONLY"):
     sys.exit(0)
-os.environ["SRH_SHARDED_GRAPH"] = "1"        # (let use_graph decide below)
 kw = dict(model="XSimGCL", n_layers=3, layer_cl=1, eps=0.2, cl_rate=0.2, tau=0.2, batch_size=2048)
 worlds = [int(w) for w in os.environ.get("COLS_PROBE_WORLDS", "1,2,4,8").split(",")]
 modes = [m == "graph" for m in os.environ.get("COLS_PROBE_MODES", "graph,eager").split(",")]
