@@ -1050,26 +1050,19 @@ __global__ __launch_bounds__(256) void spmm_thin_kernel(const Task* __restrict__
 // and a 2-step butterfly over the 4 pairs (xor 4, xor 2) leaves each lane one column of the row.
 // 60 VGPRs instead of 90: 8 waves per SIMD.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__ tasks, int n_tasks,
-                                                        const Seg* __restrict__ segs,
-                                                        const int32_t* __restrict__ indices,
-                                                        const float* __restrict__ vals, const float* __restrict__ X,
-                                                        float* __restrict__ Y, float* __restrict__ partial,
-                                                        const Heavy* __restrict__ heavy,
-                                                        const int32_t* __restrict__ slot_owner,
-                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
+// one task of spmm_pair_kernel: tk / sg are this lane's copies of the task record and of its segment
+// (kind 0: the wave's one segment; kind 1: the short row of the lane's 8-lane group)
+__device__ __forceinline__ void pair_task(const Task& tk, const Seg& sgl, const int32_t* __restrict__ indices,
+                                          const float* __restrict__ vals, const float* __restrict__ X,
+                                          float* __restrict__ Y, float* __restrict__ partial,
+                                          const Heavy* __restrict__ heavy, const int32_t* __restrict__ slot_owner,
+                                          int32_t* __restrict__ tickets, const DevEpilogue& ep, int stamp, int lane) {
   constexpr int DL = 8;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_tasks) return;
-  const int lane = threadIdx.x & 63;
   const int g = lane >> 3, e8 = lane & 7, h = lane & 1, pg = e8 >> 1;     // group, lane in group, half, pair in group
   const bool b2 = (e8 & 4) != 0, b1 = (e8 & 2) != 0;
   const int el = h * 4 + (b2 ? 2 : 0) + (b1 ? 1 : 0);                      // the column this lane ends up with
-  const Task tk = tasks[wave];
   const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
-  const int first = __builtin_amdgcn_readfirstlane(tk.first);
   const int count = __builtin_amdgcn_readfirstlane(tk.count);
-  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
   const float4* Xh = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + h * 16);
   float4 acc = f4_zero();
 
@@ -1110,9 +1103,8 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__
   float out[1];
 
   if (kind == 0) {
-    const Seg sg = segs[first];
-    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
-    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    const int row = __builtin_amdgcn_readfirstlane(sgl.row), s = __builtin_amdgcn_readfirstlane(sgl.start);
+    const int e = __builtin_amdgcn_readfirstlane(sgl.end), slot = __builtin_amdgcn_readfirstlane(sgl.slot);
     if (ep.row_mark && ep.row_mark[row] != stamp) return;
     for (int base = s; base < e; base += 256) accumulate(base + (lane >> 1), 32, e);
     out[0] = reduce4();
@@ -1149,13 +1141,32 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__
 
   // ---- one short row per 8-lane group, 4 pairs striding over its entries ----
   const bool have = g < count;
-  const Seg sg = segs[first + (have ? g : 0)];
-  const int row = sg.row, s = sg.start;
+  const int row = sgl.row, s = sgl.start;
   const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
-  const int e = live ? sg.end : s;
+  const int e = live ? sgl.end : s;
   for (int base = s; __any(base < e); base += 32) accumulate(base + pg, 4, e);
   out[0] = reduce4();
   thin_epilogue<DL>(out, row, el, live, Y, ep);
+}
+
+__global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__ tasks, int n_tasks,
+                                                        const Seg* __restrict__ segs,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ vals, const float* __restrict__ X,
+                                                        float* __restrict__ Y, float* __restrict__ partial,
+                                                        const Heavy* __restrict__ heavy,
+                                                        const int32_t* __restrict__ slot_owner,
+                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
+  // (one task per wave: giving a wave 2 / 4 tasks with their records fetched up front -- half / a quarter of the
+  // waves, two round trips saved per extra task -- measured 22.9 / 22.8 us against 19.1: this launch wants MORE
+  // waves in flight, not fewer)
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const Task tk = tasks[wave];
+  const Seg sg = segs[tk.first + ((tk.kind == 1 && (lane >> 3) < tk.count) ? (lane >> 3) : 0)];
+  pair_task(tk, sg, indices, vals, X, Y, partial, heavy, slot_owner, tickets, ep, stamp, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1358,6 +1369,7 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
   if (split_len <= 0) split_len = 512;
+  if (const char* env = getenv("SRH_SPMM_SPLIT")) split_len = std::max(64, atoi(env) / 64 * 64);      // A/B knob
   SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
   SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
   SRH_REQUIRE(xcd_split_row >= 0 && xcd_split_row <= n_rows, "spmm_plan_create: xcd_split_row out of range");
@@ -1755,11 +1767,11 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
   spmm_thin_kernel<DLV><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(                                              \
       plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, d_x, d_y, plan->d_partial, plan->d_heavy, \
       plan->d_slot_owner, plan->d_tickets, ep)
-    if (d == 8 && !(plan->flags & 32))
+    if (d == 8 && !(plan->flags & 32)) {
       spmm_pair_kernel<<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices,
                                                                  d_vals, d_x, d_y, plan->d_partial, plan->d_heavy,
                                                                  plan->d_slot_owner, plan->d_tickets, ep);
-    else if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
+    } else if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
 #undef SRH_THIN
     SRH_LAUNCH_CHECK();
     return SRH_OK;
