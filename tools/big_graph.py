@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE.json config 4 on ONE MI355X: XSimGCL, synthetic 1 M users x 500 k items, d=128, E = 50 M
 interactions (avg user degree 50; the config leaves E open).  The config is specified for 8 GPUs with the
-table row-sharded; on 288 GB it also fits one GPU, which is what this measures."""
+table sharded; on 288 GB it also fits one GPU, which is what this measures -- followed by ONE rank's share of
+the column-sharded step at 4 and 8 ranks (rank 0 with a stand-in communicator: same kernels and bytes as on
+an 8-GPU node, no wire time; BIG_COLS_WORLDS=4,8)."""
 import os
 import sys
 import time
@@ -39,3 +41,36 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"XSimGCL 1M x 500k d=128 L=3: {dt * 1e3:.2f} ms/step  {2048 / dt / 1e3:.1f} k pairs/s  losses={tr.read_losses()} "
       f"finite={bool(torch.isfinite(tr.E0).all())}", flush=True)
+
+del tr
+torch.cuda.empty_cache()
+
+
+class SelfComm:
+    def __init__(self, world):
+        self.world, self.rank = world, 0
+
+    def all_gather(self, out, inp):
+        out.view(self.world, -1).copy_(inp.reshape(1, -1).expand(self.world, -1))
+
+
+from selfrec_amd.dist import ShardedTrainer  # noqa: E402
+for world in [int(w) for w in os.environ.get("BIG_COLS_WORLDS", "4,8").split(",") if w]:
+    t0 = time.time()
+    tr = ShardedTrainer(data, 128, layout="cols", comm=SelfComm(world), model="XSimGCL", n_layers=3, layer_cl=1, eps=0.2,
+                        cl_rate=0.2, tau=0.2, batch_size=2048, use_graph=True)
+    tr.sampler.seed(1)
+    tr.upload_epoch(host if not tr.sharded else tr.sample_epoch_host())
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"column-sharded, rank 0 of {world} (w = {tr.w} columns, no wire time): {dt * 1e3:.2f} ms/step  "
+          f"{2048 / dt / 1e3:.1f} k pairs/s  losses={tr.read_losses()} finite={bool(torch.isfinite(tr.E0).all())}  "
+          f"HBM in use {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
+    del tr
+    torch.cuda.empty_cache()
