@@ -222,6 +222,38 @@ def eval_throughput(trainer, data, k=20):
             "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS}
 
 
+def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
+    """Full-rank evaluation over N GPUs: the item table is replicated (`embeddings()` gathers it),
+    the test users are dealt over the ranks, every rank scores / masks / ranks its share, and the ranked ids meet on
+    every rank with one all-gather.  users/s = all test users / the slowest rank's time, D2H of its share included."""
+    import numpy as np
+    from selfrec_amd.base.graph_recommender import GraphRecommender
+    users = list(data.test_set)
+    if not users:
+        return None
+    rec = GraphRecommender.__new__(GraphRecommender)
+    rec.data, rec.max_N = data, k
+    rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())      # (a collective when sharded)
+    uid = [data.user[u] for u in users]
+    mine = uid[rank::world]
+    n_max = (len(uid) + world - 1) // world
+    rec.rank_on_device(mine[:256])                                                   # warm-up
+    pad = torch.full((n_max, k), -1, dtype=torch.int32, device="cuda")
+    everyone = torch.empty((world * n_max, k), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.time()
+    ids, _ = rec.rank_on_device(mine)
+    pad[:len(mine)] = torch.from_numpy(np.ascontiguousarray(ids)).to("cuda")
+    dist.all_gather_into_tensor(everyone, pad)
+    torch.cuda.synchronize()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranked = int((everyone[:, 0] >= 0).sum().item())
+    return {"users": len(uid), "k": k, "users_ranked_and_gathered": ranked,
+            "device_users_per_s": round(len(uid) / float(t.item()), 1),
+            "note": f"test users dealt over {world} ranks, item table replicated, ranked ids all-gathered; slowest rank's time"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -340,6 +372,11 @@ def main():
             if out.get("eval"):
                 out["eval"]["cpu_baseline"] = eval_cpu_baseline(trainer, data)
     if dist is not None:
+        dist.barrier()
+        if not args.no_eval:
+            ev = eval_throughput_sharded(trainer, data, dist, rank, world)      # every rank takes part
+            if rank == 0:
+                out["eval"] = ev
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
