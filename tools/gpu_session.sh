@@ -82,6 +82,15 @@ pmcdense)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" --tail 40 | grep spmm_rows > $OUT/pmcdense_$tag.summary.txt; cat $OUT/pmcdense_$tag.summary.txt
     find $OUT/pmcdense_$tag -name "*.db" -size +40M -delete
   done;;
+pmccols)
+  # SpMM launches of the column-sharded layout: HBM-side traffic and issue counters, one counter group per pass
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"; do
+    tag=$(echo $c | tr ' ' '_' | cut -c1-40); rm -rf $OUT/pmccols_$tag
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmccols_$tag -o pmc -- python $OLDPWD/tools/spmm_pmc_cols.py > $OLDPWD/$OUT/pmccols_$tag.log 2>&1); echo "pmccols $c exit $?"
+    f=$(find $OUT/pmccols_$tag -name "*.db" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" --tail 30 | grep "spmm_" > $OUT/pmccols_$tag.summary.txt; cat $OUT/pmccols_$tag.summary.txt
+    find $OUT/pmccols_$tag -name "*.db" -size +30M -delete
+  done;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $c | tr ' ' '_'); rm -rf $OUT/pmc_$tag
