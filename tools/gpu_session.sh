@@ -51,6 +51,10 @@ colsprof)
     f=$(find $OUT/prof_cols$G -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" | grep -v "at::native\|rocclr\|normalize_kernel\|degree_kernel" > $OUT/prof_cols${G}_kernel_stats.txt && head -16 $OUT/prof_cols${G}_kernel_stats.txt
     find $OUT/prof_cols$G -name "*.db" -size +30M -delete
   done;;
+profcols1)
+  rm -rf $OUT/profcols1; (cd /tmp && SRH_FORCE_SHARDED=1 SRH_SHARD_LAYOUT=cols timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profcols1 -o trace -- python $OLDPWD/bench.py --steps 300 --warmup 30 --no-cpu-baseline > $OLDPWD/$OUT/profcols1.log 2>&1); echo "profcols1 exit $?"
+  f=$(find $OUT/profcols1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py "$f" > $OUT/profcols1_kernel_stats.txt && head -24 $OUT/profcols1_kernel_stats.txt; tail -1 $OUT/profcols1.log | cut -c1-300
+  find $OUT/profcols1 -name "*.db" -size +30M -delete;;
 sharded1cols)
   SRH_FORCE_SHARDED=1 SRH_SHARD_LAYOUT=cols timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_sharded1cols.log 2> $OUT/bench_sharded1cols.err; echo "sharded1cols exit $?"; tail -3 $OUT/bench_sharded1cols.err; tail -1 $OUT/bench_sharded1cols.log | cut -c1-700;;
 zipf)
