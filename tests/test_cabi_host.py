@@ -140,3 +140,42 @@ def test_column_class_order_is_a_stable_partition_of_long_rows():
         else:
             assert np.array_equal(new_row, old_row)
             assert row_mid[r] == (-2 if (old_row % 2 == 1).sum() > (old_row % 2 == 0).sum() else -1)
+
+
+def test_exchange_entry_points_validate_their_arguments_before_any_launch():
+    """srh_batch_pack / unpack / scatter (column-sharded layout) reject bad arguments with a message instead of
+    launching: checked here without a GPU (nothing below reaches a kernel)."""
+    import ctypes as C
+    lib = _lib.load()
+    assert lib.srh_batch_pack(None, 1, None, 8, None, None, None, None) == -1
+    assert b"null lists" in lib.srh_last_error_string()
+    bl = _lib.BatchLists()
+    bl.B = 0
+    assert lib.srh_batch_pack(C.byref(bl), 1, None, 8, None, None, None, None) == -1
+    assert b"bad batch size" in lib.srh_last_error_string()
+    bl.B = 16
+    assert lib.srh_batch_pack(C.byref(bl), 1, None, 8, None, None, None, None) == -1
+    assert b"null index list" in lib.srh_last_error_string()
+    fake = (C.c_int32 * 16)()
+    for s in range(5):
+        bl.d_idx[s] = C.cast(fake, C.c_void_p)
+    tabs = (C.c_void_p * 1)(C.cast(fake, C.c_void_p))
+    assert lib.srh_batch_pack(C.byref(bl), 1, tabs, 6, C.cast(fake, C.c_void_p), None, None, None) == -1
+    assert b"multiple of 4" in lib.srh_last_error_string()
+    assert lib.srh_batch_pack(C.byref(bl), _lib.SRH_MAX_EXCHANGE + 1, tabs, 8, C.cast(fake, C.c_void_p), None, None, None) == -1
+    assert lib.srh_batch_unpack(C.byref(bl), 5, 2, 8, C.cast(fake, C.c_void_p), tabs, 4, tabs, None) == -1
+    assert b"tables + gradient tables" in lib.srh_last_error_string()
+    assert lib.srh_batch_scatter(C.byref(bl), 1, tabs, tabs, 64, 60, 8, None) == -1
+    assert b"outside 64 columns" in lib.srh_last_error_string()
+    # the epilogue's column-slice fields are validated the same way
+    ep = _lib.SpmmEpilogue()
+    ep.noise_d_full, ep.noise_col0 = 64, 4
+    plan = C.c_void_p()
+    indptr = np.array([0, 1, 2], dtype=np.int32)
+    if lib.srh_device_count() < 1:
+        return                     # (creating a plan allocates device memory)
+    _lib.check(lib.srh_spmm_plan_create(C.byref(plan), 2, 2, indptr.ctypes.data_as(C.c_void_p), 0, 0, None))
+    assert lib.srh_spmm_f32(plan, None, C.cast(fake, C.c_void_p), C.cast(fake, C.c_void_p), C.cast(fake, C.c_void_p),
+                            C.cast((C.c_int32 * 16)(), C.c_void_p), 8, C.byref(ep), None) == -1
+    assert b"column slice" in lib.srh_last_error_string()
+    lib.srh_spmm_plan_destroy(plan)
