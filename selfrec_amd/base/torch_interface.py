@@ -65,6 +65,16 @@ class SparseAdjHandle:
     def _nnz(self):
         return self.csr.nnz
 
+    # BUIR.py:118-127 / MixGCF.py:84-94 drop entries of the adjacency themselves: they read the COO parts of the
+    # tensor and build a new torch sparse tensor, which then multiplies through torch (outside the accelerated path)
+    def _indices(self):
+        if getattr(self, "_coo_idx", None) is None:
+            self._coo_idx = self.to_sparse_coo()._indices()
+        return self._coo_idx
+
+    def _values(self):
+        return self.csr.vals
+
     def transposed(self):
         if self._symmetric:
             return self

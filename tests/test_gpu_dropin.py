@@ -104,3 +104,21 @@ def test_sgl_style_views_stay_on_device(golden_ops, tiny_data):
     ref = O.info_nce(a, torch.tensor(got[:300]), 0.2); ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
     assert rel_err(v1.grad.cpu().numpy(), a.grad.numpy()) < 2e-5
+
+
+def test_handle_exposes_the_coo_parts_for_sparse_dropout_models(fresh_tiny_data):
+    """BUIR.py:118-127 / MixGCF.py:84-94 read ``_nnz() / _indices() / _values()`` of the uploaded adjacency and
+    build their own (dropped) torch sparse tensor: the handle serves the same entries as the reference's COO tensor."""
+    data = fresh_tiny_data
+    h = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj).cuda()
+    coo = data.norm_adj.tocsr()
+    coo.sort_indices()
+    coo = coo.tocoo()
+    i, v = h._indices(), h._values()
+    assert h._nnz() == coo.nnz and i.shape == (2, coo.nnz) and i.dtype == torch.int64
+    assert np.array_equal(i.cpu().numpy(), np.stack([coo.row, coo.col])) and np.array_equal(v.cpu().numpy(), coo.data)
+    keep = torch.rand(h._nnz(), device=h.device) < 0.7          # the models' own dropout, then a torch product
+    dropped = torch.sparse_coo_tensor(i[:, keep], v[keep], tuple(h.shape)) * (1.0 / 0.7)
+    x = torch.randn((h.shape[0], 8), device=h.device)
+    want = torch.sparse.mm(dropped, x)
+    assert want.shape == (h.shape[0], 8) and torch.isfinite(want).all()
