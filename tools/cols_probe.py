@@ -63,7 +63,10 @@ if False:
 
 if os.environ.get("COLS_PROBE_KERNELS_ONLY"):
     sys.exit(0)
-kw = dict(model="XSimGCL", n_layers=3, layer_cl=1, eps=0.2, cl_rate=0.2, tau=0.2, batch_size=2048)
+model = os.environ.get("COLS_PROBE_MODEL", "XSimGCL")
+kw = dict(model=model, n_layers=3, layer_cl=1, eps=0.2, cl_rate=0.2 if model != "SGL" else 0.1, tau=0.2, drop_rate=0.1,
+          batch_size=2048)
+print(f"# {model} L=3, B=2048")
 worlds = [int(w) for w in os.environ.get("COLS_PROBE_WORLDS", "1,2,4,8").split(",")]
 modes = [m == "graph" for m in os.environ.get("COLS_PROBE_MODES", "graph,eager").split(",")]
 for world in worlds:
