@@ -187,7 +187,7 @@ typedef struct srh_spmm_epilogue {
   const float* d_extra_noise[SRH_MAX_EXTRA];
   uint64_t extra_rng_offset[SRH_MAX_EXTRA];
   /* Column-sharded tables (multi-GPU): y / x / every epilogue tensor hold columns
-   * [noise_col0, noise_col0 + d) of rows that are noise_d_full wide on the whole job (d in {8, 16, 32}).
+   * [noise_col0, noise_col0 + d) of rows that are noise_d_full wide on the whole job (any supported d).
    * Only PERTURB cares: its unit vector is normalised over the WHOLE row (XSimGCL.py:90), so d_noise /
    * d_extra_noise are (n_rows, noise_d_full) and the counter RNG regenerates the other ranks' columns.
    * 0 = the rows are d wide (everything above). */

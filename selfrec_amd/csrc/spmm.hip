@@ -1697,9 +1697,9 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     ep.add_mark = epi->d_add_mark;
     ep.add_sparse = epi->add_sparse_mask;
     if (epi->noise_d_full) {       // y is a column slice of noise_d_full-wide rows (column-sharded tables)
-      SRH_REQUIRE(d <= 32 && epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
+      SRH_REQUIRE(epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
                       epi->noise_col0 + d <= epi->noise_d_full,
-                  "spmm_f32: column slice [%d, %d) of %d-wide rows is not supported (slices of 8, 16 or 32 columns)",
+                  "spmm_f32: column slice [%d, %d) of %d-wide rows is not supported (aligned slices of rows a multiple of 32 wide)",
                   epi->noise_col0, epi->noise_col0 + d, epi->noise_d_full);
       ep.noise_d_full = epi->noise_d_full;
       ep.noise_col0 = epi->noise_col0;

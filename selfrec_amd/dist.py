@@ -1,7 +1,7 @@
 """(e) Multi-GPU: the fused step over the GPUs of one node -- one process per GPU, ``torch.distributed``
 (backend "nccl" = RCCL over xGMI).  Two LAYOUTS of ``engine.FusedTrainer`` (not second engines):
 
-**"cols" -- column-sharded tables (the default whenever d / G is 8, 16 or 32).**  Rank r keeps columns
+**"cols" -- column-sharded tables (the default whenever d / G is 8, 16, 32, 64 or 128).**  Rank r keeps columns
 [r.w, (r+1).w), w = d / G, of every (N, d) table -- parameters, Adam moments, layer outputs, gradient
 buffers -- and the whole graph (Yelp2018 shape: 26 MB; the 1 M x 500 k graph: 1 GB of 288 GB).
 
@@ -21,7 +21,7 @@ N.d.4 bytes per step (17.8 MB each at the Yelp2018 shape against a 0.32 ms step)
 < 1 MB per step instead, and every rank still streams the (col, val) arrays -- the price: the index stream
 is read G times in total, and gathered x rows are 32 .. 128 bytes.
 
-**"rows" -- row-sharded graph and tables (for d / G outside the thin kernel's widths).**
+**"rows" -- row-sharded graph and tables (for d / G outside those widths, e.g. 3 ranks).**
 Nodes are dealt round-robin (node p -> rank p % G, local row p // G: power-law rows balance
 without a partitioner), every (.., d) table is kept in all-gather order, each rank owns one slice of
 the parameters, the Adam moments and every layer output, and computes it with the same kernels from
@@ -47,18 +47,19 @@ import os
 
 import torch.distributed as _dist
 
-from .engine import THIN_WIDTHS, FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacency: public helper)
+from .engine import SLICE_WIDTHS, FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacency: public helper)
 
 
 def pick_layout(emb_size: int, world: int, layout: str | None = None) -> str:
-    """"cols" whenever the column slice d / world is a width the thin SpMM kernel serves, else "rows".
+    """"cols" whenever the column slice d / world is a width the SpMM kernels serve, else "rows".
     ``layout`` / ``SRH_SHARD_LAYOUT`` = rows | cols | auto overrides."""
     layout = (layout or os.environ.get("SRH_SHARD_LAYOUT") or "auto").lower()
     if layout in ("rows", "cols"):
         return layout
     if layout != "auto":
         raise ValueError(f"shard layout {layout!r}: rows, cols or auto")
-    return "cols" if emb_size % world == 0 and emb_size // world in THIN_WIDTHS else "rows"
+    # (a single rank has nothing to split: "auto" keeps it on the row layout's code path, "cols" can still be asked for)
+    return "cols" if world > 1 and emb_size % world == 0 and emb_size // world in SLICE_WIDTHS else "rows"
 
 
 class ShardedTrainer(FusedTrainer):

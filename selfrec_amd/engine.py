@@ -44,7 +44,7 @@ from . import ops
 from ._lib import SelfrecHipError
 
 MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
-THIN_WIDTHS = (8, 16, 32)        # column slices the thin SpMM kernel serves (csrc/spmm.hip)
+SLICE_WIDTHS = (8, 16, 32, 64, 128)   # column slices the SpMM kernels serve (csrc/spmm.hip: pair, slice<4/8>, rows<16/32>)
 
 
 class TorchComm:
@@ -126,8 +126,8 @@ class FusedTrainer:
         if self.cols:
             # (a single rank keeps whole rows: the layout then only adds the batch-row exchange -- a way to run
             # this code path, collective included, on one GPU)
-            if d % self.G or ((d // self.G) not in THIN_WIDTHS and self.G > 1):
-                raise SelfrecHipError(f"column-sharded layout: d / world = {d}/{self.G} must be one of {THIN_WIDTHS}")
+            if d % self.G or ((d // self.G) not in SLICE_WIDTHS and self.G > 1):
+                raise SelfrecHipError(f"column-sharded layout: d / world = {d}/{self.G} must be one of {SLICE_WIDTHS}")
             self.w = d // self.G
         self.col0 = self.rank * self.w if self.cols else 0
         G = self.G if self.sharded else 1                # ranks the ROWS are dealt over

@@ -118,4 +118,5 @@ def test_shard_adjacency_layout():
 def test_layout_choice():
     from selfrec_amd.dist import pick_layout
     assert [pick_layout(64, w) for w in (1, 2, 3, 4, 8, 16)] == ["rows", "cols", "rows", "cols", "cols", "rows"]
-    assert pick_layout(128, 8) == "cols" and pick_layout(128, 2) == "rows" and pick_layout(64, 2, "rows") == "rows"
+    assert pick_layout(128, 8) == "cols" and pick_layout(128, 2) == "cols" and pick_layout(64, 2, "rows") == "rows"
+    assert pick_layout(256, 8) == "cols" and pick_layout(128, 3) == "rows"

@@ -313,3 +313,24 @@ def test_cols_layout_through_rccl_single_rank(golden_models, golden_meta, tiny_d
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_wide_slices_of_wider_rows(csr_case):
+    """64 of 128 columns (d = 128 over 2 ranks) runs the 16-lane row kernel on a slice: PERTURB still normalises over
+    the whole 128-wide row -- every slice equals the same columns of the d = 128 launch."""
+    m, csr, _ = csr_case
+    n = m.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((n, 128), device="cuda", generator=gen)
+    noise = torch.rand((n, 128), device="cuda", generator=gen)
+    step = torch.tensor([2], dtype=torch.int64, device="cuda")
+    wide_n = ops.spmm(csr, x, epilogue=ops.make_epilogue(perturb_eps=0.2, noise=noise))
+    wide_r = ops.spmm(csr, x, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=5, rng_offset=n, rng_step=step, rng_stride=16 * n))
+    for w in (64, 16):
+        for c0 in range(0, 128, w):
+            xs = x[:, c0:c0 + w].contiguous()
+            got_n = ops.spmm(csr, xs, epilogue=ops.make_epilogue(perturb_eps=0.2, noise=noise, d_full=128, col0=c0))
+            got_r = ops.spmm(csr, xs, epilogue=ops.make_epilogue(perturb_eps=0.2, rng_seed=5, rng_offset=n, rng_step=step,
+                                                                 rng_stride=16 * n, d_full=128, col0=c0))
+            assert rel_err(got_n.cpu().numpy(), wide_n[:, c0:c0 + w].cpu().numpy()) < 3e-6, (w, c0)
+            assert rel_err(got_r.cpu().numpy(), wide_r[:, c0:c0 + w].cpu().numpy()) < 3e-6, (w, c0)
