@@ -85,6 +85,17 @@ def pmc_traffic(args):
     return rec["traffic_bytes_per_launch"], f"{rec['summary']}: {rec['how']}"
 
 
+def pmc_traffic_cols(args, w):
+    """Same for one rank's launch on (N, w) tables in the column-sharded layout: profiles/spmm_cols_traffic.json."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "spmm_cols_traffic.json")
+    if not (args.shape == "yelp2018" and args.emb == 64) or not os.path.exists(path):
+        return None, "no PMC pass committed for this workload"
+    with open(path) as f:
+        rec = json.load(f)
+    t = rec["traffic_bytes_per_launch"].get(str(w))
+    return t, f"{rec['summary']}: {rec['how']}"
+
+
 def time_spmm_kernel(trainer, iters=50):
     """Mean duration (s) of the propagation SpMM launch in the three flavours a step issues, HIP events on
     the launch stream: dense (forward layers / inner backward layers: all rows, perturb epilogue),
@@ -345,7 +356,12 @@ def main():
         if t_spmm:
             alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
             ach = alg / t_spmm["dense"] / 1e9
-            traffic, traffic_note = pmc_traffic(args) if not sharded else (None, "PMC pass exists for the unsharded launch only")
+            if not sharded:
+                traffic, traffic_note = pmc_traffic(args)
+            elif getattr(trainer, "cols", False) and trainer.w != args.emb:
+                traffic, traffic_note = pmc_traffic_cols(args, trainer.w)
+            else:
+                traffic, traffic_note = None, "PMC passes exist for the unsharded and the column-sharded launches only"
             out["roofline"] = {"bound": "hbm",
                                "kernel": (f"{'spmm_pair_kernel' if trainer.w == 8 else f'spmm_slice_kernel<{trainer.w // 4}>'} "
                                           f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
