@@ -334,3 +334,24 @@ def test_wide_slices_of_wider_rows(csr_case):
                                                                  rng_stride=16 * n, d_full=128, col0=c0))
             assert rel_err(got_n.cpu().numpy(), wide_n[:, c0:c0 + w].cpu().numpy()) < 3e-6, (w, c0)
             assert rel_err(got_r.cpu().numpy(), wide_r[:, c0:c0 + w].cpu().numpy()) < 3e-6, (w, c0)
+
+
+def test_bench_helpers_accept_a_column_sharded_trainer(golden_models, golden_meta, tiny_data):
+    """What bench.py's rank 0 does after an N > 1 run -- time the rank's SpMM launch in its three flavours, look up
+    the committed PMC traffic -- works on a column-sharded trainer (here: rank 1 of 4 virtual ranks)."""
+    import bench
+    gm, meta = golden_models, golden_meta
+    group = LockstepGroup(4)
+    trainers = [ShardedTrainer(tiny_data, 64, layout="cols", comm=group.comm(r), noise_fn=None, **make_kw("XSimGCL", gm, meta, noise=False))
+                for r in range(4)]
+    for tr in trainers:
+        tr.sampler.seed(3)
+        tr.begin_epoch()
+    lockstep_step(group, trainers)
+    t = bench.time_spmm_kernel(trainers[1], iters=3)
+    assert set(t) == {"dense", "row_masked", "col_masked", "step_mix"} and all(v > 0 for v in t.values())
+    args = bench.parse([])
+    traffic, note = bench.pmc_traffic_cols(args, trainers[1].w)
+    assert trainers[1].w == 16 and traffic > 0 and "pmc" in note
+    alg = bench.spmm_alg_bytes(trainers[1].adj.nnz, trainers[1].adj.shape[0], trainers[1].adj.shape[1], trainers[1].w)
+    assert alg > 0
