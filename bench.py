@@ -96,6 +96,11 @@ def pmc_traffic_cols(args, w):
     return t, f"{rec['summary']}: {rec['how']}"
 
 
+def slice_kernel_name(w):
+    """The SpMM kernel that serves (N, w) tables (csrc/spmm.hip)."""
+    return {8: "spmm_pair_kernel", 16: "spmm_slice_kernel<4>", 32: "spmm_slice_kernel<8>"}.get(w, f"spmm_rows_kernel<{w // 4}>")
+
+
 def time_spmm_kernel(trainer, iters=50):
     """Mean duration (s) of the propagation SpMM launch in the three flavours a step issues, HIP events on
     the launch stream: dense (forward layers / inner backward layers: all rows, perturb epilogue),
@@ -352,7 +357,12 @@ def main():
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     if rank == 0:
-        t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
+        try:
+            t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
+        except RuntimeError as e:             # (never lose a multi-GPU line to its footnotes)
+            if not sharded:
+                raise
+            t_spmm, out["roofline"] = None, {"error": str(e)}
         if t_spmm:
             alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
             ach = alg / t_spmm["dense"] / 1e9
@@ -363,7 +373,7 @@ def main():
             else:
                 traffic, traffic_note = None, "PMC passes exist for the unsharded and the column-sharded launches only"
             out["roofline"] = {"bound": "hbm",
-                               "kernel": (f"{'spmm_pair_kernel' if trainer.w == 8 else f'spmm_slice_kernel<{trainer.w // 4}>'} "
+                               "kernel": (f"{slice_kernel_name(trainer.w)} "
                                           f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
                                           f"{args.emb} columns, perturb epilogue)") if getattr(trainer, "cols", False) else
                                          (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
