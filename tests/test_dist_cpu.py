@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, model, layout, out_path):
+def _worker(rank, world, port, model, layout, out_path, d=64):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -35,16 +35,16 @@ def _worker(rank, world, port, model, layout, out_path):
     tu, ti, su, si, U, I = synth.make_dataset("tiny")
     data = Interaction({}, synth.as_triples(tu, ti), [])
     torch.manual_seed(0)
-    ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, d)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, d))
     gen = torch.Generator().manual_seed(7)
-    tr = ShardedTrainer(data, 64, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
+    tr = ShardedTrainer(data, d, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
                         drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu",
                         layout=layout)
     assert tr.G == world
     if layout == "rows":
         assert tr.sharded and tr.P == world * tr.n_pad
     else:
-        assert tr.cols and tr.w == 64 // world and tr.E0.shape == (U + I, 64 // world)
+        assert tr.cols and tr.w == d // world and tr.E0.shape == (U + I, d // world)
     import random
     random.seed(11)
     tr.seed_sampler_from_python()             # (SGL: the two dropped views come out of this stream first)
@@ -69,13 +69,15 @@ CASES = [("XSimGCL", 2, "rows"), ("LightGCN", 2, "rows"), ("MF", 2, "rows"), ("X
          ("SimGCL", 2, "cols"), ("SGL", 2, "cols")]
 
 
-@pytest.mark.parametrize("model,world,layout", CASES)
+@pytest.mark.parametrize("model,world,layout", CASES + [("XSimGCL", 2, "cols128")])
 def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), model, layout, out), nprocs=world, join=True)
+    d = 128 if layout == "cols128" else 64              # (d = 128 over 2 ranks: 64-column slices)
+    layout = layout[:4]
+    mp.spawn(_worker, args=(world, _free_port(), model, layout, out, d), nprocs=world, join=True)
     r = np.load(out)
     gen = torch.Generator().manual_seed(7)
-    ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, 64, n_layers=3, batch_size=1000, layer_cl=2,
+    ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, d, n_layers=3, batch_size=1000, layer_cl=2,
                           tau=0.2, eps=0.2, cl_rate=0.2, drop_rate=0.1, user_emb=r["ue"], item_emb=r["ie"],
                           noise_fn=lambda s: torch.rand(s, generator=gen))
     if model == "SGL":                       # the oracle draws its two dropped views from the same stream
