@@ -158,7 +158,9 @@ def edge_dropout(r_mat, drop_rate):
 
 
 def node_dropout(r_mat, drop_rate):
-    """Reference data/augmentor.py:10-27 (dropped rows/cols stay as explicit zeros)."""
+    """Reference data/augmentor.py:10-27.  (scipy's sparse product drops the zeroed entries: the result holds no
+    explicit zeros -- pinned by tests/golden/shapes_meta.json N_node_dropout -- which is why the reference's
+    convert_to_laplacian_mat, pairing ``adj.nonzero()`` with ``adj.data``, works on it.)"""
     nu, ni = r_mat.shape
     rows, cols = r_mat.nonzero()
     du = random.sample(range(nu), int(nu * drop_rate))
@@ -339,8 +341,9 @@ class OracleTrainer:
 
     def __init__(self, model, edges_u, edges_i, n_users, n_items, emb_size, *, n_layers=2,
                  lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1,
-                 drop_rate=0.1, batch_size=2048, user_emb=None, item_emb=None, noise_fn=None):
+                 drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None, noise_fn=None):
         self.model, self.n_users, self.n_items, self.d = model, n_users, n_items, emb_size
+        self.aug_type = aug_type
         self.L, self.lr, self.reg, self.cl_rate, self.eps, self.tau = n_layers, lr, reg, cl_rate, eps, tau
         self.layer_cl, self.drop_rate, self.batch_size = layer_cl, drop_rate, batch_size
         self.r_mat = interaction_matrix(edges_u, edges_i, n_users, n_items)
@@ -377,8 +380,10 @@ class OracleTrainer:
         return (*self._split(final), *self._split(cl))
 
     def resample_views(self):
-        """SGL: two edge-dropped, re-normalised graphs per epoch (SGL.py:28-29,89-96)."""
-        self.dropped = [to_torch_sparse(laplacian_of(edge_dropout(self.r_mat, self.drop_rate))) for _ in range(2)]
+        """SGL: two dropped, re-normalised graphs per epoch (SGL.py:28-29,89-96): node dropout for aug_type 0,
+        edge dropout for 1 and 2."""
+        drop = node_dropout if self.aug_type == 0 else edge_dropout
+        self.dropped = [to_torch_sparse(laplacian_of(drop(self.r_mat, self.drop_rate))) for _ in range(2)]
 
     # -- one step -------------------------------------------------------------------
     def losses(self, u_idx, i_idx, j_idx):

@@ -27,6 +27,7 @@ MASKED_SCORE = -10e8
 SCORE_SLAB_BYTES = 96 << 20
 # filtered ranking: items scored exactly to bound each user's K-th score, survivor slots per user, users per chunk
 FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 4096
+DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered): k <= 128
 
 
 class GraphRecommender(Recommender):
@@ -116,7 +117,10 @@ class GraphRecommender(Recommender):
 
     def test(self):
         users, uid, names = self._test_users()
-        if self._device_embeddings() is not None and users:
+        # (the device top-K kernels keep K <= 128 candidates per user in LDS: a longer list, or one longer than the
+        # catalogue, takes the reference's per-user loop below -- slow, but every config the reference runs, runs)
+        on_device = self.max_N <= min(DEVICE_TOPK_MAX, self.data.item_num)
+        if on_device and self._device_embeddings() is not None and users:
             ids, scores, flags = self.rank_on_device(uid, with_hits=True)
             sizes = np.diff(self._test_csr(self.item_emb.device)[2])[uid]
             # reads like the reference's {user: [(item, score), ...]}; rows are built on access and

@@ -74,8 +74,10 @@ class DeviceGraph:
         graph, as reference ui_graph.py:58-65 recomputes them."""
         if out is None:
             out = torch.empty_like(self.adj.vals)
+        # (unit weights: GraphAugmentor rebuilds the dropped matrix with np.ones_like -- augmentor.py:22-25,36-39 --
+        # so an interaction duplicated in the training file weighs 2 in norm_adj but 1 in every dropped view)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep_mask, self.n_nodes,
-                              weight=self.weight, out=out, deg_ws=self._deg_ws, inv_sqrt_table=self._inv_sqrt)
+                              weight=None, out=out, deg_ws=self._deg_ws, inv_sqrt_table=self._inv_sqrt)
         return self.adj.with_values(out)
 
 
@@ -102,6 +104,7 @@ class ShardedDeviceGraph:
         indices = np.concatenate([r.indices.astype(np.int64) + self.n_users, rt.indices])
         edge_id = np.concatenate([eid, rt.data - 1]).astype(np.int32)
         w_full = None if np.all(r.data == 1.0) else np.concatenate([r.data, r.data[rt.data - 1]]).astype(np.float32)
+        self.h_r_indptr, self.h_r_indices = r.indptr.astype(np.int32), r.indices.astype(np.int32)
         self.n_pad = n_pad = (N + world - 1) // world
         self.P = world * n_pad
         own = np.arange(rank, N, world)
@@ -126,7 +129,8 @@ class ShardedDeviceGraph:
         self._normalize(None, self.adj.vals)
 
     def _normalize(self, keep, out):
-        kw = dict(weight=self.weight, out=out, deg_ws=self._dinv, inv_sqrt_table=self._inv_sqrt, row_offset=self.row_offset)
+        # (dropped views are rebuilt with unit weights: see DeviceGraph.dropped_view)
+        kw = dict(weight=self.weight if keep is None else None, out=out, deg_ws=self._dinv, inv_sqrt_table=self._inv_sqrt, row_offset=self.row_offset)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep, self.n_pad, phase=1, **kw)
         self._all_gather(self._dinv)                 # every rank needs D^-1/2 of the columns it references
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, keep, self.n_pad, phase=2, **kw)

@@ -59,6 +59,19 @@ class TorchComm:
         # (flat views: rank r's contribution is the r-th equal piece of `out`, whatever the shapes)
         _dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
 
+    def assert_replicated(self, what, values, device):
+        """Every rank must hold the same `values` (a short list of floats: checksums of state the step code
+        assumes replicated -- initial tables, the epoch's sampled indices).  Raises on the ranks that differ
+        from rank 0 AND on rank 0, so a mis-seeded job stops instead of training on different batches."""
+        mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+        everyone = torch.empty((self.world, mine.numel()), dtype=torch.float64, device=device)
+        _dist.all_gather_into_tensor(everyone.view(-1), mine)
+        bad = [r for r in range(self.world) if not torch.equal(everyone[r], everyone[0])]
+        if bad:
+            raise SelfrecHipError(f"{what} differs between ranks (rank 0 vs ranks {bad}): every rank must be seeded "
+                                  f"identically (torch.manual_seed for the tables, the sampler seed / python `random` "
+                                  f"state for the batches); this rank is {self.rank}")
+
 
 def shard_adjacency(norm_adj_csr, rank, world):
     """CSR rows of the nodes owned by `rank` (nodes rank, rank + world, ...), columns rewritten to the
@@ -159,6 +172,10 @@ class FusedTrainer:
         else:
             ue, ie = torch.as_tensor(user_emb, dtype=torch.float32), torch.as_tensor(item_emb, dtype=torch.float32)
         self.E0[self._pos_dev] = torch.cat([ue, ie])[:, self.col0:self.col0 + w].contiguous().to(dev)
+        # the step code assumes the tables (and, per epoch, the sampled batches) are replicated: check, don't trust
+        self._assert_replicated("initial embedding tables",
+                                [ue.double().sum().item(), ie.double().sum().item(), ue.double().abs().sum().item(),
+                                 ie.double().abs().sum().item()])
         self.m, self.v = buf(self.n_pad), buf(self.n_pad)       # Adam state: owned rows only
         self.gE0 = buf()
         self.F = self.E0 if model == "MF" else buf()
@@ -208,6 +225,9 @@ class FusedTrainer:
         self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols) or env == "1" or (self.cols and env != "0"))
         self._graph = None
         self._noise_call = 0
+        # counter RNG layout: (optimiser step) * rng_stride + (perturbed-layer call of the step) * P + row; SimGCL makes
+        # 2L calls per step, XSimGCL L -- the stride leaves room for all of them at any depth
+        self._rng_calls = max(16, 2 * self.L)
         if self.cols:
             self._init_exchange()
 
@@ -253,6 +273,11 @@ class FusedTrainer:
     def _unpack(self):
         ops.batch_unpack(self._x_lists, self._x_recv, self.G, self.w, [self._x_compact[id(t)] for t in self._x_tables],
                          [c for c, _ in self._x_pairs])
+
+    def _assert_replicated(self, what, values):
+        check = getattr(self.comm, "assert_replicated", None)      # (test stand-in communicators may not have it)
+        if check is not None and self.G > 1:
+            check(what, values, self.dev)
 
     def _full(self, t):
         """(rows, w) slice on every rank -> the whole (rows, d) table (a collective; plumbing, not per step)."""
@@ -300,13 +325,21 @@ class FusedTrainer:
         out = {}
         if self.model == "SGL":
             masks = []
+            e = self.graph.n_edges
             for _ in range(2):
                 if self.aug_type == 0:
-                    raise SelfrecHipError("SGL aug_type 0 (node dropout) is not wired into the fused engine")
-                e = self.graph.n_edges
-                keep = self.sampler.sample_range(e, int(e * (1 - self.drop_rate)))
-                mk = np.zeros(e, dtype=np.uint8)
-                mk[keep] = 1
+                    # node dropout (augmentor.py:10-27): int(U rho) users and int(I rho) items lose all their edges;
+                    # as a keep mask over interactions it is the same value-array view as edge dropout
+                    dead_u = np.zeros(self.U, dtype=bool)
+                    dead_i = np.zeros(self.I, dtype=bool)
+                    dead_u[self.sampler.sample_range(self.U, int(self.U * self.drop_rate))] = True
+                    dead_i[self.sampler.sample_range(self.I, int(self.I * self.drop_rate))] = True
+                    rows = np.repeat(np.arange(self.U), np.diff(self.graph.h_r_indptr))
+                    mk = (~dead_u[rows] & ~dead_i[self.graph.h_r_indices]).astype(np.uint8)
+                else:                       # aug_type 1 and 2 both take SGL.py:92-93's edge_dropout branch
+                    keep = self.sampler.sample_range(e, int(e * (1 - self.drop_rate)))
+                    mk = np.zeros(e, dtype=np.uint8)
+                    mk[keep] = 1
                 masks.append(mk)
             out["masks"] = masks
         ep = self.sampler.epoch(self.B, 1, with_unique=True)
@@ -337,6 +370,12 @@ class FusedTrainer:
                 self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
         for k, t in self._epoch_dev.items():
             t.copy_(torch.from_numpy(host[k]), non_blocking=True)
+        if self.G > 1:            # replicated sampler: same seed => same batches; one tiny collective per epoch says so
+            w3 = np.arange(1, 4, dtype=np.int64)
+            self._assert_replicated("the sampled epoch (u, i, j streams)",
+                                    [int(host[k].astype(np.int64).sum()) for k in ("u", "i", "j")] +
+                                    [int((host[k][:3 * (host[k].size // 3)].astype(np.int64).reshape(-1, 3) * w3).sum())
+                                     for k in ("u", "i", "j")])
         self._epoch_host = host
         self._epoch_ready = True
         self.cursor[0:1].zero_()
@@ -383,7 +422,7 @@ class FusedTrainer:
                 call = self._noise_call if call_base is None else call_base + k
                 kw.update(perturb_eps=self.eps, noise=noise, rng_seed=self.rng_seed, rng_offset=self._rng_offset(call),
                           rng_step=self.cursor[1:2] if noise is None else None,
-                          rng_stride=self.P * 16, **self._slice_kw())
+                          rng_stride=self.P * self._rng_calls, **self._slice_kw())
                 self._noise_call += 1
             if k == L - 1:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
@@ -412,7 +451,7 @@ class FusedTrainer:
         nb = [self._noise() for _ in range(L)] if self.noise_fn is not None else [None] * L
         ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), epilogue=ops.make_epilogue(
             perturb_eps=self.eps, noise=None, rng_seed=self.rng_seed, rng_offset=0,
-            rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * 16, main_clean=True,
+            rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * self._rng_calls, main_clean=True,
             **self._slice_kw(),
             extra_out=[self._loc(a["Y"][0]), self._loc(b["Y"][0])], extra_noise=[na[0], nb[0]],
             extra_rng_offset=[self._rng_offset(0), self._rng_offset(L)]))

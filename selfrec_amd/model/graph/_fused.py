@@ -9,8 +9,16 @@ import random
 
 import torch
 
+from ..._lib import SelfrecHipError
 from ...base.graph_recommender import GraphRecommender
 from ...engine import EpochPrefetcher, FusedTrainer
+
+
+def _as_bool(v):
+    """YAML gives real booleans, but a quoted 'false' / 'off' / '0' must not read as True."""
+    if isinstance(v, str):
+        return v.strip().lower() not in ("", "0", "false", "no", "off", "none")
+    return bool(v)
 
 
 class FusedGraphModel(GraphRecommender):
@@ -25,10 +33,17 @@ class FusedGraphModel(GraphRecommender):
     def __init__(self, conf, training_set, test_set, **kwargs):
         super().__init__(conf, training_set, test_set, **kwargs)
         get = getattr(self.config, 'get', lambda k, d=None: d)
+        if self.engine_model in ("XSimGCL", "SimGCL", "SGL") and int(self.emb_size) not in (64, 128):
+            raise SelfrecHipError(f"{self.engine_model}: embedding.size = {self.emb_size} -- the fused InfoNCE kernels serve "
+                                  f"64 and 128 (use the op-level drop-in tier, selfrec_amd.dropin, for other sizes)")
+        # the in-kernel perturbation noise follows torch's seed (torch.manual_seed / `seed` in the conf), like the
+        # reference's torch.rand_like does
+        seed = get('seed', None)
+        rng_seed = (int(seed) if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
         self.trainer = FusedTrainer(self.data, self.emb_size, model=self.engine_model, lr=self.lRate,
-                                    reg=self.reg, batch_size=self.batch_size,
-                                    use_graph=bool(get('engine.hipgraph', True)), **self.engine_kwargs())
-        self.exact_sampling = bool(get('sampler.python_state', True))
+                                    reg=self.reg, batch_size=self.batch_size, rng_seed=rng_seed,
+                                    use_graph=_as_bool(get('engine.hipgraph', True)), **self.engine_kwargs())
+        self.exact_sampling = _as_bool(get('sampler.python_state', True))
 
     def train(self):
         tr = self.trainer

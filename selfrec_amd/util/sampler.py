@@ -7,18 +7,39 @@ the reference would leave it (after every batch, so interleaved ``random`` calls
 caller see the same stream), and shuffles ``data.training_data`` in place into the same
 order.
 """
+import numpy as np
+
 from .. import ops
+
+_PROBES = 64
+
+
+def _list_matches(data, smp, edge_u, edge_i):
+    """Does ``data.training_data`` still have the order the C++ sampler believes it has?  Probed at 64 positions
+    (first, last, evenly spaced): caller code that re-orders or edits the list in place between epochs -- same
+    object, same length -- is caught here and the sampler is rebuilt from the list."""
+    td, n = data.training_data, smp.n_edges
+    if n == 0:
+        return True
+    order = smp.order()
+    for k in np.unique(np.linspace(0, n - 1, num=min(_PROBES, n)).astype(np.int64)).tolist():
+        rec, e = td[k], int(order[k])
+        if data.user.get(rec[0]) != int(edge_u[e]) or data.item.get(rec[1]) != int(edge_i[e]):
+            return False
+    return True
 
 
 def _sampler_for(data):
-    """One C++ sampler per data object, rebuilt if the training list was replaced."""
+    """One C++ sampler per data object, rebuilt if the training list was replaced or re-ordered by the caller."""
     cached = getattr(data, '_srh_sampler', None)
-    if cached is not None and cached[1] is data.training_data and cached[2] == len(data.training_data):
+    if cached is not None and cached[1] is data.training_data and cached[2] == len(data.training_data) and \
+            _list_matches(data, cached[0], cached[3], cached[4]):
         return cached[0]
     edge_u, edge_i = data._edge_ids_in_list_order() if hasattr(data, '_edge_ids_in_list_order') else (
         [data.user[r[0]] for r in data.training_data], [data.item[r[1]] for r in data.training_data])
+    edge_u, edge_i = np.asarray(edge_u, dtype=np.int32), np.asarray(edge_i, dtype=np.int32)
     smp = ops.Sampler(edge_u, edge_i, len(data.user), len(data.item))
-    data._srh_sampler = (smp, data.training_data, len(data.training_data))
+    data._srh_sampler = (smp, data.training_data, len(data.training_data), edge_u, edge_i)
     return smp
 
 
