@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 13
+#define SRH_ABI_VERSION 14
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -281,6 +281,17 @@ typedef struct srh_infonce_problem {
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems,
                                        int32_t d, float tau, float loss_scale, double* d_loss,
                                        void* d_ws, void* stream);
+
+/* Arithmetic of InfoNCE's two n x n x d products (util/loss_torch.py:46-47's matmul and its backward).  The
+ * reference computes them in fp32; the default here carries every operand as hi + lo bf16 and evaluates
+ * a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 MFMA with f32 accumulation (logits within 2e-5 absolute,
+ * loss / gradients within 2e-5 relative of the reference; north_star's budget is 1e-4).  SRH_NCE_F32 evaluates them
+ * as exact f32 multiply-adds on the f32 MFMA (2e-6) at ~2.5x the time of the two passes.  Process-wide; the
+ * environment variable SRH_NCE_F32 (set to anything) selects F32 as the initial mode. */
+#define SRH_NCE_SPLIT_BF16 0
+#define SRH_NCE_F32 1
+srh_status_t srh_infonce_set_precision(int32_t mode);
+int32_t srh_infonce_get_precision(void);
 
 /* The whole batch objective of XSimGCL.py:30-35 / SimGCL.py:33-36 / SGL.py:33-37 --
  *   rec_loss + l2_reg_loss + cl_rate * cl_loss  and its gradients w.r.t. the gathered tables --

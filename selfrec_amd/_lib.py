@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
@@ -97,6 +97,8 @@ SIGNATURES = {
     "srh_bpr_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "srh_sumsq": (_i32, [_vp, _i64, _vp, _vp]),
     "srh_infonce_ws_bytes": (_i64, [_i64, _i32]),
+    "srh_infonce_set_precision": (_i32, [_i32]),
+    "srh_infonce_get_precision": (_i32, []),
     "srh_infonce_fwd_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "srh_infonce_fwd_bwd_multi": (_i32, [C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
     "srh_bpr_infonce_fwd_bwd": (_i32, [C.POINTER(BprProblem), C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp,

@@ -4,6 +4,7 @@
 // These kernels touch only O(batch) rows; what matters is launch count and, for InfoNCE,
 // the 4 x (2 n^2 d) flops of the similarity products, which run on the fp32 MFMA pipe
 // (v_mfma_f32_16x16x4_f32: exact f32 fma chains, so the 1e-4 parity budget is untouched).
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -201,6 +202,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // InfoNCE
 // ---------------------------------------------------------------------------------------
 constexpr int kNceSplits = 16;      // workspace is sized for this many key splits; batch.splits <= it are used
+
+// Arithmetic of the two n x n x d products (srh_infonce_set_precision): split-bf16 x 3 on the bf16 MFMA (default;
+// logits within 2e-5 absolute of fp32, loss and gradients within 2e-5 relative of the reference) or exact f32
+// multiply-adds on the f32 MFMA (2e-6; ~2.5x the time of the two passes).  Process-wide, read at launch time.
+std::atomic<int> g_nce_precision{getenv("SRH_NCE_F32") ? SRH_NCE_F32 : SRH_NCE_SPLIT_BF16};
 
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
   }
 }
 
-// Split-bf16 version of nce_tile (the default): every f32 operand x is carried as hi + lo with
+// Split-bf16 arithmetic of nce_tile_lds (the default path): every f32 operand x is carried as hi + lo with
 // hi = bf16(x), lo = bf16(x - hi), and a product a.b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
 // on v_mfma_f32_16x16x32_bf16 with f32 accumulation -- 3 MFMAs at 16x the f32-MFMA rate.  The dropped
 // a_lo b_lo term is 2^-16 relative; measured against fp64 at n = 2048, d = 64, tau = 0.2 the logits are
@@ -451,125 +457,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
-}
-
-// QT query tiles (16 queries each) per wave share every K / V fragment load: the kernel is bound by
-// operand traffic from L2 (each query tile re-reads all keys), not by the matrix pipe.
-template <int D, bool PASS2, int QT>
-__global__ __launch_bounds__(256) void nce_tile_bf16(NceBatch batch, float inv_tau) {
-  constexpr int NT = D / 16;     // 16-column n-tiles of the P.V product
-  constexpr int KS = D / 32;     // k-slices of 32 dims per S product
-  const NceWs& w = batch.w[blockIdx.z];
-  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
-  const int np = (int)w.np;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c16 = lane & 15, g = lane >> 4;
-  const int q0 = (blockIdx.x * 4 + wv) * (16 * QT);
-  const int ks = blockIdx.y;
-  if (q0 >= np) return;
-  const int qv = PASS2 ? 1 : 0, kv = PASS2 ? 0 : 1;    // pass 1: Q = v1, K = V = v2; pass 2 the other way
-  const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
-  const int kb = ks * per, ke = min(np, kb + per);
-
-  bf16x8 qh[QT][KS], ql[QT][KS];
-#pragma unroll
-  for (int t = 0; t < QT; ++t)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int tile = min((q0 >> 4) + t, (np >> 4) - 1);          // np is a multiple of 64: clamp is for safety only
-      const size_t at = (((size_t)tile * KS + s) * 64 + lane) * 8;
-      qh[t][s] = ld_bf16x8(w.kq_hi[qv] + at);
-      ql[t][s] = ld_bf16x8(w.kq_lo[qv] + at);
-    }
-  floatx4 O[QT][NT];
-#pragma unroll
-  for (int t = 0; t < QT; ++t)
-#pragma unroll
-    for (int u = 0; u < NT; ++u) O[t][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
-  float lsum[QT];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) lsum[t] = 0.f;
-
-  for (int j0 = kb; j0 < ke; j0 += 32) {
-    bf16x8 kh[2][KS], kl[2][KS];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const size_t at = (((size_t)((j0 >> 4) + h) * KS + s) * 64 + lane) * 8;
-        kh[h][s] = ld_bf16x8(w.kq_hi[kv] + at);
-        kl[h][s] = ld_bf16x8(w.kq_lo[kv] + at);
-      }
-    bf16x8 vh[NT], vl[NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const size_t at = (((size_t)(j0 >> 5) * NT + u) * 64 + lane) * 8;
-      vh[u] = ld_bf16x8(w.vt_hi[kv] + at);
-      vl[u] = ld_bf16x8(w.vt_lo[kv] + at);
-    }
-    float il[2][4];
-    if (PASS2) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) il[h][r] = w.invl[min(j0 + 16 * h + 4 * g + r, np - 1)];
-    }
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      floatx4 a[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
-          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
-          a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
-        }
-      }
-      bf16x8 ph, pl;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = j0 + 16 * h + 4 * g + r;
-          float e = expf(a[h][r] * inv_tau - inv_tau);
-          if (PASS2) e *= il[h][r];
-          const float wt = (key < n) ? e : 0.f;
-          lsum[t] += wt;
-          const __bf16 bh = (__bf16)wt;
-          ph[4 * h + r] = bh;
-          pl[4 * h + r] = (__bf16)(wt - (float)bh);
-        }
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], O[t][u], 0, 0, 0);
-        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
-        O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
-      }
-    }
-  }
-
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int qt0 = q0 + 16 * t;
-    if (qt0 >= np) break;
-    float* op = w.opart + ((size_t)ks * np + qt0) * D;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
-#pragma unroll
-      for (int u = 0; u < NT / 4; ++u)
-        reinterpret_cast<float4*>(rowp)[u] =
-            make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
-    }
-    if (!PASS2) {
-      float l = lsum[t];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      if (g == 0) w.lpart[(size_t)ks * np + qt0 + c16] = l;
-    }
-  }
 }
 
 
@@ -916,7 +803,6 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   NceBatch batch{};
   batch.count = count;
   batch.splits = 8;
-  if (const char* env = getenv("SRH_NCE_SPLITS")) batch.splits = std::min(kNceSplits, std::max(1, atoi(env)));
   int np_max = 0;
   char* cursor = reinterpret_cast<char*>(ws);
   for (int k = 0; k < count; ++k) {
@@ -939,55 +825,37 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     nce_prep<LPR><<<gp, 256, 0, st>>>(batch);
   }
   SRH_LAUNCH_CHECK();
-  dim3 gt(np_max / 64, batch.splits, count);
-  static const bool f32_path = getenv("SRH_NCE_F32") != nullptr;     // A/B knob: exact-f32 MFMA path
-  static const int qt = getenv("SRH_NCE_QT") ? atoi(getenv("SRH_NCE_QT")) : 1;      // query tiles per wave (A/B knob)
-  static const bool lds_path = !(getenv("SRH_NCE_LDS") && atoi(getenv("SRH_NCE_LDS")) == 0);   // A/B knob
-  dim3 gt2((np_max + 127) / 128, batch.splits, count);
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
-  if (!f32_path && lds_path) {
+  if (g_nce_precision.load(std::memory_order_relaxed) == SRH_NCE_SPLIT_BF16) {
     constexpr int kLds = 4 * (16384 / D) * D * 2 + (16384 / D) * 4;
-    static const int waves = getenv("SRH_NCE_WAVES") ? atoi(getenv("SRH_NCE_WAVES")) : 8;     // A/B knob
-#define SRH_NCE_LDS_LAUNCH(QTV, WV)                                                                            \
-  do {                                                                                                         \
-    static const bool attr_set = [] {                                                                          \
-      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, QTV, WV>,                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                             \
-      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, true, QTV, WV>,                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                             \
-      return true;                                                                                             \
-    }();                                                                                                       \
-    (void)attr_set;                                                                                            \
-    dim3 gl((np_max + 16 * QTV * WV - 1) / (16 * QTV * WV), batch.splits, count);                              \
-    nce_tile_lds<D, false, QTV, WV><<<gl, 64 * WV, kLds, st>>>(batch, inv_tau);                                \
-    SRH_LAUNCH_CHECK();                                                                                        \
-    nce_tile_lds<D, true, QTV, WV><<<gl, 64 * WV, kLds, st>>>(batch, inv_tau);                                 \
-    SRH_LAUNCH_CHECK();                                                                                        \
-  } while (0)
-    if (waves == 8 && qt == 1) SRH_NCE_LDS_LAUNCH(1, 8);
-    else if (waves == 8) SRH_NCE_LDS_LAUNCH(2, 8);
-    else if (qt == 1) SRH_NCE_LDS_LAUNCH(1, 4);
-    else SRH_NCE_LDS_LAUNCH(2, 4);
-#undef SRH_NCE_LDS_LAUNCH
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, true, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      return true;
+    }();
+    (void)attr_set;
+    dim3 gl((np_max + 127) / 128, batch.splits, count);          // 8 waves x 16 queries per workgroup
+    nce_tile_lds<D, false, 1, 8><<<gl, 512, kLds, st>>>(batch, inv_tau);
+    SRH_LAUNCH_CHECK();
+    nce_tile_lds<D, true, 1, 8><<<gl, 512, kLds, st>>>(batch, inv_tau);
+    SRH_LAUNCH_CHECK();
     if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
     else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
     SRH_LAUNCH_CHECK();
     return SRH_OK;
   }
-  if (bpr) {            // the A/B paths below keep BPR as its own launch
+  // ---- SRH_NCE_F32: both products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds), one finish per pass ----
+  if (bpr) {
     bpr_phase2<LPR><<<n_bpr, 256, 0, st>>>(bp);
     SRH_LAUNCH_CHECK();
   }
-  if (f32_path) nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
-  else if (qt == 2) nce_tile_bf16<D, false, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
-  else nce_tile_bf16<D, false, 1><<<gt, 256, 0, st>>>(batch, inv_tau);
+  dim3 gt(np_max / 64, batch.splits, count);
+  nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
-  if (f32_path) nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
-  else if (qt == 2) nce_tile_bf16<D, true, 2><<<gt2, 256, 0, st>>>(batch, inv_tau);
-  else nce_tile_bf16<D, true, 1><<<gt, 256, 0, st>>>(batch, inv_tau);
+  nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
   SRH_LAUNCH_CHECK();
   nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
@@ -1113,6 +981,13 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
   if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
   return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
 }
+
+srh_status_t srh_infonce_set_precision(int32_t mode) {
+  SRH_REQUIRE(mode == SRH_NCE_SPLIT_BF16 || mode == SRH_NCE_F32, "infonce_set_precision: unknown mode %d", mode);
+  g_nce_precision.store(mode, std::memory_order_relaxed);
+  return SRH_OK;
+}
+int32_t srh_infonce_get_precision(void) { return g_nce_precision.load(std::memory_order_relaxed); }
 
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,
                                        float tau, float loss_scale, double* d_loss, void* d_ws, void* stream) {

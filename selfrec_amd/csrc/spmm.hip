@@ -6,35 +6,25 @@
 // Bound: HBM / L2 gather bandwidth.  Algorithmic bytes per call:
 //   nnz*8 (int32 col + fp32 val) + (n_rows+1)*4 + n_cols*d*4 (x read once) + n_rows*d*4 (y)
 //
-// Mapping for gfx950 (wave64):
-//   * one embedding row is d fp32 = d/4 lanes x float4 (LPR lanes); a wave therefore holds
-//     G = 64/LPR row-vectors side by side (d=64: 16 lanes per row, 4 rows per wave).
-//   * work unit = "segment" = (row, [start,end)) of at most split_len non-zeros, one wave per
-//     segment.  The wave loads 64 (col,val) pairs with one coalesced dword load each, then
-//     walks them G at a time: group g takes entry k+g via ds_bpermute (__shfl), gathers the
-//     256-byte x row with one dwordx4 per lane, and FMAs.  Four gathers are kept in flight
-//     per group (16 x-rows per wave) before the first use.
-//   * groups are summed with xor-shuffles; the epilogue runs on the reduced row.
-//   * power-law rows: rows longer than split_len are cut into several segments that write
-//     partial sums to a workspace; the segment that arrives last (agent-scope release ->
-//     relaxed ticket -> acquire, cdna_hip_programming.md G16) adds them in slot order -- a fixed
-//     order, so results are run-to-run deterministic -- and applies the epilogue.  No second
-//     launch.
-//   * segments are issued longest-first so the tail of the launch is short rows.
-//   * XCD-aware issue order for the bipartite adjacency: measured on MI355X the kernel is bound
-//     by L2-miss traffic (43% TCC hit rate, ~400 MB fetched per launch for 56 MB algorithmic,
-//     profiles/r01_a_pmc_*): every XCD gathers from both the user and the item half of x
-//     (17.8 MB at Yelp shape) through a 4 MiB L2.  Workgroup b runs on XCD b % 8, so the plan
-//     hands user rows to XCDs 0-3 and item rows to XCDs 4-7: each L2 then serves one half of x.
-//   * the (col, val) stream is read once: non-temporal loads keep it from evicting x rows.
-//   * optional row / column activity marks skip whole rows (last forward layer: only the batch's
-//     rows are needed) and zero columns (first backward layer: the incoming gradient is
-//     non-zero only on the batch's rows); zero-valued entries never issue their gather.
+// Mapping for gfx950 (wave64) -- see the comment above spmm_rows_kernel:
+//   * one embedding row is d fp32 = d/4 lanes x float4 (LPR lanes); a wave holds G = 64/LPR row-vectors side by
+//     side (d=64: 16 lanes per row, 4 rows per wave); (col,val) pairs are loaded coalesced and broadcast inside a
+//     16-lane DPP row; 8 gathers of 256-byte x rows are in flight per row-group before the first FMA.
+//   * power-law rows: rows longer than split_len are cut into segments that publish partial sums with
+//     write-through stores; the segment that arrives last (relaxed agent-scope ticket, cdna_hip_programming.md G16)
+//     adds them in slot order -- run-to-run deterministic -- and applies the epilogue.  No second launch.
+//   * XCD-aware issue order: workgroup b runs on XCD b % 8; the plan deals row classes (user / item rows of the
+//     bipartite adjacency) and column classes (even / odd columns of long rows) to XCD groups so that each 4 MiB
+//     L2 caches one part of x (measured: TCC hit rate 43 % -> 65 %, profiles/r01_a_pmc_*, r01_n_*).
+//   * optional row / column activity marks skip whole rows (last forward layer: only the batch's rows are
+//     needed) and zero columns (first backward layer: the incoming gradient is non-zero only on the batch's
+//     rows); zero-valued entries never issue their gather.
+// Earlier generations of this kernel (one wave per segment with ds_bpermute broadcasts, a persistent software-
+// pipelined form, a two-launch split-row finish, lane-per-row thin tables) were measured and retired: their
+// A/B numbers live in profiles/r01_* and DESIGN.md section 4.1, not in this library.
 #include <algorithm>
 #include <cstdlib>
 #include <new>
-#include <numeric>
-#include <queue>
 #include <vector>
 
 #include "common.h"
@@ -195,109 +185,15 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   }
 }
 
-// FLAGS: 1 = non-temporal (col,val) loads, 2 = skip the gather of zero-valued entries,
-//        4 = split rows are finished in-kernel by the last arriver (else by spmm_heavy_kernel)
-template <int LPR, int FLAGS>
-__global__ __launch_bounds__(256) void spmm_seg_kernel(const Seg* __restrict__ segs, int n_segs,
-                                                       const int32_t* __restrict__ indices,
-                                                       const float* __restrict__ vals,
-                                                       const float4* __restrict__ X, float4* __restrict__ Y,
-                                                       float4* __restrict__ partial,
-                                                       const Heavy* __restrict__ heavy,
-                                                       const int32_t* __restrict__ slot_owner,
-                                                       int32_t* __restrict__ tickets, DevEpilogue ep) {
-  constexpr int G = 64 / LPR;      // row-vectors per wave
-  constexpr int STEP = 4 * G;      // entries consumed per unrolled iteration
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_segs) return;
-  const int lane = threadIdx.x & 63;
-  const int g = lane / LPR, sub = lane % LPR;
-  const Seg sg = segs[wave];
-  const int row = __builtin_amdgcn_readfirstlane(sg.row);
-  const int s = __builtin_amdgcn_readfirstlane(sg.start);
-  const int e = __builtin_amdgcn_readfirstlane(sg.end);
-  const int slot = __builtin_amdgcn_readfirstlane(sg.slot);
-  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-  if (ep.row_mark && ep.row_mark[row] != stamp) return;     // row not needed this step
-
-  float4 acc = f4_zero();
-  for (int base = s; base < e; base += 64) {
-    const int j = base + lane;
-    const bool in = j < e;
-    int c = 0;
-    float v = 0.f;
-    if (in) {
-      if (FLAGS & 1) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
-      else { c = indices[j]; v = vals[j]; }
-    }
-    if (ep.col_mark && in && ep.col_mark[c] != stamp) v = 0.f;   // x row known to be zero
-    const int cnt = min(64, e - base);
-    const int cnt_up = (cnt + STEP - 1) / STEP * STEP;   // <= 64 because STEP divides 64
-    for (int k = 0; k < cnt_up; k += STEP) {
-      const int c0 = __shfl(c, k + g), c1 = __shfl(c, k + G + g);
-      const int c2 = __shfl(c, k + 2 * G + g), c3 = __shfl(c, k + 3 * G + g);
-      const float v0 = __shfl(v, k + g), v1 = __shfl(v, k + G + g);
-      const float v2 = __shfl(v, k + 2 * G + g), v3 = __shfl(v, k + 3 * G + g);
-      float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
-      if (FLAGS & 2) {
-        if (v0 != 0.f) x0 = X[(size_t)c0 * LPR + sub];    // zero entries (padding, dropped edges,
-        if (v1 != 0.f) x1 = X[(size_t)c1 * LPR + sub];    // inactive columns) issue no gather
-        if (v2 != 0.f) x2 = X[(size_t)c2 * LPR + sub];
-        if (v3 != 0.f) x3 = X[(size_t)c3 * LPR + sub];
-      } else {
-        x0 = X[(size_t)c0 * LPR + sub];
-        x1 = X[(size_t)c1 * LPR + sub];
-        x2 = X[(size_t)c2 * LPR + sub];
-        x3 = X[(size_t)c3 * LPR + sub];
-      }
-      acc = f4_fma(v0, x0, acc);
-      acc = f4_fma(v1, x1, acc);
-      acc = f4_fma(v2, x2, acc);
-      acc = f4_fma(v3, x3, acc);
-    }
-  }
-#pragma unroll
-  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-
-  if (slot < 0) {
-    row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
-    return;
-  }
-  // ---- split row: publish the partial, the last segment to arrive reduces and finishes ----
-  if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
-  if (!(FLAGS & 4)) return;                               // two-pass mode: spmm_heavy_kernel finishes
-  const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
-  const Heavy h = heavy[hid];
-  const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
-  const int n = __builtin_amdgcn_readfirstlane(h.n_slots);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep the wait the compiler may drop (G16 pitfall)
-  int ticket = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != n - 1) return;
-  if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-  float4 sum = f4_zero();
-  for (int t = g; t < n; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(first + t) * LPR + sub));
-#pragma unroll
-  for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
-  row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Default kernel.  The two earlier variants turned out to be bound by instruction issue, not by
-// memory (same speed with x folded into 1 MB of L2; profiles/r01_b_*): ~400 wave-instructions per
-// short row, most of them the per-row epilogue run redundantly by all four row-groups and the
-// ds_bpermute broadcasts of (col,val).  This kernel
-//   * broadcasts (col,val) inside each 16-lane DPP row with v_mov_dpp row_newbcast (one VALU op,
-//     no LDS traffic): the lanes of a DPP row hold 16 consecutive entries and round t uses lane t;
-//   * gives every row-group its OWN short row (<= 64 non-zeros; 4 rows per wave at d=64), so the
-//     epilogue -- noise, normalisation, mean, stores -- runs once per wave for G rows and needs no
-//     cross-group reduction; rows are issued longest-first, so the G rows of a wave have (nearly)
-//     the same length;
-//   * keeps one wave per long row / split segment ("coop" tasks): there each row-group takes a
-//     block of 16 entries of a 16*G-entry chunk and the groups are summed at the end.
+// spmm_rows_kernel: one task per wave.
+//   * (col,val) are broadcast inside each 16-lane DPP row with v_mov_dpp row_newbcast (one VALU op, no LDS
+//     traffic): the lanes of a DPP row hold 16 consecutive entries and round t uses lane t;
+//   * every row-group gets its OWN short row (<= 64 non-zeros; 4 rows per wave at d=64), so the epilogue --
+//     noise, normalisation, mean, stores -- runs once per wave for G rows and needs no cross-group reduction;
+//     rows are issued longest-first, so the G rows of a wave have (nearly) the same length;
+//   * one wave per long row / split segment ("coop" tasks): each row-group takes a block of 16 entries of a
+//     16*G-entry chunk and the groups are summed at the end.
 // ---------------------------------------------------------------------------------------------
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
@@ -337,25 +233,6 @@ __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
-// all 16 entries of the DPP row: 16 gathers in flight before the first FMA
-template <int LPR>
-__device__ __forceinline__ void gather16(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
-  int cc[16];
-  float vv[16];
-  float4 xx[16];
-#define SRH_BC(T) cc[T] = row_bcast_i<T>(c); vv[T] = row_bcast_f<T>(v);
-  SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3) SRH_BC(4) SRH_BC(5) SRH_BC(6) SRH_BC(7)
-  SRH_BC(8) SRH_BC(9) SRH_BC(10) SRH_BC(11) SRH_BC(12) SRH_BC(13) SRH_BC(14) SRH_BC(15)
-#undef SRH_BC
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    xx[t] = f4_zero();
-    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);
-  }
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc = f4_fma(vv[t], xx[t], acc);
-}
-
 // 16-byte write-through store (sc1): the partial goes straight to memory and is not left dirty in this
 // XCD's L2, so publishing it needs no L2 write-back fence (cdna_hip_programming.md G16, form R1)
 __device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
@@ -363,11 +240,10 @@ __device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
 }
 
-// FINISH: split rows are completed inside this launch by whichever of their segments arrives last
-// (write-through partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver reads the partials
-// with agent-scope loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms
-// the ticket).  Otherwise spmm_heavy_kernel does it in a second launch.
-template <int LPR, bool NT, bool DEEP, bool FINISH>
+// Split rows are completed inside this launch by whichever of their segments arrives last (write-through
+// partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver reads the partials with agent-scope
+// loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms the ticket).
+template <int LPR>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
                                                         const Seg* __restrict__ segs,
                                                         const int32_t* __restrict__ indices,
@@ -399,26 +275,15 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
       const int j = base + 16 * g + e16;
       int c = 0;
       float v = 0.f;
-      if (j < e) {
-        if (NT) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
-        else { c = indices[j]; v = vals[j]; }
-      }
+      if (j < e) { c = indices[j]; v = vals[j]; }
       if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
-      if (DEEP && e - base > 8) {
-        gather16<LPR>(c, v, X, sub, acc);
-      } else {
-        gather8<LPR, 0>(c, v, X, sub, acc);
-        if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
-      }
+      gather8<LPR, 0>(c, v, X, sub, acc);
+      if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
     }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
     if (slot < 0) {
       row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
-      return;
-    }
-    if (!FINISH) {
-      if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
       return;
     }
     if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, acc);
@@ -450,35 +315,11 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-  if (DEEP) {
-    // all (col,val) chunks of the row up front (one latency), then 16 gathers in flight per round
-    int cq[kShortRow / 16];
-    float vq[kShortRow / 16];
-#pragma unroll
-    for (int q = 0; q < kShortRow / 16; ++q) {
-      const int j = s + 16 * q + e16;
-      cq[q] = 0; vq[q] = 0.f;
-      if (j < e) { cq[q] = indices[j]; vq[q] = vals[j]; }
-      if (ep.col_mark && vq[q] != 0.f && ep.col_mark[cq[q]] != stamp) vq[q] = 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < kShortRow / 16; ++q) {
-      if (q * 16 < maxlen) {
-        if (maxlen - 16 * q > 8) gather16<LPR>(cq[q], vq[q], X, sub, acc);
-        else gather8<LPR, 0>(cq[q], vq[q], X, sub, acc);
-      }
-    }
-    row_epilogue<LPR>(acc, row, sub, live, Y, ep);
-    return;
-  }
   for (int q = 0; q * 16 < maxlen; ++q) {
     const int j = s + 16 * q + e16;
     int c = 0;
     float v = 0.f;
-    if (j < e) {
-      if (NT) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
-      else { c = indices[j]; v = vals[j]; }
-    }
+    if (j < e) { c = indices[j]; v = vals[j]; }
     if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
     gather8<LPR, 0>(c, v, X, sub, acc);
     if (maxlen - 16 * q > 8) gather8<LPR, 8>(c, v, X, sub, acc);
@@ -612,142 +453,16 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
   }
 }
 
-// Persistent, software-pipelined variant (the default).  Profiling the one-wave-per-segment kernel
-// showed it is latency-bound, not bandwidth-bound: with x folded into an L2-resident 1 MB it ran
-// exactly as fast (tools/spmm_ab.py, profiles/r01_b_spmm_ab.txt), because every wave serialises
-// three memory latencies -- segment descriptor -> (col,val) chunk -> x gathers -> store -- and only
-// the third carries payload.  Here a fixed set of resident waves each walks its own list of
-// segments (balanced on the host, longest first) and keeps the next descriptor and the next
-// (col,val) chunk in flight while the current chunk's gathers are outstanding; 8 gathers per
-// row-group (32 x-rows per wave at d=64) are issued before the first use.
-template <int LPR, int FLAGS>
-__global__ __launch_bounds__(256) void spmm_stream_kernel(const Seg* __restrict__ wsegs,
-                                                          const int32_t* __restrict__ wave_ptr, int n_waves,
-                                                          const int32_t* __restrict__ indices,
-                                                          const float* __restrict__ vals,
-                                                          const float4* __restrict__ X, float4* __restrict__ Y,
-                                                          float4* __restrict__ partial, DevEpilogue ep) {
-  constexpr int G = 64 / LPR;
-  constexpr int STEP = (8 * G < 64) ? 8 * G : 64;     // entries per inner iteration
-  constexpr int NLOAD = STEP / G;                     // gathers in flight per row-group
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_waves) return;
-  const int lane = threadIdx.x & 63;
-  const int g = lane / LPR, sub = lane % LPR;
-  int li = __builtin_amdgcn_readfirstlane(wave_ptr[wave]);
-  const int le = __builtin_amdgcn_readfirstlane(wave_ptr[wave + 1]);
-  if (li >= le) return;
-  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-
-  Seg cur = wsegs[li];
-  Seg nxt = (li + 1 < le) ? wsegs[li + 1] : cur;
-  int row = __builtin_amdgcn_readfirstlane(cur.row), e = __builtin_amdgcn_readfirstlane(cur.end);
-  int slot = __builtin_amdgcn_readfirstlane(cur.slot), base = __builtin_amdgcn_readfirstlane(cur.start);
-  bool live = !ep.row_mark || ep.row_mark[row] == stamp;
-  int c = 0;
-  float v = 0.f;
-  if (live && base + lane < e) { c = indices[base + lane]; v = vals[base + lane]; }
-  float4 acc = f4_zero();
-
-  while (true) {
-    // ---- where the next chunk comes from (uniform control flow) ----
-    int nbase = base + 64;
-    const bool seg_done = nbase >= e;
-    int nrow = row, ne = e, nslot = slot;
-    bool nlive = live, more = true;
-    if (seg_done) {
-      ++li;
-      if (li < le) {
-        nrow = __builtin_amdgcn_readfirstlane(nxt.row); ne = __builtin_amdgcn_readfirstlane(nxt.end);
-        nslot = __builtin_amdgcn_readfirstlane(nxt.slot); nbase = __builtin_amdgcn_readfirstlane(nxt.start);
-        nlive = !ep.row_mark || ep.row_mark[nrow] == stamp;
-        if (li + 1 < le) nxt = wsegs[li + 1];              // descriptor after next: in flight early
-      } else {
-        more = false;
-      }
-    }
-    // ---- prefetch the next chunk's (col,val) before touching the current gathers ----
-    int cn = 0;
-    float vn = 0.f;
-    if (more && nlive && nbase + lane < ne) { cn = indices[nbase + lane]; vn = vals[nbase + lane]; }
-    // ---- current chunk ----
-    if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;     // x row known to be zero
-    const int cnt = live ? min(64, e - base) : 0;
-    for (int k = 0; k < cnt; k += STEP) {
-      int cc[NLOAD];
-      float vv[NLOAD];
-      float4 xx[NLOAD];
-#pragma unroll
-      for (int t = 0; t < NLOAD; ++t) {
-        const int src = (k + t * G + g) & 63;
-        cc[t] = __shfl(c, src);
-        vv[t] = (k + t * G + g < 64) ? __shfl(v, src) : 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < NLOAD; ++t) {
-        xx[t] = f4_zero();
-        if (vv[t] != 0.f) xx[t] = X[(size_t)cc[t] * LPR + sub];    // padding / dropped / dead columns: no gather
-      }
-#pragma unroll
-      for (int t = 0; t < NLOAD; ++t) acc = f4_fma(vv[t], xx[t], acc);
-    }
-    // ---- end of a segment: reduce the row-groups, finish or publish ----
-    if (seg_done) {
-#pragma unroll
-      for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-      if (live) {
-        if (slot < 0) row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
-        else if (g == 0) partial[(size_t)slot * LPR + sub] = acc;
-      }
-      acc = f4_zero();
-    }
-    if (!more) break;
-    row = nrow; e = ne; slot = nslot; live = nlive; base = nbase; c = cn; v = vn;
-  }
-}
-
-template <int LPR>
-__global__ __launch_bounds__(256) void spmm_heavy_kernel(const Heavy* __restrict__ heavy, int n_heavy,
-                                                         const float4* __restrict__ partial,
-                                                         float4* __restrict__ Y, DevEpilogue ep) {
-  constexpr int G = 64 / LPR;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_heavy) return;
-  const int lane = threadIdx.x & 63;
-  const int g = lane / LPR, sub = lane % LPR;
-  const Heavy h = heavy[wave];
-  const int row = __builtin_amdgcn_readfirstlane(h.row);
-  const int first = __builtin_amdgcn_readfirstlane(h.first_slot);
-  const int n = __builtin_amdgcn_readfirstlane(h.n_slots);
-  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-  if (ep.row_mark && ep.row_mark[row] != stamp) return;
-  float4 acc = f4_zero();
-  for (int t = g; t < n; t += G) acc = f4_add(acc, partial[(size_t)(first + t) * LPR + sub]);
-#pragma unroll
-  for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-  row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Thin tables: the column-sharded multi-GPU layout keeps DL = d / G columns of
-// every (N, d) table on each rank, so a propagation layer needs no exchange at all -- the product is
-// independent per column -- and a gathered x row is only DL * 4 = 32 .. 128 bytes.  A 16-lane float4
-// row-group would leave most lanes idle there, so the mapping is turned round:
-//   * one LANE owns a whole (DL-float) x row per entry: DL/4 dwordx4 gathers, DL FMAs into DL private
-//     accumulators; eight float4 gathers are in flight per lane before the first FMA;
-//   * 8 lanes share a short row (<= 64 non-zeros: the plan's 8-rows-per-wave task list), taking entries
-//     e8, e8 + 8, ...; all 64 lanes share a long row / split segment (entries lane, lane + 64, ...);
-//   * the 8 partial vectors of a group meet in a 3-step butterfly reduce-scatter (xor 4, 2, 1: each
-//     step halves the values a lane keeps), which leaves lane e8 with columns [e8 * DL/8, (e8+1) * DL/8)
-//     of the finished row -- the epilogue then runs on DL/8 values per lane and a row is stored as one
-//     contiguous DL * 4-byte piece per group; coop tasks add the 8 groups with xor 8 / 16 / 32;
-//   * split rows use the same write-through partials + ticket hand-off as spmm_rows_kernel (a slot holds
-//     DL floats), summed in slot order: bitwise reproducible.
-// The PERTURB unit vector is normalised over the whole d-wide row (XSimGCL.py:90): with the counter RNG
-// every rank regenerates the row's other columns (hash only, no memory), with injected noise it reads
-// the full noise row; its own columns use exactly the counters of the one-GPU kernel, so a sharded
-// run sees the same perturbation as an unsharded one.
+// Column slices: the column-sharded multi-GPU layout keeps DL = d / G columns of every
+// (N, d) table on each rank, so a propagation layer needs no exchange at all -- the product is independent per
+// column -- and a gathered x row is only DL * 4 = 32 .. 128 bytes.  The helpers below serve the 8-column kernel
+// (spmm_pair_kernel): vector loads / stores of EPL = DL / 8 floats, the perturbation and the epilogue on a lane
+// that ends up holding EPL columns of a finished row.
+// The PERTURB unit vector is normalised over the whole d-wide row (XSimGCL.py:90): with the counter RNG every
+// rank regenerates the row's other columns (hash only, no memory), with injected noise it reads the full noise
+// row; its own columns use exactly the counters of the one-GPU kernel, so a sharded run sees the same
+// perturbation as an unsharded one.
 // ---------------------------------------------------------------------------------------------
 template <int EPL> struct ThinVec;
 template <> struct ThinVec<1> { using type = float; };
@@ -793,83 +508,6 @@ __device__ __forceinline__ void ld_epl_agent(const float* p, float (&v)[EPL]) {
 __device__ __forceinline__ float pick4(uint4 r, int comp) {
   const uint32_t w = (comp == 0) ? r.x : (comp == 1) ? r.y : (comp == 2) ? r.z : r.w;
   return u01(w);
-}
-
-// up to 8 entries of this lane (j, j + stride, ...; all below e): acc += val * x[col, 0:DL]
-template <int DL>
-__device__ __forceinline__ void thin_accumulate(const int32_t* __restrict__ indices, const float* __restrict__ vals,
-                                                const float* __restrict__ X, int j, int stride, int e,
-                                                const int32_t* __restrict__ col_mark, int stamp, float (&acc)[DL]) {
-  constexpr int NV = DL / 4;                       // float4 per x row
-  constexpr int U = (DL >= 32) ? 1 : 32 / DL;      // entries whose gathers fly together (8 float4)
-  int c[8];
-  float v[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int jj = j + k * stride;
-    c[k] = 0;
-    v[k] = 0.f;
-    if (jj < e) { c[k] = indices[jj]; v[k] = vals[jj]; }
-  }
-  if (col_mark) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (v[k] != 0.f && col_mark[c[k]] != stamp) v[k] = 0.f;      // x row known to be zero
-  }
-#pragma unroll
-  for (int k0 = 0; k0 < 8; k0 += U) {
-    bool mine = false;
-#pragma unroll
-    for (int k = 0; k < U; ++k) mine |= (v[k0 + k] != 0.f);
-    if (!__any(mine)) continue;                    // the whole wave is past its entries
-    float4 x[U][NV];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const float4* xr = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) +
-                                                         (unsigned)c[k0 + k] * (unsigned)(DL * 4));
-#pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        x[k][q] = f4_zero();
-        if (v[k0 + k] != 0.f) x[k][q] = xr[q];      // padding / dropped edges / dead columns: no gather
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const float w = v[k0 + k];
-#pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        acc[4 * q + 0] = fmaf(w, x[k][q].x, acc[4 * q + 0]);
-        acc[4 * q + 1] = fmaf(w, x[k][q].y, acc[4 * q + 1]);
-        acc[4 * q + 2] = fmaf(w, x[k][q].z, acc[4 * q + 2]);
-        acc[4 * q + 3] = fmaf(w, x[k][q].w, acc[4 * q + 3]);
-      }
-    }
-  }
-}
-
-// butterfly reduce-scatter over the 8 lanes of a group: lane e8 ends with columns [e8*DL/8, (e8+1)*DL/8)
-template <int DL>
-__device__ __forceinline__ void thin_reduce8(const float (&acc)[DL], float (&out)[DL / 8], int e8) {
-  const bool b2 = (e8 & 4) != 0, b1 = (e8 & 2) != 0, b0 = (e8 & 1) != 0;
-  float a1[DL / 2], a2[DL / 4];
-#pragma unroll
-  for (int i = 0; i < DL / 2; ++i) {
-    const float keep = b2 ? acc[i + DL / 2] : acc[i];
-    const float send = b2 ? acc[i] : acc[i + DL / 2];
-    a1[i] = keep + __shfl_xor(send, 4);
-  }
-#pragma unroll
-  for (int i = 0; i < DL / 4; ++i) {
-    const float keep = b1 ? a1[i + DL / 4] : a1[i];
-    const float send = b1 ? a1[i] : a1[i + DL / 4];
-    a2[i] = keep + __shfl_xor(send, 2);
-  }
-#pragma unroll
-  for (int i = 0; i < DL / 8; ++i) {
-    const float keep = b0 ? a2[i + DL / 8] : a2[i];
-    const float send = b0 ? a2[i] : a2[i + DL / 8];
-    out[i] = keep + __shfl_xor(send, 1);
-  }
 }
 
 template <int DL>
@@ -954,94 +592,8 @@ __device__ __forceinline__ void thin_epilogue(float (&y)[DL / 8], int row, int e
   }
 }
 
-template <int DL>
-__global__ __launch_bounds__(256) void spmm_thin_kernel(const Task* __restrict__ tasks, int n_tasks,
-                                                        const Seg* __restrict__ segs,
-                                                        const int32_t* __restrict__ indices,
-                                                        const float* __restrict__ vals, const float* __restrict__ X,
-                                                        float* __restrict__ Y, float* __restrict__ partial,
-                                                        const Heavy* __restrict__ heavy,
-                                                        const int32_t* __restrict__ slot_owner,
-                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
-  constexpr int EPL = DL / 8;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-  if (wave >= n_tasks) return;
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 3, e8 = lane & 7;
-  const Task tk = tasks[wave];
-  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
-  const int first = __builtin_amdgcn_readfirstlane(tk.first);
-  const int count = __builtin_amdgcn_readfirstlane(tk.count);
-  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-  float acc[DL];
-#pragma unroll
-  for (int i = 0; i < DL; ++i) acc[i] = 0.f;
-  float out[EPL];
-
-  if (kind == 0) {
-    // ---- the whole wave on one long row / split segment ----
-    const Seg sg = segs[first];
-    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
-    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
-    if (ep.row_mark && ep.row_mark[row] != stamp) return;
-    for (int base = s; base < e; base += 512)
-      thin_accumulate<DL>(indices, vals, X, base + lane, 64, e, ep.col_mark, stamp, acc);
-    thin_reduce8<DL>(acc, out, e8);
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-      out[i] += __shfl_xor(out[i], 8);
-      out[i] += __shfl_xor(out[i], 16);
-      out[i] += __shfl_xor(out[i], 32);
-    }
-    if (slot < 0) {
-      thin_epilogue<DL>(out, row, e8, g == 0, Y, ep);
-      return;
-    }
-    if (g == 0) st_epl_sc1<EPL>(partial + (size_t)slot * DL + e8 * EPL, out);
-    const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
-    const Heavy h = heavy[hid];
-    const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
-    const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
-    int ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != hn - 1) return;
-    if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    float sum[EPL];
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) sum[i] = 0.f;
-    for (int t = g; t < hn; t += 8) {
-      float pz[EPL];
-      ld_epl_agent<EPL>(partial + (size_t)(hfirst + t) * DL + e8 * EPL, pz);
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) sum[i] += pz[i];
-    }
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-      sum[i] += __shfl_xor(sum[i], 8);
-      sum[i] += __shfl_xor(sum[i], 16);
-      sum[i] += __shfl_xor(sum[i], 32);
-    }
-    thin_epilogue<DL>(sum, row, e8, g == 0, Y, ep);
-    return;
-  }
-
-  // ---- one short row (<= 64 non-zeros) per 8-lane group ----
-  const bool have = g < count;
-  const Seg sg = segs[first + (have ? g : 0)];
-  const int row = sg.row, s = sg.start;
-  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
-  const int e = live ? sg.end : s;
-  for (int base = s; __any(base < e); base += 64)
-    thin_accumulate<DL>(indices, vals, X, base + e8, 8, e, ep.col_mark, stamp, acc);
-  thin_reduce8<DL>(acc, out, e8);
-  thin_epilogue<DL>(out, row, e8, live, Y, ep);
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// 8-column slices, two lanes per x row.  Where the time of spmm_thin_kernel<8> goes was measured by
+// 8-column slices, two lanes per x row.  Where the time of a lane-per-row kernel went was measured by
 // knocking parts out (Yelp2018 shape, 23.5 us): without the x gathers 11.0, without the (col, val) loads
 // 21.1, without both 10.2 -- the gathers cost 12.5 us, and they cost it per L1 LOOK-UP (a lane that owns
 // a 32-byte row issues two 16-byte loads = two look-ups of the same line), not per byte.  Here the two
@@ -1172,7 +724,7 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__
 // ---------------------------------------------------------------------------------------------
 // 16- and 32-column slices (column-sharded layout at G = 4 / 2 for d = 64): spmm_rows_kernel's
 // schedule with LPR = 4 / 8 lanes per row, so that ONE gather instruction fetches a whole 64 / 128-byte
-// x row per row-group -- one L1 lookup per entry (the lane-per-entry mapping of spmm_thin_kernel pays
+// x row per row-group -- one L1 lookup per entry (a lane-per-entry mapping pays
 // one per 16 bytes: measured 39 / 67 us per Yelp-shape launch at 16 / 32 columns against 26 us at 8).
 //   * a row-group consumes 8 entries per iteration, held by its own lanes as 8 / LPR sub-blocks of LPR
 //     consecutive entries; entry t of a sub-block is broadcast inside the group with DPP -- quad_perm
@@ -1344,16 +896,12 @@ __global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict_
 
 struct srh_spmm_plan {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
-  int32_t n_segs = 0, n_heavy = 0, n_slots = 0, split_len = 0, short_max = 64;
-  int32_t flags = 0;               // kernel variant, see spmm_seg_kernel; bit 8 = streaming kernel
-  // default kernel: one task per wave; a task list per row-group count (index log2(LPR / 8))
-  int32_t n_tasks[5] = {0, 0, 0, 0, 0};         // index 4: 16 rows per wave (LPR = 4: 16-column slices)
+  int32_t n_heavy = 0, n_slots = 0, split_len = 0;
+  // one task per wave; one task list per row-group count G = 64 / LPR: index 0..3 = 8, 4, 2, 1 rows per wave
+  // (LPR = 8, 16, 32, 64), index 4 = 16 rows per wave (LPR = 4: 16-column slices)
+  int32_t n_tasks[5] = {0, 0, 0, 0, 0};
   Task* d_tasks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  Seg* d_tsegs = nullptr;          // segments in task order
-  int32_t n_waves = 0;             // streaming kernel: resident waves, each with its own segment list
-  Seg* d_wsegs = nullptr;          // segments grouped by wave
-  int32_t* d_wave_ptr = nullptr;   // n_waves + 1 offsets into d_wsegs
-  Seg* d_segs = nullptr;
+  Seg* d_tsegs = nullptr;          // segments in task order (+ 16 padding records: a short-row task may read past its count)
   Heavy* d_heavy = nullptr;
   int32_t* d_slot_owner = nullptr;
   int32_t* d_tickets = nullptr;    // one arrival counter per split row, self re-arming
@@ -1368,15 +916,16 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
   SRH_REQUIRE(out && h_indptr, "spmm_plan_create: null argument");
   SRH_REQUIRE(n_rows > 0 && n_cols > 0, "spmm_plan_create: bad shape");
   SRH_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31), "spmm_plan_create: shape exceeds int32");
+  // rows longer than split_len are cut into cooperative segments; 512 sits at the measured optimum
+  // (384 / 512 / 768 -> 50.4 / 48.8 / 53.3 us per Yelp2018-shape launch, profiles/r01_i_spmm_short_split_sweep.txt)
   if (split_len <= 0) split_len = 512;
-  if (const char* env = getenv("SRH_SPMM_SPLIT")) split_len = std::max(64, atoi(env) / 64 * 64);      // A/B knob
   SRH_REQUIRE(split_len % 64 == 0, "spmm_plan_create: split_len must be a multiple of 64");
   SRH_REQUIRE(h_indptr[0] == 0, "spmm_plan_create: indptr[0] != 0");
   SRH_REQUIRE(xcd_split_row >= 0 && xcd_split_row <= n_rows, "spmm_plan_create: xcd_split_row out of range");
-  std::vector<Seg> segs;
+  struct ClsSeg { Seg seg; int8_t half; };
+  std::vector<ClsSeg> segs;
   std::vector<Heavy> heavy;
   std::vector<int32_t> slot_owner;
-  std::vector<int8_t> seg_half;            // column class of a segment's entries (0 when the plan has none)
   segs.reserve((size_t)n_rows + 1024);
   int32_t n_slots = 0;
   for (int64_t r = 0; r < n_rows; ++r) {
@@ -1401,79 +950,47 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     int32_t pieces = 0;
     for (int k = 0; k < n_parts; ++k) pieces += std::max(1, (parts[k].e - parts[k].s + split_len - 1) / split_len);
     if (pieces == 1) {
-      segs.push_back({(int32_t)r, parts[0].s, parts[0].e, -1});
-      seg_half.push_back(parts[0].half);
+      segs.push_back({{(int32_t)r, parts[0].s, parts[0].e, -1}, parts[0].half});
       continue;
     }
     heavy.push_back({(int32_t)r, n_slots, pieces, 0});
     for (int k = 0; k < n_parts; ++k) {
       const int32_t np_k = std::max(1, (parts[k].e - parts[k].s + split_len - 1) / split_len);
       for (int32_t q = 0; q < np_k; ++q) {
-        segs.push_back({(int32_t)r, parts[k].s + q * split_len, std::min(parts[k].e, parts[k].s + (q + 1) * split_len), n_slots++});
-        seg_half.push_back(parts[k].half);
+        segs.push_back({{(int32_t)r, parts[k].s + q * split_len, std::min(parts[k].e, parts[k].s + (q + 1) * split_len), n_slots++},
+                        parts[k].half});
         slot_owner.push_back((int32_t)heavy.size() - 1);
       }
     }
-  }
-  const int n_col_classes = h_row_mid ? 2 : 1;
-  // segment -> class: (row class) * n_col_classes + column class; used by the default kernel's task order
-  std::vector<std::pair<Seg, int8_t>> seg_cls(segs.size());
-  for (size_t i = 0; i < segs.size(); ++i) seg_cls[i] = {segs[i], seg_half[i]};
-  // longest first; ties keep row order (stable) so neighbouring waves touch neighbouring y rows
-  auto longer = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
-  if (xcd_split_row > 0 && xcd_split_row < n_rows) {
-    // workgroup b (4 segments) runs on XCD b % 8 (observed dispatch rule, performance only):
-    // XCDs 0-3 take rows < xcd_split_row, XCDs 4-7 the rest, so each L2 caches one half of x
-    std::vector<Seg> lo, hi;
-    for (const Seg& sgm : segs) (sgm.row < xcd_split_row ? lo : hi).push_back(sgm);
-    std::stable_sort(lo.begin(), lo.end(), longer);
-    std::stable_sort(hi.begin(), hi.end(), longer);
-    segs.clear();
-    size_t il = 0, ih = 0;
-    for (size_t blk = 0; il < lo.size() || ih < hi.size(); ++blk) {
-      const bool want_lo = (blk % 8) < 4;
-      for (int w = 0; w < 4; ++w) {
-        const bool take_lo = (want_lo && il < lo.size()) || ih >= hi.size();
-        if (take_lo && il < lo.size()) segs.push_back(lo[il++]);
-        else if (ih < hi.size()) segs.push_back(hi[ih++]);
-      }
-    }
-  } else {
-    std::stable_sort(segs.begin(), segs.end(), longer);
   }
 
   srh_spmm_plan* p = new (std::nothrow) srh_spmm_plan();
   if (!p) { srh::set_error("spmm_plan_create: out of memory"); return SRH_ERR_NOMEM; }
   p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = h_indptr[n_rows];
-  p->n_segs = (int32_t)segs.size(); p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
+  p->n_heavy = (int32_t)heavy.size(); p->n_slots = n_slots;
   p->split_len = split_len;
-  p->flags = 16 | 4;
-  if (const char* env = getenv("SRH_SPMM_FLAGS")) p->flags = atoi(env) & 31;  // A/B knob for tools/spmm_ab.py
-  if (const char* env = getenv("SRH_SPMM_THIN")) p->flags |= atoi(env) ? 32 : 0;   // A/B: 16 / 32 columns lane-per-row too
-  // ---- default kernel: coop tasks (long rows / split pieces) then G short rows per task ----
-  // tsegs = coop(class 0) ++ coop(class 1) ++ short(class 0) ++ short(class 1), each longest first;
-  // one task list per row-group count G = 64/LPR in {8, 4, 2, 1}
+  // ---- coop tasks (long rows / split pieces) then G short rows per task ----
+  // tsegs = coop(class 0) ++ coop(class 1) .. ++ short(class 0) ++ short(class 1) .., each longest first (ties keep
+  // row order, so neighbouring waves touch neighbouring y rows); one task list per row-group count.
+  // Task classes: row class (user rows / item rows of a bipartite adjacency, split at xcd_split_row) x column class.
+  // Workgroup b = 4 consecutive tasks runs on XCD b % 8 (observed dispatch rule, performance only); the 8 XCDs are
+  // dealt to the classes in equal groups, so each L2 caches only the x rows of one row class AND one column class.
   std::vector<Seg> tsegs;
   std::vector<Task> tasks[5];
   {
-    // task classes: row class (user rows / item rows of a bipartite adjacency) x column class.  Workgroup b
-    // = 4 consecutive tasks runs on XCD b % 8; the 8 XCDs are dealt to the classes in equal groups, so each
-    // L2 caches only the x rows of one row class AND one column class.
+    const int n_col_classes = h_row_mid ? 2 : 1;
     const bool two_row = xcd_split_row > 0 && xcd_split_row < n_rows;
     const int NC = (two_row ? 2 : 1) * n_col_classes;             // 1, 2 or 4
-    int short_max = kShortRow;                                   // A/B knob (non-DEEP kernels take any length)
-    if (const char* env = getenv("SRH_SPMM_SHORT")) short_max = std::max(1, atoi(env));
-    p->short_max = short_max;
     std::vector<Seg> coop[4], shorts[4];
-    for (const auto& sc : seg_cls) {
-      const Seg& sgm = sc.first;
-      const int cls = ((two_row && sgm.row >= xcd_split_row) ? n_col_classes : 0) + (n_col_classes > 1 ? sc.second : 0);
-      (((sgm.end - sgm.start) > short_max || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
+    for (const ClsSeg& sc : segs) {
+      const Seg& sgm = sc.seg;
+      const int cls = ((two_row && sgm.row >= xcd_split_row) ? n_col_classes : 0) + (n_col_classes > 1 ? sc.half : 0);
+      (((sgm.end - sgm.start) > kShortRow || sgm.slot >= 0) ? coop : shorts)[cls].push_back(sgm);
     }
-    auto longer2 = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
+    auto longer = [](const Seg& a, const Seg& b) { return (a.end - a.start) > (b.end - b.start); };
     int32_t coop_off[4], short_off[4];
-    for (int c = 0; c < NC; ++c) { std::stable_sort(coop[c].begin(), coop[c].end(), longer2); }
-    for (int c = 0; c < NC; ++c) { std::stable_sort(shorts[c].begin(), shorts[c].end(), longer2); }
+    for (int c = 0; c < NC; ++c) std::stable_sort(coop[c].begin(), coop[c].end(), longer);
+    for (int c = 0; c < NC; ++c) std::stable_sort(shorts[c].begin(), shorts[c].end(), longer);
     for (int c = 0; c < NC; ++c) { coop_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), coop[c].begin(), coop[c].end()); }
     for (int c = 0; c < NC; ++c) { short_off[c] = (int32_t)tsegs.size(); tsegs.insert(tsegs.end(), shorts[c].begin(), shorts[c].end()); }
     for (int gi = 0; gi < 5; ++gi) {
@@ -1505,48 +1022,15 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
       emit(shorts, 1, short_off, Gr);
     }
   }
-  // ---- streaming kernel: balance the segments over a fixed set of resident waves (LPT greedy) ----
-  std::vector<Seg> wsegs;
-  std::vector<int32_t> wave_ptr;
-  {
-    int n_waves = 256 * 6 * 4;                       // 6 workgroups of 4 waves per CU (<= 85 VGPRs)
-    if (const char* env = getenv("SRH_SPMM_WAVES")) n_waves = std::max(4, atoi(env) / 4 * 4);
-    n_waves = std::min<int64_t>(n_waves, ((int64_t)segs.size() + 3) / 4 * 4);
-    const bool two_class = xcd_split_row > 0 && xcd_split_row < n_rows && n_waves >= 64;
-    std::vector<std::vector<int32_t>> lists(n_waves);
-    using Load = std::pair<int64_t, int32_t>;        // (assigned cost, wave)
-    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap[2];
-    for (int w = 0; w < n_waves; ++w) heap[two_class ? (((w / 4) % 8) < 4 ? 0 : 1) : 0].push({0, w});
-    std::vector<int32_t> order(segs.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-      return (segs[a].end - segs[a].start) > (segs[b].end - segs[b].start); });
-    for (int32_t si : order) {
-      auto& hq = heap[two_class ? (segs[si].row < xcd_split_row ? 0 : 1) : 0];
-      Load top = hq.top(); hq.pop();
-      lists[top.second].push_back(si);
-      hq.push({top.first + (segs[si].end - segs[si].start) + 24, top.second});   // 24 ~ per-segment overhead
-    }
-    wave_ptr.assign(n_waves + 1, 0);
-    for (int w = 0; w < n_waves; ++w) {
-      for (int32_t si : lists[w]) wsegs.push_back(segs[si]);
-      wave_ptr[w + 1] = (int32_t)wsegs.size();
-    }
-    p->n_waves = n_waves;
-  }
-  hipError_t err = hipMalloc(&p->d_segs, sizeof(Seg) * segs.size());
-  if (err == hipSuccess) err = hipMemcpy(p->d_segs, segs.data(), sizeof(Seg) * segs.size(), hipMemcpyHostToDevice);
-  if (err == hipSuccess) err = hipMalloc(&p->d_tsegs, sizeof(Seg) * tsegs.size());
+  for (int k = 0; k < 16; ++k) tsegs.push_back({0, 0, 0, -1});       // padding records (see d_tsegs)
+  hipError_t err = hipMalloc(&p->d_tsegs, sizeof(Seg) * tsegs.size());
   if (err == hipSuccess) err = hipMemcpy(p->d_tsegs, tsegs.data(), sizeof(Seg) * tsegs.size(), hipMemcpyHostToDevice);
   for (int gi = 0; gi < 5 && err == hipSuccess; ++gi) {
     p->n_tasks[gi] = (int32_t)tasks[gi].size();
-    err = hipMalloc(&p->d_tasks[gi], sizeof(Task) * tasks[gi].size());
-    if (err == hipSuccess) err = hipMemcpy(p->d_tasks[gi], tasks[gi].data(), sizeof(Task) * tasks[gi].size(), hipMemcpyHostToDevice);
+    err = hipMalloc(&p->d_tasks[gi], sizeof(Task) * std::max<size_t>(1, tasks[gi].size()));
+    if (err == hipSuccess && !tasks[gi].empty())
+      err = hipMemcpy(p->d_tasks[gi], tasks[gi].data(), sizeof(Task) * tasks[gi].size(), hipMemcpyHostToDevice);
   }
-  if (err == hipSuccess) err = hipMalloc(&p->d_wsegs, sizeof(Seg) * wsegs.size());
-  if (err == hipSuccess) err = hipMemcpy(p->d_wsegs, wsegs.data(), sizeof(Seg) * wsegs.size(), hipMemcpyHostToDevice);
-  if (err == hipSuccess) err = hipMalloc(&p->d_wave_ptr, sizeof(int32_t) * wave_ptr.size());
-  if (err == hipSuccess) err = hipMemcpy(p->d_wave_ptr, wave_ptr.data(), sizeof(int32_t) * wave_ptr.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess && !heavy.empty()) {
     err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
     if (err == hipSuccess) err = hipMemcpy(p->d_heavy, heavy.data(), sizeof(Heavy) * heavy.size(), hipMemcpyHostToDevice);
@@ -1567,99 +1051,23 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
 
 void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (!p) return;
-  if (p->d_segs) (void)hipFree(p->d_segs);
   if (p->d_heavy) (void)hipFree(p->d_heavy);
   if (p->d_partial) (void)hipFree(p->d_partial);
   if (p->d_slot_owner) (void)hipFree(p->d_slot_owner);
   if (p->d_tickets) (void)hipFree(p->d_tickets);
   if (p->d_tsegs) (void)hipFree(p->d_tsegs);
   for (int gi = 0; gi < 5; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
-  if (p->d_wsegs) (void)hipFree(p->d_wsegs);
-  if (p->d_wave_ptr) (void)hipFree(p->d_wave_ptr);
   delete p;
 }
 
-}  // extern "C"
-
-namespace {
-
-template <int LPR, int FLAGS>
-srh_status_t launch_variant(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
-                            const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
-  const int blocks = (p->n_segs + 3) / 4;
-  spmm_seg_kernel<LPR, FLAGS><<<blocks, 256, 0, st>>>(p->d_segs, p->n_segs, d_indices, d_vals,
-                                                      reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
-                                                      reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,
-                                                      p->d_tickets, ep);
-  SRH_LAUNCH_CHECK();
-  if (!(FLAGS & 4) && p->n_heavy > 0) {
-    spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
-                                                                reinterpret_cast<const float4*>(p->d_partial),
-                                                                reinterpret_cast<float4*>(d_y), ep);
-    SRH_LAUNCH_CHECK();
-  }
-  return SRH_OK;
-}
-
-template <int LPR>
-srh_status_t launch_spmm(const srh_spmm_plan* p, const int32_t* d_indices, const float* d_vals,
-                         const float* d_x, float* d_y, const DevEpilogue& ep, hipStream_t st) {
-  if ((p->flags & 16) && LPR >= 16) {        // (a DPP row is 16 lanes: d = 32 keeps the shuffle kernel)
-    constexpr int gi = (LPR == 8) ? 0 : (LPR == 16) ? 1 : (LPR == 32) ? 2 : 3;
-#define SRH_ROWS(NTF, DEEPF, FINF)                                                                              \
-  spmm_rows_kernel<LPR, NTF, DEEPF, FINF><<<(p->n_tasks[gi] + 3) / 4, 256, 0, st>>>(                             \
-      p->d_tasks[gi], p->n_tasks[gi], p->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),       \
-      reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), p->d_heavy, p->d_slot_owner,     \
-      p->d_tickets, ep)
-    const bool finish = (p->flags & 4) != 0;
-    if (p->flags & 1) { if (finish) SRH_ROWS(true, false, true); else SRH_ROWS(true, false, false); }
-    else if (p->flags & 2) { if (finish) SRH_ROWS(false, true, true); else SRH_ROWS(false, true, false); }
-    else { if (finish) SRH_ROWS(false, false, true); else SRH_ROWS(false, false, false); }
-#undef SRH_ROWS
-    SRH_LAUNCH_CHECK();
-    if (p->n_heavy > 0 && !finish) {
-      spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
-                                                                  reinterpret_cast<const float4*>(p->d_partial),
-                                                                  reinterpret_cast<float4*>(d_y), ep);
-      SRH_LAUNCH_CHECK();
-    }
-    return SRH_OK;
-  }
-  if (p->flags & 8) {
-    spmm_stream_kernel<LPR, 0><<<p->n_waves / 4, 256, 0, st>>>(
-        p->d_wsegs, p->d_wave_ptr, p->n_waves, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-        reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(p->d_partial), ep);
-    SRH_LAUNCH_CHECK();
-    if (p->n_heavy > 0) {
-      spmm_heavy_kernel<LPR><<<(p->n_heavy + 3) / 4, 256, 0, st>>>(p->d_heavy, p->n_heavy,
-                                                                  reinterpret_cast<const float4*>(p->d_partial),
-                                                                  reinterpret_cast<float4*>(d_y), ep);
-      SRH_LAUNCH_CHECK();
-    }
-    return SRH_OK;
-  }
-  switch (p->flags & 7) {
-    case 0: return launch_variant<LPR, 0>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 1: return launch_variant<LPR, 1>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 2: return launch_variant<LPR, 2>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 3: return launch_variant<LPR, 3>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 4: return launch_variant<LPR, 4>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 5: return launch_variant<LPR, 5>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    case 6: return launch_variant<LPR, 6>(p, d_indices, d_vals, d_x, d_y, ep, st);
-    default: return launch_variant<LPR, 7>(p, d_indices, d_vals, d_x, d_y, ep, st);
-  }
-}
-
-}  // namespace
-
-extern "C" srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals0,
-                                      const float* d_vals1, const float* d_vals2, const float* d_x, float* d_y0,
-                                      float* d_y1, float* d_y2, int32_t d, void* stream) {
+srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals0,
+                           const float* d_vals1, const float* d_vals2, const float* d_x, float* d_y0,
+                           float* d_y1, float* d_y2, int32_t d, void* stream) {
   SRH_REQUIRE(plan && d_indices && d_vals0 && d_vals1 && d_vals2 && d_x && d_y0 && d_y1 && d_y2, "spmm3_f32: null argument");
   SRH_REQUIRE(d_x != d_y0 && d_x != d_y1 && d_x != d_y2 && d_y0 != d_y1 && d_y0 != d_y2 && d_y1 != d_y2,
               "spmm3_f32: x and the three outputs must be distinct");
-  if (d != 64 || (plan->flags & 20) != 20) {
-    srh::set_error("spmm3_f32: d=%d / kernel flags %d unsupported (d = 64 with the default kernel only)", d, plan->flags);
+  if (d != 64) {
+    srh::set_error("spmm3_f32: d=%d unsupported (d = 64 only)", d);
     return SRH_ERR_UNSUPPORTED;
   }
   constexpr int gi = 1;                      // LPR = 16
@@ -1672,9 +1080,9 @@ extern "C" srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t
   return SRH_OK;
 }
 
-extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
-                                     const int32_t* d_indices, const float* d_vals, const float* d_x,
-                                     float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
+srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
+                          const int32_t* d_indices, const float* d_vals, const float* d_x,
+                          float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
   (void)d_indptr;  // the schedule in `plan` already encodes the row extents
   SRH_REQUIRE(plan && d_indices && d_vals && d_x && d_y, "spmm_f32: null argument");
   SRH_REQUIRE(srh::dim_supported(d) || d == 8 || d == 16, "spmm_f32: d=%d unsupported (need 8, 16, 32, 64, 128 or 256)", d);
@@ -1743,43 +1151,26 @@ extern "C" srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t*
     }
   }
   hipStream_t st = srh::as_stream(stream);
-  // thin tables (8 / 16 columns, or a 32-column slice of wider rows): one lane per gathered x row
-  const bool slice = ep.noise_d_full != 0;
-  if (!slice) { ep.noise_d_full = d; ep.noise_col0 = 0; }
-  if (d <= 32) {
-    SRH_REQUIRE(ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
-                "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
-    if (d >= 16 && !(plan->flags & 32)) {       // 16 / 32 columns: a row-group per gathered row (flag 32: A/B, lane per row)
-      if (d == 16)
-        spmm_slice_kernel<4><<<(plan->n_tasks[4] + 3) / 4, 256, 0, st>>>(
-            plan->d_tasks[4], plan->n_tasks[4], plan->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-            reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
-            plan->d_tickets, ep);
-      else
-        spmm_slice_kernel<8><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(
-            plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
-            reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
-            plan->d_tickets, ep);
-      SRH_LAUNCH_CHECK();
-      return SRH_OK;
-    }
-#define SRH_THIN(DLV)                                                                                              \
-  spmm_thin_kernel<DLV><<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(                                              \
-      plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices, d_vals, d_x, d_y, plan->d_partial, plan->d_heavy, \
-      plan->d_slot_owner, plan->d_tickets, ep)
-    if (d == 8 && !(plan->flags & 32)) {
-      spmm_pair_kernel<<<(plan->n_tasks[0] + 3) / 4, 256, 0, st>>>(plan->d_tasks[0], plan->n_tasks[0], plan->d_tsegs, d_indices,
-                                                                 d_vals, d_x, d_y, plan->d_partial, plan->d_heavy,
-                                                                 plan->d_slot_owner, plan->d_tickets, ep);
-    } else if (d == 8) SRH_THIN(8); else if (d == 16) SRH_THIN(16); else SRH_THIN(32);
-#undef SRH_THIN
-    SRH_LAUNCH_CHECK();
-    return SRH_OK;
-  }
+  if (!ep.noise_d_full) { ep.noise_d_full = d; ep.noise_col0 = 0; }
+  SRH_REQUIRE(d > 32 || ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
+              "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
+  // one kernel per table width: a row-group of d/4 lanes per gathered x row (d >= 16), two lanes per row at d = 8
+#define SRH_LAUNCH(KERNEL, GI, XT, YT)                                                                              \
+  KERNEL<<<(plan->n_tasks[GI] + 3) / 4, 256, 0, st>>>(plan->d_tasks[GI], plan->n_tasks[GI], plan->d_tsegs, d_indices,  \
+                                                      d_vals, reinterpret_cast<const XT*>(d_x), reinterpret_cast<YT*>(d_y), \
+                                                      reinterpret_cast<YT*>(plan->d_partial), plan->d_heavy,          \
+                                                      plan->d_slot_owner, plan->d_tickets, ep)
   switch (d) {
-    case 32: return launch_spmm<8>(plan, d_indices, d_vals, d_x, d_y, ep, st);
-    case 64: return launch_spmm<16>(plan, d_indices, d_vals, d_x, d_y, ep, st);
-    case 128: return launch_spmm<32>(plan, d_indices, d_vals, d_x, d_y, ep, st);
-    default: return launch_spmm<64>(plan, d_indices, d_vals, d_x, d_y, ep, st);
+    case 8: SRH_LAUNCH(spmm_pair_kernel, 0, float, float); break;
+    case 16: SRH_LAUNCH(spmm_slice_kernel<4>, 4, float4, float4); break;
+    case 32: SRH_LAUNCH(spmm_slice_kernel<8>, 0, float4, float4); break;
+    case 64: SRH_LAUNCH(spmm_rows_kernel<16>, 1, float4, float4); break;
+    case 128: SRH_LAUNCH(spmm_rows_kernel<32>, 2, float4, float4); break;
+    default: SRH_LAUNCH(spmm_rows_kernel<64>, 3, float4, float4); break;
   }
+#undef SRH_LAUNCH
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
 }
+
+}  // extern "C"

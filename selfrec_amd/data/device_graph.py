@@ -13,8 +13,6 @@ Layout (all int32 structure / fp32 values, sized for one MI355X's 288 GB):
   adj.vals                     D^-1/2 A D^-1/2 computed on device by srh_adj_sym_normalize
 Edge-dropped views share the structure and own only a value array (``dropped_view``).
 """
-import os
-
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -43,7 +41,7 @@ class DeviceGraph:
         # long rows are stored [even columns | odd columns] so the SpMM plan can give each half to its own
         # XCDs (each 4 MiB L2 then caches a quarter of the table instead of a half; ops.column_class_order)
         row_mid = None
-        min_len = int(os.environ.get("SRH_SPMM_COLSPLIT", "64"))
+        min_len = 64          # = the SpMM plan's short-row bound: only cooperative rows are split by column class
         # (a column slice of 8 .. 32 columns fits every XCD's L2 whole: the split would only add hand-offs --
         # measured 26.5 -> 22.1 us per 8-column launch at the Yelp2018 shape without it)
         if min_len > 0 and column_classes:

@@ -17,7 +17,7 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 require_gpu = _lib.require_gpu
 
 __all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
+           "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",
            "SelfrecHipError"]
 
@@ -360,6 +360,22 @@ def bpr_bwd(u, p, n, coef, scale, gu, gp, gn):
 
 def sumsq(x, out):
     check(_lib.load().srh_sumsq(_p(x, torch.float32), x.numel(), _p(out, torch.float64), _stream()), "srh_sumsq")
+
+
+NCE_PRECISIONS = {"bf16x3": 0, "f32": 1}      # SRH_NCE_SPLIT_BF16, SRH_NCE_F32 (include/selfrec_hip.h)
+
+
+def set_infonce_precision(mode: str):
+    """'bf16x3' (default: split-bf16, 3 bf16 MFMAs per product) or 'f32' (exact f32 MFMA).  Process-wide; a step already
+    captured in a hipGraph keeps the kernels it was captured with."""
+    if mode not in NCE_PRECISIONS:
+        raise SelfrecHipError(f"InfoNCE precision {mode!r}: one of {sorted(NCE_PRECISIONS)}")
+    check(_lib.load().srh_infonce_set_precision(NCE_PRECISIONS[mode]), "srh_infonce_set_precision")
+
+
+def get_infonce_precision() -> str:
+    got = int(_lib.load().srh_infonce_get_precision())
+    return {v: k for k, v in NCE_PRECISIONS.items()}[got]
 
 
 def infonce_ws(n: int, d: int, device):

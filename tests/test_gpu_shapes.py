@@ -1,0 +1,215 @@
+"""The fused engine (HIP kernels through the C ABI) against REFERENCE runs at the BASELINE.json config shapes
+(tests/golden/shapes.npz; make_golden_shapes.py):
+
+  configs[1]/[2]  Yelp2018 shape, LightGCN L=3 / XSimGCL L=3 (tau 0.2, eps 0.2, l*=1, injected noise): 2 steps --
+                  sampled batches, per-step losses, 1,024 sampled parameter / final-embedding rows, test() ranking
+                  of 64 users;
+  configs[4]      iFashion shape, SGL edge-drop views: keep-sets (host) + 1 step;
+  configs[0]      the real douban-book file, MF + BPR: 3 steps + test() + ranking_evaluation;
+  a-13            SGL with node dropout (aug_type 0): 3 steps; node-dropped Laplacian on the device;
+  ADVICE r01      duplicate interactions: weight 2 in norm_adj, unit weights in the dropped views.
+Tolerances: indices bit-exact; losses 1e-5 (InfoNCE 2e-5, split-bf16 products; 2e-6 on the exact-f32 path);
+parameters / embeddings 1e-4 relative (north_star)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from selfrec_amd import ops, synth
+from selfrec_amd.data.loader import FileIO
+from selfrec_amd.data.ui_graph import Interaction
+from selfrec_amd.engine import FusedTrainer
+from tests.test_shapes_cpu import GOLDEN, seeded_init, sha, write_douban
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def shapes():
+    return np.load(os.path.join(GOLDEN, "shapes.npz"))
+
+
+@pytest.fixture(scope="module")
+def smeta():
+    with open(os.path.join(GOLDEN, "shapes_meta.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def yelp_data():
+    tu, ti, su, si, U, I = synth.make_dataset("yelp2018", seed=2024)
+    return Interaction({}, synth.as_triples(tu, ti), synth.as_triples(su, si))
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def trainer_for(info, data, ue, ie, **over):
+    c = info["conf"]
+    gen = torch.Generator().manual_seed(info["noise_seed"])
+    kw = dict(model=info["model"], n_layers=int(c.get("n_layer", 0)), lr=info["lr"], reg=info["reg"],
+              cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)), tau=float(c.get("tau", c.get("temp", 0.2))),
+              layer_cl=int(c.get("l_star", 1)), drop_rate=float(c.get("drop_rate", 0.1)), aug_type=int(c.get("aug_type", 1)),
+              batch_size=info["batch"], user_emb=ue, item_emb=ie, noise_fn=lambda shape: torch.rand(shape, generator=gen))
+    kw.update(over)
+    return FusedTrainer(data, info["emb"], **kw)
+
+
+def run_and_check(tag, shapes, info, tr, *, rows=True, nce_rtol=2e-5):
+    """Seed the sampler like the reference run, train its steps, compare everything the golden holds."""
+    random.seed(info["sampler_seed"])
+    tr.seed_sampler_from_python()
+    tr.begin_epoch()
+    sizes = shapes[f"{tag}_batch_sizes"]
+    n = int(sizes.sum())
+    eu, ei, ej = tr.epoch_node_ids()
+    for got, col in ((eu, "u"), (ei, "i"), (ej, "j")):                  # bit-exact index streams
+        assert np.array_equal(got[:n], shapes[f"{tag}_batch_{col}"])
+    losses = []
+    for _ in range(len(sizes)):
+        tr.step()
+        losses.append(tr.read_losses())
+    losses = np.asarray(losses)
+    np.testing.assert_allclose(losses[:, 0], shapes[f"{tag}_loss_bpr"], rtol=1e-5)
+    reg_div = info["batch"] if info["model"] in ("MF", "LightGCN") else 1.0
+    np.testing.assert_allclose(losses[:, 1], shapes[f"{tag}_loss_reg"] / reg_div, rtol=1e-5)
+    nce = shapes[f"{tag}_loss_nce"]
+    if nce.size:
+        np.testing.assert_allclose(losses[:, 2], nce.reshape(len(sizes), -1).sum(1) * tr.cl_rate, rtol=nce_rtol)
+    ru = torch.from_numpy(shapes[f"{tag}_rows_user"].astype(np.int64)).to(DEV) if rows else slice(None)
+    ri = torch.from_numpy(shapes[f"{tag}_rows_item"].astype(np.int64)).to(DEV) if rows else slice(None)
+    pu, pi = tr.user_emb[ru].cpu().numpy(), tr.item_emb[ri].cpu().numpy()
+    assert rel_err(pu, shapes[f"{tag}_param_user"]) < 1e-4 and rel_err(pi, shapes[f"{tag}_param_item"]) < 1e-4
+    # element-wise: far inside one Adam step (lr = 1e-3)
+    assert np.abs(pu - shapes[f"{tag}_param_user"]).max() < 1e-5 and np.abs(pi - shapes[f"{tag}_param_item"]).max() < 1e-5
+    fu, fi = tr.embeddings()
+    assert rel_err(fu[ru].cpu().numpy(), shapes[f"{tag}_final_user"]) < 1e-4
+    assert rel_err(fi[ri].cpu().numpy(), shapes[f"{tag}_final_item"]) < 1e-4
+    return fu, fi
+
+
+@pytest.mark.parametrize("tag", ["Y_XSimGCL", "Y_LightGCN"])
+def test_yelp_shape_two_steps_match_reference_run(yelp_data, shapes, smeta, tag):
+    info = smeta[tag]
+    ue, ie = seeded_init(info)
+    tr = trainer_for(info, yelp_data, ue, ie)
+    fu, fi = run_and_check(tag, shapes, info, tr)
+    # graph_recommender.py:46-53 for the golden's 64 test users: same ranked ids, same scores
+    users = torch.from_numpy(shapes[f"{tag}_eval_users"]).to(DEV)
+    ids, sc = ops.score_mask_topk(fu.contiguous(), users, fi.contiguous(), tr.graph.r_indptr, tr.graph.r_indices, 20)
+    want_ids, want_sc = shapes[f"{tag}_eval_ids"], shapes[f"{tag}_eval_scores"]
+    assert (ids.cpu().numpy() == want_ids).mean() > 0.995          # (exact ties / 1-ulp neighbours may swap)
+    np.testing.assert_allclose(sc.cpu().numpy(), want_sc, rtol=1e-4, atol=1e-7)
+
+
+def test_yelp_shape_xsimgcl_exact_f32_infonce(yelp_data, shapes, smeta):
+    """The same run with InfoNCE's products on the exact-f32 MFMA path (srh_infonce_set_precision): the contrastive
+    loss then agrees with the reference to 2e-6 instead of the split-bf16 path's 2e-5."""
+    info = smeta["Y_XSimGCL"]
+    ue, ie = seeded_init(info)
+    ops.set_infonce_precision("f32")
+    try:
+        run_and_check("Y_XSimGCL", shapes, info, trainer_for(info, yelp_data, ue, ie), nce_rtol=2e-6)
+    finally:
+        ops.set_infonce_precision("bf16x3")
+
+
+def test_ifashion_shape_sgl_step_matches_reference_run(shapes, smeta):
+    info = smeta["F_SGL"]
+    tu, ti, su, si, U, I = synth.make_dataset("ifashion", seed=2024)
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    assert (data.user_num, data.item_num) == (info["n_users"], info["n_items"])
+    ue, ie = seeded_init(info)
+    tr = trainer_for(info, data, ue, ie)
+    assert tr.graph.n_edges == info["n_edges"]
+    run_and_check("F_SGL", shapes, info, tr)
+    for mk, want in zip(tr._epoch_host["masks"], info["keep_sorted_sha"]):       # the two views of the epoch
+        assert sha(np.flatnonzero(mk), np.int64) == want
+
+
+def test_douban_book_mf_three_steps_and_ranking(tmp_path, shapes, smeta):
+    """configs[0] end to end on the shipped file: native loader -> Interaction -> MF + BPR (MF.py:13-31) ->
+    test() -> ranking_evaluation."""
+    from selfrec_amd.base.graph_recommender import GraphRecommender
+    from selfrec_amd.util.evaluation import ranking_evaluation
+    train_p, test_p = write_douban(str(tmp_path))
+    data = Interaction({}, FileIO.open_data_set(train_p, "graph"), FileIO.open_data_set(test_p, "graph"))
+    info = smeta["D_MF"]
+    ue, ie = seeded_init(info)
+    tr = trainer_for(info, data, ue, ie)
+    fu, fi = run_and_check("D_MF", shapes, info, tr)
+    rec = GraphRecommender.__new__(GraphRecommender)
+    rec.data, rec.max_N, rec.topN = data, 20, [10, 20]
+    rec.user_emb, rec.item_emb = fu.contiguous(), fi.contiguous()
+    out = rec.test()
+    measure = ranking_evaluation(data.test_set, out, [10, 20])
+    want = info["measure"]
+    assert [m.split(":")[0] for m in measure] == [m.split(":")[0] for m in want]
+    got_v = [float(m.split(":")[1]) for m in measure if ":" in m]
+    want_v = [float(m.split(":")[1]) for m in want if ":" in m]
+    np.testing.assert_allclose(got_v, want_v, atol=2e-5)            # round(.., 5) strings; a 1-ulp rank swap moves one digit
+    uid = {u: k for k, u in enumerate(out.users)} if hasattr(out, "users") else None
+    users = shapes["D_MF_rec_users"]
+    ids, _ = rec.rank_on_device(users)
+    assert (ids == shapes["D_MF_rec_ids"]).mean() > 0.995
+    del uid
+
+
+def test_sgl_node_dropout_steps_match_reference_run(shapes, smeta, tiny_data):
+    """a-13: SGL with aug_type = 0 (augmentor.py:10-27 via SGL.py:89-96) in the fused engine, 3 reference steps."""
+    info = smeta["N_SGL"]
+    tr = trainer_for(info, tiny_data, shapes["N_SGL_init_user"], shapes["N_SGL_init_item"])
+    assert tr.aug_type == 0
+    run_and_check("N_SGL", shapes, info, tr, rows=False)
+
+
+def test_node_dropout_dropin_laplacian_on_device(shapes, fresh_tiny_data):
+    """GraphAugmentor.node_dropout -> convert_to_laplacian_mat -> convert_sparse_mat_to_tensor, as SGL.py:89-96 chains
+    them with aug_type 0: the dropped, re-normalised adjacency never leaves the GPU and is bit-identical."""
+    from selfrec_amd.base.torch_interface import SparseAdjHandle, TorchGraphInterface
+    from selfrec_amd.data.augmentor import GraphAugmentor
+    data = fresh_tiny_data
+    random.seed(77)
+    dropped = GraphAugmentor.node_dropout(data.interaction_mat, 0.1)
+    assert random.getrandbits(32) == int(shapes["node_dropout_next_u32"][0])
+    h = TorchGraphInterface.convert_sparse_mat_to_tensor(data.convert_to_laplacian_mat(dropped)).cuda()
+    assert isinstance(h, SparseAdjHandle)
+    g = data.device_graph()
+    view = g.dropped_view(torch.from_numpy(dropped.keep_mask).to(DEV))
+    m = sp.csr_matrix((view.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()),
+                      shape=(g.n_nodes, g.n_nodes))
+    m.eliminate_zeros(); m.sort_indices()
+    assert np.array_equal(m.indptr, shapes["node_dropout_lap_indptr"])
+    assert np.array_equal(m.indices, shapes["node_dropout_lap_indices"])
+    assert np.array_equal(m.data, shapes["node_dropout_lap_data"])             # bit-exact (host pow table)
+    x = np.random.default_rng(3).standard_normal((g.n_nodes, 64)).astype(np.float32)
+    got = torch.sparse.mm(h, torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel_err(got, m.astype(np.float64) @ x.astype(np.float64)) < 2e-6
+
+
+def test_duplicate_interactions_weigh_two_in_adj_and_one_in_views(shapes):
+    tu, ti = shapes["dup_train_u"], shapes["dup_train_i"]
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    g = data.device_graph()
+    assert g.weight is not None
+    mine = sp.csr_matrix((g.adj.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()),
+                         shape=(g.n_nodes, g.n_nodes))
+    mine.sort_indices()
+    assert np.array_equal(mine.indices, shapes["dup_norm_adj_indices"])
+    assert np.array_equal(mine.data, shapes["dup_norm_adj_data"])
+    random.seed(5)
+    from selfrec_amd.data.augmentor import GraphAugmentor
+    dropped = GraphAugmentor.edge_dropout(data.interaction_mat, 0.1)
+    view = g.dropped_view(torch.from_numpy(dropped.keep_mask).to(DEV))
+    m = sp.csr_matrix((view.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()),
+                      shape=(g.n_nodes, g.n_nodes))
+    m.eliminate_zeros(); m.sort_indices()
+    assert np.array_equal(m.indices, shapes["dup_drop_lap_indices"])
+    assert np.array_equal(m.data, shapes["dup_drop_lap_data"])
