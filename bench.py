@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
     return ap.parse_args(argv)
 
@@ -190,6 +191,65 @@ def eval_cpu_baseline(trainer, data, k=20, n_users=300):
             "sample": f"{len(users)} test users through the oracle's per-user loop (python heap top-{k}; numba absent)"}
 
 
+def dropin_throughput(args, raw, steps=60, warmup=8):
+    """pairs/s of the OP-LEVEL drop-in tier: what a SELFRec user gets without switching to selfrec_amd's model
+    classes -- a model file written the reference's way (torch.sparse.mm on the uploaded adjacency, rand_like /
+    normalize / sign perturbation, stack + mean, fancy-index gathers, util.loss_torch losses, torch.optim.Adam,
+    the next_batch_pairwise generator pulled synchronously: XSimGCL.py:23-50,83-101) running on this package's
+    sampler, SpMM handle and loss kernels.  The unmodified reference files were run the same way in a gpurun
+    session (profiles/r02_dropin_reference_models.txt); /root/reference does not exist where bench.py runs."""
+    import random
+    import torch.nn.functional as F
+    from selfrec_amd import synth
+    from selfrec_amd.base.torch_interface import TorchGraphInterface
+    from selfrec_amd.data.ui_graph import Interaction
+    from selfrec_amd.util.loss_torch import InfoNCE, bpr_loss, l2_reg_loss
+    from selfrec_amd.util.sampler import next_batch_pairwise
+    tu, ti, su, si, U, I = raw
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    adj = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj).cuda()
+    torch.manual_seed(args.seed)
+    emb = torch.nn.ParameterDict({
+        "user_emb": torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(U, args.emb))),
+        "item_emb": torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(I, args.emb)))}).cuda()
+    opt = torch.optim.Adam(emb.parameters(), lr=1e-3)
+    eps, lam, tau, l_star, reg = 0.2, 0.2, args.tau, 1, 1e-4
+
+    def encode(perturbed):
+        h = torch.cat([emb["user_emb"], emb["item_emb"]], 0)
+        layers, view = [], None
+        for k in range(args.layers):
+            h = torch.sparse.mm(adj, h)
+            if perturbed:
+                h = h + torch.sign(h) * F.normalize(torch.rand_like(h), dim=-1) * eps
+            layers.append(h)
+            if k == l_star - 1:
+                view = h
+        out = torch.stack(layers, dim=1).mean(dim=1)
+        return torch.split(out, [U, I]) + torch.split(view, [U, I])
+
+    random.seed(args.seed)
+    done, t0 = 0, None
+    for u_idx, i_idx, j_idx in next_batch_pairwise(data, args.batch):
+        if done == warmup:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        ue, ie, cu, ci = encode(True)
+        u, p, n = ue[u_idx], ie[i_idx], ie[j_idx]
+        uu = torch.unique(torch.tensor(u_idx, device="cuda")); ui = torch.unique(torch.tensor(i_idx, device="cuda"))
+        cl = InfoNCE(ue[uu], cu[uu], tau) + InfoNCE(ie[ui], ci[ui], tau)
+        loss = bpr_loss(u, p, n) + l2_reg_loss(reg, u, p) + lam * cl
+        opt.zero_grad(); loss.backward(); opt.step()
+        done += 1
+        if done == warmup + steps:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"pairs_per_s": round(steps * args.batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "what": "XSimGCL written against SELFRec's API (raw torch.sparse.mm on the handle, torch autograd, torch Adam, "
+                    "python generator sampler pulled synchronously), HIP SpMM / loss / sampler kernels underneath",
+            "final_loss": float(loss.item())}
+
+
 def stream_bandwidth(dev):
     """Measured streaming rates of this GPU with the library's own elementwise kernel, y = a*x + b*y
     (srh_axpby: 2 reads + 1 write per element): arrays that stay in the 256 MiB Infinity Cache (the regime
@@ -312,6 +372,7 @@ def main():
         done = 0
         while done < n_steps:
             if state["left"] == 0:
+                state["uploads"] = state.get("uploads", 0) + 1
                 trainer.upload_epoch(pre.take())
                 pre.start()                       # host samples the next epoch while this one runs
                 state["left"] = trainer.epoch_batches
@@ -327,12 +388,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    state["uploads"] = 0
     run(args.warmup)
     fence()
+    uploads0 = state["uploads"]
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    epochs_in_region = state["uploads"] - uploads0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,14 +412,46 @@ def main():
         "metric": "train pairs/sec (XSimGCL, Yelp2018-shape)", "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" + (" (InfoNCE's two n x n x d products: 3-term split-bf16 MFMA with f32 accumulation, 2e-5 rel; "
+                          "exact-f32 MFMA path timed in ms_per_step_nce_f32)" if args.model in ("XSimGCL", "SimGCL", "SGL") else ""),
+        "data": "synthetic",
         "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
-                               f"d={args.emb}, B={args.batch}, Adam lr=1e-3; sampling on a host thread inside the timed region",
+                               f"d={args.emb}, B={args.batch}, Adam lr=1e-3; epochs are sampled by a host thread one epoch ahead and "
+                               f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
+                               f"(see steady_state for a region that always spans >= 1)",
                    "global_batch": args.batch, "parallelism": f"{layout} x{world}" if sharded else "single",
                    "launch": "hipGraph replay" if trainer.use_graph else "eager"},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
+    # ---- steady state: >= 2 epochs (>= 1 epoch boundary: sampler hand-over + 25 MB index upload inside the region)
+    # and >= 0.6 s of device time, whatever --steps the driver passed
+    ss_steps = max(2 * trainer.epoch_batches, int(0.6 / max(elapsed / args.steps, 1e-6)))
+    uploads0 = state["uploads"]
+    fence()
+    t0 = time.perf_counter()
+    run(ss_steps)
+    fence()
+    ss = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([ss], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ss = float(t.item())
+    out["steady_state"] = {"steps": ss_steps, "seconds": round(ss, 4), "ms_per_step": round(ss / ss_steps * 1e3, 4),
+                           "pairs_per_s": round(ss_steps * args.batch / ss, 1),
+                           "epoch_boundaries_inside": state["uploads"] - uploads0}
+    if not sharded and args.model in ("XSimGCL", "SimGCL", "SGL"):
+        # the same step with InfoNCE's products on the exact-f32 MFMA path (re-captured graph)
+        from selfrec_amd import ops as _ops
+        _ops.set_infonce_precision("f32")
+        trainer.reset_graph()
+        run(20); fence()
+        t0 = time.perf_counter(); run(300); fence()
+        out["ms_per_step_nce_f32"] = round((time.perf_counter() - t0) / 300 * 1e3, 4)
+        _ops.set_infonce_precision("bf16x3")
+        trainer.reset_graph()
+        run(5); fence()
     if rank == 0:
         try:
             t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
@@ -393,6 +489,9 @@ def main():
                                                   / (elapsed / args.steps) / 1e9, 1)}
         if not args.no_eval and not sharded:
             out["eval"] = eval_throughput(trainer, data)
+        if not sharded and not args.no_dropin and args.model == "XSimGCL":
+            out["dropin"] = dropin_throughput(args, raw)
+            out["dropin_pairs_per_s"] = out["dropin"]["pairs_per_s"]
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
             if out.get("eval"):

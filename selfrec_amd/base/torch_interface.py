@@ -67,13 +67,22 @@ class SparseAdjHandle:
 
     # BUIR.py:118-127 / MixGCF.py:84-94 drop entries of the adjacency themselves: they read the COO parts of the
     # tensor and build a new torch sparse tensor, which then multiplies through torch (outside the accelerated path)
-    def _indices(self):
+    def _coo(self):
+        """(2, nnz) int64 indices in (row, column) order and the permutation that puts the CSR's entries in that order
+        (the resident graph stores long rows by column class: data/device_graph.py)."""
         if getattr(self, "_coo_idx", None) is None:
-            self._coo_idx = self.to_sparse_coo()._indices()
-        return self._coo_idx
+            indptr = self.csr.indptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), indptr[1:] - indptr[:-1])
+            cols = self.csr.indices.to(torch.int64)
+            perm = torch.argsort(rows * self.shape[1] + cols)
+            self._coo_idx, self._coo_perm = torch.stack([rows[perm], cols[perm]]), perm
+        return self._coo_idx, self._coo_perm
+
+    def _indices(self):
+        return self._coo()[0]
 
     def _values(self):
-        return self.csr.vals
+        return self.csr.vals[self._coo()[1]]
 
     def transposed(self):
         if self._symmetric:
@@ -88,10 +97,7 @@ class SparseAdjHandle:
     def to_sparse_coo(self):
         """Escape hatch for code that wants the reference's COO tensor (BUIR/MixGCF style
         ``_indices()/_values()`` access is outside the accelerated path)."""
-        indptr = self.csr.indptr.to(torch.int64)
-        rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), indptr[1:] - indptr[:-1])
-        idx = torch.stack([rows, self.csr.indices.to(torch.int64)])
-        return torch.sparse_coo_tensor(idx, self.csr.vals, tuple(self.shape))
+        return torch.sparse_coo_tensor(self._indices(), self._values(), tuple(self.shape))
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -115,6 +121,12 @@ class TorchGraphInterface:
     def convert_sparse_mat_to_tensor(X):
         if isinstance(X, SparseAdjHandle):     # already on device (dropped views)
             return X
+        owner = getattr(X, "_srh_owner", None)
+        owner = owner() if owner is not None else None
+        if owner is not None and ops.gpu_available():
+            # data.norm_adj itself: the Interaction's resident device graph IS this matrix (normalised on device,
+            # bit-identical values -- tests/test_gpu_kernels.py) with the row / column-class SpMM schedule
+            return SparseAdjHandle(owner.device_graph().adj, symmetric=True, scipy_source=X)
         csr = X.tocsr().astype(np.float32)
         csr.sort_indices()
         return SparseAdjHandle(ops.DeviceCSR.from_scipy(csr), _is_symmetric(csr), scipy_source=csr)

@@ -908,6 +908,75 @@ struct srh_spmm_plan {
   float* d_partial = nullptr;      // n_slots * 256 floats (enough for d <= 256)
 };
 
+// host view of the epilogue (include/selfrec_hip.h) -> the kernels' argument block, with every check the ABI promises
+static srh_status_t translate_epilogue(const srh_spmm_epilogue_t* epi, int32_t d, const float* d_x, const float* d_y,
+                                       DevEpilogue& ep) {
+  if (epi) {
+    SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY)) == 0, "spmm_f32: unknown epilogue flag");
+    ep.flags = epi->flags;
+    ep.eps = epi->eps;
+    ep.noise = epi->d_noise;
+    ep.seed_lo = (uint32_t)epi->rng_seed; ep.seed_hi = (uint32_t)(epi->rng_seed >> 32);
+    ep.off_lo = (uint32_t)epi->rng_offset; ep.off_hi = (uint32_t)(epi->rng_offset >> 32);
+    ep.rng_step = epi->d_rng_step;
+    ep.rng_stride = epi->rng_stride;
+    ep.row_mark = epi->d_row_mark;
+    ep.col_mark = epi->d_col_mark;
+    ep.mark_stamp = epi->d_mark_stamp;
+    ep.add_mark = epi->d_add_mark;
+    ep.add_sparse = epi->add_sparse_mask;
+    if (epi->noise_d_full) {       // y is a column slice of noise_d_full-wide rows (column-sharded tables)
+      SRH_REQUIRE(epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
+                      epi->noise_col0 + d <= epi->noise_d_full,
+                  "spmm_f32: column slice [%d, %d) of %d-wide rows is not supported (aligned slices of rows a multiple of 32 wide)",
+                  epi->noise_col0, epi->noise_col0 + d, epi->noise_d_full);
+      ep.noise_d_full = epi->noise_d_full;
+      ep.noise_col0 = epi->noise_col0;
+    }
+    if (epi->n_extra || epi->main_clean) {
+      SRH_REQUIRE((epi->flags & SRH_EPI_PERTURB) && !(epi->flags & SRH_EPI_MEAN) && epi->n_extra >= 0 &&
+                      epi->n_extra <= SRH_MAX_EXTRA,
+                  "spmm_f32: extra perturbed outputs need PERTURB without MEAN and at most %d of them", SRH_MAX_EXTRA);
+      ep.n_extra = epi->n_extra;
+      ep.main_clean = epi->main_clean != 0;
+      for (int k = 0; k < epi->n_extra; ++k) {
+        SRH_REQUIRE(epi->d_extra_out[k] && epi->d_extra_out[k] != d_y && epi->d_extra_out[k] != d_x,
+                    "spmm_f32: bad extra output %d", k);
+        ep.extra_out[k] = epi->d_extra_out[k];
+        ep.extra_noise[k] = epi->d_extra_noise[k];
+        ep.extra_off_lo[k] = (uint32_t)epi->extra_rng_offset[k];
+        ep.extra_off_hi[k] = (uint32_t)(epi->extra_rng_offset[k] >> 32);
+      }
+    }
+    SRH_REQUIRE(!(ep.row_mark || ep.col_mark || ep.add_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
+    if (epi->flags & SRH_EPI_MEAN) {
+      SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,
+                  "spmm_f32: bad MEAN epilogue");
+      ep.n_prev = epi->n_prev;
+      for (int t = 0; t < epi->n_prev; ++t) {
+        SRH_REQUIRE(epi->d_prev[t], "spmm_f32: null prev[%d]", t);
+        ep.prev[t] = epi->d_prev[t];
+      }
+      ep.mean_rcp = 1.0f / epi->mean_div;
+      ep.mean_out = epi->d_mean_out;
+    }
+    if (epi->flags & SRH_EPI_AXPY) {
+      SRH_REQUIRE(epi->n_add >= 0 && epi->n_add <= SRH_MAX_ADD, "spmm_f32: bad AXPY epilogue");
+      ep.n_add = epi->n_add;
+      ep.alpha = epi->alpha;
+      for (int t = 0; t < epi->n_add; ++t) {
+        SRH_REQUIRE(epi->d_add[t], "spmm_f32: null add[%d]", t);
+        ep.add[t] = epi->d_add[t];
+        ep.add_scale[t] = epi->add_scale[t];
+      }
+    }
+  }
+  if (!ep.noise_d_full) { ep.noise_d_full = d; ep.noise_col0 = 0; }
+  SRH_REQUIRE(d > 32 || ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
+              "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
+  return SRH_OK;
+}
+
 extern "C" {
 
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
@@ -1090,70 +1159,8 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
   SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 32), "spmm_f32: x (%lld rows x %d) must be smaller than 4 GiB",
               (long long)plan->n_cols, d);
   DevEpilogue ep{};
-  if (epi) {
-    SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY)) == 0, "spmm_f32: unknown epilogue flag");
-    ep.flags = epi->flags;
-    ep.eps = epi->eps;
-    ep.noise = epi->d_noise;
-    ep.seed_lo = (uint32_t)epi->rng_seed; ep.seed_hi = (uint32_t)(epi->rng_seed >> 32);
-    ep.off_lo = (uint32_t)epi->rng_offset; ep.off_hi = (uint32_t)(epi->rng_offset >> 32);
-    ep.rng_step = epi->d_rng_step;
-    ep.rng_stride = epi->rng_stride;
-    ep.row_mark = epi->d_row_mark;
-    ep.col_mark = epi->d_col_mark;
-    ep.mark_stamp = epi->d_mark_stamp;
-    ep.add_mark = epi->d_add_mark;
-    ep.add_sparse = epi->add_sparse_mask;
-    if (epi->noise_d_full) {       // y is a column slice of noise_d_full-wide rows (column-sharded tables)
-      SRH_REQUIRE(epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
-                      epi->noise_col0 + d <= epi->noise_d_full,
-                  "spmm_f32: column slice [%d, %d) of %d-wide rows is not supported (aligned slices of rows a multiple of 32 wide)",
-                  epi->noise_col0, epi->noise_col0 + d, epi->noise_d_full);
-      ep.noise_d_full = epi->noise_d_full;
-      ep.noise_col0 = epi->noise_col0;
-    }
-    if (epi->n_extra || epi->main_clean) {
-      SRH_REQUIRE((epi->flags & SRH_EPI_PERTURB) && !(epi->flags & SRH_EPI_MEAN) && epi->n_extra >= 0 &&
-                      epi->n_extra <= SRH_MAX_EXTRA,
-                  "spmm_f32: extra perturbed outputs need PERTURB without MEAN and at most %d of them", SRH_MAX_EXTRA);
-      ep.n_extra = epi->n_extra;
-      ep.main_clean = epi->main_clean != 0;
-      for (int k = 0; k < epi->n_extra; ++k) {
-        SRH_REQUIRE(epi->d_extra_out[k] && epi->d_extra_out[k] != d_y && epi->d_extra_out[k] != d_x,
-                    "spmm_f32: bad extra output %d", k);
-        ep.extra_out[k] = epi->d_extra_out[k];
-        ep.extra_noise[k] = epi->d_extra_noise[k];
-        ep.extra_off_lo[k] = (uint32_t)epi->extra_rng_offset[k];
-        ep.extra_off_hi[k] = (uint32_t)(epi->extra_rng_offset[k] >> 32);
-      }
-    }
-    SRH_REQUIRE(!(ep.row_mark || ep.col_mark || ep.add_mark) || ep.mark_stamp, "spmm_f32: activity marks need d_mark_stamp");
-    if (epi->flags & SRH_EPI_MEAN) {
-      SRH_REQUIRE(epi->n_prev >= 0 && epi->n_prev <= SRH_MAX_PREV && epi->d_mean_out && epi->mean_div != 0.f,
-                  "spmm_f32: bad MEAN epilogue");
-      ep.n_prev = epi->n_prev;
-      for (int t = 0; t < epi->n_prev; ++t) {
-        SRH_REQUIRE(epi->d_prev[t], "spmm_f32: null prev[%d]", t);
-        ep.prev[t] = epi->d_prev[t];
-      }
-      ep.mean_rcp = 1.0f / epi->mean_div;
-      ep.mean_out = epi->d_mean_out;
-    }
-    if (epi->flags & SRH_EPI_AXPY) {
-      SRH_REQUIRE(epi->n_add >= 0 && epi->n_add <= SRH_MAX_ADD, "spmm_f32: bad AXPY epilogue");
-      ep.n_add = epi->n_add;
-      ep.alpha = epi->alpha;
-      for (int t = 0; t < epi->n_add; ++t) {
-        SRH_REQUIRE(epi->d_add[t], "spmm_f32: null add[%d]", t);
-        ep.add[t] = epi->d_add[t];
-        ep.add_scale[t] = epi->add_scale[t];
-      }
-    }
-  }
+  if (srh_status_t rc = translate_epilogue(epi, d, d_x, d_y, ep)) return rc;
   hipStream_t st = srh::as_stream(stream);
-  if (!ep.noise_d_full) { ep.noise_d_full = d; ep.noise_col0 = 0; }
-  SRH_REQUIRE(d > 32 || ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
-              "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
   // one kernel per table width: a row-group of d/4 lanes per gathered x row (d >= 16), two lanes per row at d = 8
 #define SRH_LAUNCH(KERNEL, GI, XT, YT)                                                                              \
   KERNEL<<<(plan->n_tasks[GI] + 3) / 4, 256, 0, st>>>(plan->d_tasks[GI], plan->n_tasks[GI], plan->d_tsegs, d_indices,  \

@@ -10,6 +10,7 @@ Differences are internal: one pass builds flat int32 id arrays (``train_u`` / ``
 feed the C++ sampler and the device CSR; the dict-of-dict views (``training_set_u`` ...) and
 the scipy matrices are materialised on first use.
 """
+import weakref
 from collections import defaultdict
 
 import numpy as np
@@ -195,7 +196,14 @@ class Interaction(Data, Graph):
 
     @property
     def norm_adj(self):
-        return self._lazy('Ahat', lambda: self.normalize_graph_mat(self.ui_adj))
+        def build():
+            m = self.normalize_graph_mat(self.ui_adj)
+            # convert_sparse_mat_to_tensor(data.norm_adj) -- what every model file does (e.g. XSimGCL.py:73) -- can then
+            # hand out the RESIDENT device adjacency (same values bit for bit, XCD-aware schedule) instead of
+            # uploading a second copy with a plain schedule
+            m._srh_owner = weakref.ref(self)
+            return m
+        return self._lazy('Ahat', build)
 
     def convert_to_laplacian_mat(self, adj_mat):
         lazy = getattr(adj_mat, 'to_device_laplacian', None)

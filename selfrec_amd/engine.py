@@ -691,6 +691,11 @@ class FusedTrainer:
             return (front, self._exchange, back, done)
         return (self._graph.replay if graphed else self._step_kernels, done)
 
+    def reset_graph(self):
+        """Forget the captured hipGraph (it is re-captured on the next step): needed after anything that changes which
+        kernels a step launches, e.g. ops.set_infonce_precision."""
+        self._graph = None
+
     def _capture(self):
         # warm up once eagerly on a side stream (allocator + lazy module loads), then capture.  (Column-
         # sharded: the warm-up skips the all-gather -- its numbers are thrown away with the snapshot -- so

@@ -16,6 +16,10 @@ from ._lib import SelfrecHipError, SpmmEpilogue, check
 
 require_gpu = _lib.require_gpu
 
+
+def gpu_available() -> bool:
+    return torch.cuda.is_available()
+
 __all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Run the reference's UNMODIFIED model files (model/graph/{XSimGCL,LightGCN,SimGCL,SGL}.py) on the HIP kernels.
+
+    python tools/run_reference_models.py --ref <dir holding the reference's model/ directory> [--models XSimGCL,LightGCN]
+
+`selfrec_amd.dropin.install()` registers this package's mirrors as `base.*`, `data.*`, `util.*`; the reference's
+`model/` directory is imported as it is.  /root/reference does not travel to the GPU box and reference sources are
+never committed here: for a gpurun session the directory is staged untracked (`_refstage/`, git-ignored) and removed
+afterwards -- VERDICT r01 "Next round" #3.  Per model, on the Yelp2018-shape synthetic graph (bench.py's):
+  1. parity: the first steps with the golden run's seeds and injected noise (torch.rand_like is patched in THIS
+     process to draw the golden's CPU noise stream; the model file is untouched) against tests/golden/shapes.npz;
+  2. throughput: one full epoch of `train()` as shipped (pairs/s, evaluation timed separately)."""
+import argparse
+import importlib
+import json
+import os
+import random
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+CONF = {
+    "XSimGCL": {"n_layer": 3, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2},
+    "LightGCN": {"n_layer": 3},
+    "SimGCL": {"n_layer": 3, "lambda": 0.5, "eps": 0.1},
+    "SGL": {"n_layer": 3, "lambda": 0.1, "drop_rate": 0.1, "aug_type": 1, "temp": 0.2},
+}
+
+
+def make_conf(tmp, model, extra, epochs):
+    from util.conf import ModelConf
+    lines = ["training.set: ./train.txt", "test.set: ./test.txt", "model:", f"  name: {model}", "  type: graph",
+             "item.ranking.topN: [10,20]", "embedding.size: 64", f"max.epoch: {epochs}", "batch.size: 2048",
+             "learning.rate: 0.001", "reg.lambda: 0.0001", "output: ./results/", f"{model}:"]
+    lines += [f"  {k}: {v}" for k, v in extra.items()]
+    path = os.path.join(tmp, f"{model}.yaml")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return ModelConf(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", required=True)
+    ap.add_argument("--models", default="XSimGCL,LightGCN,SimGCL,SGL")
+    ap.add_argument("--shape", default="yelp2018")
+    args = ap.parse_args()
+    from selfrec_amd import dropin, synth
+    dropin.install()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.abspath(args.ref))
+    golden = np.load(os.path.join(REPO, "tests", "golden", "shapes.npz"))
+    with open(os.path.join(REPO, "tests", "golden", "shapes_meta.json")) as f:
+        meta = json.load(f)
+    tu, ti, su, si, U, I = synth.make_dataset(args.shape, seed=2024)
+    train, test = synth.as_triples(tu, ti), synth.as_triples(su, si)
+    print(f"# {args.shape}-shape graph: {U} users x {I} items, {len(tu)} train / {len(su)} test interactions; "
+          f"torch {torch.__version__}, {torch.cuda.get_device_name(0)}")
+    real_rand_like = torch.rand_like
+    cwd = os.getcwd()
+    for name in args.models.split(","):
+        mod = importlib.import_module(f"model.graph.{name}")
+        src = os.path.abspath(mod.__file__)
+        assert src.startswith(os.path.abspath(args.ref)), src
+        assert mod.next_batch_pairwise.__module__ == "selfrec_amd.util.sampler", mod.next_batch_pairwise.__module__
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                tag = f"Y_{name}"
+                if tag in meta and args.shape == "yelp2018":
+                    # ---- 1. parity with the reference's CPU run of the same file (same seeds, same noise stream)
+                    info = meta[tag]
+                    rec = {"bpr": [], "nce": []}
+                    real = (mod.next_batch_pairwise, mod.bpr_loss, getattr(mod, "InfoNCE", None))
+
+                    def batches(data, bs, n_negs=1, real=real, n=info["n_steps"]):
+                        for k, b in enumerate(real[0](data, bs, n_negs)):
+                            if k == n:
+                                return
+                            yield b
+
+                    def wrap(fn, key):
+                        def inner(*a, **k):
+                            r = fn(*a, **k)
+                            rec[key].append(float(r))
+                            return r
+                        return inner
+                    mod.next_batch_pairwise = batches
+                    mod.bpr_loss = wrap(real[1], "bpr")
+                    if real[2] is not None:
+                        mod.InfoNCE = wrap(real[2], "nce")
+                    gen = torch.Generator().manual_seed(info["noise_seed"])
+                    torch.rand_like = lambda t, **k: torch.rand(t.shape, generator=gen).to(t.device)
+                    torch.manual_seed(info["init_seed"])
+                    random.seed(info["sampler_seed"])
+                    model = getattr(mod, name)(make_conf(tmp, name, info["conf"], 1), [list(t) for t in train], [list(t) for t in test])
+                    model.fast_evaluation = lambda epoch: None
+                    try:
+                        model.train()
+                    except AttributeError as e:
+                        assert "best_user_emb" in str(e), e
+                    mod.next_batch_pairwise, mod.bpr_loss = real[0], real[1]
+                    if real[2] is not None:
+                        mod.InfoNCE = real[2]
+                    torch.rand_like = real_rand_like
+                    params = model.model.embedding_dict
+                    pu = params["user_emb"].detach().cpu().numpy()[golden[f"{tag}_rows_user"]]
+                    pi = params["item_emb"].detach().cpu().numpy()[golden[f"{tag}_rows_item"]]
+                    d_bpr = np.abs(np.asarray(rec["bpr"]) / golden[f"{tag}_loss_bpr"] - 1).max()
+                    d_nce = np.abs(np.asarray(rec["nce"]) / golden[f"{tag}_loss_nce"] - 1).max() if rec["nce"] else 0.0
+                    d_par = max(np.abs(pu - golden[f"{tag}_param_user"]).max(), np.abs(pi - golden[f"{tag}_param_item"]).max())
+                    ok = d_bpr < 1e-5 and d_nce < 2e-5 and d_par < 1e-5
+                    print(f"{name}: parity vs the reference's CPU run of the same file, {info['n_steps']} steps: "
+                          f"bpr {rec['bpr']} (rel diff {d_bpr:.1e}), InfoNCE rel diff {d_nce:.1e}, max |param diff| {d_par:.1e} "
+                          f"-> {'OK' if ok else 'MISMATCH'}")
+                # ---- 2. one epoch of train() as shipped
+                torch.manual_seed(1)
+                random.seed(1)
+                model = getattr(mod, name)(make_conf(tmp, name, CONF[name], 1), [list(t) for t in train], [list(t) for t in test])
+                t_eval = [0.0]
+                real_eval = model.fast_evaluation
+
+                def timed_eval(epoch):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    r = real_eval(epoch)
+                    torch.cuda.synchronize(); t_eval[0] += time.perf_counter() - t0
+                    return r
+                model.fast_evaluation = timed_eval
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                try:
+                    model.train()
+                except AttributeError as e:                # SGL evaluates from epoch 5 on: no best_* after one epoch
+                    assert "best_user_emb" in str(e), e
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0 - t_eval[0]
+                print(f"{name}: 1 epoch of the unmodified {os.path.relpath(src, os.path.abspath(args.ref))}: {len(tu)} pairs in "
+                      f"{dt:.2f} s = {len(tu) / dt:,.0f} pairs/s ({dt / ((len(tu) + 2047) // 2048) * 1e3:.2f} ms/step, "
+                      f"sampling included); fast_evaluation {t_eval[0]:.2f} s")
+            finally:
+                os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()

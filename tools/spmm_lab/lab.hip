@@ -1,0 +1,388 @@
+// SpMM laboratory (tools only -- NOT part of libselfrec_hip.so): candidate kernels for the d = 64 propagation
+// launch, built next to the product kernels (this file #includes csrc/spmm.hip, so it shares DevEpilogue,
+// row_epilogue, the plan structure and the split-row hand-off) and driven by tools/spmm_lab/run.py, which
+// checks every variant against the product launch and times it.  A variant that wins is ported into
+// csrc/spmm.hip; the measurements go to profiles/ and DESIGN.md.  VERDICT r01 "Next round" #4.
+//
+// Variants (lab_spmm `variant` argument):
+//   1  asm inner loop.  The compiler's gather loop spends ~12 VALU + 4 SALU instructions per gathered x row
+//      (zero-init movs for the DPP 'old' operand, a v_lshl_or per address, 4 zero-fill movs + saveexec/branch
+//      per predicated load).  Here: address = v_or_b32_dpp(col << 8, lane offset) -- the DPP broadcast and the
+//      address arithmetic are ONE instruction --, value = one v_mov_b32_dpp, predicate = v_cmpx on the value
+//      (padding / dropped / dead entries issue no gather; their destination registers keep older, finite x
+//      values and are multiplied by 0), loads counted with explicit vmcnt waits so FMAs start as rows arrive.
+//   2  variant 1 + one 64-byte task record per wave read with scalar loads (the product reads a 16-byte task,
+//      then 16-byte segment records with vector loads: two dependent vector-memory round trips before the first
+//      (col, val) load; here one s_load_dwordx16), next chunk's (col, val) in flight under the current gathers.
+//   3  variant 2 without values (timing probe for the value-free form A_ij = d_i^-1/2 d_j^-1/2: x pre-scaled,
+//      y scaled per row): entries carry only a column, padding = sign bit; compare against the product launch
+//      on an all-ones value array.
+//      (x must carry one extra all-zero row: padding entries point at it and every gather is unconditional)
+//   6  variant 2 with unconditional gathers (padding -> the zero row, value 0): what the predicate costs / saves.
+//   4  variant 2 with the column-activity test on a BITMAP (1 bit per column, L1-resident 8.7 KB at the Yelp2018
+//      shape) instead of one 4-byte mark gather per entry;  5  the same with the bitmap staged in LDS.
+#include "../../selfrec_amd/csrc/spmm.hip"
+
+namespace lab {
+
+using namespace srh;
+
+struct alignas(64) Task64 {
+  int32_t kind, count, slot, pad;      // kind 0: coop on (row[0], start[0], end[0], slot); kind 1: `count` short rows
+  int32_t row[4], start[4], end[4];
+};
+
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+#define LAB_DPP_OR(T)                                                                                          \
+  asm volatile("v_or_b32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(off[T & 7]) : "v"(cs), "v"(sub16))
+#define LAB_DPP_MOV(T)                                                                                         \
+  asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(vv[T & 7]) : "v"(v))
+
+// Eight x rows at byte offsets off[0..7] of X; an entry whose offset has the sign bit set (padding, dropped edge,
+// dead column: its value is 0) issues no gather -- its destination keeps an older, finite x row that is then
+// multiplied by 0.  One exec save per eight loads; v_cmpx writes exec directly (no saveexec / branch / zero-fill).
+__device__ __forceinline__ void pred_load8(floatx4_t (&xx)[8], const unsigned (&off)[8], const void* X) {
+  unsigned long long save;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_le_i32_e32 0, %[o0]\n\tglobal_load_dwordx4 %[x0], %[o0], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o1]\n\tglobal_load_dwordx4 %[x1], %[o1], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o2]\n\tglobal_load_dwordx4 %[x2], %[o2], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o3]\n\tglobal_load_dwordx4 %[x3], %[o3], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o4]\n\tglobal_load_dwordx4 %[x4], %[o4], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o5]\n\tglobal_load_dwordx4 %[x5], %[o5], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o6]\n\tglobal_load_dwordx4 %[x6], %[o6], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o7]\n\tglobal_load_dwordx4 %[x7], %[o7], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "s_nop 4"        // VALU-written exec -> DPP op needs 5 wait states (the value broadcasts follow)
+      : [x0] "+v"(xx[0]), [x1] "+v"(xx[1]), [x2] "+v"(xx[2]), [x3] "+v"(xx[3]), [x4] "+v"(xx[4]), [x5] "+v"(xx[5]),
+        [x6] "+v"(xx[6]), [x7] "+v"(xx[7]), [sv] "=&s"(save)
+      : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
+        [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X)
+      : "memory", "vcc");
+}
+// unconditional form (padding entries point at an all-zero x row appended to the table)
+__device__ __forceinline__ void plain_load(floatx4_t& xr, unsigned off, const void* X) {
+  asm volatile("global_load_dwordx4 %[x], %[off], %[base]" : [x] "=v"(xr) : [off] "v"(off), [base] "s"(X) : "memory");
+}
+
+#define LAB_WAIT(N, XR) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(XR))
+
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+struct Acc { floatx2_t lo, hi; };       // columns 0-1 / 2-3 of this lane's float4 of the output row
+
+// acc += value * x for one gathered row, as soon as it has landed (N loads may still be in flight): two packed FMAs.
+// Two consecutive entries keep their values in ONE even-aligned register pair (SEL = 0: low dword, 1: high dword,
+// via op_sel) -- a pair per entry, as the compiler allocates them, costs 8 extra VGPRs and a wave per SIMD.
+#define LAB_FMA(N, SEL, VP, XR)                                                                                 \
+  asm volatile("s_waitcnt vmcnt(" #N ")\n\t"                                                                    \
+               "v_pk_fma_f32 %[lo], %[vp], %[xlo], %[lo] op_sel:[" #SEL ",0,0] op_sel_hi:[" #SEL ",1,1]\n\t"      \
+               "v_pk_fma_f32 %[hi], %[vp], %[xhi], %[hi] op_sel:[" #SEL ",0,0] op_sel_hi:[" #SEL ",1,1]"          \
+               : [lo] "+v"(acc.lo), [hi] "+v"(acc.hi)                                                           \
+               : [vp] "v"(VP), [xlo] "v"(__builtin_shufflevector(XR, XR, 0, 1)), [xhi] "v"(__builtin_shufflevector(XR, XR, 2, 3)))
+
+// entries T0 .. T0+7 of the 16 this lane's DPP row holds: cs = col << 8 (bytes of a 256-byte x row; sign bit = no
+// gather), v = value.  xx[] persists across calls (stale rows are finite).  HI selects row_newbcast 8..15.
+// The value broadcasts are issued AFTER the loads: VALU work under the memory latency, and off[] / vv[] never live
+// together.
+template <bool HI, bool PRED>
+__device__ __forceinline__ void gather8_asm(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
+                                            Acc& acc) {
+  unsigned off[8];
+  float vv[8];
+  // (VALU write -> DPP read of the same VGPR needs 2 wait states; inline asm is invisible to the hazard recogniser)
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  if (!HI) {
+    LAB_DPP_OR(0); LAB_DPP_OR(1); LAB_DPP_OR(2); LAB_DPP_OR(3); LAB_DPP_OR(4); LAB_DPP_OR(5); LAB_DPP_OR(6); LAB_DPP_OR(7);
+  } else {
+    LAB_DPP_OR(8); LAB_DPP_OR(9); LAB_DPP_OR(10); LAB_DPP_OR(11); LAB_DPP_OR(12); LAB_DPP_OR(13); LAB_DPP_OR(14); LAB_DPP_OR(15);
+  }
+  if (PRED) {
+    pred_load8(xx, off, X);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) plain_load(xx[t], off[t], X);
+  }
+  if (!HI) {
+    LAB_DPP_MOV(0); LAB_DPP_MOV(1); LAB_DPP_MOV(2); LAB_DPP_MOV(3); LAB_DPP_MOV(4); LAB_DPP_MOV(5); LAB_DPP_MOV(6); LAB_DPP_MOV(7);
+  } else {
+    LAB_DPP_MOV(8); LAB_DPP_MOV(9); LAB_DPP_MOV(10); LAB_DPP_MOV(11); LAB_DPP_MOV(12); LAB_DPP_MOV(13); LAB_DPP_MOV(14); LAB_DPP_MOV(15);
+  }
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  LAB_FMA(7, 0, p0, xx[0]);
+  LAB_FMA(6, 1, p0, xx[1]);
+  LAB_FMA(5, 0, p1, xx[2]);
+  LAB_FMA(4, 1, p1, xx[3]);
+  LAB_FMA(3, 0, p2, xx[4]);
+  LAB_FMA(2, 1, p2, xx[5]);
+  LAB_FMA(1, 0, p3, xx[6]);
+  LAB_FMA(0, 1, p3, xx[7]);
+}
+
+// value-free: every entry (padding included: it points at the zero row) is gathered and added
+template <bool HI>
+__device__ __forceinline__ void gather8_novals(unsigned cs, unsigned sub16, const void* X, floatx4_t (&xx)[8],
+                                               Acc& acc) {
+  unsigned off[8];
+  asm volatile("s_nop 1" : "+v"(cs));
+  if (!HI) {
+    LAB_DPP_OR(0); LAB_DPP_OR(1); LAB_DPP_OR(2); LAB_DPP_OR(3); LAB_DPP_OR(4); LAB_DPP_OR(5); LAB_DPP_OR(6); LAB_DPP_OR(7);
+  } else {
+    LAB_DPP_OR(8); LAB_DPP_OR(9); LAB_DPP_OR(10); LAB_DPP_OR(11); LAB_DPP_OR(12); LAB_DPP_OR(13); LAB_DPP_OR(14); LAB_DPP_OR(15);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) plain_load(xx[t], off[t], X);
+  LAB_WAIT(7, xx[0]); acc.lo += __builtin_shufflevector(xx[0], xx[0], 0, 1); acc.hi += __builtin_shufflevector(xx[0], xx[0], 2, 3);
+  LAB_WAIT(6, xx[1]); acc.lo += __builtin_shufflevector(xx[1], xx[1], 0, 1); acc.hi += __builtin_shufflevector(xx[1], xx[1], 2, 3);
+  LAB_WAIT(5, xx[2]); acc.lo += __builtin_shufflevector(xx[2], xx[2], 0, 1); acc.hi += __builtin_shufflevector(xx[2], xx[2], 2, 3);
+  LAB_WAIT(4, xx[3]); acc.lo += __builtin_shufflevector(xx[3], xx[3], 0, 1); acc.hi += __builtin_shufflevector(xx[3], xx[3], 2, 3);
+  LAB_WAIT(3, xx[4]); acc.lo += __builtin_shufflevector(xx[4], xx[4], 0, 1); acc.hi += __builtin_shufflevector(xx[4], xx[4], 2, 3);
+  LAB_WAIT(2, xx[5]); acc.lo += __builtin_shufflevector(xx[5], xx[5], 0, 1); acc.hi += __builtin_shufflevector(xx[5], xx[5], 2, 3);
+  LAB_WAIT(1, xx[6]); acc.lo += __builtin_shufflevector(xx[6], xx[6], 0, 1); acc.hi += __builtin_shufflevector(xx[6], xx[6], 2, 3);
+  LAB_WAIT(0, xx[7]); acc.lo += __builtin_shufflevector(xx[7], xx[7], 0, 1); acc.hi += __builtin_shufflevector(xx[7], xx[7], 2, 3);
+}
+
+__device__ __forceinline__ float4 to_f4(const Acc& a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
+
+// in-kernel finish of a split row (same protocol as spmm_rows_kernel)
+__device__ __forceinline__ void finish_split(float4 acc, int row, int slot, int lane, int g, int sub, float4* __restrict__ Y,
+                                             float4* __restrict__ partial, const Heavy* __restrict__ heavy,
+                                             const int32_t* __restrict__ slot_owner, int32_t* __restrict__ tickets,
+                                             const DevEpilogue& ep) {
+  constexpr int LPR = 16, G = 4;
+  if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, acc);
+  const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
+  const Heavy h = heavy[hid];
+  const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
+  const int hn = __builtin_amdgcn_readfirstlane(h.n_slots);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != hn - 1) return;
+  if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float4 sum = f4_zero();
+  for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
+  row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
+}
+
+// MODE 1: product task / segment records, asm inner loop
+//      2: Task64 records (scalar loads) + (col, val) prefetch
+//      3: 2, value-free
+//      4: 2, column activity from a global bitmap;  5: from an LDS copy of the bitmap
+template <int MODE>
+__global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ tasks, const Task64* __restrict__ tasks64,
+                                                   int n_tasks, const Seg* __restrict__ segs,
+                                                   const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                                   const float4* __restrict__ X, float4* __restrict__ Y,
+                                                   float4* __restrict__ partial, const Heavy* __restrict__ heavy,
+                                                   const int32_t* __restrict__ slot_owner, int32_t* __restrict__ tickets,
+                                                   const uint32_t* __restrict__ col_bits, int n_bit_words, int pad_row, DevEpilogue ep) {
+  constexpr int LPR = 16, G = 4, CH = 64;
+  extern __shared__ uint32_t lds_bits[];
+  if (MODE == 5) {
+    for (int k = threadIdx.x; k < n_bit_words; k += 256) lds_bits[k] = col_bits[k];
+    __syncthreads();
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, sub = lane & 15, e16 = sub;
+  const unsigned sub16 = (unsigned)sub * 16u;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
+  Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
+  floatx4_t xx[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xx[t] = zero;
+
+  int kind, count, slot0;
+  int row, s, e;              // this row-group's row / entry range (coop: the wave's segment)
+  if (MODE == 1) {
+    const Task tk = tasks[wave];
+    kind = __builtin_amdgcn_readfirstlane(tk.kind);
+    const int first = __builtin_amdgcn_readfirstlane(tk.first);
+    count = __builtin_amdgcn_readfirstlane(tk.count);
+    const Seg sg = segs[first + ((kind == 1 && g < count) ? g : 0)];
+    row = sg.row; s = sg.start; e = sg.end; slot0 = sg.slot;
+  } else {
+    const Task64* tp = tasks64 + wave;       // uniform address: scalar loads
+    kind = tp->kind; count = tp->count; slot0 = tp->slot;
+    const int r0 = tp->row[0], r1 = tp->row[1], r2 = tp->row[2], r3 = tp->row[3];
+    const int s0 = tp->start[0], s1 = tp->start[1], s2 = tp->start[2], s3 = tp->start[3];
+    const int e0 = tp->end[0], e1 = tp->end[1], e2 = tp->end[2], e3 = tp->end[3];
+    const int gg = (kind == 1) ? g : 0;
+    row = gg == 0 ? r0 : gg == 1 ? r1 : gg == 2 ? r2 : r3;
+    s = gg == 0 ? s0 : gg == 1 ? s1 : gg == 2 ? s2 : s3;
+    e = gg == 0 ? e0 : gg == 1 ? e1 : gg == 2 ? e2 : e3;
+  }
+
+  // (col, val) of one entry as the gather wants them; col-activity test folded in
+  auto fetch = [&](int j, int end, unsigned& cs, float& v) {
+    int c = 0;
+    v = 0.f;
+    if (j < end) { c = indices[j]; if (MODE != 3) v = vals[j]; }
+    else if (MODE == 3 || MODE == 6) c = pad_row;        // the all-zero row appended to x
+    if (MODE == 3) { cs = (unsigned)c << 8; return; }
+    if (ep.col_mark && v != 0.f) {
+      bool live;
+      if (MODE == 4) live = (col_bits[c >> 5] >> (c & 31)) & 1u;
+      else if (MODE == 5) live = (lds_bits[c >> 5] >> (c & 31)) & 1u;
+      else live = ep.col_mark[c] == stamp;
+      if (!live) v = 0.f;
+    }
+    cs = (unsigned)c << 8;
+    if (MODE != 6 && v == 0.f) cs = 0x80000000u;      // padding / dropped edge / dead column: no gather
+  };
+
+  if (kind == 0) {
+    row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
+    const int slot = __builtin_amdgcn_readfirstlane(slot0);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    unsigned cs, csn = 0;
+    float v, vn = 0.f;
+    fetch(s + 16 * g + e16, e, cs, v);
+    for (int base = s; base < e; base += CH) {
+      if (MODE >= 2 && base + CH < e) fetch(base + CH + 16 * g + e16, e, csn, vn);     // next chunk in flight
+      if (MODE == 3) {
+        gather8_novals<false>(cs, sub16, X, xx, acc);
+        if (e - base > 8) gather8_novals<true>(cs, sub16, X, xx, acc);
+      } else {
+        gather8_asm<false, MODE != 6>(cs, v, sub16, X, xx, acc);
+        if (e - base > 8) gather8_asm<true, MODE != 6>(cs, v, sub16, X, xx, acc);
+      }
+      if (MODE >= 2) { cs = csn; v = vn; }
+      else if (base + CH < e) fetch(base + CH + 16 * g + e16, e, cs, v);
+    }
+    float4 a4 = to_f4(acc);
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
+    if (slot < 0) { row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep); return; }
+    finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+    return;
+  }
+
+  // ---- one short row per row-group ----
+  const bool have = g < count;
+  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
+  if (!live) e = s;
+  int maxlen = e - s;
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  unsigned cs, csn = 0;
+  float v, vn = 0.f;
+  fetch(s + e16, e, cs, v);
+  for (int q = 0; q * 16 < maxlen; ++q) {
+    if (MODE >= 2 && (q + 1) * 16 < maxlen) fetch(s + 16 * (q + 1) + e16, e, csn, vn);
+    if (MODE == 3) {
+      gather8_novals<false>(cs, sub16, X, xx, acc);
+      if (maxlen - 16 * q > 8) gather8_novals<true>(cs, sub16, X, xx, acc);
+    } else {
+      gather8_asm<false, MODE != 6>(cs, v, sub16, X, xx, acc);
+      if (maxlen - 16 * q > 8) gather8_asm<true, MODE != 6>(cs, v, sub16, X, xx, acc);
+    }
+    if (MODE >= 2) { cs = csn; v = vn; }
+    else if ((q + 1) * 16 < maxlen) fetch(s + 16 * (q + 1) + e16, e, cs, v);
+  }
+  row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
+}
+
+// marks -> bitmap (1 = column live this step)
+__global__ void build_bits(const int32_t* __restrict__ mark, const int64_t* __restrict__ stamp, int n, uint32_t* __restrict__ bits) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 32 >= n) return;
+  const int st = (int)*stamp;
+  uint32_t b = 0;
+  for (int k = 0; k < 32 && w * 32 + k < n; ++k) b |= (mark[w * 32 + k] == st ? 1u : 0u) << k;
+  bits[w] = b;
+}
+
+struct Lab {
+  Task64* d_tasks64 = nullptr;
+  int n_tasks = 0;
+  uint32_t* d_bits = nullptr;
+  int n_bit_words = 0;
+};
+
+}  // namespace lab
+
+extern "C" {
+
+// Task64 records for the plan's 4-rows-per-wave task list (LPR = 16)
+int lab_create(void** out, const srh_spmm_plan_t* plan) {
+  using namespace lab;
+  const int n = plan->n_tasks[1];
+  std::vector<Task> tasks(n);
+  if (hipMemcpy(tasks.data(), plan->d_tasks[1], sizeof(Task) * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int n_segs = 0;
+  for (const Task& t : tasks) n_segs = std::max(n_segs, t.first + std::max(1, t.count));
+  std::vector<Seg> segs(n_segs);
+  if (hipMemcpy(segs.data(), plan->d_tsegs, sizeof(Seg) * n_segs, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  std::vector<Task64> t64(n);
+  for (int k = 0; k < n; ++k) {
+    Task64 r{};
+    r.kind = tasks[k].kind; r.count = tasks[k].count; r.slot = -1;
+    for (int q = 0; q < 4; ++q) {
+      const Seg& sg = segs[tasks[k].first + ((tasks[k].kind == 1 && q < tasks[k].count) ? q : 0)];
+      r.row[q] = sg.row; r.start[q] = sg.start; r.end[q] = (tasks[k].kind == 1 && q >= tasks[k].count) ? sg.start : sg.end;
+      if (q == 0) r.slot = sg.slot;
+    }
+    t64[k] = r;
+  }
+  Lab* L = new Lab();
+  L->n_tasks = n;
+  L->n_bit_words = (int)((plan->n_cols + 31) / 32);
+  if (hipMalloc(&L->d_tasks64, sizeof(Task64) * std::max(1, n)) != hipSuccess) return -1;
+  if (hipMemcpy(L->d_tasks64, t64.data(), sizeof(Task64) * n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (hipMalloc(&L->d_bits, sizeof(uint32_t) * L->n_bit_words) != hipSuccess) return -1;
+  if (hipMemset(L->d_bits, 0, sizeof(uint32_t) * L->n_bit_words) != hipSuccess) return -1;
+  *out = L;
+  return 0;
+}
+
+void lab_destroy(void* h) {
+  lab::Lab* L = reinterpret_cast<lab::Lab*>(h);
+  if (!L) return;
+  (void)hipFree(L->d_tasks64); (void)hipFree(L->d_bits);
+  delete L;
+}
+
+// refresh the column bitmap from the epilogue's col_mark / stamp (not timed with the product: batch_fetch would write it)
+int lab_build_bits(void* h, const int32_t* d_mark, const int64_t* d_stamp, int n, void* stream) {
+  lab::Lab* L = reinterpret_cast<lab::Lab*>(h);
+  const int words = (n + 31) / 32;
+  lab::build_bits<<<(words + 255) / 256, 256, 0, srh::as_stream(stream)>>>(d_mark, d_stamp, n, L->d_bits);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
+             float* d_y, const srh_spmm_epilogue_t* epi, void* stream, int variant) {
+  using namespace lab;
+  Lab* L = reinterpret_cast<Lab*>(h);
+  DevEpilogue ep{};
+  if (translate_epilogue(epi, 64, d_x, d_y, ep) != SRH_OK) return -2;
+  hipStream_t st = srh::as_stream(stream);
+  const int n = plan->n_tasks[1];
+  const int blocks = (n + 3) / 4;
+#define LAB_LAUNCH(M, SH)                                                                                           \
+  rows_kernel<M><<<blocks, 256, SH, st>>>(plan->d_tasks[1], L->d_tasks64, n, plan->d_tsegs, d_indices, d_vals,       \
+                                          reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),      \
+                                          reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy,                 \
+                                          plan->d_slot_owner, plan->d_tickets, L->d_bits, L->n_bit_words, (int)plan->n_cols, ep)
+  switch (variant) {
+    case 1: LAB_LAUNCH(1, 0); break;
+    case 2: LAB_LAUNCH(2, 0); break;
+    case 3: LAB_LAUNCH(3, 0); break;
+    case 4: LAB_LAUNCH(4, 0); break;
+    case 5: LAB_LAUNCH(5, L->n_bit_words * 4); break;
+    case 6: LAB_LAUNCH(6, 0); break;
+    default: return -3;
+  }
+#undef LAB_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Drive tools/spmm_lab/liblab.so: every candidate SpMM kernel against the product launch (correctness first,
+then HIP-event timing) on the Yelp2018-shape graph, in the three flavours a training step issues.
+
+    python tools/spmm_lab/run.py [--shape yelp2018] [--iters 100]          (on the GPU box)
+
+Build (cross-compiles here):  make -C tools/spmm_lab
+Prints one table; copy it to profiles/ with the round tag."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from selfrec_amd import _lib, ops, synth  # noqa: E402
+from selfrec_amd.data.ui_graph import Interaction  # noqa: E402
+
+VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) prefetch", 6: "2, unconditional gathers (zero row)",
+            3: "2, value-free (vs product on all-ones values)", 4: "2, column bitmap (global)", 5: "2, column bitmap (LDS)"}
+
+
+def timed(fn, iters):
+    for _ in range(10):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3          # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=2024)
+    args = ap.parse_args()
+    _lib.require_gpu()
+    lab = C.CDLL(os.path.join(HERE, "liblab.so"))
+    vp, i32 = C.c_void_p, C.c_int32
+    lab.lab_create.argtypes = [C.POINTER(vp), vp]
+    lab.lab_spmm.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(_lib.SpmmEpilogue), vp, i32]
+    lab.lab_build_bits.argtypes = [vp, vp, vp, i32, vp]
+    dev = torch.device("cuda", 0)
+    tu, ti, su, si, U, I = synth.make_dataset(args.shape, seed=args.seed)
+    data = Interaction.from_id_arrays({}, tu, ti, su, si, U, I)
+    g = data.device_graph(dev)
+    adj, N, d = g.adj, g.n_nodes, 64
+    gen = torch.Generator().manual_seed(1)
+    xfull = torch.zeros((N + 1, d), device=dev)
+    xfull[:N] = (torch.randn((N, d), generator=gen) * 0.1).to(dev)
+    x = xfull[:N]                                     # row N = zeros: the padding row of variants 3 / 6
+    ones = adj.with_values(torch.ones_like(adj.vals))
+    # one batch worth of activity marks (B edges: their users, items and as many negatives)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(len(tu), size=2048, replace=False)
+    marked = np.unique(np.concatenate([tu[pick], ti[pick] + U, rng.integers(0, I, 2048) + U]))
+    mark = torch.zeros(N, dtype=torch.int32, device=dev)
+    mark[torch.from_numpy(marked).to(dev)] = 7
+    stamp = torch.tensor([7], dtype=torch.int64, device=dev)
+    h = vp()
+    assert lab.lab_create(C.byref(h), adj._plan) == 0
+    assert lab.lab_build_bits(h, mark.data_ptr(), stamp.data_ptr(), N, None) == 0
+    torch.cuda.synchronize()
+    flavours = {
+        "dense": lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=1, rng_offset=0),
+        "row_masked": lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=1, rng_offset=0, row_mark=mark, mark_stamp=stamp),
+        "col_masked": lambda: ops.make_epilogue(col_mark=mark, mark_stamp=stamp),
+        "plain": lambda: None,
+    }
+    st = torch.cuda.current_stream().cuda_stream
+    y_ref, y = torch.zeros((N, d), device=dev), torch.zeros((N, d), device=dev)
+
+    def lab_call(csr, ep, variant, out):
+        rc = lab.lab_spmm(h, csr._plan, csr.indices.data_ptr(), csr.vals.data_ptr(), x.data_ptr(), out.data_ptr(),
+                          C.byref(ep) if ep is not None else None, st, variant)
+        assert rc == 0, (variant, rc)
+
+    print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
+    print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
+    base = {}
+    for name, mk in flavours.items():
+        ep = mk()
+        base[name] = timed(lambda: ops.spmm(adj, x, out=y_ref, epilogue=ep), args.iters)
+    print(f"{'0  product (spmm_rows_kernel<16>)':<58}" + "".join(f"{base[k]:>14.2f}" for k in flavours))
+    for variant, label in VARIANTS.items():
+        cells = []
+        for name, mk in flavours.items():
+            if variant in (4, 5) and name != "col_masked":
+                cells.append(f"{'-':>14}")
+                continue
+            csr = ones if variant == 3 else adj
+            ep = mk()
+            y_ref.zero_(); y.fill_(float("nan"))
+            ops.spmm(csr, x, out=y_ref, epilogue=ep)
+            lab_call(csr, ep, variant, y)
+            torch.cuda.synchronize()
+            rows = torch.nonzero(mark == 7).flatten() if name == "row_masked" else slice(None)   # others are not written
+            a, b = y[rows], y_ref[rows]
+            bad = int((a != b).sum().item()) + int(torch.isnan(a).sum().item())
+            err = float((a - b).abs().max().item()) if bad else 0.0
+            t = timed(lambda: lab_call(csr, ep, variant, y), args.iters)
+            cells.append(f"{t:>9.2f}{'  ok ' if bad == 0 else f' e{err:.0e}'[:5]:>5}")
+        print(f"{str(variant) + '  ' + label:<58}" + "".join(cells))
+    # bitwise repeatability of the best candidate under load
+    ep = flavours["dense"]()
+    lab_call(adj, ep, 2, y_ref)
+    same = True
+    for _ in range(10):
+        lab_call(adj, ep, 2, y)
+        same &= bool(torch.equal(y, y_ref))
+    print(f"# variant 2 dense: 10 repeats bitwise identical: {same}")
+
+
+if __name__ == "__main__":
+    main()
