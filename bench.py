@@ -197,7 +197,7 @@ def dropin_throughput(args, raw, steps=60, warmup=8):
     normalize / sign perturbation, stack + mean, fancy-index gathers, util.loss_torch losses, torch.optim.Adam,
     the next_batch_pairwise generator pulled synchronously: XSimGCL.py:23-50,83-101) running on this package's
     sampler, SpMM handle and loss kernels.  The unmodified reference files were run the same way in a gpurun
-    session (profiles/r02_dropin_reference_models.txt); /root/reference does not exist where bench.py runs."""
+    session (profiles/r02_a_dropin_reference_models.txt); /root/reference does not exist where bench.py runs."""
     import random
     import torch.nn.functional as F
     from selfrec_amd import synth

@@ -95,6 +95,20 @@ __device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned
   if (rows <= 0) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int b = (int)((block_id * 256u + threadIdx.x) >> 6) * G + g;
+  // the row data does not depend on the fold of phase 1's partials below: its loads go first (row-groups past the
+  // batch re-read its last row and are dropped at the end)
+  const int bq = min(b, rows - 1);
+  const int bu = a.u_idx[bq], bi = a.i_idx[bq], bj = a.j_idx[bq];
+  const float cf = a.coef[bq];
+  const float4 u = reinterpret_cast<const float4*>(a.user)[(size_t)bu * LPR + sub];
+  const float4 p = reinterpret_cast<const float4*>(a.item)[(size_t)bi * LPR + sub];
+  const float4 n = reinterpret_cast<const float4*>(a.item)[(size_t)bj * LPR + sub];
+  float4 ru = u, rp = p, rn = n;
+  if (a.reg_user != a.user) ru = reinterpret_cast<const float4*>(a.reg_user)[(size_t)bu * LPR + sub];
+  if (a.reg_item != a.item) {
+    rp = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bi * LPR + sub];
+    rn = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bj * LPR + sub];
+  }
   __shared__ double s_tot[4];
   if (threadIdx.x < 64) {                 // wave 0 folds the per-workgroup partials (fixed order)
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -114,11 +128,7 @@ __device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned
     a.losses[1] += (double)(a.loss_scale * (r * a.reg_coef));
   }
   if (b >= rows) return;
-  const int bu = a.u_idx[b], bi = a.i_idx[b], bj = a.j_idx[b];
-  const float4 u = reinterpret_cast<const float4*>(a.user)[(size_t)bu * LPR + sub];
-  const float4 p = reinterpret_cast<const float4*>(a.item)[(size_t)bi * LPR + sub];
-  const float4 n = reinterpret_cast<const float4*>(a.item)[(size_t)bj * LPR + sub];
-  const float c = a.coef[b] * (a.loss_scale / (float)rows);
+  const float c = cf * (a.loss_scale / (float)rows);
   float4 gu = make_float4(c * (p.x - n.x), c * (p.y - n.y), c * (p.z - n.z), c * (p.w - n.w));
   float4 gp = f4_scale(u, c);
   float4 gn = f4_scale(u, -c);
@@ -128,12 +138,6 @@ __device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned
   const float cn = (a.reg_include_neg && nn > 0.f) ? rs / nn : 0.f;
   const bool same_u = (a.reg_user == a.user) && (a.greg_user == a.g_user);
   const bool same_i = (a.reg_item == a.item) && (a.greg_item == a.g_item);
-  float4 ru = u, rp = p, rn = n;
-  if (a.reg_user != a.user) ru = reinterpret_cast<const float4*>(a.reg_user)[(size_t)bu * LPR + sub];
-  if (a.reg_item != a.item) {
-    rp = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bi * LPR + sub];
-    rn = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bj * LPR + sub];
-  }
   if (same_u) gu = f4_fma(cu, ru, gu);
   else atomic_add_f4(a.greg_user + ((size_t)bu * LPR + sub) * 4, f4_scale(ru, cu));
   if (same_i) {
@@ -201,7 +205,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // ---------------------------------------------------------------------------------------
 // InfoNCE
 // ---------------------------------------------------------------------------------------
-constexpr int kNceSplits = 16;      // workspace is sized for this many key splits; batch.splits <= it are used
+constexpr int kNceSplits = 16;      // workspace is sized for this many key splits
+constexpr int kNceUsedSplits = 8;   // key-range splits per query tile (NceBatch::splits; the finish kernel unrolls over it)
 
 // Arithmetic of the two n x n x d products (srh_infonce_set_precision): split-bf16 x 3 on the bf16 MFMA (default;
 // logits within 2e-5 absolute of fp32, loss and gradients within 2e-5 relative of the reference) or exact f32
@@ -483,20 +488,32 @@ __device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, floa
 // gradients of both views through the normalisation and scatter them.  Returns the row's loss term
 // (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
 template <int LPR>
-__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int splits, int n, int i,
-                                                 int sub) {
+__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub) {
   const bool valid = i < n;
   const int ii = valid ? i : 0;
   const size_t at = (size_t)ii * LPR + sub;
-  float4 O1 = f4_zero(), O2 = f4_zero();
-  float l = 0.f;
-  for (int ks = 0; ks < splits; ++ks) {
-    O1 = f4_add(O1, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
-    O2 = f4_add(O2, reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at]);
-    l += w.lpart[(size_t)ks * w.np + ii];
+  // every load of the row is issued before the first use: this kernel is a chain of dependent round trips for
+  // O(batch) bytes, and a split loop with a run-time trip count serialised eight of them
+  float4 p1[kNceUsedSplits], p2[kNceUsedSplits];
+  float lp[kNceUsedSplits];
+#pragma unroll
+  for (int ks = 0; ks < kNceUsedSplits; ++ks) {
+    p1[ks] = reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at];
+    p2[ks] = reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at];
+    lp[ks] = w.lpart[(size_t)ks * w.np + ii];
   }
   const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
   const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
+  const float n1 = w.norm1[ii], n2 = w.norm2[ii];
+  const int dst = w.idx ? w.idx[ii] : ii;
+  float4 O1 = f4_zero(), O2 = f4_zero();
+  float l = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < kNceUsedSplits; ++ks) {      // split order: the order pass 2 folded 1 / l in
+    O1 = f4_add(O1, p1[ks]);
+    O2 = f4_add(O2, p2[ks]);
+    l += lp[ks];
+  }
   const float coef = a.loss_scale * a.inv_tau / (float)n;
   const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
   const float lse = a.inv_tau + logf(l);
@@ -504,10 +521,9 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const float4 dn1 = make_float4(coef * (O1.x * il - vb.x), coef * (O1.y * il - vb.y), coef * (O1.z * il - vb.z),
                                  coef * (O1.w * il - vb.w));
   const float4 dn2 = make_float4(coef * (O2.x - va.x), coef * (O2.y - va.y), coef * (O2.z - va.z), coef * (O2.w - va.w));
-  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, w.norm1[ii]);
-  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, w.norm2[ii]);
+  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, n1);
+  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, n2);
   if (valid) {
-    const int dst = w.idx ? w.idx[i] : i;
     // atomic: BPR phase 2 shares this launch and adds to the same rows (a plain read-modify-write of
     // the rows nobody else touches was measured: 2 us of 330)
     atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
@@ -762,7 +778,7 @@ __device__ __forceinline__ void nce_finish_both_body(const NceBatch& batch, cons
   const int n_waves = (int)(w.np / G);
   if (n <= 0 || wave >= n_waves) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, batch.splits, n, wave * G + g, sub));
+  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub));
   // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
   __shared__ double wg_part[4];
   if (lane == 0) wg_part[threadIdx.x >> 6] = part;
@@ -802,7 +818,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   constexpr int LPR = D / 4, G = 64 / LPR;
   NceBatch batch{};
   batch.count = count;
-  batch.splits = 8;
+  batch.splits = kNceUsedSplits;
   int np_max = 0;
   char* cursor = reinterpret_cast<char*>(ws);
   for (int k = 0; k < count; ++k) {

@@ -215,9 +215,91 @@ __device__ __forceinline__ float4 ld_x(const float4* __restrict__ X, int c, int 
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + off);
 }
 
-// entries T0 .. T0+7 of the 16 that this lane's DPP row holds: 8 gathers in flight, then 8 FMAs
+// 16-byte write-through store (sc1): the partial goes straight to memory and is not left dirty in this
+// XCD's L2, so publishing it needs no L2 write-back fence (cdna_hip_programming.md G16, form R1)
+__device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
+  floatx4_t x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
+// ---- the gather loop of spmm_rows_kernel, in inline assembly -------------------------------------------
+// What the compiler makes of the C++ form (profiles/r02_a_spmm_lab.txt, variant 0): ~12 VALU + 4 SALU
+// instructions per gathered x row -- a zero-init mov for each DPP broadcast's `old` operand, a v_lshl_or per
+// address, four zero-fill movs + saveexec / branch / restore around every predicated load, and one even-aligned
+// VGPR PAIR per broadcast value for v_pk_fma's 64-bit operand (8 pairs: the kernel sat at 70 VGPRs).  Here, per
+// entry: address = v_or_b32_dpp(col * row bytes, lane offset) -- DPP broadcast and address arithmetic in ONE
+// instruction --, predicate = v_cmpx on the offset's sign bit (padding / dropped edges / dead columns carry it:
+// they issue no gather, their destination keeps an older, FINITE x row that is then multiplied by 0), value =
+// one v_mov_b32_dpp issued after the loads (VALU under the memory latency), two v_pk_fma_f32 with two entries'
+// values sharing one register pair (op_sel).  5 VALU + 1 SALU per entry, 62 VGPRs: 8 waves per SIMD.
+// Inline asm is invisible to the compiler's hazard recogniser and waitcnt insertion, hence the explicit s_nop
+// (VALU write -> DPP read: 2 wait states; VALU-written exec -> DPP: 5) and the explicit vmcnt counts; a load the
+// compiler issues in between only makes those waits conservative (returns are in order).
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+struct Acc2 { floatx2_t lo, hi; };       // columns 0-1 / 2-3 of this lane's float4 of the output row
+
+#define SRH_DPP_OR(T)                                                                                          \
+  asm volatile("v_or_b32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(off[T & 7]) : "v"(cs), "v"(sub16))
+#define SRH_DPP_MOV(T)                                                                                         \
+  asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(vv[T & 7]) : "v"(v))
+// acc += value * x for one gathered row, as soon as it has landed (N younger loads may still be in flight)
+#define SRH_FMA(N, SEL, VP, XR)                                                                                 \
+  asm volatile("s_waitcnt vmcnt(" #N ")\n\t"                                                                    \
+               "v_pk_fma_f32 %[lo], %[vp], %[xlo], %[lo] op_sel:[" #SEL ",0,0] op_sel_hi:[" #SEL ",1,1]\n\t"      \
+               "v_pk_fma_f32 %[hi], %[vp], %[xhi], %[hi] op_sel:[" #SEL ",0,0] op_sel_hi:[" #SEL ",1,1]"          \
+               : [lo] "+v"(acc.lo), [hi] "+v"(acc.hi)                                                           \
+               : [vp] "v"(VP), [xlo] "v"(__builtin_shufflevector(XR, XR, 0, 1)), [xhi] "v"(__builtin_shufflevector(XR, XR, 2, 3)))
+
+__device__ __forceinline__ void pred_load8(floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3, floatx4_t& x4,
+                                           floatx4_t& x5, floatx4_t& x6, floatx4_t& x7, const unsigned (&off)[8],
+                                           const void* X) {
+  unsigned long long save;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_le_i32_e32 0, %[o0]\n\tglobal_load_dwordx4 %[x0], %[o0], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o1]\n\tglobal_load_dwordx4 %[x1], %[o1], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o2]\n\tglobal_load_dwordx4 %[x2], %[o2], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o3]\n\tglobal_load_dwordx4 %[x3], %[o3], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o4]\n\tglobal_load_dwordx4 %[x4], %[o4], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o5]\n\tglobal_load_dwordx4 %[x5], %[o5], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o6]\n\tglobal_load_dwordx4 %[x6], %[o6], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_le_i32_e32 0, %[o7]\n\tglobal_load_dwordx4 %[x7], %[o7], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+      "s_nop 4"
+      : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),
+        [x7] "+v"(x7), [sv] "=&s"(save)
+      : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
+        [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X)
+      : "memory", "vcc");
+}
+
+// entries 0-7 (HI false) or 8-15 (HI true) of the 16 this lane's DPP row holds.  cs = column * row bytes (sign bit:
+// no gather), v = value, sub16 = this lane's byte offset inside an x row; xx[] persists across calls.
+template <bool HI>
+__device__ __forceinline__ void gather8(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8], Acc2& acc) {
+  unsigned off[8];
+  float vv[8];
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  if (!HI) {
+    SRH_DPP_OR(0); SRH_DPP_OR(1); SRH_DPP_OR(2); SRH_DPP_OR(3); SRH_DPP_OR(4); SRH_DPP_OR(5); SRH_DPP_OR(6); SRH_DPP_OR(7);
+  } else {
+    SRH_DPP_OR(8); SRH_DPP_OR(9); SRH_DPP_OR(10); SRH_DPP_OR(11); SRH_DPP_OR(12); SRH_DPP_OR(13); SRH_DPP_OR(14); SRH_DPP_OR(15);
+  }
+  pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  if (!HI) {
+    SRH_DPP_MOV(0); SRH_DPP_MOV(1); SRH_DPP_MOV(2); SRH_DPP_MOV(3); SRH_DPP_MOV(4); SRH_DPP_MOV(5); SRH_DPP_MOV(6); SRH_DPP_MOV(7);
+  } else {
+    SRH_DPP_MOV(8); SRH_DPP_MOV(9); SRH_DPP_MOV(10); SRH_DPP_MOV(11); SRH_DPP_MOV(12); SRH_DPP_MOV(13); SRH_DPP_MOV(14); SRH_DPP_MOV(15);
+  }
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  SRH_FMA(7, 0, p0, xx[0]); SRH_FMA(6, 1, p0, xx[1]); SRH_FMA(5, 0, p1, xx[2]); SRH_FMA(4, 1, p1, xx[3]);
+  SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
+}
+
+// The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
+// entries are dead): the compiler's version branches over a gather whose whole wave is dead, where the asm form
+// still issues the exec = 0 load -- measured 34.2 against 38.1 us at the Yelp2018 shape (profiles/r02_a_spmm_lab.txt).
 template <int LPR, int T0>
-__device__ __forceinline__ void gather8(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
+__device__ __forceinline__ void gather8_branchy(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
   int cc[8];
   float vv[8];
   float4 xx[8];
@@ -227,25 +309,27 @@ __device__ __forceinline__ void gather8(int c, float v, const float4* __restrict
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     xx[t] = f4_zero();
-    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // padding / dropped / dead columns: no gather
+    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
-// 16-byte write-through store (sc1): the partial goes straight to memory and is not left dirty in this
-// XCD's L2, so publishing it needs no L2 write-back fence (cdna_hip_programming.md G16, form R1)
-__device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
-  floatx4_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-}
+// One record per wave, read with scalar loads (the task -> segment -> (col, val) chain of dependent VECTOR round
+// trips loses its first two links): kind 0 = the wave's cooperative segment (row[0], start[0], end[0], slot),
+// kind 1 = `count` <= G short rows, one per row-group.
+struct alignas(64) Task64 {
+  int32_t kind, count, slot, pad;
+  int32_t row[4], start[4], end[4];
+};
 
 // Split rows are completed inside this launch by whichever of their segments arrives last (write-through
 // partials -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver reads the partials with agent-scope
 // loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms the ticket).
-template <int LPR>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__ tasks, int n_tasks,
-                                                        const Seg* __restrict__ segs,
+// COLMASK: the launch carries column activity marks (its own instantiation: the unmasked kernel then has no mark
+// code and always prefetches; a run-time switch between the two cost 2.5 us per launch).
+template <int LPR, bool COLMASK>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,
@@ -255,38 +339,79 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
                                                         int32_t* __restrict__ tickets, DevEpilogue ep) {
   constexpr int G = 64 / LPR;          // row-groups per wave
   constexpr int CH = 16 * G;           // entries per coop chunk
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
-  const Task tk = tasks[wave];
-  const int kind = __builtin_amdgcn_readfirstlane(tk.kind);
-  const int first = __builtin_amdgcn_readfirstlane(tk.first);
-  const int count = __builtin_amdgcn_readfirstlane(tk.count);
+  const unsigned sub16 = (unsigned)sub * 16u;
   const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-  float4 acc = f4_zero();
+  const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
+  Acc2 acc = {{0.f, 0.f}, {0.f, 0.f}};
+  floatx4_t xx[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xx[t] = zero;
+
+  const Task64* tp = tasks + wave;       // uniform address: s_load
+  const int kind = tp->kind, count = tp->count, slot = tp->slot;
+  int row = tp->row[0], s = tp->start[0], e = tp->end[0];
+  if (kind == 1 && G > 1) {
+    const int r1 = tp->row[1], s1 = tp->start[1], e1 = tp->end[1];
+    if (g == 1) { row = r1; s = s1; e = e1; }
+    if (G > 2) {
+      const int r2 = tp->row[2], s2 = tp->start[2], e2 = tp->end[2], r3 = tp->row[3], s3 = tp->start[3], e3 = tp->end[3];
+      if (g == 2) { row = r2; s = s2; e = e2; }
+      if (g == 3) { row = r3; s = s3; e = e3; }
+    }
+  }
+  // (col, val) of one entry as the gather wants them: the column pre-multiplied by the row bytes, the sign bit on
+  // entries that must not gather (padding, zero values = SGL's dropped edges, columns dead this step)
+  auto fetch = [&](int j, int end, unsigned& cs, float& v) {
+    int c = 0;
+    v = 0.f;
+    if (j < end) { c = indices[j]; v = vals[j]; }
+    if (COLMASK) {
+      if (v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
+      cs = (unsigned)c;                                   // (gather8_branchy takes the plain column)
+    } else {
+      cs = (v == 0.f) ? 0x80000000u : (unsigned)c * (unsigned)(LPR * 16);
+    }
+  };
+  // the next chunk's (col, val) are in flight under the current gathers -- except on column-masked launches, where
+  // the mark gather hangs off the column load and prefetching two dependent loads was measured to lose
+  constexpr bool prefetch = !COLMASK;
+  unsigned cs, csn = 0x80000000u;
+  float v, vn = 0.f;
+  float4 accm = f4_zero();                                // COLMASK accumulator
+  auto chunk = [&](int rem) {
+    if (COLMASK) {
+      gather8_branchy<LPR, 0>((int)cs, v, X, sub, accm);
+      if (rem > 8) gather8_branchy<LPR, 8>((int)cs, v, X, sub, accm);
+    } else {
+      gather8<false>(cs, v, sub16, X, xx, acc);
+      if (rem > 8) gather8<true>(cs, v, sub16, X, xx, acc);
+    }
+  };
+  auto total = [&]() { return COLMASK ? accm : make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y); };
 
   if (kind == 0) {
-    const Seg sg = segs[first];
-    const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
-    const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
+    row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
     if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    fetch(s + 16 * g + e16, e, cs, v);
     for (int base = s; base < e; base += CH) {
-      const int j = base + 16 * g + e16;
-      int c = 0;
-      float v = 0.f;
-      if (j < e) { c = indices[j]; v = vals[j]; }
-      if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
-      gather8<LPR, 0>(c, v, X, sub, acc);
-      if (e - base > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+      const bool more = base + CH < e;
+      if (prefetch && more) fetch(base + CH + 16 * g + e16, e, csn, vn);
+      chunk(e - base);
+      if (prefetch) { cs = csn; v = vn; }
+      else if (more) fetch(base + CH + 16 * g + e16, e, cs, v);
     }
+    float4 a4 = total();
 #pragma unroll
-    for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
-      row_epilogue<LPR>(acc, row, sub, g == 0, Y, ep);
+      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
       return;
     }
-    if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, acc);
+    if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, a4);
     const int hid = __builtin_amdgcn_readfirstlane(slot_owner[slot]);
     const Heavy h = heavy[hid];
     const int hfirst = __builtin_amdgcn_readfirstlane(h.first_slot);
@@ -306,25 +431,21 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task* __restrict__
   }
 
   // ---- one short row per row-group ----
-  const bool have = g < count;
-  const Seg sg = segs[first + (have ? g : 0)];
-  const int row = sg.row, s = sg.start;
-  const bool live = have && (!ep.row_mark || ep.row_mark[row] == stamp);
-  const int e = live ? sg.end : s;
+  const bool live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
+  if (!live) e = s;
   int maxlen = e - s;
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  fetch(s + e16, e, cs, v);
   for (int q = 0; q * 16 < maxlen; ++q) {
-    const int j = s + 16 * q + e16;
-    int c = 0;
-    float v = 0.f;
-    if (j < e) { c = indices[j]; v = vals[j]; }
-    if (ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
-    gather8<LPR, 0>(c, v, X, sub, acc);
-    if (maxlen - 16 * q > 8) gather8<LPR, 8>(c, v, X, sub, acc);
+    const bool more = (q + 1) * 16 < maxlen;
+    if (prefetch && more) fetch(s + 16 * (q + 1) + e16, e, csn, vn);
+    chunk(maxlen - 16 * q);
+    if (prefetch) { cs = csn; v = vn; }
+    else if (more) fetch(s + 16 * (q + 1) + e16, e, cs, v);
   }
-  row_epilogue<LPR>(acc, row, sub, live, Y, ep);
+  row_epilogue<LPR>(total(), row, sub, live, Y, ep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -902,6 +1023,7 @@ struct srh_spmm_plan {
   int32_t n_tasks[5] = {0, 0, 0, 0, 0};
   Task* d_tasks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Seg* d_tsegs = nullptr;          // segments in task order (+ 16 padding records: a short-row task may read past its count)
+  Task64* d_tasks64[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // spmm_rows_kernel's records (index 1..3)
   Heavy* d_heavy = nullptr;
   int32_t* d_slot_owner = nullptr;
   int32_t* d_tickets = nullptr;    // one arrival counter per split row, self re-arming
@@ -1100,6 +1222,26 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     if (err == hipSuccess && !tasks[gi].empty())
       err = hipMemcpy(p->d_tasks[gi], tasks[gi].data(), sizeof(Task) * tasks[gi].size(), hipMemcpyHostToDevice);
   }
+  // spmm_rows_kernel (d = 64 / 128 / 256) reads one self-contained 64-byte record per wave
+  for (int gi = 1; gi <= 3 && err == hipSuccess; ++gi) {
+    const int Gr = 8 >> gi;
+    std::vector<Task64> t64(tasks[gi].size());
+    for (size_t k = 0; k < tasks[gi].size(); ++k) {
+      const Task& tk = tasks[gi][k];
+      Task64 r{};
+      r.kind = tk.kind; r.count = tk.count; r.slot = -1;
+      for (int q = 0; q < 4; ++q) {
+        const bool have = tk.kind == 1 ? (q < tk.count && q < Gr) : q == 0;
+        const Seg& sg = tsegs[tk.first + (have ? q : 0)];
+        r.row[q] = sg.row; r.start[q] = sg.start; r.end[q] = have ? sg.end : sg.start;
+        if (q == 0) r.slot = sg.slot;
+      }
+      t64[k] = r;
+    }
+    err = hipMalloc(&p->d_tasks64[gi], sizeof(Task64) * std::max<size_t>(1, t64.size()));
+    if (err == hipSuccess && !t64.empty())
+      err = hipMemcpy(p->d_tasks64[gi], t64.data(), sizeof(Task64) * t64.size(), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess && !heavy.empty()) {
     err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
     if (err == hipSuccess) err = hipMemcpy(p->d_heavy, heavy.data(), sizeof(Heavy) * heavy.size(), hipMemcpyHostToDevice);
@@ -1126,6 +1268,7 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_tickets) (void)hipFree(p->d_tickets);
   if (p->d_tsegs) (void)hipFree(p->d_tsegs);
   for (int gi = 0; gi < 5; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
+  for (int gi = 0; gi < 5; ++gi) if (p->d_tasks64[gi]) (void)hipFree(p->d_tasks64[gi]);
   delete p;
 }
 
@@ -1171,9 +1314,26 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
     case 8: SRH_LAUNCH(spmm_pair_kernel, 0, float, float); break;
     case 16: SRH_LAUNCH(spmm_slice_kernel<4>, 4, float4, float4); break;
     case 32: SRH_LAUNCH(spmm_slice_kernel<8>, 0, float4, float4); break;
-    case 64: SRH_LAUNCH(spmm_rows_kernel<16>, 1, float4, float4); break;
-    case 128: SRH_LAUNCH(spmm_rows_kernel<32>, 2, float4, float4); break;
-    default: SRH_LAUNCH(spmm_rows_kernel<64>, 3, float4, float4); break;
+    default: {
+      // (the gather offsets carry "no gather" in their sign bit: the table must stay below 2 GiB)
+      SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
+                  (long long)plan->n_cols, d);
+#define SRH_LAUNCH_ROWS(LPRV, GI, CM)                                                                                \
+  spmm_rows_kernel<LPRV, CM><<<(plan->n_tasks[GI] + 3) / 4, 256, 0, st>>>(                                           \
+      plan->d_tasks64[GI], plan->n_tasks[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),              \
+      reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
+      plan->d_tickets, ep)
+      if (ep.col_mark) {
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, true);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true);
+        else SRH_LAUNCH_ROWS(64, 3, true);
+      } else {
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false);
+        else SRH_LAUNCH_ROWS(64, 3, false);
+      }
+#undef SRH_LAUNCH_ROWS
+    }
   }
 #undef SRH_LAUNCH
   SRH_LAUNCH_CHECK();

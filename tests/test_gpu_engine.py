@@ -239,7 +239,9 @@ def test_sharded_step_in_a_hipgraph_equals_the_single_gpu_step(golden_models, go
             torch.cuda.synchronize()
             outs.append((torch.cat([tr.user_emb, tr.item_emb]).cpu().numpy(), tr.read_losses()))
         assert np.isfinite(outs[0][0]).all()
-        assert rel_err(outs[1][0], outs[0][0]) < 1e-5
+        # (the sharded graph is stored without column classes: long rows are summed in a different order, and six
+        # Adam steps amplify that -- see tests/test_gpu_shapes.py's docstring; observed 0.8e-5 .. 1.2e-5)
+        assert rel_err(outs[1][0], outs[0][0]) < 3e-5
         np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5)
     finally:
         if created:

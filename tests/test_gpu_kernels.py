@@ -215,7 +215,8 @@ def test_device_normalisation_matches_reference(golden_ops, tiny_data):
 
 
 def test_normalisation_isolated_nodes_and_weights():
-    # node 2 isolated after dropping its only edge; duplicate interaction -> weight 2
+    # node 2 isolated after dropping its only edge; duplicate interaction -> weight 2 in the full adjacency
+    # (scipy sums it, ui_graph.py:47-56) but 1 in a dropped view (augmentor.py:36-39 rebuilds with ones)
     r = sp.csr_matrix((np.array([1, 2, 1, 1], dtype=np.float32), ([0, 0, 1, 2], [0, 1, 1, 2])), shape=(3, 3))
     from selfrec_amd.data.device_graph import DeviceGraph
     g = DeviceGraph(r)
@@ -223,7 +224,7 @@ def test_normalisation_isolated_nodes_and_weights():
     np.testing.assert_allclose(g.adj.vals.cpu().numpy(), want.data, rtol=3e-7)
     keep = torch.tensor([1, 1, 1, 0], dtype=torch.uint8, device=DEV)
     v = g.dropped_view(keep).vals.cpu().numpy()
-    r2 = r.copy(); r2.data[3] = 0; r2.eliminate_zeros()
+    r2 = r.copy(); r2.data[:] = 1.0; r2.data[3] = 0; r2.eliminate_zeros()
     with np.errstate(divide="ignore"):
         want2 = O.laplacian_of(r2).toarray()
     got2 = sp.csr_matrix((v, g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()), shape=(6, 6)).toarray()

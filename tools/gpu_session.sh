@@ -23,7 +23,11 @@ testsnew)
   timeout 1500 python -m pytest tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests_new.log 2>&1; echo "testsnew exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed|Error|assert" $OUT/tests_new.log | tail -40;;
 lab)
-  timeout 900 python tools/spmm_lab/run.py > $OUT/spmm_lab.log 2>&1; echo "lab exit $?"; grep -v amdgpu.ids $OUT/spmm_lab.log | tail -14;;
+  timeout 900 python tools/spmm_lab/run.py ${LAB_ARGS:-} > $OUT/spmm_lab.log 2>&1; echo "lab exit $?"; grep -v amdgpu.ids $OUT/spmm_lab.log | tail -${LAB_TAIL:-20};;
+lab2)
+  timeout 900 python tools/spmm_lab/run.py --ids first-appearance > $OUT/spmm_lab_fa.log 2>&1; echo "lab2 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_fa.log | tail -${LAB_TAIL:-20};;
+precision)
+  timeout 900 python tools/precision_probe.py > $OUT/precision_probe.log 2>&1; echo "precision exit $?"; grep -v amdgpu.ids $OUT/precision_probe.log | tail -8;;
 bench)
   timeout 1200 python bench.py --steps ${BENCH_STEPS:-1300} --warmup 50 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"
   tail -3 $OUT/bench.err; tail -1 $OUT/bench.log | cut -c1-3000;;

@@ -27,10 +27,7 @@ namespace lab {
 
 using namespace srh;
 
-struct alignas(64) Task64 {
-  int32_t kind, count, slot, pad;      // kind 0: coop on (row[0], start[0], end[0], slot); kind 1: `count` short rows
-  int32_t row[4], start[4], end[4];
-};
+// (Task64: the product's record, csrc/spmm.hip)
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
@@ -42,7 +39,8 @@ typedef float floatx4_t __attribute__((ext_vector_type(4)));
 // Eight x rows at byte offsets off[0..7] of X; an entry whose offset has the sign bit set (padding, dropped edge,
 // dead column: its value is 0) issues no gather -- its destination keeps an older, finite x row that is then
 // multiplied by 0.  One exec save per eight loads; v_cmpx writes exec directly (no saveexec / branch / zero-fill).
-__device__ __forceinline__ void pred_load8(floatx4_t (&xx)[8], const unsigned (&off)[8], const void* X) {
+__device__ __forceinline__ void pred_load8(floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3, floatx4_t& x4,
+                                           floatx4_t& x5, floatx4_t& x6, floatx4_t& x7, const unsigned (&off)[8], const void* X) {
   unsigned long long save;
   asm volatile(
       "s_mov_b64 %[sv], exec\n\t"
@@ -55,8 +53,8 @@ __device__ __forceinline__ void pred_load8(floatx4_t (&xx)[8], const unsigned (&
       "v_cmpx_le_i32_e32 0, %[o6]\n\tglobal_load_dwordx4 %[x6], %[o6], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
       "v_cmpx_le_i32_e32 0, %[o7]\n\tglobal_load_dwordx4 %[x7], %[o7], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
       "s_nop 4"        // VALU-written exec -> DPP op needs 5 wait states (the value broadcasts follow)
-      : [x0] "+v"(xx[0]), [x1] "+v"(xx[1]), [x2] "+v"(xx[2]), [x3] "+v"(xx[3]), [x4] "+v"(xx[4]), [x5] "+v"(xx[5]),
-        [x6] "+v"(xx[6]), [x7] "+v"(xx[7]), [sv] "=&s"(save)
+      : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5),
+        [x6] "+v"(x6), [x7] "+v"(x7), [sv] "=&s"(save)
       : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
         [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X)
       : "memory", "vcc");
@@ -98,7 +96,7 @@ __device__ __forceinline__ void gather8_asm(unsigned cs, float v, unsigned sub16
     LAB_DPP_OR(8); LAB_DPP_OR(9); LAB_DPP_OR(10); LAB_DPP_OR(11); LAB_DPP_OR(12); LAB_DPP_OR(13); LAB_DPP_OR(14); LAB_DPP_OR(15);
   }
   if (PRED) {
-    pred_load8(xx, off, X);
+    pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
   } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) plain_load(xx[t], off[t], X);
@@ -117,6 +115,48 @@ __device__ __forceinline__ void gather8_asm(unsigned cs, float v, unsigned sub16
   LAB_FMA(2, 1, p2, xx[5]);
   LAB_FMA(1, 0, p3, xx[6]);
   LAB_FMA(0, 1, p3, xx[7]);
+}
+
+// all 16 entries of the DPP row in flight at once (xx[16]): twice the bytes in flight per wave, ~100 VGPRs
+__device__ __forceinline__ void gather16_asm(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[16], Acc& acc) {
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  {
+    unsigned off[8];
+    LAB_DPP_OR(0); LAB_DPP_OR(1); LAB_DPP_OR(2); LAB_DPP_OR(3); LAB_DPP_OR(4); LAB_DPP_OR(5); LAB_DPP_OR(6); LAB_DPP_OR(7);
+    pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  }
+  {
+    unsigned off[8];
+    LAB_DPP_OR(8); LAB_DPP_OR(9); LAB_DPP_OR(10); LAB_DPP_OR(11); LAB_DPP_OR(12); LAB_DPP_OR(13); LAB_DPP_OR(14); LAB_DPP_OR(15);
+    pred_load8(xx[8], xx[9], xx[10], xx[11], xx[12], xx[13], xx[14], xx[15], off, X);
+  }
+  {
+    float vv[8];
+    LAB_DPP_MOV(0); LAB_DPP_MOV(1); LAB_DPP_MOV(2); LAB_DPP_MOV(3); LAB_DPP_MOV(4); LAB_DPP_MOV(5); LAB_DPP_MOV(6); LAB_DPP_MOV(7);
+    const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+    LAB_FMA(15, 0, p0, xx[0]); LAB_FMA(14, 1, p0, xx[1]); LAB_FMA(13, 0, p1, xx[2]); LAB_FMA(12, 1, p1, xx[3]);
+    LAB_FMA(11, 0, p2, xx[4]); LAB_FMA(10, 1, p2, xx[5]); LAB_FMA(9, 0, p3, xx[6]); LAB_FMA(8, 1, p3, xx[7]);
+  }
+  {
+    float vv[8];
+    LAB_DPP_MOV(8); LAB_DPP_MOV(9); LAB_DPP_MOV(10); LAB_DPP_MOV(11); LAB_DPP_MOV(12); LAB_DPP_MOV(13); LAB_DPP_MOV(14); LAB_DPP_MOV(15);
+    const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+    LAB_FMA(7, 0, p0, xx[8]); LAB_FMA(6, 1, p0, xx[9]); LAB_FMA(5, 0, p1, xx[10]); LAB_FMA(4, 1, p1, xx[11]);
+    LAB_FMA(3, 0, p2, xx[12]); LAB_FMA(2, 1, p2, xx[13]); LAB_FMA(1, 0, p3, xx[14]); LAB_FMA(0, 1, p3, xx[15]);
+  }
+}
+
+// the low 8 entries on a 16-row register array (DEPTH 2 kernels, chunks with <= 8 entries left)
+__device__ __forceinline__ void gather8_lo16(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[16], Acc& acc) {
+  unsigned off[8];
+  float vv[8];
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  LAB_DPP_OR(0); LAB_DPP_OR(1); LAB_DPP_OR(2); LAB_DPP_OR(3); LAB_DPP_OR(4); LAB_DPP_OR(5); LAB_DPP_OR(6); LAB_DPP_OR(7);
+  pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  LAB_DPP_MOV(0); LAB_DPP_MOV(1); LAB_DPP_MOV(2); LAB_DPP_MOV(3); LAB_DPP_MOV(4); LAB_DPP_MOV(5); LAB_DPP_MOV(6); LAB_DPP_MOV(7);
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  LAB_FMA(7, 0, p0, xx[0]); LAB_FMA(6, 1, p0, xx[1]); LAB_FMA(5, 0, p1, xx[2]); LAB_FMA(4, 1, p1, xx[3]);
+  LAB_FMA(3, 0, p2, xx[4]); LAB_FMA(2, 1, p2, xx[5]); LAB_FMA(1, 0, p3, xx[6]); LAB_FMA(0, 1, p3, xx[7]);
 }
 
 // value-free: every entry (padding included: it points at the zero row) is gathered and added
@@ -290,6 +330,137 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
   row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
 }
 
+// Second generation: K tasks per wave (tasks b, b + NB, ... of its workgroup column, so a wave keeps its XCD class),
+// every task record read with scalar loads up front, and the FIRST (col, val) chunk of task j+1 in flight under the
+// last gathers of task j -- the per-task chain "record -> (col, val) -> gathers -> store" loses its first two links.
+// DEPTH 2: all 16 entries of a chunk in flight (xx[16]) instead of 8 + 8.  VALS false: value-free (zero row padding).
+template <int K, int DEPTH, bool VALS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 5 : 7, 8))) void rows_kernel2(const Task64* __restrict__ tasks64, int n_tasks,
+                                                    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                                    const float4* __restrict__ X, float4* __restrict__ Y,
+                                                    float4* __restrict__ partial, const Heavy* __restrict__ heavy,
+                                                    const int32_t* __restrict__ slot_owner, int32_t* __restrict__ tickets,
+                                                    int pad_row, DevEpilogue ep) {
+  constexpr int LPR = 16;
+  constexpr int NX = (DEPTH == 2 && VALS) ? 16 : 8;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, sub = lane & 15, e16 = sub;
+  const unsigned sub16 = (unsigned)sub * 16u;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nb = (int)gridDim.x;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
+  // this lane's view of a task: entry cursor of chunk 0, stride between chunks, end, row; uniform: kind, chunks, slot
+  struct View { int kind, n_chunks, slot, rem0; int row, j0, stride, end; bool live; };
+  auto view_of = [&](int t) {
+    View w{};
+    if (t >= n_tasks) { w.n_chunks = 0; w.kind = -1; return w; }
+    const Task64* tp = tasks64 + t;
+    const int kind = tp->kind, count = tp->count;
+    const int r0 = tp->row[0], r1 = tp->row[1], r2 = tp->row[2], r3 = tp->row[3];
+    const int s0 = tp->start[0], s1 = tp->start[1], s2 = tp->start[2], s3 = tp->start[3];
+    const int e0 = tp->end[0], e1 = tp->end[1], e2 = tp->end[2], e3 = tp->end[3];
+    w.kind = kind; w.slot = tp->slot;
+    if (kind == 0) {
+      w.row = r0; w.end = e0; w.stride = 64; w.j0 = s0 + 16 * g + e16;
+      w.live = !ep.row_mark || ep.row_mark[r0] == stamp;
+      w.rem0 = w.live ? e0 - s0 : 0;
+      w.n_chunks = (w.rem0 + 63) >> 6;
+    } else {
+      w.row = g == 0 ? r0 : g == 1 ? r1 : g == 2 ? r2 : r3;
+      const int s = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+      int e = g == 0 ? e0 : g == 1 ? e1 : g == 2 ? e2 : e3;
+      w.live = g < count && (!ep.row_mark || ep.row_mark[w.row] == stamp);
+      if (!w.live) e = s;
+      w.end = e; w.stride = 16; w.j0 = s + e16;
+      int maxlen;
+      if (!ep.row_mark) {
+        maxlen = max(max(e0 - s0, e1 - s1), max(e2 - s2, e3 - s3));          // scalar unit: the record is in SGPRs
+      } else {
+        maxlen = e - s;
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+        maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+      }
+      w.rem0 = maxlen;
+      w.n_chunks = (maxlen + 15) >> 4;
+    }
+    return w;
+  };
+  auto fetch = [&](int j, int end, unsigned& cs, float& v) {
+    int c = VALS ? 0 : pad_row;
+    v = 0.f;
+    if (j < end) { c = indices[j]; if (VALS) v = vals[j]; }
+    if (VALS && ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
+    cs = (unsigned)c << 8;
+    if (VALS && v == 0.f) cs = 0x80000000u;
+  };
+
+  // first chunk of a task as seen WITHOUT its row marks (the full view is derived when the task starts: carrying a
+  // second View through the chunk loop cost 36 VGPRs and 57 spilled SGPRs)
+  auto peek = [&](int t, int& j0, int& end) {
+    j0 = 0; end = 0;
+    if (t >= n_tasks) return false;
+    const Task64* tp = tasks64 + t;
+    const int kind = tp->kind, count = tp->count;
+    if (kind == 0) { j0 = tp->start[0] + 16 * g + e16; end = tp->end[0]; return true; }
+    const int s = g == 0 ? tp->start[0] : g == 1 ? tp->start[1] : g == 2 ? tp->start[2] : tp->start[3];
+    const int e = g == 0 ? tp->end[0] : g == 1 ? tp->end[1] : g == 2 ? tp->end[2] : tp->end[3];
+    j0 = s + e16; end = g < count ? e : s;
+    return true;
+  };
+
+  unsigned cs = 0x80000000u, csn = 0x80000000u;
+  float v = 0.f, vn = 0.f;
+  {
+    int j0, end;
+    if (peek((int)blockIdx.x * 4 + wv, j0, end)) fetch(j0, end, cs, v);
+  }
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const int t = ((int)blockIdx.x + k * nb) * 4 + wv;
+    if (t >= n_tasks) break;
+    const View cur = view_of(t);
+    if (!cur.live && cur.kind == 1 && VALS) cs = 0x80000000u;      // prefetched entries of a dead row: no gathers
+    int nj0 = 0, nend = 0;
+    const bool has_next = (k + 1 < K) && peek(t + 4 * nb, nj0, nend);
+    Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
+    floatx4_t xx[NX];            // (per task, so that the gather registers are dead during the epilogue)
+#pragma unroll
+    for (int t = 0; t < NX; ++t) xx[t] = zero;
+    for (int q = 0; q < cur.n_chunks; ++q) {
+      if (q + 1 < cur.n_chunks) fetch(cur.j0 + cur.stride * (q + 1), cur.end, csn, vn);     // next chunk of this task
+      else if (has_next) fetch(nj0, nend, csn, vn);                                          // first chunk of the next
+      const int rem = cur.rem0 - (cur.kind == 0 ? 64 : 16) * q;
+      if constexpr (!VALS) {
+        gather8_novals<false>(cs, sub16, X, xx, acc);
+        if (rem > 8) gather8_novals<true>(cs, sub16, X, xx, acc);
+      } else if constexpr (DEPTH == 2) {
+        if (rem > 8) gather16_asm(cs, v, sub16, X, xx, acc);
+        else gather8_lo16(cs, v, sub16, X, xx, acc);
+      } else {
+        gather8_asm<false, true>(cs, v, sub16, X, xx, acc);
+        if (rem > 8) gather8_asm<true, true>(cs, v, sub16, X, xx, acc);
+      }
+      cs = csn; v = vn;
+    }
+    if (cur.n_chunks == 0 && has_next) fetch(nj0, nend, cs, v);       // (whole task dead: nothing was prefetched)
+    // ---- epilogue of task k
+    if (cur.kind == 0) {
+      if (cur.live) {
+        const int row = __builtin_amdgcn_readfirstlane(cur.row), slot = __builtin_amdgcn_readfirstlane(cur.slot);
+        float4 a4 = to_f4(acc);
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
+        if (slot < 0) row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
+        else finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+      }
+    } else {
+      row_epilogue<LPR>(to_f4(acc), cur.row, sub, cur.live, Y, ep);
+    }
+  }
+}
+
 // marks -> bitmap (1 = column live this step)
 __global__ void build_bits(const int32_t* __restrict__ mark, const int64_t* __restrict__ stamp, int n, uint32_t* __restrict__ bits) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,6 +550,24 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
     case 4: LAB_LAUNCH(4, 0); break;
     case 5: LAB_LAUNCH(5, L->n_bit_words * 4); break;
     case 6: LAB_LAUNCH(6, 0); break;
+#define LAB_LAUNCH2(KK, DD, VV)                                                                                      \
+  do {                                                                                                               \
+    int nblk = (blocks + KK - 1) / KK;                                                                               \
+    nblk = (nblk + 7) / 8 * 8; /* a wave's tasks b, b + NB, ... keep one XCD class when NB % 8 == 0 */               \
+    rows_kernel2<KK, DD, VV><<<nblk, 256, 0, st>>>(L->d_tasks64, n, d_indices, d_vals,                                \
+                                                   reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), \
+                                                   reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy,        \
+                                                   plan->d_slot_owner, plan->d_tickets, (int)plan->n_cols, ep);      \
+  } while (0)
+    case 10: LAB_LAUNCH2(1, 1, true); break;
+    case 11: LAB_LAUNCH2(2, 1, true); break;
+    case 12: LAB_LAUNCH2(3, 1, true); break;
+    case 13: LAB_LAUNCH2(4, 1, true); break;
+    case 14: LAB_LAUNCH2(1, 2, true); break;
+    case 15: LAB_LAUNCH2(2, 2, true); break;
+    case 16: LAB_LAUNCH2(2, 1, false); break;
+    case 17: LAB_LAUNCH2(3, 1, false); break;
+    case 18: LAB_LAUNCH2(6, 1, true); break;
     default: return -3;
   }
 #undef LAB_LAUNCH

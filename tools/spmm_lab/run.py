@@ -21,7 +21,11 @@ from selfrec_amd import _lib, ops, synth  # noqa: E402
 from selfrec_amd.data.ui_graph import Interaction  # noqa: E402
 
 VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) prefetch", 6: "2, unconditional gathers (zero row)",
-            3: "2, value-free (vs product on all-ones values)", 4: "2, column bitmap (global)", 5: "2, column bitmap (LDS)"}
+            3: "2, value-free (vs product on all-ones values)", 4: "2, column bitmap (global)", 5: "2, column bitmap (LDS)",
+            10: "gen2 K=1 depth 1", 11: "gen2 K=2 (next task's first chunk prefetched)", 12: "gen2 K=3", 13: "gen2 K=4",
+            18: "gen2 K=6", 14: "gen2 K=1, 16 gathers in flight", 15: "gen2 K=2, 16 gathers in flight",
+            16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)"}
+VALUE_FREE = (3, 16, 17)
 
 
 def timed(fn, iters):
@@ -42,6 +46,9 @@ def main():
     ap.add_argument("--shape", default="yelp2018")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--ids", default="raw", choices=["raw", "first-appearance"],
+                    help="node labelling: the generator's ids, or ids in first-appearance order of the training list (what "
+                         "Interaction / bench.py use)")
     args = ap.parse_args()
     _lib.require_gpu()
     lab = C.CDLL(os.path.join(HERE, "liblab.so"))
@@ -51,7 +58,10 @@ def main():
     lab.lab_build_bits.argtypes = [vp, vp, vp, i32, vp]
     dev = torch.device("cuda", 0)
     tu, ti, su, si, U, I = synth.make_dataset(args.shape, seed=args.seed)
-    data = Interaction.from_id_arrays({}, tu, ti, su, si, U, I)
+    data = Interaction.from_id_arrays({}, tu, ti, su, si, U, I) if args.ids == "raw" else \
+        Interaction({}, synth.as_triples(tu, ti), [])
+    if args.ids != "raw":
+        tu, ti = data.train_u.astype(np.int64), data.train_i.astype(np.int64)
     g = data.device_graph(dev)
     adj, N, d = g.adj, g.n_nodes, 64
     gen = torch.Generator().manual_seed(1)
@@ -84,6 +94,7 @@ def main():
                           C.byref(ep) if ep is not None else None, st, variant)
         assert rc == 0, (variant, rc)
 
+    print(f"# ids: {args.ids}")
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
@@ -97,7 +108,7 @@ def main():
             if variant in (4, 5) and name != "col_masked":
                 cells.append(f"{'-':>14}")
                 continue
-            csr = ones if variant == 3 else adj
+            csr = ones if variant in VALUE_FREE else adj
             ep = mk()
             y_ref.zero_(); y.fill_(float("nan"))
             ops.spmm(csr, x, out=y_ref, epilogue=ep)
