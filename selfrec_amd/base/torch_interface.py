@@ -84,9 +84,44 @@ class SparseAdjHandle:
     def _values(self):
         return self.csr.vals[self._coo()[1]]
 
+    def dropout(self, keep, scale=1.0):
+        """Entry-wise dropped copy as a VALUE ARRAY over this structure: entry k (in (row, column) order, the order
+        of ``_indices()``) survives where ``keep[k]`` and is multiplied by ``scale`` -- what BUIR.py:118-127 /
+        MixGCF.py:84-94 build as a new torch COO tensor.  The result multiplies on the HIP SpMM, backward included
+        (its transpose is the same structure with mirrored values)."""
+        idx, perm = self._coo()
+        keep = torch.as_tensor(keep).to(device=self.device, dtype=torch.float32)
+        if keep.numel() != self.csr.nnz:
+            raise ops.SelfrecHipError(f"dropout: mask has {keep.numel()} entries, the matrix {self.csr.nnz}")
+        vals = torch.zeros_like(self.csr.vals)
+        vals[perm] = self.csr.vals[perm] * keep * float(scale)
+        out = SparseAdjHandle(self.csr.with_values(vals), symmetric=False)
+        if self._symmetric or getattr(self, "_mirror", None) is not None:
+            out._mirror = self._mirror_perm()
+        out._coo_idx, out._coo_perm = idx, perm
+        return out
+
+    def _mirror_perm(self):
+        """mirror[p] = storage position of entry (j, i) for the entry (i, j) stored at p (structurally symmetric
+        matrices only): A^T has this structure with values vals[mirror]."""
+        if getattr(self, "_mirror", None) is None:
+            idx, perm = self._coo()
+            n = self.shape[1]
+            keys = idx[0] * n + idx[1]                       # ascending: idx is in (row, column) order
+            where = torch.searchsorted(keys, idx[1] * n + idx[0])
+            if where.numel() and (int(where.max()) >= keys.numel() or not torch.equal(keys[where], idx[1] * n + idx[0])):
+                raise ops.SelfrecHipError("transpose by mirroring needs a structurally symmetric matrix")
+            mirror = torch.empty_like(perm)
+            mirror[perm] = perm[where]
+            self._mirror = mirror
+        return self._mirror
+
     def transposed(self):
         if self._symmetric:
             return self
+        if self._t is None and getattr(self, "_mirror", None) is not None:
+            self._t = SparseAdjHandle(self.csr.with_values(self.csr.vals[self._mirror]), symmetric=False)
+            self._t._t, self._t._mirror = self, self._mirror
         if self._t is None:
             if self._scipy is None:
                 raise ops.SelfrecHipError("transpose of a device-only non-symmetric adjacency is not available")

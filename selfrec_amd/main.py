@@ -14,7 +14,7 @@ from . import synth
 from .SELFRec import SELFRec
 from .util.conf import ModelConf
 
-MODELS = ['MF', 'LightGCN', 'XSimGCL', 'SimGCL', 'SGL']
+MODELS = ['MF', 'LightGCN', 'XSimGCL', 'SimGCL', 'SGL', 'DirectAU', 'MixGCF', 'BUIR', 'SelfCF']
 
 
 def main(argv=None):

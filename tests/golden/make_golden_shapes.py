@@ -20,6 +20,12 @@ index streams and keep-sets:
   N  GraphAugmentor.node_dropout (augmentor.py:10-27) on the 200 x 300 graph: dropped users /
      items, dropped Laplacian, next raw MT word; 3 SGL steps with aug_type = 0.
   W  duplicated interaction lines: weight-2 entries in norm_adj, unit weights in the dropped views.
+  M  the other torch graph models of SURVEY 8(f-4) -- DirectAU, MixGCF, BUIR, SelfCF -- on the 200 x 300 graph: 2 steps
+     each (losses, parameters, get_embedding / model() outputs, test() ranking), MixGCF's n_negs = 64 sampler stream
+     (SHA-256; also 20 batches at the Yelp2018 shape), BUIR's sparse-dropout keep masks.  Randomness the models draw on
+     the DEVICE in the reference (nn.Dropout, rand_like) is drawn from seeded CPU generators by patching
+     torch.nn.functional.dropout / torch.rand_like in this process; what they draw on the host (torch.rand(..).cuda(),
+     torch.randn(..).cuda(), np.random.random()) needs only the seeds.
 
 Run:  python tests/golden/make_golden_shapes.py [Y] [F] [D] [N] [W]      (default: all)
 Writes shapes.npz / shapes_meta.json / douban_book.npz next to this file.
@@ -287,15 +293,129 @@ def section_W(out, meta):
                      "drop_seed": 5}
 
 
+F4_MODELS = {
+    "DirectAU": {"gamma": 2, "n_layers": 3},
+    "MixGCF": {"n_layer": 3, "n_negs": 64},
+    "BUIR": {"n_layer": 2, "tau": 0.995, "drop_rate": 0.2},
+    "SelfCF": {"n_layer": 2, "tau": 0.05},
+}
+
+
+def section_M(out, meta):
+    import torch.nn.functional as F
+    tu, ti, su, si = MG.tiny_graph()
+    train, test = synth.as_triples(tu, ti), synth.as_triples(su, si)
+    real_dropout, real_rand_like = F.dropout, torch.rand_like
+    cwd = os.getcwd()
+    for name, extra in F4_MODELS.items():
+        mod = importlib.import_module(f"model.graph.{name}")
+        n_steps = 2
+        rec = {"batches": [], "loss": []}
+
+        def batches(data, bs, n_negs=1):
+            for k, b in enumerate(ref_sampler.next_batch_pairwise(data, bs, n_negs)):
+                if k == n_steps:
+                    return
+                rec["batches"].append([list(x) for x in b])
+                yield b
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                conf = make_conf(tmp, name, dict(extra), batch=1024)
+                mod.next_batch_pairwise = batches
+                gen = torch.Generator().manual_seed(777)
+
+                def cpu_dropout(x, p=0.5, training=True, inplace=False):
+                    if not training or p == 0.0:
+                        return x
+                    keep = (torch.rand(x.shape, generator=gen) >= p).to(x.dtype)
+                    return x * keep / (1.0 - p)
+                F.dropout = cpu_dropout
+                torch.rand_like = lambda t, **k: torch.rand(t.shape, generator=gen)
+                torch.manual_seed(31); np.random.seed(32); random.seed(2718)
+                model = getattr(mod, name)(conf, [list(t) for t in train], [list(t) for t in test])
+                model.fast_evaluation = lambda epoch: None
+                enc = model.model
+                named0 = {k: v.detach().numpy().copy() for k, v in enc.named_parameters()}
+                if name == "SelfCF":
+                    named0["u_target_his"], named0["i_target_his"] = enc.u_target_his.numpy().copy(), enc.i_target_his.numpy().copy()
+                # per-step losses: optimizer.zero_grad() follows each loss in every train() loop
+                real_adam = torch.optim.Adam
+
+                class SpyAdam(real_adam):
+                    def step(self, *a, **k):
+                        return super().step(*a, **k)
+                losses = []
+                real_backward = torch.Tensor.backward
+
+                def spy_backward(t, *a, **k):
+                    losses.append(float(t.detach()))
+                    return real_backward(t, *a, **k)
+                torch.Tensor.backward = spy_backward
+                try:
+                    model.train()
+                except AttributeError as e:
+                    assert "best_" in str(e), e
+                finally:
+                    torch.Tensor.backward = real_backward
+                F.dropout, torch.rand_like = real_dropout, real_rand_like
+                for k, v in named0.items():
+                    out[f"M_{name}_init_{k}"] = v
+                for k, v in enc.named_parameters():
+                    out[f"M_{name}_param_{k}"] = v.detach().numpy().copy()
+                if name in ("BUIR", "SelfCF"):
+                    embs = enc.get_embedding()
+                    for k, v in zip(("p_u", "u", "p_i", "i"), embs):
+                        out[f"M_{name}_emb_{k}"] = v.detach().numpy().copy()
+                    model.p_u_online, model.u_online, model.p_i_online, model.i_online = embs
+                elif name == "MixGCF":
+                    with torch.no_grad():
+                        model.user_emb, model.item_emb = enc.get_embeddings()
+                    out[f"M_{name}_emb_u"], out[f"M_{name}_emb_i"] = model.user_emb.numpy().copy(), model.item_emb.numpy().copy()
+                else:
+                    with torch.no_grad():
+                        model.user_emb, model.item_emb = enc()
+                    out[f"M_{name}_emb_u"], out[f"M_{name}_emb_i"] = model.user_emb.numpy().copy(), model.item_emb.numpy().copy()
+                rec_list = model.test()
+                d = model.data
+                users = list(d.test_set.keys())
+                out[f"M_{name}_test_users"] = np.asarray([d.user[u] for u in users], dtype=np.int32)
+                out[f"M_{name}_rec_ids"] = np.asarray([[d.item[it] for it, _ in rec_list[u]] for u in users], dtype=np.int32)
+                out[f"M_{name}_loss"] = np.asarray(losses, dtype=np.float64)
+                out[f"M_{name}_batch_sizes"] = np.asarray([len(b[0]) for b in rec["batches"]], dtype=np.int32)
+                for k, col in enumerate("uij"):
+                    out[f"M_{name}_batch_{col}"] = np.concatenate([b[k] for b in rec["batches"]]).astype(np.int32)
+                meta[f"M_{name}"] = {"conf": extra, "n_steps": n_steps, "emb": 64, "batch": 1024, "lr": 0.001, "reg": 0.0001,
+                                     "torch_seed": 31, "numpy_seed": 32, "sampler_seed": 2718, "device_rng_seed": 777,
+                                     "measure": ranking_evaluation(d.test_set, rec_list, [10, 20])}
+                print(f"M_{name}", losses, flush=True)
+            finally:
+                os.chdir(cwd)
+                F.dropout, torch.rand_like = real_dropout, real_rand_like
+    # MixGCF's sampler regime at the Yelp2018 shape: 64 negatives per pair (MixGCF.py:24,96-114), first 20 batches
+    tu, ti, su, si, U, I = synth.make_dataset("yelp2018", seed=SEED_GRAPH)
+    data = Interaction({"dummy": 1}, [list(t) for t in synth.as_triples(tu, ti)], [])
+    random.seed(64064)
+    hs = [hashlib.sha256() for _ in range(3)]
+    for k, (u, i, j) in enumerate(ref_sampler.next_batch_pairwise(data, 2048, 64)):
+        if k == 20:
+            break
+        for h, a in zip(hs, (u, i, j)):
+            h.update(np.asarray(a, dtype=np.int32).tobytes())
+    meta["M_sampler_negs64"] = {"seed": 64064, "batch": 2048, "n_negs": 64, "batches": 20, "sha_u": hs[0].hexdigest(),
+                                "sha_i": hs[1].hexdigest(), "sha_j": hs[2].hexdigest()}
+    print("M_sampler_negs64", meta["M_sampler_negs64"], flush=True)
+
+
 def main():
-    want = [a for a in sys.argv[1:]] or ["N", "W", "D", "Y", "F"]
+    want = [a for a in sys.argv[1:]] or ["N", "W", "D", "Y", "F", "M"]
     npz_path, meta_path = os.path.join(HERE, "shapes.npz"), os.path.join(HERE, "shapes_meta.json")
     out = dict(np.load(npz_path)) if os.path.exists(npz_path) else {}
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
     meta.update(torch=torch.__version__, numpy=np.__version__)
     for s in want:
         t0 = time.time()
-        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W}[s](out, meta)
+        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W, "M": section_M}[s](out, meta)
         print(f"section {s}: {time.time() - t0:.0f} s", flush=True)
         np.savez_compressed(npz_path, **out)
         with open(meta_path, "w") as f:

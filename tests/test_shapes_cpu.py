@@ -225,3 +225,24 @@ def test_duplicate_interactions_weights(shapes):
     lap = O.laplacian_of(O.edge_dropout(r, 0.1)).tocsr(); lap.sort_indices()
     assert np.array_equal(lap.indices, shapes["dup_drop_lap_indices"])
     assert np.array_equal(lap.data.astype(np.float32), shapes["dup_drop_lap_data"])
+
+
+def test_sampler_with_64_negatives_per_pair(yelp_data, smeta):
+    """MixGCF's regime (MixGCF.py:24,96-114): next_batch_pairwise(data, 2048, n_negs=64) at the Yelp2018 shape, first 20
+    batches bit-exact against the reference's generator; the C++ replay's rate is printed (131 k draws per batch)."""
+    import time
+    m = smeta["M_sampler_negs64"]
+    smp = ops.Sampler(yelp_data.train_u, yelp_data.train_i, yelp_data.user_num, yelp_data.item_num)
+    random.seed(m["seed"])
+    smp.set_state_from_python()
+    smp.shuffle()
+    hs = [hashlib.sha256() for _ in range(3)]
+    t0 = time.perf_counter()
+    for k in range(m["batches"]):
+        u, i, j = smp.next_batch(k * m["batch"], m["batch"], m["n_negs"])
+        assert j.size == m["batch"] * m["n_negs"]
+        for h, a in zip(hs, (u, i, j)):
+            h.update(a.astype(np.int32).tobytes())
+    dt = time.perf_counter() - t0
+    assert [h.hexdigest() for h in hs] == [m["sha_u"], m["sha_i"], m["sha_j"]]
+    print(f"n_negs=64: {m['batches'] * m['batch'] * m['n_negs'] / dt / 1e6:.1f} M negatives/s on one host core")

@@ -19,13 +19,22 @@ tests)
 testsall)
   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed" $OUT/tests.log | tail -40;;
+testsf4)
+  timeout 900 python -m pytest tests/test_gpu_f4.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests_f4.log 2>&1; echo "testsf4 exit $?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_f4.log | head -40;;
 testsnew)
   timeout 1500 python -m pytest tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests_new.log 2>&1; echo "testsnew exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed|Error|assert" $OUT/tests_new.log | tail -40;;
 lab)
   timeout 900 python tools/spmm_lab/run.py ${LAB_ARGS:-} > $OUT/spmm_lab.log 2>&1; echo "lab exit $?"; grep -v amdgpu.ids $OUT/spmm_lab.log | tail -${LAB_TAIL:-20};;
+lab3)
+  timeout 900 python tools/spmm_lab/run.py --ids first-appearance --no-colclass > $OUT/spmm_lab_nocc.log 2>&1; echo "lab3 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_nocc.log | tail -${LAB_TAIL:-20};;
 lab2)
   timeout 900 python tools/spmm_lab/run.py --ids first-appearance > $OUT/spmm_lab_fa.log 2>&1; echo "lab2 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_fa.log | tail -${LAB_TAIL:-20};;
+lossprobe)
+  rm -rf $OUT/lossprobe; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/lossprobe -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/lossprobe.log 2>&1); echo "lossprobe exit $?"
+  stats $OUT/lossprobe | grep -E "kernel  |bpr_|nce_" > $OUT/lossprobe_kernel_stats.txt; cat $OUT/lossprobe_kernel_stats.txt; tail -1 $OUT/lossprobe.log
+  find $OUT/lossprobe -name "*.db" -size +40M -delete;;
 precision)
   timeout 900 python tools/precision_probe.py > $OUT/precision_probe.log 2>&1; echo "precision exit $?"; grep -v amdgpu.ids $OUT/precision_probe.log | tail -8;;
 bench)

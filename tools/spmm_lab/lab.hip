@@ -19,6 +19,7 @@
 //      on an all-ones value array.
 //      (x must carry one extra all-zero row: padding entries point at it and every gather is unconditional)
 //   6  variant 2 with unconditional gathers (padding -> the zero row, value 0): what the predicate costs / saves.
+//  20 / 21 / 22  knock-outs of variant 2: no epilogue on short rows / no x gathers / no (col, val) loads (hashed columns)
 //   4  variant 2 with the column-activity test on a BITMAP (1 bit per column, L1-resident 8.7 KB at the Yelp2018
 //      shape) instead of one 4-byte mark gather per entry;  5  the same with the bitmap staged in LDS.
 #include "../../selfrec_amd/csrc/spmm.hip"
@@ -83,7 +84,7 @@ struct Acc { floatx2_t lo, hi; };       // columns 0-1 / 2-3 of this lane's floa
 // gather), v = value.  xx[] persists across calls (stale rows are finite).  HI selects row_newbcast 8..15.
 // The value broadcasts are issued AFTER the loads: VALU work under the memory latency, and off[] / vv[] never live
 // together.
-template <bool HI, bool PRED>
+template <bool HI, bool PRED, bool NOLOAD = false>
 __device__ __forceinline__ void gather8_asm(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
                                             Acc& acc) {
   unsigned off[8];
@@ -95,7 +96,9 @@ __device__ __forceinline__ void gather8_asm(unsigned cs, float v, unsigned sub16
   } else {
     LAB_DPP_OR(8); LAB_DPP_OR(9); LAB_DPP_OR(10); LAB_DPP_OR(11); LAB_DPP_OR(12); LAB_DPP_OR(13); LAB_DPP_OR(14); LAB_DPP_OR(15);
   }
-  if (PRED) {
+  if (NOLOAD) {
+    asm volatile("" :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]));
+  } else if (PRED) {
     pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
   } else {
 #pragma unroll
@@ -263,7 +266,11 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
   auto fetch = [&](int j, int end, unsigned& cs, float& v) {
     int c = 0;
     v = 0.f;
-    if (j < end) { c = indices[j]; if (MODE != 3) v = vals[j]; }
+    if (MODE == 22) { if (j < end) { c = (int)(((unsigned)j * 2654435761u) % (unsigned)pad_row); v = 1.f; } }
+    else if (j < end) {
+      if (MODE == 23) { c = __builtin_nontemporal_load(indices + j); v = __builtin_nontemporal_load(vals + j); }
+      else { c = indices[j]; if (MODE != 3) v = vals[j]; }
+    }
     else if (MODE == 3 || MODE == 6) c = pad_row;        // the all-zero row appended to x
     if (MODE == 3) { cs = (unsigned)c << 8; return; }
     if (ep.col_mark && v != 0.f) {
@@ -290,8 +297,8 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
         gather8_novals<false>(cs, sub16, X, xx, acc);
         if (e - base > 8) gather8_novals<true>(cs, sub16, X, xx, acc);
       } else {
-        gather8_asm<false, MODE != 6>(cs, v, sub16, X, xx, acc);
-        if (e - base > 8) gather8_asm<true, MODE != 6>(cs, v, sub16, X, xx, acc);
+        gather8_asm<false, MODE != 6, MODE == 21>(cs, v, sub16, X, xx, acc);
+        if (e - base > 8) gather8_asm<true, MODE != 6, MODE == 21>(cs, v, sub16, X, xx, acc);
       }
       if (MODE >= 2) { cs = csn; v = vn; }
       else if (base + CH < e) fetch(base + CH + 16 * g + e16, e, cs, v);
@@ -321,13 +328,14 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
       gather8_novals<false>(cs, sub16, X, xx, acc);
       if (maxlen - 16 * q > 8) gather8_novals<true>(cs, sub16, X, xx, acc);
     } else {
-      gather8_asm<false, MODE != 6>(cs, v, sub16, X, xx, acc);
-      if (maxlen - 16 * q > 8) gather8_asm<true, MODE != 6>(cs, v, sub16, X, xx, acc);
+      gather8_asm<false, MODE != 6, MODE == 21>(cs, v, sub16, X, xx, acc);
+      if (maxlen - 16 * q > 8) gather8_asm<true, MODE != 6, MODE == 21>(cs, v, sub16, X, xx, acc);
     }
     if (MODE >= 2) { cs = csn; v = vn; }
     else if ((q + 1) * 16 < maxlen) fetch(s + 16 * (q + 1) + e16, e, cs, v);
   }
-  row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
+  if (MODE == 20) { if (live) Y[(size_t)row * LPR + sub] = to_f4(acc); }
+  else row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
 }
 
 // Second generation: K tasks per wave (tasks b, b + NB, ... of its workgroup column, so a wave keeps its XCD class),
@@ -461,6 +469,147 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
   }
 }
 
+// Third generation: a ROLLING window of eight gathers.  Variant 2 issues 8 loads, drains them, issues the next 8: two
+// memory round trips per 16-entry chunk, and between them the wave has nothing in flight.  Here entry t of batch b+1 is
+// issued into the register entry t of batch b has just been consumed from, so eight rows stay in flight from the first
+// batch of a row to its last (across chunk boundaries too: the next chunk's (col, val) are prefetched).
+// (two statements: with the halves of xx[T] as inputs AND xx[T] as the tied load destination in ONE asm, the compiler
+// copies the halves to fresh registers -- 156 VGPRs)
+#define LAB_ROLL(T, TN, VP, SEL, SRC)                                                                              \
+  LAB_FMA(7, SEL, VP, xx[T]);                                                                                      \
+  asm volatile("s_nop 1\n\t"                                                                                       \
+               "v_or_b32_dpp %[of], %[cs], %[s16] row_newbcast:" #TN " row_mask:0xf bank_mask:0xf\n\t"              \
+               "s_mov_b64 %[sv], exec\n\t"                                                                         \
+               "v_cmpx_le_i32_e32 0, %[of]\n\t"                                                                    \
+               "global_load_dwordx4 %[x], %[of], %[b]\n\t"                                                         \
+               "s_mov_b64 exec, %[sv]"                                                                             \
+               : [x] "+v"(xx[T]), [of] "=&v"(otmp), [sv] "=&s"(stmp)                                               \
+               : [cs] "v"(SRC), [s16] "v"(sub16), [b] "s"(X)                                                       \
+               : "memory", "vcc")
+
+// consume batch (values VLO/VHI half of `v`) while issuing the next batch from `src` (half NEXT_HI)
+template <bool CUR_HI, bool NEXT_HI>
+__device__ __forceinline__ void roll8(float v, unsigned src, unsigned sub16, const void* X, floatx4_t (&xx)[8], Acc& acc) {
+  float vv[8];
+  unsigned otmp;
+  unsigned long long stmp;
+  asm volatile("s_nop 4" : "+v"(v), "+v"(src));     // (exec was last written by a v_cmpx: 5 wait states before a DPP op)
+  if (!CUR_HI) {
+    LAB_DPP_MOV(0); LAB_DPP_MOV(1); LAB_DPP_MOV(2); LAB_DPP_MOV(3); LAB_DPP_MOV(4); LAB_DPP_MOV(5); LAB_DPP_MOV(6); LAB_DPP_MOV(7);
+  } else {
+    LAB_DPP_MOV(8); LAB_DPP_MOV(9); LAB_DPP_MOV(10); LAB_DPP_MOV(11); LAB_DPP_MOV(12); LAB_DPP_MOV(13); LAB_DPP_MOV(14); LAB_DPP_MOV(15);
+  }
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  if (!NEXT_HI) {
+    LAB_ROLL(0, 0, p0, 0, src); LAB_ROLL(1, 1, p0, 1, src); LAB_ROLL(2, 2, p1, 0, src); LAB_ROLL(3, 3, p1, 1, src);
+    LAB_ROLL(4, 4, p2, 0, src); LAB_ROLL(5, 5, p2, 1, src); LAB_ROLL(6, 6, p3, 0, src); LAB_ROLL(7, 7, p3, 1, src);
+  } else {
+    LAB_ROLL(0, 8, p0, 0, src); LAB_ROLL(1, 9, p0, 1, src); LAB_ROLL(2, 10, p1, 0, src); LAB_ROLL(3, 11, p1, 1, src);
+    LAB_ROLL(4, 12, p2, 0, src); LAB_ROLL(5, 13, p2, 1, src); LAB_ROLL(6, 14, p3, 0, src); LAB_ROLL(7, 15, p3, 1, src);
+  }
+}
+// the last batch of a row: consume only
+template <bool CUR_HI>
+__device__ __forceinline__ void drain8(float v, const void* X, floatx4_t (&xx)[8], Acc& acc) {
+  float vv[8];
+  asm volatile("s_nop 4" : "+v"(v));
+  if (!CUR_HI) {
+    LAB_DPP_MOV(0); LAB_DPP_MOV(1); LAB_DPP_MOV(2); LAB_DPP_MOV(3); LAB_DPP_MOV(4); LAB_DPP_MOV(5); LAB_DPP_MOV(6); LAB_DPP_MOV(7);
+  } else {
+    LAB_DPP_MOV(8); LAB_DPP_MOV(9); LAB_DPP_MOV(10); LAB_DPP_MOV(11); LAB_DPP_MOV(12); LAB_DPP_MOV(13); LAB_DPP_MOV(14); LAB_DPP_MOV(15);
+  }
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  LAB_FMA(7, 0, p0, xx[0]); LAB_FMA(6, 1, p0, xx[1]); LAB_FMA(5, 0, p1, xx[2]); LAB_FMA(4, 1, p1, xx[3]);
+  LAB_FMA(3, 0, p2, xx[4]); LAB_FMA(2, 1, p2, xx[5]); LAB_FMA(1, 0, p3, xx[6]); LAB_FMA(0, 1, p3, xx[7]);
+}
+// the first batch of a row: issue only (entries 0-7 of `cs`)
+__device__ __forceinline__ void issue8(unsigned cs, unsigned sub16, const void* X, floatx4_t (&xx)[8]) {
+  unsigned off[8];
+  asm volatile("s_nop 4" : "+v"(cs));
+  LAB_DPP_OR(0); LAB_DPP_OR(1); LAB_DPP_OR(2); LAB_DPP_OR(3); LAB_DPP_OR(4); LAB_DPP_OR(5); LAB_DPP_OR(6); LAB_DPP_OR(7);
+  pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+}
+
+__global__ __launch_bounds__(256) void rows_kernel3(const Task64* __restrict__ tasks64, int n_tasks,
+                                                    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                                    const float4* __restrict__ X, float4* __restrict__ Y,
+                                                    float4* __restrict__ partial, const Heavy* __restrict__ heavy,
+                                                    const int32_t* __restrict__ slot_owner, int32_t* __restrict__ tickets,
+                                                    DevEpilogue ep) {
+  constexpr int LPR = 16;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+  if (wave >= n_tasks) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, sub = lane & 15, e16 = sub;
+  const unsigned sub16 = (unsigned)sub * 16u;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
+  Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
+  floatx4_t xx[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xx[t] = zero;
+  const Task64* tp = tasks64 + wave;
+  const int kind = tp->kind, count = tp->count, slot = tp->slot;
+  int row = tp->row[0], s = tp->start[0], e = tp->end[0];
+  if (kind == 1) {
+    const int r1 = tp->row[1], s1 = tp->start[1], e1 = tp->end[1], r2 = tp->row[2], s2 = tp->start[2], e2 = tp->end[2];
+    const int r3 = tp->row[3], s3 = tp->start[3], e3 = tp->end[3];
+    if (g == 1) { row = r1; s = s1; e = e1; }
+    if (g == 2) { row = r2; s = s2; e = e2; }
+    if (g == 3) { row = r3; s = s3; e = e3; }
+  }
+  auto fetch = [&](int j, int end, unsigned& cs, float& v) {
+    int c = 0;
+    v = 0.f;
+    if (j < end) { c = indices[j]; v = vals[j]; }
+    cs = (v == 0.f) ? 0x80000000u : (unsigned)c << 8;
+  };
+  // per-lane cursor of chunk 0, stride between chunks; uniform entry count of the longest row-group
+  int j0, stride, total;
+  bool live = true;
+  if (kind == 0) {
+    row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
+    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    j0 = s + 16 * g + e16; stride = 64;
+    // a coop chunk gives every row-group 16 entries; the last chunk may give the later groups fewer (or none)
+    total = ((e - s) >> 6) * 16 + min(16, (e - s) & 63);      // entries of row-group 0 (the longest)
+  } else {
+    live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
+    if (!live) e = s;
+    int maxlen = e - s;
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+    total = __builtin_amdgcn_readfirstlane(maxlen);
+    j0 = s + e16; stride = 16;
+  }
+  // straight-line body (no special first / last batch: an exhausted half carries sign-bit offsets and v = 0, its
+  // loads are exec = 0 no-ops that still count in vmcnt, so every wait below stays exact)
+  const int nchunks = (total + 15) >> 4;
+  if (nchunks > 0) {
+    unsigned cs, csn = 0x80000000u;
+    float v, vn = 0.f;
+    fetch(j0, e, cs, v);
+    if (nchunks > 1) fetch(j0 + stride, e, csn, vn);
+    issue8(cs, sub16, X, xx);
+    for (int q = 0; q < nchunks; ++q) {
+      roll8<false, true>(v, cs, sub16, X, xx, acc);       // consume entries 0-7 of chunk q, issue its entries 8-15
+      roll8<true, false>(v, csn, sub16, X, xx, acc);      // consume entries 8-15, issue entries 0-7 of chunk q + 1
+      cs = csn; v = vn;
+      csn = 0x80000000u; vn = 0.f;
+      if (q + 2 < nchunks) fetch(j0 + stride * (q + 2), e, csn, vn);
+    }
+  }
+  if (kind == 0) {
+    float4 a4 = to_f4(acc);
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
+    if (slot < 0) { row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep); return; }
+    finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+    return;
+  }
+  row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
+}
+
 // marks -> bitmap (1 = column live this step)
 __global__ void build_bits(const int32_t* __restrict__ mark, const int64_t* __restrict__ stamp, int n, uint32_t* __restrict__ bits) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,6 +699,10 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
     case 4: LAB_LAUNCH(4, 0); break;
     case 5: LAB_LAUNCH(5, L->n_bit_words * 4); break;
     case 6: LAB_LAUNCH(6, 0); break;
+    case 20: LAB_LAUNCH(20, 0); break;
+    case 23: LAB_LAUNCH(23, 0); break;
+    case 21: LAB_LAUNCH(21, 0); break;
+    case 22: LAB_LAUNCH(22, 0); break;
 #define LAB_LAUNCH2(KK, DD, VV)                                                                                      \
   do {                                                                                                               \
     int nblk = (blocks + KK - 1) / KK;                                                                               \
@@ -559,6 +712,11 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
                                                    reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy,        \
                                                    plan->d_slot_owner, plan->d_tickets, (int)plan->n_cols, ep);      \
   } while (0)
+    case 30:
+      rows_kernel3<<<blocks, 256, 0, st>>>(L->d_tasks64, n, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
+                                           reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial),
+                                           plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep);
+      break;
     case 10: LAB_LAUNCH2(1, 1, true); break;
     case 11: LAB_LAUNCH2(2, 1, true); break;
     case 12: LAB_LAUNCH2(3, 1, true); break;

@@ -22,10 +22,15 @@ from selfrec_amd.data.ui_graph import Interaction  # noqa: E402
 
 VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) prefetch", 6: "2, unconditional gathers (zero row)",
             3: "2, value-free (vs product on all-ones values)", 4: "2, column bitmap (global)", 5: "2, column bitmap (LDS)",
+            20: "2 minus the short-row epilogue (timing only)", 21: "2 minus the x gathers (timing only)",
+            22: "2 minus the (col,val) loads (timing only)",
+            23: "2 with non-temporal (col,val) loads",
+            30: "gen3: rolling window of 8 gathers (no column marks)",
             10: "gen2 K=1 depth 1", 11: "gen2 K=2 (next task's first chunk prefetched)", 12: "gen2 K=3", 13: "gen2 K=4",
             18: "gen2 K=6", 14: "gen2 K=1, 16 gathers in flight", 15: "gen2 K=2, 16 gathers in flight",
             16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)"}
 VALUE_FREE = (3, 16, 17)
+SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
 
 
 def timed(fn, iters):
@@ -46,6 +51,8 @@ def main():
     ap.add_argument("--shape", default="yelp2018")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--all", action="store_true")
+    ap.add_argument("--no-colclass", action="store_true", help="plain row storage (no [even | odd] column classes)")
     ap.add_argument("--ids", default="raw", choices=["raw", "first-appearance"],
                     help="node labelling: the generator's ids, or ids in first-appearance order of the training list (what "
                          "Interaction / bench.py use)")
@@ -62,7 +69,7 @@ def main():
         Interaction({}, synth.as_triples(tu, ti), [])
     if args.ids != "raw":
         tu, ti = data.train_u.astype(np.int64), data.train_i.astype(np.int64)
-    g = data.device_graph(dev)
+    g = data.device_graph(dev, column_classes=not args.no_colclass)
     adj, N, d = g.adj, g.n_nodes, 64
     gen = torch.Generator().manual_seed(1)
     xfull = torch.zeros((N + 1, d), device=dev)
@@ -94,7 +101,7 @@ def main():
                           C.byref(ep) if ep is not None else None, st, variant)
         assert rc == 0, (variant, rc)
 
-    print(f"# ids: {args.ids}")
+    print(f"# ids: {args.ids}; column classes: {not args.no_colclass}")
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
@@ -103,9 +110,11 @@ def main():
         base[name] = timed(lambda: ops.spmm(adj, x, out=y_ref, epilogue=ep), args.iters)
     print(f"{'0  product (spmm_rows_kernel<16>)':<58}" + "".join(f"{base[k]:>14.2f}" for k in flavours))
     for variant, label in VARIANTS.items():
+        if variant in SKIP and not args.all:
+            continue
         cells = []
         for name, mk in flavours.items():
-            if variant in (4, 5) and name != "col_masked":
+            if (variant in (4, 5) and name != "col_masked") or (variant == 30 and name == "col_masked"):
                 cells.append(f"{'-':>14}")
                 continue
             csr = ones if variant in VALUE_FREE else adj
