@@ -310,21 +310,18 @@ def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
     rec = GraphRecommender.__new__(GraphRecommender)
     rec.data, rec.max_N = data, k
     rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())      # (a collective when sharded)
+    from selfrec_amd.dist import deal_users, gather_ranked
     uid = [data.user[u] for u in users]
-    mine = uid[rank::world]
-    n_max = (len(uid) + world - 1) // world
+    mine, n_max = deal_users(uid, rank, world)
     rec.rank_on_device(mine[:256])                                                   # warm-up
-    pad = torch.full((n_max, k), -1, dtype=torch.int32, device="cuda")
-    everyone = torch.empty((world * n_max, k), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     ids, _ = rec.rank_on_device(mine)
-    pad[:len(mine)] = torch.from_numpy(np.ascontiguousarray(ids)).to("cuda")
-    dist.all_gather_into_tensor(everyone, pad)
+    table = gather_ranked(ids, len(uid), rank, world, "cuda")
     torch.cuda.synchronize()
     t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ranked = int((everyone[:, 0] >= 0).sum().item())
+    ranked = int((table[:, 0] >= 0).sum().item())
     return {"users": len(uid), "k": k, "users_ranked_and_gathered": ranked,
             "device_users_per_s": round(len(uid) / float(t.item()), 1),
             "note": f"test users dealt over {world} ranks, item table replicated, ranked ids all-gathered; slowest rank's time"}

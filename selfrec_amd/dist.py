@@ -73,3 +73,27 @@ class ShardedTrainer(FusedTrainer):
 
     def parameters_full(self):
         return self.user_emb, self.item_emb
+
+
+def deal_users(user_ids, rank: int, world: int):
+    """Evaluation over N ranks: test users are dealt round-robin -- rank r ranks users r, r + N, ...
+    against the replicated item table.  Returns (this rank's users, padded share size)."""
+    mine = user_ids[rank::world]
+    return mine, (len(user_ids) + world - 1) // world
+
+
+def gather_ranked(ids_local, n_users: int, rank: int, world: int, device, all_gather=None):
+    """Reassemble the (n_users, k) ranked-id table from every rank's share (the inverse of ``deal_users``): one
+    all-gather of the padded shares, then user u's row is row u // N of rank u % N's share.  ``all_gather(out, inp)``
+    defaults to torch.distributed's; returns an int32 tensor on ``device``."""
+    import numpy as np
+    import torch
+    k = int(ids_local.shape[1])
+    n_max = (n_users + world - 1) // world
+    pad = torch.full((n_max, k), -1, dtype=torch.int32, device=device)
+    if len(ids_local):
+        pad[:len(ids_local)] = torch.as_tensor(np.ascontiguousarray(ids_local), dtype=torch.int32).to(device)
+    everyone = torch.empty((world * n_max, k), dtype=torch.int32, device=device)
+    (all_gather or _dist.all_gather_into_tensor)(everyone, pad)
+    users = torch.arange(n_users, device=device)
+    return everyone[(users % world) * n_max + users // world]

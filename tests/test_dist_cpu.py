@@ -122,3 +122,83 @@ def test_layout_choice():
     assert [pick_layout(64, w) for w in (1, 2, 3, 4, 8, 16)] == ["rows", "cols", "rows", "cols", "cols", "rows"]
     assert pick_layout(128, 8) == "cols" and pick_layout(128, 2) == "cols" and pick_layout(64, 2, "rows") == "rows"
     assert pick_layout(256, 8) == "cols" and pick_layout(128, 3) == "rows"
+
+
+def _eval_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from selfrec_amd.dist import deal_users, gather_ranked
+    n_users, k = 37, 5                                       # (not a multiple of the world size: padded shares)
+    uid = list(range(100, 100 + n_users))
+    mine, n_max = deal_users(uid, rank, world)
+    assert n_max == (n_users + world - 1) // world and len(mine) in (n_max, n_max - 1)
+    ids = np.asarray([[u * 10 + c for c in range(k)] for u in mine], dtype=np.int32).reshape(len(mine), k)   # stand-in ranking
+    table = gather_ranked(ids, n_users, rank, world, "cpu")
+    want = np.asarray([[u * 10 + c for c in range(k)] for u in uid], dtype=np.int32)
+    assert np.array_equal(table.numpy(), want)               # every rank holds every user's list, in test-set order
+    if rank == 0:
+        np.save(out_path, table.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_evaluation_deals_and_gathers(tmp_path, world):
+    """bench.py's eval_throughput_sharded: users dealt round-robin, ranked shares all-gathered and re-ordered."""
+    out = str(tmp_path / "ids.npy")
+    mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out).shape == (37, 5)
+
+
+def _seed_worker(rank, world, port, flag_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from selfrec_amd import engine, synth
+    from selfrec_amd._lib import SelfrecHipError
+    from selfrec_amd.data import device_graph
+    from selfrec_amd.data.ui_graph import Interaction
+    from selfrec_amd.dist import ShardedTrainer
+    from tests import cpu_ops
+    engine.ops = device_graph.ops = cpu_ops
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    kw = dict(model="LightGCN", n_layers=2, batch_size=1000, device="cpu", layout="cols")
+    # (1) different torch seeds -> different initial tables: construction must fail on every rank
+    torch.manual_seed(rank)
+    try:
+        ShardedTrainer(data, 64, **kw)
+        caught = False
+    except SelfrecHipError as e:
+        caught = "initial embedding tables" in str(e)
+    assert caught
+    # (2) same tables, different sampler seeds -> different batches: the first epoch upload must fail
+    torch.manual_seed(0)
+    tr = ShardedTrainer(data, 64, **kw)
+    tr.sampler.seed(100 + rank)
+    try:
+        tr.begin_epoch()
+        caught = False
+    except SelfrecHipError as e:
+        caught = "sampled epoch" in str(e)
+    assert caught
+    # (3) identical seeds: fine (a fresh trainer: the sampler keeps its shuffled edge order from epoch to epoch)
+    torch.manual_seed(0)
+    tr = ShardedTrainer(data, 64, **kw)
+    tr.sampler.seed(5)
+    tr.begin_epoch()
+    tr.step()
+    open(os.path.join(flag_dir, f"ok{rank}"), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_seeds_across_ranks_are_detected(tmp_path):
+    """the step code assumes replicated tables and batches -- a rank seeded differently now
+    stops the job with an error instead of silently training on different data."""
+    mp.spawn(_seed_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

@@ -67,6 +67,8 @@ model = os.environ.get("COLS_PROBE_MODEL", "XSimGCL")
 kw = dict(model=model, n_layers=3, layer_cl=1, eps=0.2, cl_rate=0.2 if model != "SGL" else 0.1, tau=0.2, drop_rate=0.1,
           batch_size=2048)
 print(f"# {model} L=3, B=2048")
+print("# TIMING ONLY at world > 1: one rank of G on one GPU, stand-in communicator (same kernels and bytes, NO wire time, and the "
+      "all-gather returns copies of this rank's own columns: the printed losses are meaningless there)")
 worlds = [int(w) for w in os.environ.get("COLS_PROBE_WORLDS", "1,2,4,8").split(",")]
 modes = [m == "graph" for m in os.environ.get("COLS_PROBE_MODES", "graph,eager").split(",")]
 for world in worlds:
@@ -91,5 +93,5 @@ for world in worlds:
         dt = (time.perf_counter() - t0) / steps
         losses = tr.read_losses()
         print(f"world {world}  {'graph' if use_graph else 'eager'}  {dt * 1e6:8.1f} us/step (no wire time)  "
-              f"-> {2048 / dt / 1e6:6.2f} M pairs/s   losses {tuple(round(v, 4) for v in losses)}", flush=True)
+              f"-> {2048 / dt / 1e6:6.2f} M pairs/s   losses {tuple(round(v, 4) for v in losses) if world == 1 else '(timing only)'}", flush=True)
         del tr
