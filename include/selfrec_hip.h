@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 14
+#define SRH_ABI_VERSION 16
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -330,6 +330,16 @@ srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* bpr, const srh_inf
 srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v,
                            int64_t n_elem, int64_t step, const int64_t* d_step, float lr,
                            float beta1, float beta2, float eps, void* stream);
+/* The same update of an (n_rows, d) table as the LAST kernel of the engine's step: rows whose activity mark
+ * d_row_mark[row] equals *d_step are zeroed in up to SRH_MAX_ADAM_CLEAR other (n_rows, d) tables in the same pass
+ * (the batch-sparse gradient buffers: optimizer.zero_grad() of XSimGCL.py:35 for the only rows that are non-zero),
+ * and d_cursor_advance (int64[2], optional) is incremented.  d_step must then be srh_batch_fetch's d_now copy, not
+ * the cursor itself.  A table to clear may be d_grad (MF: the gradient buffer is the batch-sparse one). */
+#define SRH_MAX_ADAM_CLEAR 4
+srh_status_t srh_adam_step_reset(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_rows,
+                                 int32_t d, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                                 const int32_t* d_row_mark, int32_t n_clear, float* const* d_clear_tables,
+                                 int64_t* d_cursor_advance, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-10, a-11) Full-catalogue scoring + training-item mask + top-K -- replaces the per
@@ -402,6 +412,9 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              double* d_zero4 /* optional: 4 loss accumulators cleared for the new step */,
                              int32_t* d_stage_cat /* optional (2*batch_size): [uniq users ; uniq items + cat_item_offset] */,
                              int32_t cat_item_offset, int32_t* d_n_cat /* optional: n_uniq_u + n_uniq_i */,
+                             int64_t* d_now /* optional int64[2]: copy of d_cursor taken by this launch -- what a kernel
+                                               that runs CONCURRENTLY with the cursor advance (Adam beside srh_zero_rows)
+                                               reads its step from */,
                              void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 16
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
@@ -104,6 +104,7 @@ SIGNATURES = {
     "srh_bpr_infonce_fwd_bwd": (_i32, [C.POINTER(BprProblem), C.POINTER(InfonceProblem), _i32, _i32, _f32, _f32, _vp, _vp,
                                        _vp]),
     "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "srh_adam_step_reset": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp]),
     "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
     "srh_score_mask_topk_filtered_ws_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "srh_score_mask_topk_filtered": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp,
@@ -113,7 +114,7 @@ SIGNATURES = {
     "srh_topk_hit_flags": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
     "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _i32, _vp, _vp, _i32, _vp, _vp]),
+                                _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
     "srh_batch_pack": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),

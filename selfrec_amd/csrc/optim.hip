@@ -8,11 +8,24 @@
 namespace {
 using namespace srh;
 
-__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+// Optional fused reset (the engine's step): tables in `clr` get the rows whose activity mark equals this step's stamp
+// zeroed in the same pass -- the batch-sparse gradient buffers (gF, gCL, ...) hold non-zeros only there -- and
+// `cursor` (batch no, step) is advanced by block 0.  The step itself is read from d_step, which in that mode is
+// batch_fetch's COPY of the cursor: nobody reads `cursor` while this kernel runs.
+struct AdamClear {
+  float4* table[SRH_MAX_ADAM_CLEAR];
+  int32_t n;
+  const int32_t* mark;
+  int32_t lpr_shift;      // log2(float4 per table row)
+  int64_t* cursor;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* g /* may alias a table to clear */,
                                                    float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
                                                    int64_t step, const int64_t* __restrict__ d_step, float lr,
-                                                   float b1, float b2, float eps) {
+                                                   float b1, float b2, float eps, AdamClear clr) {
   const int64_t t = d_step ? *d_step : step;
+  if (clr.cursor && blockIdx.x == 0 && threadIdx.x == 0) { clr.cursor[0] += 1; clr.cursor[1] += 1; }
   // torch: bias_correction = 1 - beta ** step (python double), step_size = lr / bc1,
   //        denom = sqrt(v) / sqrt(bc2) + eps, p -= step_size * m / denom
   const double bc1 = 1.0 - pow((double)b1, (double)t);
@@ -31,6 +44,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
 #undef SRH_ADAM_LANE
     m[i] = mm; v[i] = vv; p[i] = pp;
+    if (clr.n > 0 && clr.mark[i >> clr.lpr_shift] == (int32_t)t) {
+      for (int k = 0; k < clr.n; ++k) clr.table[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(256) void batch_fetch_kernel(
     const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, const int64_t* __restrict__ cursor, int32_t* su,
     int32_t* si, int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta, int32_t* __restrict__ mark,
     int32_t item_offset, double* __restrict__ zero4, int32_t* __restrict__ cat, int32_t cat_item_offset,
-    int32_t* __restrict__ n_cat) {
+    int32_t* __restrict__ n_cat, int64_t* __restrict__ now) {
   const int64_t b = cursor[0];
   const int32_t stamp = (int32_t)cursor[1];
   const int64_t ptr = b * bs;
@@ -85,6 +101,7 @@ __global__ __launch_bounds__(256) void batch_fetch_kernel(
   }
   if (n_cat && tid == 0) *n_cat = a + c;
   if (zero4 && tid < 4) zero4[tid] = 0.0;        // the step's loss accumulators
+  if (now && tid < 2) now[tid] = cursor[tid];
   if (tid == 0) {
     meta[0] = (int32_t)rows;
     meta[1] = a;
@@ -124,9 +141,9 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(ZeroList z, int lpr) {
 
 extern "C" {
 
-srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_elem,
-                           int64_t step, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
-                           void* stream) {
+static srh_status_t adam_launch(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_elem,
+                                int64_t step, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                                const AdamClear& clr, void* stream) {
   SRH_REQUIRE(d_param && d_grad && d_m && d_v, "adam_step: null argument");
   SRH_REQUIRE(n_elem > 0 && n_elem % 4 == 0, "adam_step: n_elem must be a positive multiple of 4");
   SRH_REQUIRE(d_step || step >= 1, "adam_step: step is 1-based");
@@ -134,9 +151,36 @@ srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, floa
   const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
   adam_kernel<<<blocks, 256, 0, srh::as_stream(stream)>>>(
       reinterpret_cast<float4*>(d_param), reinterpret_cast<const float4*>(d_grad), reinterpret_cast<float4*>(d_m),
-      reinterpret_cast<float4*>(d_v), n4, step, d_step, lr, beta1, beta2, eps);
+      reinterpret_cast<float4*>(d_v), n4, step, d_step, lr, beta1, beta2, eps, clr);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
+}
+
+srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_elem,
+                           int64_t step, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                           void* stream) {
+  return adam_launch(d_param, d_grad, d_m, d_v, n_elem, step, d_step, lr, beta1, beta2, eps, AdamClear{}, stream);
+}
+
+srh_status_t srh_adam_step_reset(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_rows,
+                                 int32_t d, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                                 const int32_t* d_row_mark, int32_t n_clear, float* const* d_clear_tables,
+                                 int64_t* d_cursor_advance, void* stream) {
+  SRH_REQUIRE(d_step && d_row_mark, "adam_step_reset: the step and the row marks live in device memory");
+  SRH_REQUIRE(n_rows > 0 && d > 0 && d % 4 == 0, "adam_step_reset: bad shape");
+  SRH_REQUIRE(n_clear >= 0 && n_clear <= SRH_MAX_ADAM_CLEAR && (n_clear == 0 || d_clear_tables),
+              "adam_step_reset: at most %d tables to clear", SRH_MAX_ADAM_CLEAR);
+  AdamClear clr{};
+  for (int k = 0; k < n_clear; ++k) {
+    SRH_REQUIRE(d_clear_tables[k], "adam_step_reset: null table %d", k);
+    clr.table[k] = reinterpret_cast<float4*>(d_clear_tables[k]);
+  }
+  const int lpr = d / 4;
+  SRH_REQUIRE((lpr & (lpr - 1)) == 0, "adam_step_reset: d = %d (rows of a power-of-two number of float4)", d);
+  int shift = 0;
+  while ((1 << shift) < lpr) ++shift;
+  clr.n = n_clear; clr.mark = d_row_mark; clr.lpr_shift = shift; clr.cursor = d_cursor_advance;
+  return adam_launch(d_param, d_grad, d_m, d_v, n_rows * d, 0, d_step, lr, beta1, beta2, eps, clr, stream);
 }
 
 srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n_elem, void* stream) {
@@ -156,7 +200,8 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
                              int64_t batch_size, const int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
                              int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
                              int32_t* d_meta, int32_t* d_row_mark, int32_t mark_item_offset, double* d_zero4,
-                             int32_t* d_stage_cat, int32_t cat_item_offset, int32_t* d_n_cat, void* stream) {
+                             int32_t* d_stage_cat, int32_t cat_item_offset, int32_t* d_n_cat, int64_t* d_now,
+                             void* stream) {
   SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
               "batch_fetch: null argument");
   const bool uq = d_epoch_uniq_u != nullptr;
@@ -166,7 +211,7 @@ srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
   batch_fetch_kernel<<<kFetchBlocks, 256, 0, srh::as_stream(stream)>>>(
       d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u, d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges, batch_size,
       d_cursor, d_stage_u, d_stage_i, d_stage_j, d_stage_uniq_u, d_stage_uniq_i, d_meta, d_row_mark,
-      mark_item_offset, d_zero4, uq ? d_stage_cat : nullptr, cat_item_offset, uq ? d_n_cat : nullptr);
+      mark_item_offset, d_zero4, uq ? d_stage_cat : nullptr, cat_item_offset, uq ? d_n_cat : nullptr, d_now);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

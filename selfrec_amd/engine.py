@@ -200,6 +200,11 @@ class FusedTrainer:
         self.stage_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev)  # SGL: [uniq users ; uniq items + U]
         self.meta = torch.zeros(4, dtype=torch.int32, device=dev)          # rows, n_uniq_u, n_uniq_i, batch no
         self.cursor = torch.tensor([0, 1], dtype=torch.int64, device=dev)  # batch no, optimiser step (1-based)
+        self.now = self.cursor.clone()             # batch_fetch's copy of the cursor: what Adam reads its step from
+        # (running batch_fetch beside the first L - 1 products and zero_rows beside Adam on a side stream was measured:
+        # 0.3435 against 0.3167 ms per step -- fork / join edges inside the captured graph cost more than the two
+        # launches; round 1 saw the same with BPR beside InfoNCE.  The reset is folded into Adam instead.)
+        self.fused_reset = dev.type == "cuda" and not self.sharded and not self.cols
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -540,7 +545,7 @@ class FusedTrainer:
         # the staged ids are table rows (items already offset / permuted): one table, one index space
         cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
         ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
-                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses, **cat)
+                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now, **cat)
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
 
         include_ego = m in ("LightGCN", "SGL")
@@ -639,7 +644,17 @@ class FusedTrainer:
             self._backward_chain(adj, self.gF, include_ego=True)
             for vi, v in enumerate(self.views):
                 self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True)
-        ops.adam_step(self._loc(self.E0), self._loc(self.gE0), self.m, self.v, step_dev=self.cursor[1:2], lr=self.lr)
+        if self.fused_reset and self.sparse_reset:
+            # Adam's pass over the table also clears this batch's rows (the marked ones) of the batch-sparse gradient
+            # buffers and advances the cursor: the separate zero_rows launch (4.5 us) is gone.  Adam reads its step from
+            # `now` (batch_fetch's copy), so the advance cannot race with it.
+            clear = [self.gF] + [t for t in (self.gCL, self.gReg) if t is not None]
+            if m == "SGL":
+                clear += [v["gF"] for v in self.views]
+            ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.now[1:2], lr=self.lr, clear=clear,
+                          row_mark=self.mark, advance_cursor=self.cursor)
+            return
+        ops.adam_step(self._loc(self.E0), self._loc(self.gE0), self.m, self.v, step_dev=self.now[1:2], lr=self.lr)
         self._allgather(self.E0)                     # every rank's next forward pass reads the whole table
         if self.sparse_reset:
             # the gradient buffers hold non-zeros only on this batch's rows: clear just those

@@ -444,7 +444,18 @@ def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n
 # ----------------------------------------------------------------------------------------
 # (a-9) optimiser, (a-10/11) evaluation, utilities
 # ----------------------------------------------------------------------------------------
-def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_step(param, grad, m, v, *, step=0, step_dev=None, lr, beta1=0.9, beta2=0.999, eps=1e-8, clear=None,
+              row_mark=None, advance_cursor=None):
+    """clear / row_mark / advance_cursor: the fused end-of-step reset (srh_adam_step_reset)."""
+    if clear is not None or advance_cursor is not None:
+        clear = list(clear or [])
+        tables = (C.c_void_p * max(1, len(clear)))(*[_p(t, torch.float32, "clear") for t in clear])
+        check(_lib.load().srh_adam_step_reset(_p(param, torch.float32), _p(grad, torch.float32), _p(m, torch.float32),
+                                              _p(v, torch.float32), int(param.shape[0]), int(param.shape[1]),
+                                              _p(step_dev, torch.int64), float(lr), float(beta1), float(beta2), float(eps),
+                                              _p(row_mark, torch.int32), len(clear), tables,
+                                              _p(advance_cursor, torch.int64), _stream()), "srh_adam_step_reset")
+        return
     check(_lib.load().srh_adam_step(_p(param, torch.float32), _p(grad, torch.float32), _p(m, torch.float32),
                                     _p(v, torch.float32), param.numel(), int(step), _p(step_dev, torch.int64),
                                     float(lr), float(beta1), float(beta2), float(eps), _stream()), "srh_adam_step")
@@ -545,7 +556,7 @@ def zero_rows(lists, d, cursor_advance=None):
 
 
 def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
-                stage_cat=None, cat_item_offset=0, n_cat=None):
+                stage_cat=None, cat_item_offset=0, n_cat=None, now=None):
     """ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
     check(_lib.load().srh_batch_fetch(
         _p(ep["u"], torch.int32), _p(ep["i"], torch.int32), _p(ep["j"], torch.int32),
@@ -554,7 +565,8 @@ def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mar
         _p(cursor, torch.int64), _p(stage["u"], torch.int32), _p(stage["i"], torch.int32),
         _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
         _p(meta, torch.int32), _p(row_mark, torch.int32), int(mark_item_offset), _p(zero4, torch.float64),
-        _p(stage_cat, torch.int32), int(cat_item_offset), _p(n_cat, torch.int32), _stream()), "srh_batch_fetch")
+        _p(stage_cat, torch.int32), int(cat_item_offset), _p(n_cat, torch.int32), _p(now, torch.int64), _stream()),
+        "srh_batch_fetch")
 
 
 # ----------------------------------------------------------------------------------------

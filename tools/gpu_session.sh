@@ -47,6 +47,11 @@ benchdriver)
 benchquick)
   timeout 600 python bench.py --steps 600 --warmup 30 --no-cpu-baseline --no-eval --no-dropin > $OUT/benchquick.log 2> $OUT/benchquick.err; echo "benchquick exit $?"
   tail -3 $OUT/benchquick.err; tail -1 $OUT/benchquick.log | cut -c1-1500;;
+benchab)
+  for flag in "" "--no-overlap"; do
+    timeout 600 python bench.py --steps 1300 --warmup 30 --no-cpu-baseline --no-eval --no-dropin $flag > $OUT/benchab.log 2> $OUT/benchab.err; echo "benchab [$flag] exit $?"
+    python -c "import json,sys; d=json.loads(open('$OUT/benchab.log').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['steady_state']['ms_per_step'], d['value'])"
+  done;;
 refmodels)
   timeout 1500 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels.log 2>&1; echo "refmodels exit $?"
   grep -E "^#|parity|1 epoch|Error|error" $OUT/refmodels.log | tail -20;;
