@@ -44,6 +44,10 @@ class FusedGraphModel(GraphRecommender):
                                     reg=self.reg, batch_size=self.batch_size, rng_seed=rng_seed,
                                     use_graph=_as_bool(get('engine.hipgraph', True)), **self.engine_kwargs())
         self.exact_sampling = _as_bool(get('sampler.python_state', True))
+        precision = get('engine.nce_precision', None)          # "f32" | "bf16x3" (process-wide; default bf16x3)
+        if precision is not None:
+            from ... import ops
+            ops.set_infonce_precision(str(precision))
 
     def train(self):
         tr = self.trainer
