@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 16
+#define SRH_ABI_VERSION 17
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -193,11 +193,26 @@ typedef struct srh_spmm_epilogue {
    * 0 = the rows are d wide (everything above). */
   int32_t noise_d_full;
   int32_t noise_col0;
+  /* Row scaling (any epilogue; d = 64 / 128 / 256): with r = d_row_scale[row] (e.g. D^-1/2 of the adjacency),
+   *   SRH_SCALE_IN    the product is multiplied by r before everything else  -- with d_vals == NULL (pattern matrix,
+   *                   every stored entry = 1) and x = D^-1/2 x' this IS D^-1/2 A D^-1/2 x' (graph.py:10-24) without
+   *                   streaming a value per entry;
+   *   SRH_SCALE_OUT   y (and the FANOUT outputs) are STORED multiplied by r -- the next layer's pre-scaled input
+   *                   (mean_out is not: it holds true values);
+   *   bit t of prev_unscale_mask / add_rowscale_mask: MEAN's d_prev[t] is stored pre-scaled (multiply by 1 / r,
+   *                   0 where r = 0) / AXPY's d_add[t] is multiplied by r.
+   * Lets the engine keep layer outputs in the pre-scaled domain between products. */
+  const float* d_row_scale;
+  int32_t scale_flags;
+  int32_t prev_unscale_mask;
+  int32_t add_rowscale_mask;
 } srh_spmm_epilogue_t;
+enum { SRH_SCALE_IN = 1, SRH_SCALE_OUT = 2 };
 
 /* y (n_rows, d) = A (CSR, fp32 values, int32 structure) * x (n_cols, d); d in {8,16,32,64,128,256}
  * (8 and 16: the thin-table kernel of the column-sharded layout).
- * x and y must not alias.  epi may be NULL. */
+ * x and y must not alias.  epi may be NULL.  d_vals may be NULL for d >= 64: A is then the PATTERN of the structure
+ * (all stored entries 1) -- no value stream; column marks are not combined with it. */
 srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                           const int32_t* d_indices, const float* d_vals, const float* d_x,
                           float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream);

@@ -14,9 +14,10 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
+SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
 SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
 
 
@@ -56,6 +57,8 @@ class SpmmEpilogue(C.Structure):
         ("n_extra", C.c_int32), ("main_clean", C.c_int32), ("d_extra_out", C.c_void_p * SRH_MAX_EXTRA),
         ("d_extra_noise", C.c_void_p * SRH_MAX_EXTRA), ("extra_rng_offset", C.c_uint64 * SRH_MAX_EXTRA),
         ("noise_d_full", C.c_int32), ("noise_col0", C.c_int32),
+        ("d_row_scale", C.c_void_p), ("scale_flags", C.c_int32), ("prev_unscale_mask", C.c_int32),
+        ("add_rowscale_mask", C.c_int32),
     ]
 
 

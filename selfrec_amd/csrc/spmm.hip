@@ -68,6 +68,9 @@ struct DevEpilogue {
   // column-sharded tables (thin kernel): y holds columns [noise_col0, noise_col0 + d) of rows that are
   // noise_d_full wide -- the perturbation's unit vector is normalised over the WHOLE row
   int32_t noise_d_full, noise_col0;
+  // row scaling (value-free products: include/selfrec_hip.h)
+  const float* row_scale;
+  int32_t scale_flags, prev_unscale, add_rowscale;
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -146,10 +149,13 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
   return y;
 }
 
+// r: the row's scale factor (1 when the launch has none) -- loaded by the caller BEFORE its gathers: these waves run on
+// their chain of dependent round trips, and a load issued here would add one to every row
 template <int LPR>
 __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
-                                             const DevEpilogue& ep) {
+                                             const DevEpilogue& ep, const float r = 1.0f) {
   const size_t at = (size_t)row * LPR + sub;
+  if (ep.scale_flags & SRH_SCALE_IN) y = f4_scale(y, r);
   if (ep.flags & SRH_EPI_AXPY) {
     y = f4_scale(y, ep.alpha);
     // addends that are non-zero only on this step's batch rows are not even read elsewhere
@@ -157,26 +163,34 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
     for (int t = 0; t < ep.n_add; ++t) {
       if (((ep.add_sparse >> t) & 1) && !marked) continue;
       float4 a = reinterpret_cast<const float4*>(ep.add[t])[at];
-      y = f4_fma(ep.add_scale[t], a, y);
+      const float sc = ((ep.add_rowscale >> t) & 1) ? ep.add_scale[t] * r : ep.add_scale[t];
+      y = f4_fma(sc, a, y);
     }
   }
+  const bool out_scaled = (ep.scale_flags & SRH_SCALE_OUT) != 0;
   if (ep.flags & SRH_EPI_PERTURB) {
     const float4 raw = y;
     if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep);
     for (int k = 0; k < ep.n_extra; ++k) {
       const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
-      if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = yk;
+      if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = out_scaled ? f4_scale(yk, r) : yk;
     }
   }
-  if (store) Y[at] = y;
+  if (store) Y[at] = out_scaled ? f4_scale(y, r) : y;
   if (ep.flags & SRH_EPI_MEAN) {
-    float4 m;
+    const float rinv = (ep.prev_unscale && r > 0.f) ? 1.0f / r : 0.f;
+    float4 m = y;
+    // (earlier layers first, this layer last: the reference's stack order -- and, without unscaled terms, the
+    // summation order of the previous form of this loop, bit for bit)
     if (ep.n_prev > 0) {
       m = reinterpret_cast<const float4*>(ep.prev[0])[at];
-      for (int t = 1; t < ep.n_prev; ++t) m = f4_add(m, reinterpret_cast<const float4*>(ep.prev[t])[at]);
+      if (ep.prev_unscale & 1) m = f4_scale(m, rinv);
+      for (int t = 1; t < ep.n_prev; ++t) {
+        float4 pt = reinterpret_cast<const float4*>(ep.prev[t])[at];
+        if ((ep.prev_unscale >> t) & 1) pt = f4_scale(pt, rinv);
+        m = f4_add(m, pt);
+      }
       m = f4_add(m, y);
-    } else {
-      m = y;
     }
     if (store) {
       float4 o = f4_scale(m, ep.mean_rcp);
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   auto fetch = [&](int j, int end, unsigned& cs, float& v) {
     int c = 0;
     v = 0.f;
-    if (j < end) { c = indices[j]; v = vals[j]; }
+    if (j < end) { c = indices[j]; v = vals ? vals[j] : 1.0f; }      // vals == NULL: pattern matrix
     if (COLMASK) {
       if (v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
       cs = (unsigned)c;                                   // (gather8_branchy takes the plain column)
@@ -396,6 +410,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   if (kind == 0) {
     row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
     if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
     fetch(s + 16 * g + e16, e, cs, v);
     for (int base = s; base < e; base += CH) {
       const bool more = base + CH < e;
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
-      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
+      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r);
       return;
     }
     if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, a4);
@@ -426,12 +441,13 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
     for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
-    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
+    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
     return;
   }
 
   // ---- one short row per row-group ----
   const bool live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
+  const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
   if (!live) e = s;
   int maxlen = e - s;
 #pragma unroll
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
     if (prefetch) { cs = csn; v = vn; }
     else if (more) fetch(s + 16 * (q + 1) + e16, e, cs, v);
   }
-  row_epilogue<LPR>(total(), row, sub, live, Y, ep);
+  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,7 +508,8 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
   static_assert(3 * LPR <= 64, "three partial rows must fit one 256-float partial slot");
   constexpr int G = 64 / LPR;
   constexpr int CH = 16 * G;
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  // (wave-uniform by construction: readfirstlane lets the compiler fetch the task record with a scalar load)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
@@ -833,7 +850,8 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(const Task* __restrict__
   // (one task per wave: giving a wave 2 / 4 tasks with their records fetched up front -- half / a quarter of the
   // waves, two round trips saved per extra task -- measured 22.9 / 22.8 us against 19.1: this launch wants MORE
   // waves in flight, not fewer; workgroups of 64 .. 1024 threads: 19.1 / 19.2 / 19.1 / 20.5 / 20.8 us)
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  // (wave-uniform by construction: readfirstlane lets the compiler fetch the task record with a scalar load)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
@@ -908,7 +926,8 @@ __global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict_
   static_assert(LPR == 4 || LPR == 8, "16- and 32-column slices");
   constexpr int G = 64 / LPR;          // row-groups per wave
   constexpr int NB = 8 / LPR;          // sub-blocks of LPR entries a group holds per iteration
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+  // (wave-uniform by construction: readfirstlane lets the compiler fetch the task record with a scalar load)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, sub = lane % LPR;
@@ -1047,6 +1066,14 @@ static srh_status_t translate_epilogue(const srh_spmm_epilogue_t* epi, int32_t d
     ep.mark_stamp = epi->d_mark_stamp;
     ep.add_mark = epi->d_add_mark;
     ep.add_sparse = epi->add_sparse_mask;
+    if (epi->d_row_scale || epi->scale_flags || epi->prev_unscale_mask || epi->add_rowscale_mask) {
+      SRH_REQUIRE(epi->d_row_scale && d >= 64, "spmm_f32: row scaling needs d_row_scale and d >= 64");
+      SRH_REQUIRE((epi->scale_flags & ~(SRH_SCALE_IN | SRH_SCALE_OUT)) == 0, "spmm_f32: unknown scale flag");
+      ep.row_scale = epi->d_row_scale;
+      ep.scale_flags = epi->scale_flags;
+      ep.prev_unscale = epi->prev_unscale_mask;
+      ep.add_rowscale = epi->add_rowscale_mask;
+    }
     if (epi->noise_d_full) {       // y is a column slice of noise_d_full-wide rows (column-sharded tables)
       SRH_REQUIRE(epi->noise_d_full % 32 == 0 && epi->noise_col0 >= 0 && epi->noise_col0 % d == 0 &&
                       epi->noise_col0 + d <= epi->noise_d_full,
@@ -1296,7 +1323,9 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                           const int32_t* d_indices, const float* d_vals, const float* d_x,
                           float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
   (void)d_indptr;  // the schedule in `plan` already encodes the row extents
-  SRH_REQUIRE(plan && d_indices && d_vals && d_x && d_y, "spmm_f32: null argument");
+  SRH_REQUIRE(plan && d_indices && d_x && d_y, "spmm_f32: null argument");
+  SRH_REQUIRE(d_vals || (d >= 64 && !(epi && epi->d_col_mark)),
+              "spmm_f32: a pattern matrix (d_vals == NULL) needs d >= 64 and no column marks");
   SRH_REQUIRE(srh::dim_supported(d) || d == 8 || d == 16, "spmm_f32: d=%d unsupported (need 8, 16, 32, 64, 128 or 256)", d);
   SRH_REQUIRE(d_x != d_y, "spmm_f32: x and y must not alias");
   SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 32), "spmm_f32: x (%lld rows x %d) must be smaller than 4 GiB",

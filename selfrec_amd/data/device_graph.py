@@ -65,6 +65,8 @@ class DeviceGraph:
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, None, self.n_nodes,
                               weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws,
                               inv_sqrt_table=self._inv_sqrt)
+        # D^-1/2 of the full graph (the workspace is reused by dropped views): the row scale of value-free products
+        self.dinv = self._deg_ws.clone()
 
     def dropped_view(self, keep_mask: torch.Tensor, out: torch.Tensor | None = None) -> "ops.DeviceCSR":
         """Normalised adjacency of the graph restricted to interactions with keep_mask != 0

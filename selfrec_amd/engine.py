@@ -205,6 +205,16 @@ class FusedTrainer:
         # 0.3435 against 0.3167 ms per step -- fork / join edges inside the captured graph cost more than the two
         # launches; round 1 saw the same with BPR beside InfoNCE.  The reset is folded into Adam instead.)
         self.fused_reset = dev.type == "cuda" and not self.sharded and not self.cols
+        # Value-free products: on a unit-weight graph A_hat_ij = d_i^-1/2 d_j^-1/2, so a layer that reads
+        # a table stored PRE-SCALED by D^-1/2 needs no value stream -- the kernel sums x rows over the pattern and the
+        # epilogue multiplies the row by d_i^-1/2 (-10 % per launch at the Yelp2018 shape).  Layer outputs Y_1 .. Y_(L-1)
+        # and the backward intermediates are therefore kept as Z = D^-1/2 Y: the next product gathers them as they are,
+        # the last layer's mean un-scales them on the batch rows, InfoNCE is invariant to a positive row scale (its
+        # gradient w.r.t. Z re-enters the chain times d_i^-1/2), BPR / L2 read the true mean F.  The first product of a
+        # chain reads true values (E0, gF) and keeps the value array.
+        self.vfree = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
+                      and model in ("LightGCN", "XSimGCL", "SimGCL") and self.graph.weight is None)
+        self.dinv = self.graph.dinv if self.vfree else None
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -420,6 +430,7 @@ class FusedTrainer:
         product); noises / call_base: injected noise per layer and the RNG call number of layer 0."""
         L = self.L
         x = self.E0 if start_layer == 0 else Ys[start_layer - 1]
+        vf = self.vfree and adj is self.adj            # (Ys[0 .. L-2] then hold D^-1/2 Y: see __init__)
         for k in range(start_layer, L):
             kw = {}
             if perturbed:
@@ -433,9 +444,16 @@ class FusedTrainer:
                 prev = ([self.E0] if include_ego else []) + Ys[:L - 1]
                 kw.update(prev=[self._loc(t) for t in prev], mean_div=float(L + 1 if include_ego else L),
                           mean_out=self._loc(F))
+                if vf:
+                    kw.update(prev_unscale=([False] if include_ego else []) + [True] * (L - 1))
                 if batch_rows_only and self.use_marks:
                     kw.update(row_mark=self._loc(self.mark), mark_stamp=self.cursor[1:2])
-            ops.spmm(adj, x, out=self._loc(Ys[k]), epilogue=ops.make_epilogue(**kw) if kw else None)
+            if vf:
+                # layer 1 reads the true table E0 through the value array; later layers read pre-scaled tables through
+                # the pattern.  Every layer but the last stores its output pre-scaled.
+                kw.update(row_scale=self.dinv, scale_in=k > 0, scale_out=k < L - 1)
+            ops.spmm(adj, x, out=self._loc(Ys[k]), epilogue=ops.make_epilogue(**kw) if kw else None,
+                     **({"pattern": True} if vf and k > 0 else {}))
             if k < L - 1 or need_last:
                 self._allgather(Ys[k])          # the next layer (or the contrast view) reads every row
             x = Ys[k]
@@ -457,7 +475,7 @@ class FusedTrainer:
         ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), epilogue=ops.make_epilogue(
             perturb_eps=self.eps, noise=None, rng_seed=self.rng_seed, rng_offset=0,
             rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * self._rng_calls, main_clean=True,
-            **self._slice_kw(),
+            **self._slice_kw(), **(dict(row_scale=self.dinv, scale_out=True) if self.vfree and adj is self.adj else {}),
             extra_out=[self._loc(a["Y"][0]), self._loc(b["Y"][0])], extra_noise=[na[0], nb[0]],
             extra_rng_offset=[self._rng_offset(0), self._rng_offset(L)]))
         for t in (self.Y[0], a["Y"][0], b["Y"][0]):
@@ -477,6 +495,10 @@ class FusedTrainer:
         L = self.L
         s = 1.0 / (L + 1 if include_ego else L)
         cl_at = layer_cl if gCL is not None else None
+        vf = self.vfree and adj is self.adj
+        # (value-free: the contrast view at layer 1 .. L-1 was the pre-scaled table, so gCL is the gradient w.r.t.
+        # D^-1/2 Y and enters the chain times d_i^-1/2; at layer 0 / L the view held true values)
+        cl_rowscale = vf and cl_at is not None and 0 < cl_at < L
         if cl_at == L:
             H = self.Ha
             ops.axpby(s, gF, 0.0, H)
@@ -496,17 +518,28 @@ class FusedTrainer:
                 return {}
             return dict(add_mark=loc(self.mark), mark_stamp=self.cursor[1:2], add_sparse=[id(a) in batch_sparse for a in add])
         bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
+        first = True                               # the chain's first product reads true values (gF / H_L)
+
+        def scale_kw(add, last):
+            """value-free bookkeeping of one product: pattern + row scale on input unless it is the chain's first,
+            pre-scaled store unless it is the chain's last."""
+            if not vf:
+                return {}, {}
+            kw = dict(row_scale=self.dinv, scale_in=not first, scale_out=not last,
+                      add_rowscale=[cl_rowscale and a is gCL for a in add])
+            return kw, ({"pattern": True} if not first else {})
         for k in range(L - 1, 0, -1):              # produce H_k
             add, sc = [gF], [s]
             if cl_at == k:
                 add.append(gCL)
                 sc.append(1.0)
             dst = bufs[0]
+            skw, pkw = scale_kw(add, last=False)
             ops.spmm(adj, src, out=loc(dst),
                      epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
-                                                **{**sparse_add(add), **sparse_src}))
+                                                **{**sparse_add(add), **sparse_src, **skw}), **pkw)
             self._allgather(dst)
-            src, alpha, sparse_src = dst, 1.0, {}
+            src, alpha, sparse_src, first = dst, 1.0, {}, False
             bufs.reverse()
         add, sc = ([self.gE0], [1.0]) if accumulate else ([], [])   # (aliasing y is allowed)
         if include_ego:
@@ -522,9 +555,10 @@ class FusedTrainer:
             if not accumulate:
                 raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
+        skw, pkw = scale_kw(add, last=True)
         ops.spmm(adj, src, out=loc(self.gE0),
                  epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
-                                            **{**sparse_add(add), **sparse_src}))
+                                            **{**sparse_add(add), **sparse_src, **skw}), **pkw)
 
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch

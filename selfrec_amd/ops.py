@@ -231,8 +231,16 @@ def column_class_order(indptr, indices, min_len: int):
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
                   row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
-                  extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0):
+                  extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0,
+                  row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None):
+    """row_scale / scale_in / scale_out / prev_unscale / add_rowscale: per-row scaling for value-free products
+    (include/selfrec_hip.h: SRH_SCALE_*); prev_unscale / add_rowscale are lists of booleans aligned with prev / add."""
     ep = SpmmEpilogue()
+    if row_scale is not None:
+        ep.d_row_scale = _p(row_scale, torch.float32, "row_scale")
+        ep.scale_flags = (_lib.SRH_SCALE_IN if scale_in else 0) | (_lib.SRH_SCALE_OUT if scale_out else 0)
+        ep.prev_unscale_mask = sum(1 << t for t, f in enumerate(prev_unscale or []) if f)
+        ep.add_rowscale_mask = sum(1 << t for t, f in enumerate(add_rowscale or []) if f)
     ep.noise_d_full, ep.noise_col0 = int(d_full), int(col0)      # column-sharded tables (0 = whole rows)
     keep = []
     flags = 0
@@ -284,19 +292,21 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
         ep.add_sparse_mask = sum(1 << t for t, f in enumerate(add_sparse or []) if f)
         keep += [row_mark, col_mark, mark_stamp, add_mark]
     ep.flags = flags
-    ep._keepalive = keep
+    ep._keepalive = keep + [row_scale]
     return ep
 
 
-def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilogue: SpmmEpilogue | None = None):
-    """out = csr @ x (+ fused epilogue).  x: (n_cols, d) fp32."""
+def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilogue: SpmmEpilogue | None = None,
+         pattern: bool = False):
+    """out = csr @ x (+ fused epilogue).  x: (n_cols, d) fp32.  pattern=True: the structure with every stored entry 1
+    (no value stream; d >= 64) -- with row scaling in the epilogue this is the value-free form of D^-1/2 A D^-1/2."""
     if x.dim() != 2 or x.shape[0] != csr.shape[1]:
         raise SelfrecHipError(f"spmm: x has shape {tuple(x.shape)}, expected ({csr.shape[1]}, d)")
     d = int(x.shape[1])
     if out is None:
         out = torch.empty((csr.shape[0], d), dtype=torch.float32, device=x.device)
     check(_lib.load().srh_spmm_f32(csr._plan, _p(csr.indptr, torch.int32), _p(csr.indices, torch.int32),
-                                   _p(csr.vals, torch.float32, "vals"), _p(x, torch.float32, "x"),
+                                   None if pattern else _p(csr.vals, torch.float32, "vals"), _p(x, torch.float32, "x"),
                                    _p(out, torch.float32, "out"), d,
                                    C.byref(epilogue) if epilogue is not None else None, _stream()), "srh_spmm_f32")
     return out

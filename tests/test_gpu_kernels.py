@@ -189,6 +189,44 @@ def test_spmm_rng_perturbation_properties():
     assert torch.equal(e, f)
 
 
+def test_value_free_product_with_row_scaling(tiny_data):
+    """srh_spmm_f32 with d_vals == NULL (pattern) + SRH_SCALE_IN / SRH_SCALE_OUT / prev-unscale / addend row scale:
+    D^-1/2 A D^-1/2 x without the value stream (graph.py:10-24), as the engine chains it through pre-scaled tables."""
+    g = tiny_data.device_graph()
+    N, d = g.n_nodes, 64
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, d)).astype(np.float32)
+    a = rng.standard_normal((N, d)).astype(np.float32)
+    p0 = rng.standard_normal((N, d)).astype(np.float32)
+    A = sp.csr_matrix((g.adj.vals.cpu().numpy(), g.adj.indices.cpu().numpy(), g.adj.indptr.cpu().numpy()), shape=(N, N)).astype(np.float64)
+    dinv = g.dinv.cpu().numpy().astype(np.float64)
+    want = A @ x.astype(np.float64)                                            # true product
+    xs = torch.from_numpy((dinv[:, None] * x).astype(np.float32)).to(DEV)      # the pre-scaled input table
+    y = torch.empty((N, d), device=DEV)
+    ops.spmm(g.adj, xs, out=y, epilogue=ops.make_epilogue(row_scale=g.dinv, scale_in=True), pattern=True)
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+    # stored pre-scaled for the next layer, plus an addend that enters times d_i^-1/2 and one that does not
+    ta = torch.from_numpy(a).to(DEV)
+    ops.spmm(g.adj, xs, out=y, pattern=True,
+             epilogue=ops.make_epilogue(row_scale=g.dinv, scale_in=True, scale_out=True, add=[ta, ta], add_scale=[0.5, 2.0],
+                                        alpha=0.25, add_rowscale=[True, False]))
+    want2 = dinv[:, None] * (0.25 * want + 0.5 * dinv[:, None] * a + 2.0 * a)
+    assert rel_err(y.cpu().numpy(), want2) < 3e-6
+    # last layer: mean over a true table, a pre-scaled table and this product
+    tp = torch.from_numpy(p0).to(DEV)
+    tps = torch.from_numpy((dinv[:, None] * p0).astype(np.float32)).to(DEV)
+    mean = torch.empty((N, d), device=DEV)
+    ops.spmm(g.adj, xs, out=y, pattern=True,
+             epilogue=ops.make_epilogue(row_scale=g.dinv, scale_in=True, prev=[tp, tps], mean_div=3.0, mean_out=mean,
+                                        prev_unscale=[False, True]))
+    live = dinv > 0
+    assert rel_err(mean.cpu().numpy()[live], ((p0 + p0 + want) / 3.0)[live]) < 3e-6
+    # the value array path with the same scaling flags (first product of a chain: true input, pre-scaled output)
+    tx = torch.from_numpy(x).to(DEV)
+    ops.spmm(g.adj, tx, out=y, epilogue=ops.make_epilogue(row_scale=g.dinv, scale_out=True))
+    assert rel_err(y.cpu().numpy(), dinv[:, None] * want) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------
 # (a-2) normalisation and edge-dropped views
 # ------------------------------------------------------------------------------------------

@@ -20,8 +20,11 @@ tr.sampler.seed(args.seed)
 tr.begin_epoch()
 for _ in range(3):
     tr.step()
-ep = ops.make_epilogue(perturb_eps=tr.eps, rng_seed=1, rng_offset=0)
+# the step's dominant launch: the value-free dense product when the engine uses it, else the dense product with values
+vf = bool(getattr(tr, "vfree", False)) and not os.environ.get("SPMM_PMC_VALUES")
+kw = dict(row_scale=tr.dinv, scale_in=True, scale_out=True) if vf else {}
+ep = ops.make_epilogue(perturb_eps=tr.eps, rng_seed=1, rng_offset=0, **kw)
 for _ in range(40):
-    ops.spmm(tr.graph.adj, tr.E0, out=tr.Ha, epilogue=ep)
+    ops.spmm(tr.graph.adj, tr.E0, out=tr.Ha, epilogue=ep, **({"pattern": True} if vf else {}))
 torch.cuda.synchronize()
-print("launched 40 dense propagation SpMMs after 3 training steps")
+print(f"launched 40 dense propagation SpMMs ({'value-free' if vf else 'with values'}) after 3 training steps")
