@@ -342,8 +342,16 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
 // every task record read with scalar loads up front, and the FIRST (col, val) chunk of task j+1 in flight under the
 // last gathers of task j -- the per-task chain "record -> (col, val) -> gathers -> store" loses its first two links.
 // DEPTH 2: all 16 entries of a chunk in flight (xx[16]) instead of 8 + 8.  VALS false: value-free (zero row padding).
-template <int K, int DEPTH, bool VALS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 5 : 7, 8))) void rows_kernel2(const Task64* __restrict__ tasks64, int n_tasks,
+// the dense forward flavour only: y + perturbation (counter RNG), one store -- what a flag-specialised instantiation of the
+// epilogue would keep live across a multi-task loop
+__device__ __forceinline__ void light_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y, const DevEpilogue& ep) {
+  const size_t at = (size_t)row * 16 + sub;
+  y = perturb_row<16>(y, row, sub, at, nullptr, ep.off_lo, ep.off_hi, ep);
+  if (store) Y[at] = y;
+}
+
+template <int K, int DEPTH, bool VALS, bool LIGHT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 5 : (LIGHT ? 8 : 7), 8))) void rows_kernel2(const Task64* __restrict__ tasks64, int n_tasks,
                                                     const int32_t* __restrict__ indices, const float* __restrict__ vals,
                                                     const float4* __restrict__ X, float4* __restrict__ Y,
                                                     float4* __restrict__ partial, const Heavy* __restrict__ heavy,
@@ -371,18 +379,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
     w.kind = kind; w.slot = tp->slot;
     if (kind == 0) {
       w.row = r0; w.end = e0; w.stride = 64; w.j0 = s0 + 16 * g + e16;
-      w.live = !ep.row_mark || ep.row_mark[r0] == stamp;
+      w.live = LIGHT || !ep.row_mark || ep.row_mark[r0] == stamp;
       w.rem0 = w.live ? e0 - s0 : 0;
       w.n_chunks = (w.rem0 + 63) >> 6;
     } else {
       w.row = g == 0 ? r0 : g == 1 ? r1 : g == 2 ? r2 : r3;
       const int s = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
       int e = g == 0 ? e0 : g == 1 ? e1 : g == 2 ? e2 : e3;
-      w.live = g < count && (!ep.row_mark || ep.row_mark[w.row] == stamp);
+      w.live = g < count && (LIGHT || !ep.row_mark || ep.row_mark[w.row] == stamp);
       if (!w.live) e = s;
       w.end = e; w.stride = 16; w.j0 = s + e16;
       int maxlen;
-      if (!ep.row_mark) {
+      if (LIGHT || !ep.row_mark) {
         maxlen = max(max(e0 - s0, e1 - s1), max(e2 - s2, e3 - s3));          // scalar unit: the record is in SGPRs
       } else {
         maxlen = e - s;
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
     int c = VALS ? 0 : pad_row;
     v = 0.f;
     if (j < end) { c = indices[j]; if (VALS) v = vals[j]; }
-    if (VALS && ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
+    if (!LIGHT && VALS && ep.col_mark && v != 0.f && ep.col_mark[c] != stamp) v = 0.f;
     cs = (unsigned)c << 8;
     if (VALS && v == 0.f) cs = 0x80000000u;
   };
@@ -460,11 +468,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
         float4 a4 = to_f4(acc);
 #pragma unroll
         for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
-        if (slot < 0) row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
-        else finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+        if (slot < 0) {
+          if (LIGHT) light_epilogue(a4, row, sub, g == 0, Y, ep); else row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
+        } else {
+          finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+        }
       }
     } else {
-      row_epilogue<LPR>(to_f4(acc), cur.row, sub, cur.live, Y, ep);
+      if (LIGHT) light_epilogue(to_f4(acc), cur.row, sub, cur.live, Y, ep);
+      else row_epilogue<LPR>(to_f4(acc), cur.row, sub, cur.live, Y, ep);
     }
   }
 }
@@ -610,6 +622,102 @@ __global__ __launch_bounds__(256) void rows_kernel3(const Task64* __restrict__ t
   row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
 }
 
+// Fifth generation: PERSISTENT waves (2048 workgroups = 8 waves per SIMD, one round).  Wave w first runs the cooperative
+// tasks w, w + W, ... exactly as the product does, then walks its short-row tasks base + w, base + w + W, ... with the NEXT
+// task's record (scalar) and first (col, val) chunk in flight under the current task's last gathers -- the two loops are
+// separate so that neither carries the other's state.  `n_coop_pad`: cooperative tasks padded to a multiple of 32 with
+// empty records, so every task of a wave has the wave's XCD class.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void rows_kernel5(const Task64* __restrict__ tasks64, int n_coop_pad, int n_tasks,
+                  const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                  const float4* __restrict__ X, float4* __restrict__ Y, float4* __restrict__ partial,
+                  const Heavy* __restrict__ heavy, const int32_t* __restrict__ slot_owner, int32_t* __restrict__ tickets,
+                  DevEpilogue ep) {
+  constexpr int LPR = 16;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, sub = lane & 15, e16 = sub;
+  const unsigned sub16 = (unsigned)sub * 16u;
+  const int w0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+  const int W = (int)gridDim.x * 4;
+  const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+  const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int j, int end, unsigned& cs, float& v) {
+    int c = 0;
+    v = 0.f;
+    if (j < end) { c = indices[j]; v = vals[j]; }
+    cs = (v == 0.f) ? 0x80000000u : (unsigned)c << 8;
+  };
+  // ---- cooperative tasks (long rows / split segments): one per iteration, no cross-task pipeline
+#pragma unroll 1
+  for (int t = w0; t < n_coop_pad; t += W) {
+    const Task64* tp = tasks64 + t;
+    if (tp->kind != 0) continue;                          // padding record
+    const int row = tp->row[0], s = tp->start[0], e = tp->end[0], slot = tp->slot;
+    if (ep.row_mark && ep.row_mark[row] != stamp) continue;
+    Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
+    floatx4_t xx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xx[k] = zero;
+    unsigned cs, csn = 0x80000000u;
+    float v, vn = 0.f;
+    fetch(s + 16 * g + e16, e, cs, v);
+    for (int base = s; base < e; base += 64) {
+      if (base + 64 < e) fetch(base + 64 + 16 * g + e16, e, csn, vn);
+      gather8_asm<false, true>(cs, v, sub16, X, xx, acc);
+      if (e - base > 8) gather8_asm<true, true>(cs, v, sub16, X, xx, acc);
+      cs = csn; v = vn;
+    }
+    float4 a4 = to_f4(acc);
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
+    if (slot < 0) row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep);
+    else finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+  }
+  // ---- short rows: four per task, next task prefetched
+  int t = n_coop_pad + w0;
+  if (t >= n_tasks) return;
+  auto lane_view = [&](const Task64* tp, int& row, int& s, int& e) {
+    const int count = tp->count;
+    row = g == 0 ? tp->row[0] : g == 1 ? tp->row[1] : g == 2 ? tp->row[2] : tp->row[3];
+    s = g == 0 ? tp->start[0] : g == 1 ? tp->start[1] : g == 2 ? tp->start[2] : tp->start[3];
+    e = g == 0 ? tp->end[0] : g == 1 ? tp->end[1] : g == 2 ? tp->end[2] : tp->end[3];
+    if (g >= count) e = s;
+  };
+  unsigned cs, csn = 0x80000000u;
+  float v, vn = 0.f;
+  int row, s, e;
+  lane_view(tasks64 + t, row, s, e);
+  fetch(s + e16, e, cs, v);
+#pragma unroll 1
+  for (;;) {
+    const bool live = e > s && (!ep.row_mark || ep.row_mark[row] == stamp);
+    if (!live) { e = s; cs = 0x80000000u; }
+    int maxlen = e - s;
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    const int tn = t + W;
+    int nrow = 0, ns = 0, ne = 0;
+    if (tn < n_tasks) lane_view(tasks64 + tn, nrow, ns, ne);
+    Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
+    floatx4_t xx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xx[k] = zero;
+    const int nq = (maxlen + 15) >> 4;
+    for (int q = 0; q < nq; ++q) {
+      if (q + 1 < nq) fetch(s + 16 * (q + 1) + e16, e, csn, vn);
+      else fetch(ns + e16, ne, csn, vn);                         // first chunk of the next task (empty when none)
+      gather8_asm<false, true>(cs, v, sub16, X, xx, acc);
+      if (maxlen - 16 * q > 8) gather8_asm<true, true>(cs, v, sub16, X, xx, acc);
+      cs = csn; v = vn;
+    }
+    if (nq == 0) fetch(ns + e16, ne, cs, v);
+    row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
+    if (tn >= n_tasks) break;
+    t = tn; row = nrow; s = ns; e = ne;
+  }
+}
+
 // marks -> bitmap (1 = column live this step)
 __global__ void build_bits(const int32_t* __restrict__ mark, const int64_t* __restrict__ stamp, int n, uint32_t* __restrict__ bits) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -623,6 +731,8 @@ __global__ void build_bits(const int32_t* __restrict__ mark, const int64_t* __re
 struct Lab {
   Task64* d_tasks64 = nullptr;
   int n_tasks = 0;
+  Task64* d_tasks64p = nullptr;     // cooperative tasks padded to a multiple of 32, then the short-row tasks
+  int n_coop_pad = 0, n_tasks_p = 0;
   uint32_t* d_bits = nullptr;
   int n_bit_words = 0;
 };
@@ -657,6 +767,19 @@ int lab_create(void** out, const srh_spmm_plan_t* plan) {
   L->n_bit_words = (int)((plan->n_cols + 31) / 32);
   if (hipMalloc(&L->d_tasks64, sizeof(Task64) * std::max(1, n)) != hipSuccess) return -1;
   if (hipMemcpy(L->d_tasks64, t64.data(), sizeof(Task64) * n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  {
+    std::vector<Task64> padded;
+    size_t k = 0;
+    for (; k < t64.size() && t64[k].kind == 0; ++k) padded.push_back(t64[k]);
+    Task64 empty{};
+    empty.kind = 1; empty.count = 0;
+    while (padded.size() % 32) padded.push_back(empty);
+    L->n_coop_pad = (int)padded.size();
+    for (; k < t64.size(); ++k) { if (t64[k].kind != 1) return -5; padded.push_back(t64[k]); }
+    L->n_tasks_p = (int)padded.size();
+    if (hipMalloc(&L->d_tasks64p, sizeof(Task64) * padded.size()) != hipSuccess) return -1;
+    if (hipMemcpy(L->d_tasks64p, padded.data(), sizeof(Task64) * padded.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  }
   if (hipMalloc(&L->d_bits, sizeof(uint32_t) * L->n_bit_words) != hipSuccess) return -1;
   if (hipMemset(L->d_bits, 0, sizeof(uint32_t) * L->n_bit_words) != hipSuccess) return -1;
   *out = L;
@@ -716,6 +839,26 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
       rows_kernel3<<<blocks, 256, 0, st>>>(L->d_tasks64, n, d_indices, d_vals, reinterpret_cast<const float4*>(d_x),
                                            reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial),
                                            plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep);
+      break;
+    case 50:
+      rows_kernel5<<<2048, 256, 0, st>>>(L->d_tasks64p, L->n_coop_pad, L->n_tasks_p, d_indices, d_vals,
+                                         reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
+                                         reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
+                                         plan->d_tickets, ep);
+      break;
+    case 40: {
+      const int nblk = 2048;                      /* 8 waves per SIMD x 1024 SIMDs, one round: persistent */
+      const int kk = (blocks + nblk - 1) / nblk;
+      if (kk <= 3) rows_kernel2<3, 1, true, true><<<nblk, 256, 0, st>>>(L->d_tasks64, n, d_indices, d_vals,
+          reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial),
+          plan->d_heavy, plan->d_slot_owner, plan->d_tickets, (int)plan->n_cols, ep);
+      else return -4;
+      break;
+    }
+    case 41:
+      rows_kernel2<1, 1, true, true><<<blocks, 256, 0, st>>>(L->d_tasks64, n, d_indices, d_vals,
+          reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial),
+          plan->d_heavy, plan->d_slot_owner, plan->d_tickets, (int)plan->n_cols, ep);
       break;
     case 10: LAB_LAUNCH2(1, 1, true); break;
     case 11: LAB_LAUNCH2(2, 1, true); break;

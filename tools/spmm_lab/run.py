@@ -26,11 +26,14 @@ VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) pre
             22: "2 minus the (col,val) loads (timing only)",
             23: "2 with non-temporal (col,val) loads",
             30: "gen3: rolling window of 8 gathers (no column marks)",
+            50: "gen5 persistent: coop loop, then short rows with the next task prefetched",
+            41: "gen2 K=1, perturb-only epilogue (dense flavour only)",
+            40: "gen2 persistent: 2048 workgroups x 3 tasks, perturb-only epilogue",
             10: "gen2 K=1 depth 1", 11: "gen2 K=2 (next task's first chunk prefetched)", 12: "gen2 K=3", 13: "gen2 K=4",
             18: "gen2 K=6", 14: "gen2 K=1, 16 gathers in flight", 15: "gen2 K=2, 16 gathers in flight",
             16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)"}
 VALUE_FREE = (3, 16, 17)
-SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
+SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14, 40)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
 
 
 def timed(fn, iters):
@@ -114,7 +117,8 @@ def main():
             continue
         cells = []
         for name, mk in flavours.items():
-            if (variant in (4, 5) and name != "col_masked") or (variant == 30 and name == "col_masked"):
+            if (variant in (4, 5) and name != "col_masked") or (variant in (30, 50) and name == "col_masked") or \
+                    (variant in (40, 41) and name != "dense"):
                 cells.append(f"{'-':>14}")
                 continue
             csr = ones if variant in VALUE_FREE else adj
