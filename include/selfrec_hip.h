@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 17
+#define SRH_ABI_VERSION 18
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -292,6 +292,9 @@ typedef struct srh_infonce_problem {
   const int32_t* d_n;
   float* d_g1;
   float* d_g2;
+  int32_t g2_exclusive; /* != 0: the rows of d_g2 this problem names are written by nobody else during the call (e.g. the
+                           contrast-layer gradient table of XSimGCL: user-side and item-side problems name disjoint rows):
+                           plain read-add-store instead of 4 device-scope atomics per lane */
 } srh_infonce_problem_t;
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems,
                                        int32_t d, float tau, float loss_scale, double* d_loss,

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -28,7 +28,7 @@ class SelfrecHipError(RuntimeError):
 class InfonceProblem(C.Structure):
     """struct srh_infonce_problem (include/selfrec_hip.h)."""
     _fields_ = [("d_v1", C.c_void_p), ("d_v2", C.c_void_p), ("d_idx", C.c_void_p), ("n", C.c_int64),
-                ("d_n", C.c_void_p), ("d_g1", C.c_void_p), ("d_g2", C.c_void_p)]
+                ("d_n", C.c_void_p), ("d_g1", C.c_void_p), ("d_g2", C.c_void_p), ("g2_exclusive", C.c_int32)]
 
 
 class BprProblem(C.Structure):

@@ -231,6 +231,7 @@ struct NceWs {
   const int32_t* d_n;
   int n_max;
   float *g1, *g2;
+  int g2_plain;         // g2's rows are this problem's alone: plain read-add-store
 };
 constexpr int kNceMaxProblems = 4;
 struct NceBatch {
@@ -524,10 +525,15 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const float4 dv1 = nce_norm_backward<LPR>(va, dn1, n1);
   const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, n2);
   if (valid) {
-    // atomic: BPR phase 2 shares this launch and adds to the same rows (a plain read-modify-write of
-    // the rows nobody else touches was measured: 2 us of 330)
+    // atomic: BPR phase 2 shares this launch and adds to the same rows of g1.  g2 is a plain read-add-store
+    // when the caller declares its rows exclusive (srh_infonce_problem_t::g2_exclusive)
     atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
-    atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
+    if (w.g2_plain) {
+      float4* p2 = reinterpret_cast<float4*>(w.g2) + (size_t)dst * LPR + sub;
+      *p2 = f4_add(*p2, dv2);
+    } else {
+      atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
+    }
   }
   return (valid && sub == 0) ? (double)(lse - sii) : 0.0;
 }
@@ -826,6 +832,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     cursor += srh_infonce_ws_bytes(pr[k].n, D);
     w.src1 = pr[k].d_v1; w.src2 = pr[k].d_v2; w.idx = pr[k].d_idx; w.d_n = pr[k].d_n; w.n_max = (int)pr[k].n;
     w.g1 = pr[k].d_g1; w.g2 = pr[k].d_g2;
+    w.g2_plain = pr[k].g2_exclusive != 0 && pr[k].d_g2 != pr[k].d_g1;
     batch.w[k] = w;
     np_max = std::max(np_max, (int)w.np);
   }

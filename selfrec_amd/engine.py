@@ -648,8 +648,9 @@ class FusedTrainer:
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=[
-                (T(F), T(CL), ix["uniq_u"], self.B, nuu_dev, GT(self.gF), GT(self.gCL)),
-                (T(F), T(CL), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gCL))])
+                # (gCL's rows: the user-side problem names user rows, the item-side one item rows, nobody else writes them)
+                (T(F), T(CL), ix["uniq_u"], self.B, nuu_dev, GT(self.gF), GT(self.gCL), True),
+                (T(F), T(CL), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gCL), True)])
         elif m in ("SimGCL", "SGL"):
             a, b = self.views
             if m == "SimGCL":

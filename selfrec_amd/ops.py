@@ -408,14 +408,15 @@ def infonce_fwd_bwd(v1, v2, idx, n, *, n_dev=None, tau, loss_scale, loss, g1, g2
 
 
 def infonce_multi(problems, *, d, tau, loss_scale, loss, ws):
-    """problems: [(v1, v2, idx, n_max, n_dev, g1, g2), ...] evaluated by one set of launches."""
+    """problems: [(v1, v2, idx, n_max, n_dev, g1, g2[, g2_exclusive]), ...] evaluated by one set of launches."""
     lib = _lib.load()
     arr = (_lib.InfonceProblem * len(problems))()
     need = 0
-    for k, (v1, v2, idx, n, n_dev, g1, g2) in enumerate(problems):
+    for k, (v1, v2, idx, n, n_dev, g1, g2, *rest) in enumerate(problems):
         arr[k].d_v1, arr[k].d_v2 = _p(v1, torch.float32), _p(v2, torch.float32)
         arr[k].d_idx, arr[k].n, arr[k].d_n = _p(idx, torch.int32), int(n), _p(n_dev, torch.int32)
         arr[k].d_g1, arr[k].d_g2 = _p(g1, torch.float32), _p(g2, torch.float32)
+        arr[k].g2_exclusive = int(bool(rest[0])) if rest else 0
         need += int(lib.srh_infonce_ws_bytes(n, d))
     if ws.numel() * ws.element_size() < need:
         raise SelfrecHipError(f"infonce workspace too small: {ws.numel() * ws.element_size()} < {need}")
@@ -440,10 +441,11 @@ def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n
     b.d_losses, b.d_ws = _p(losses, torch.float64), _p(bpr_ws)
     arr = (_lib.InfonceProblem * len(problems))()
     need = 0
-    for k, (v1, v2, idx, n, n_dev, g1, g2) in enumerate(problems):
+    for k, (v1, v2, idx, n, n_dev, g1, g2, *rest) in enumerate(problems):
         arr[k].d_v1, arr[k].d_v2 = _p(v1, torch.float32), _p(v2, torch.float32)
         arr[k].d_idx, arr[k].n, arr[k].d_n = _p(idx, torch.int32), int(n), _p(n_dev, torch.int32)
         arr[k].d_g1, arr[k].d_g2 = _p(g1, torch.float32), _p(g2, torch.float32)
+        arr[k].g2_exclusive = int(bool(rest[0])) if rest else 0
         need += int(lib.srh_infonce_ws_bytes(n, d))
     if nce_ws.numel() * nce_ws.element_size() < need:
         raise SelfrecHipError(f"infonce workspace too small: {nce_ws.numel() * nce_ws.element_size()} < {need}")

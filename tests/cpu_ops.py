@@ -192,7 +192,7 @@ def bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch
 
 
 def _infonce(problems, tau, scale, loss):
-    for v1, v2, idx, n_max, n_dev, g1, g2 in problems:
+    for v1, v2, idx, n_max, n_dev, g1, g2, *_excl in problems:
         n = min(int(n_dev), n_max) if n_dev is not None else n_max
         if n <= 0:
             continue

@@ -20,6 +20,7 @@ index streams and keep-sets:
   N  GraphAugmentor.node_dropout (augmentor.py:10-27) on the 200 x 300 graph: dropped users /
      items, dropped Laplacian, next raw MT word; 3 SGL steps with aug_type = 0.
   W  duplicated interaction lines: weight-2 entries in norm_adj, unit weights in the dropped views.
+  B  configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions): one step.
   M  the other torch graph models of SURVEY 8(f-4) -- DirectAU, MixGCF, BUIR, SelfCF -- on the 200 x 300 graph: 2 steps
      each (losses, parameters, get_embedding / model() outputs, test() ranking), MixGCF's n_negs = 64 sampler stream
      (SHA-256; also 20 batches at the Yelp2018 shape), BUIR's sparse-dropout keep masks.  Randomness the models draw on
@@ -64,7 +65,11 @@ def sha(a, dtype):
     return hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=dtype)).tobytes()).hexdigest()
 
 
-def make_conf(tmp, model, extra, emb=64, batch=2048, topn="[10,20]"):
+EMB = {"default": 64}          # (section B overrides it: BASELINE.json configs[3] is d = 128)
+
+
+def make_conf(tmp, model, extra, emb=None, batch=2048, topn="[10,20]"):
+    emb = EMB["default"] if emb is None else emb
     lines = ["training.set: ./train.txt", "test.set: ./test.txt", "model:", f"  name: {model}", "  type: graph",
              f"item.ranking.topN: {topn}", f"embedding.size: {emb}", "max.epoch: 1", f"batch.size: {batch}",
              "learning.rate: 0.001", "reg.lambda: 0.0001", "output: ./results/"]
@@ -149,7 +154,7 @@ def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2
             out[f"{tag}_loss_bpr"] = np.asarray(rec["bpr"], dtype=np.float64)
             out[f"{tag}_loss_reg"] = np.asarray(rec["reg"], dtype=np.float64)
             out[f"{tag}_loss_nce"] = np.asarray(rec["nce"], dtype=np.float64)
-            info = {"model": name, "conf": extra, "n_steps": n_steps, "emb": 64, "batch": 2048, "lr": 0.001, "reg": 0.0001,
+            info = {"model": name, "conf": extra, "n_steps": n_steps, "emb": EMB["default"], "batch": 2048, "lr": 0.001, "reg": 0.0001,
                     "init_seed": init_seed, "sampler_seed": sampler_seed, "noise_seed": noise_seed,
                     "n_users": U, "n_items": I, "n_train": len(d.training_data),
                     "init_sha_user": sha(init_u, np.float32), "init_sha_item": sha(init_i, np.float32),
@@ -228,6 +233,25 @@ def section_F(out, meta):
     keeps = [random.sample(range(e), k) for _ in range(2)]
     meta["F_SGL"].update(n_edges=int(e), n_keep=k, keep_sha=[sha(x, np.int64) for x in keeps],
                          keep_sorted_sha=[sha(np.sort(np.asarray(x, dtype=np.int64)), np.int64) for x in keeps])
+
+
+def section_B(out, meta):
+    """BASELINE.json configs[3]: XSimGCL on the synthetic 1 M x 500 k graph, d = 128 -- ONE reference step (the reference
+    needs ~25 GB and a quarter of an hour for it: python triples, dict-of-dict sets, a 40 M element shuffle)."""
+    torch.set_num_threads(8)        # (summation order inside torch's CPU kernels then differs from a 1-thread run at the
+    EMB["default"] = 128            #  1e-7 level; tests/test_gpu_shapes.py's tolerances for post-Adam parameters apply)
+    try:
+        t0 = time.time()
+        tu, ti, su, si, U, I = synth.make_dataset("1m-500k", seed=SEED_GRAPH)
+        train, test = synth.as_triples(tu, ti), synth.as_triples(su[:200000], si[:200000])
+        print(f"B: graph + triples in {time.time() - t0:.0f} s", flush=True)
+        meta["B_graph"] = {"shape": "1m-500k", "seed": SEED_GRAPH, "n_users": U, "n_items": I, "n_train": len(tu),
+                           "n_test_used": 200000}
+        run_model("XSimGCL", {"n_layer": 3, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, train, test, 1, "B_XSimGCL",
+                  out, meta, eval_users=16)
+    finally:
+        torch.set_num_threads(1)
+        EMB["default"] = 64
 
 
 def section_D(out, meta):
@@ -415,7 +439,7 @@ def main():
     meta.update(torch=torch.__version__, numpy=np.__version__)
     for s in want:
         t0 = time.time()
-        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W, "M": section_M}[s](out, meta)
+        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W, "M": section_M, "B": section_B}[s](out, meta)
         print(f"section {s}: {time.time() - t0:.0f} s", flush=True)
         np.savez_compressed(npz_path, **out)
         with open(meta_path, "w") as f:

@@ -141,6 +141,31 @@ def test_ifashion_shape_sgl_step_matches_reference_run(shapes, smeta):
         assert sha(np.flatnonzero(mk), np.int64) == want
 
 
+def first_appearance_ids(raw):
+    """ids in first-appearance order of a list (ui_graph.py:29-38), vectorised"""
+    uniq, first = np.unique(raw, return_index=True)
+    rank = np.empty(int(uniq.max()) + 1, dtype=np.int64)
+    rank[uniq[np.argsort(first)]] = np.arange(uniq.size)
+    return rank[raw]
+
+
+def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
+    """BASELINE.json configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions) --
+    one step of the reference (8 torch threads, ~25 GB of python objects) against the fused engine on one MI355X."""
+    if "B_XSimGCL" not in smeta:
+        pytest.skip("golden section B not generated")
+    info = smeta["B_XSimGCL"]
+    tu, ti, su, si, U, I = synth.make_dataset("1m-500k", seed=2024)
+    data = Interaction.from_id_arrays({}, first_appearance_ids(tu), first_appearance_ids(ti), np.zeros(0, np.int64),
+                                      np.zeros(0, np.int64), U, I)
+    del tu, ti, su, si
+    assert (data.user_num, data.item_num, data.train_u.size) == (info["n_users"], info["n_items"], info["n_train"])
+    ue, ie = seeded_init(info)
+    tr = trainer_for(info, data, ue, ie)
+    assert tr.d == 128 and tr.vfree
+    run_and_check("B_XSimGCL", shapes, info, tr, param_rtol=2e-3, emb_rtol=1e-3)      # (post-Adam tolerances: module docstring)
+
+
 def test_douban_book_mf_three_steps_and_ranking(tmp_path, shapes, smeta):
     """configs[0] end to end on the shipped file: native loader -> Interaction -> MF + BPR (MF.py:13-31) ->
     test() -> ranking_evaluation."""

@@ -31,6 +31,8 @@ lab3)
   timeout 900 python tools/spmm_lab/run.py --ids first-appearance --no-colclass > $OUT/spmm_lab_nocc.log 2>&1; echo "lab3 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_nocc.log | tail -${LAB_TAIL:-20};;
 lab2)
   timeout 900 python tools/spmm_lab/run.py --ids first-appearance > $OUT/spmm_lab_fa.log 2>&1; echo "lab2 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_fa.log | tail -${LAB_TAIL:-20};;
+evalprobe)
+  timeout 600 python tools/eval_probe.py > $OUT/eval_probe.log 2>&1; echo "evalprobe exit $?"; grep -v amdgpu.ids $OUT/eval_probe.log | tail -3;;
 lossprobe)
   rm -rf $OUT/lossprobe; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/lossprobe -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/lossprobe.log 2>&1); echo "lossprobe exit $?"
   stats $OUT/lossprobe | grep -E "kernel  |bpr_|nce_" > $OUT/lossprobe_kernel_stats.txt; cat $OUT/lossprobe_kernel_stats.txt; tail -1 $OUT/lossprobe.log
