@@ -21,7 +21,7 @@ from .. import ops
 
 
 class DeviceGraph:
-    def __init__(self, interaction_mat, device=None, column_classes=True):
+    def __init__(self, interaction_mat, device=None, column_classes=True, split_len=0):
         r = interaction_mat.tocsr()
         r.sum_duplicates()
         r.sort_indices()
@@ -61,7 +61,8 @@ class DeviceGraph:
         table[0] = 0.0
         self._inv_sqrt = torch.from_numpy(table.astype(np.float32)).to(dev)
         self.adj = ops.DeviceCSR(indptr, indices, torch.zeros(indices.size, dtype=torch.float32, device=dev),
-                                 (self.n_nodes, self.n_nodes), device=dev, xcd_split_row=self.n_users, row_mid=row_mid)
+                                 (self.n_nodes, self.n_nodes), device=dev, xcd_split_row=self.n_users, row_mid=row_mid,
+                                 split_len=split_len)
         ops.adj_sym_normalize(self.adj.indptr, self.adj.indices, self.edge_id, None, self.n_nodes,
                               weight=self.weight, out=self.adj.vals, deg_ws=self._deg_ws,
                               inv_sqrt_table=self._inv_sqrt)

@@ -69,8 +69,10 @@ def trainer_for(info, data, ue, ie, **over):
     return FusedTrainer(data, info["emb"], **kw)
 
 
-def run_and_check(tag, shapes, info, tr, *, rows=True, nce_rtol=2e-5, param_rtol=2e-4, emb_rtol=1e-4):
-    """Seed the sampler like the reference run, train its steps, compare everything the golden holds."""
+def run_and_check(tag, shapes, info, tr, *, rows=True, nce_rtol=2e-5, param_rtol=2e-4, emb_rtol=1e-4, outliers=0.0):
+    """Seed the sampler like the reference run, train its steps, compare everything the golden holds.
+    outliers > 0 (the 1.5 M-node shape): the element-wise bounds hold for all but that fraction of the sampled
+    elements, and every element stays within 5 % of one Adam step -- see the test that uses it."""
     random.seed(info["sampler_seed"])
     tr.seed_sampler_from_python()
     tr.begin_epoch()
@@ -93,10 +95,19 @@ def run_and_check(tag, shapes, info, tr, *, rows=True, nce_rtol=2e-5, param_rtol
     ru = torch.from_numpy(shapes[f"{tag}_rows_user"].astype(np.int64)).to(DEV) if rows else slice(None)
     ri = torch.from_numpy(shapes[f"{tag}_rows_item"].astype(np.int64)).to(DEV) if rows else slice(None)
     pu, pi = tr.user_emb[ru].cpu().numpy(), tr.item_emb[ri].cpu().numpy()
+    fu, fi = tr.embeddings()
+    if outliers:
+        for got, key in ((pu, "param_user"), (pi, "param_item")):
+            diff = np.abs(got - shapes[f"{tag}_{key}"])
+            assert (diff > 1e-6).mean() < outliers and diff.max() < 0.05 * info["lr"], (key, (diff > 1e-6).mean(), diff.max())
+        for got, key in ((fu[ru].cpu().numpy(), "final_user"), (fi[ri].cpu().numpy(), "final_item")):
+            want = shapes[f"{tag}_{key}"]
+            diff = np.abs(got - want) / np.abs(want).max()
+            assert (diff > emb_rtol).mean() < outliers and np.median(diff) < 1e-6, (key, (diff > emb_rtol).mean(), np.median(diff), diff.max())
+        return fu, fi
     assert rel_err(pu, shapes[f"{tag}_param_user"]) < param_rtol and rel_err(pi, shapes[f"{tag}_param_item"]) < param_rtol
     # element-wise: far inside one Adam step (lr = 1e-3)
     assert np.abs(pu - shapes[f"{tag}_param_user"]).max() < 1e-5 and np.abs(pi - shapes[f"{tag}_param_item"]).max() < 1e-5
-    fu, fi = tr.embeddings()
     assert rel_err(fu[ru].cpu().numpy(), shapes[f"{tag}_final_user"]) < emb_rtol
     assert rel_err(fi[ri].cpu().numpy(), shapes[f"{tag}_final_item"]) < emb_rtol
     return fu, fi
@@ -151,7 +162,18 @@ def first_appearance_ids(raw):
 
 def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
     """BASELINE.json configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions) --
-    one step of the reference (8 torch threads, ~25 GB of python objects) against the fused engine on one MI355X."""
+    one step of the reference (8 torch threads, ~25 GB of python objects) against the fused engine on one MI355X.
+
+    Index streams bit-exact, the three losses to 1e-5 / 2e-5.  Parameters after the Adam step: the median implied
+    gradient differs by 3e-6 relative, but NOT every element can agree at this size and the test says so instead of
+    hiding it in a loose max-norm: XSimGCL.py:90 adds sign(h) * noise with |noise| ~ 10x |h| at d = 128, and of the
+    5.8e8 layer-output elements a few hundred sit within rounding of zero, where the summation order decides the
+    sign; each such element moves one column of a few batch rows' gradients, which the backward products spread
+    over every node, and where the total is ~1e-9 Adam's g / (|g| + 1e-8) turns that into 1-2 % of a step.
+    tools/b_probe.py shows the signature (the 12 largest differences sit in one or two COLUMNS, across unrelated
+    rows) and the control: the engine against ITSELF with the products' rounding order changed (pattern products +
+    row scaling vs. value products) differs the same way -- 8 of 65,536 sampled elements by > 1e-6, one by 1.1e-5.
+    So: all but 0.2 % of the sampled elements within 1e-6 absolute, every element within 5 % of one Adam step."""
     if "B_XSimGCL" not in smeta:
         pytest.skip("golden section B not generated")
     info = smeta["B_XSimGCL"]
@@ -163,7 +185,7 @@ def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
     ue, ie = seeded_init(info)
     tr = trainer_for(info, data, ue, ie)
     assert tr.d == 128 and tr.vfree
-    run_and_check("B_XSimGCL", shapes, info, tr, param_rtol=2e-3, emb_rtol=1e-3)      # (post-Adam tolerances: module docstring)
+    run_and_check("B_XSimGCL", shapes, info, tr, emb_rtol=1e-4, outliers=2e-3)
 
 
 def test_douban_book_mf_three_steps_and_ranking(tmp_path, shapes, smeta):

@@ -57,6 +57,13 @@ benchab)
 refmodels)
   timeout 1500 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels.log 2>&1; echo "refmodels exit $?"
   grep -E "^#|parity|1 epoch|Error|error" $OUT/refmodels.log | tail -20;;
+bprobe)
+  timeout 900 python tools/b_probe.py > $OUT/b_probe.log 2>&1; echo "bprobe exit $?"; grep -v amdgpu.ids $OUT/b_probe.log | tail -70;;
+splitprobe)
+  timeout 600 python tools/split_probe.py > $OUT/split_probe.log 2>&1; echo "splitprobe exit $?"; grep -v amdgpu.ids $OUT/split_probe.log | tail -12;;
+refprof)
+  timeout 900 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL} --profile 40 > $OUT/refprof.log 2>&1; echo "refprof exit $?"
+  grep -v "amdgpu.ids\|^training" $OUT/refprof.log | cut -c1-230 | tail -80;;
 prof)
   # per-kernel times of the captured step (hipGraph replay), the command bench.py times
   rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --steps 600 --warmup 50 --no-cpu-baseline --no-eval --no-dropin > $OLDPWD/$OUT/prof.log 2>&1); echo "prof exit $?"

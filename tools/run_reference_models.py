@@ -45,11 +45,45 @@ def make_conf(tmp, model, extra, epochs):
     return ModelConf(path)
 
 
+def profile_steps(mod, model, n, name, skip=20):
+    """Where a step of the unmodified file spends host and device time (torch.profiler; kernels included)."""
+    from torch.profiler import ProfilerActivity, profile
+    real = mod.next_batch_pairwise
+    state = {"prof": None, "t0": 0.0}
+
+    def batches(data, bs, n_negs=1):
+        for k, b in enumerate(real(data, bs, n_negs)):
+            if k == skip:
+                torch.cuda.synchronize()
+                state["prof"] = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+                state["prof"].__enter__()
+                state["t0"] = time.perf_counter()
+            if k == skip + n:
+                torch.cuda.synchronize()
+                state["dt"] = time.perf_counter() - state["t0"]
+                state["prof"].__exit__(None, None, None)
+                return
+            yield b
+    mod.next_batch_pairwise = batches
+    model.fast_evaluation = lambda epoch: None
+    try:
+        model.train()
+    except AttributeError as e:
+        assert "best_user_emb" in str(e), e
+    mod.next_batch_pairwise = real
+    ka = state["prof"].key_averages()
+    print(f"{name}: {n} profiled steps, {state['dt'] / n * 1e3:.2f} ms/step under the profiler")
+    print(ka.table(sort_by="self_cpu_time_total", row_limit=28, max_name_column_width=60))
+    print(ka.table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=60))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", required=True)
     ap.add_argument("--models", default="XSimGCL,LightGCN,SimGCL,SGL")
     ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--profile", type=int, default=0, help="instead of the epoch: torch.profiler over this many steps of "
+                    "train() (after 20 unprofiled ones); prints the operator tables by host and by device time")
     args = ap.parse_args()
     from selfrec_amd import dropin, synth
     dropin.install()
@@ -123,6 +157,9 @@ def main():
                 torch.manual_seed(1)
                 random.seed(1)
                 model = getattr(mod, name)(make_conf(tmp, name, CONF[name], 1), [list(t) for t in train], [list(t) for t in test])
+                if args.profile:
+                    profile_steps(mod, model, args.profile, name)
+                    continue
                 t_eval = [0.0]
                 real_eval = model.fast_evaluation
 
