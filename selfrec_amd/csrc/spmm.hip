@@ -329,6 +329,51 @@ __device__ __forceinline__ void gather8_branchy(int c, float v, const float4* __
   for (int t = 0; t < 8; ++t) acc = f4_fma(vv[t], xx[t], acc);
 }
 
+// Column-masked launches with the live entries COMPACTED first.  Three quarters of the entries of that launch are dead
+// (24 % of the non-zeros sit in the batch's columns at the Yelp2018 shape), and gather8_branchy still spends ~16
+// instructions on each of them -- two DPP broadcasts, a compare / saveexec / branch, four multiply-adds by zero, four
+// zero-fill movs: with NO live column the launch takes 22 of its 28 us, and neither shorter latency chains nor
+// coalesced per-entry marks moved that (profiles/r02_e_masked_launches.txt): it is instruction issue.  Here the 16
+// entries a DPP row holds are first permuted so that the live ones occupy lanes 0 .. n-1 (a ballot, two popcounts and
+// one ds_permute each for column and value), and the broadcast rounds stop at the fullest row's count (uniform): ~4-6
+// rounds instead of 16.  Same entries, same order within a row => the same sums, bit for bit.
+template <int LPR, int T0>
+__device__ __forceinline__ void gather4_live(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
+  int cc[4];
+  float vv[4];
+  float4 xx[4];
+#define SRH_BC(T) cc[T] = row_bcast_i<T0 + T>(c); vv[T] = row_bcast_f<T0 + T>(v);
+  SRH_BC(0) SRH_BC(1) SRH_BC(2) SRH_BC(3)
+#undef SRH_BC
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xx[t] = f4_zero();
+    if (vv[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc = f4_fma(vv[t], xx[t], acc);
+}
+
+template <int LPR>
+__device__ __forceinline__ void gather16_compact(int c, float v, const float4* __restrict__ X, int sub, float4& acc) {
+  const int lane = threadIdx.x & 63, e16 = lane & 15, row0 = lane & 48;
+  const bool alive = v != 0.f;
+  const unsigned long long bal = __ballot(alive);
+  if (bal == 0ull) return;
+  const unsigned gm = (unsigned)(bal >> row0) & 0xffffu;           // this DPP row's live lanes
+  const int n_g = __popc(gm), before = __popc(gm & ((1u << e16) - 1u));
+  // a permutation of the row: live lanes to the front in order, dead lanes behind them
+  const int dst = row0 + (alive ? before : n_g + (e16 - before));
+  c = __builtin_amdgcn_ds_permute(dst << 2, c);
+  v = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v)));
+  const int nmax = max(max(__popcll(bal & 0xffffull), __popcll((bal >> 16) & 0xffffull)),
+                       max(__popcll((bal >> 32) & 0xffffull), __popcll(bal >> 48)));
+  gather4_live<LPR, 0>(c, v, X, sub, acc);
+  if (nmax > 4) gather4_live<LPR, 4>(c, v, X, sub, acc);
+  if (nmax > 8) gather4_live<LPR, 8>(c, v, X, sub, acc);
+  if (nmax > 12) gather4_live<LPR, 12>(c, v, X, sub, acc);
+}
+
 // One record per wave, read with scalar loads (the task -> segment -> (col, val) chain of dependent VECTOR round
 // trips loses its first two links): kind 0 = the wave's cooperative segment (row[0], start[0], end[0], slot),
 // kind 1 = `count` <= G short rows, one per row-group.
@@ -398,8 +443,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   float4 accm = f4_zero();                                // COLMASK accumulator
   auto chunk = [&](int rem) {
     if (COLMASK) {
-      gather8_branchy<LPR, 0>((int)cs, v, X, sub, accm);
-      if (rem > 8) gather8_branchy<LPR, 8>((int)cs, v, X, sub, accm);
+      gather16_compact<LPR>((int)cs, v, X, sub, accm);
     } else {
       gather8<false>(cs, v, sub16, X, xx, acc);
       if (rem > 8) gather8<true>(cs, v, sub16, X, xx, acc);
