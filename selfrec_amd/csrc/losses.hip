@@ -14,11 +14,20 @@ using namespace srh;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void atomic_add_f4(float* base, float4 v) {
-  unsafeAtomicAdd(base + 0, v.x);
-  unsafeAtomicAdd(base + 1, v.y);
-  unsafeAtomicAdd(base + 2, v.z);
-  unsafeAtomicAdd(base + 3, v.w);
+// row += v for a (4 LPR)-float row held one float4 per lane by an LPR-lane row-group, with the float atomics laid out
+// DENSELY.  The obvious form -- x, y, z, w of the lane's float4, one atomic each -- issues four instructions whose lanes
+// hit every fourth dword of the row: each instruction becomes one sparse request per 64 bytes of the row, and the loss
+// section's ~0.9 M gradient atomics then wait on the L2's atomic units (nce_finish_bpr2 19.0 us; 9.2 us with racy plain
+// stores in their place: profiles/r02_f_loss_atomics.txt).  Here the row-group first transposes through 1 KB of LDS
+// per wave so that instruction k covers dwords [k LPR, (k+1) LPR) of the row -- the same atomics in a quarter of the
+// requests: 9.8 us, as fast as the plain stores.
+template <int LPR>
+__device__ __forceinline__ void atomic_add_row(float* row, float4 v, int sub, float4* scr /* this wave's 64 float4 */) {
+  const int lane = threadIdx.x & 63;
+  scr[lane] = v;                                                 // lane-linear: a row-group's row is contiguous
+  const float* grp = reinterpret_cast<const float*>(scr + (lane - sub));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) unsafeAtomicAdd(row + k * LPR + sub, grp[k * LPR + sub]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -110,6 +119,8 @@ __device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned
     rn = reinterpret_cast<const float4*>(a.reg_item)[(size_t)bj * LPR + sub];
   }
   __shared__ double s_tot[4];
+  __shared__ float4 s_scr[4][64];
+  float4* scr = s_scr[threadIdx.x >> 6];
   if (threadIdx.x < 64) {                 // wave 0 folds the per-workgroup partials (fixed order)
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int k = threadIdx.x; k < a.n_blocks; k += 64) {
@@ -139,17 +150,17 @@ __device__ __forceinline__ void bpr_phase2_body(const BprArgs& a, const unsigned
   const bool same_u = (a.reg_user == a.user) && (a.greg_user == a.g_user);
   const bool same_i = (a.reg_item == a.item) && (a.greg_item == a.g_item);
   if (same_u) gu = f4_fma(cu, ru, gu);
-  else atomic_add_f4(a.greg_user + ((size_t)bu * LPR + sub) * 4, f4_scale(ru, cu));
+  else atomic_add_row<LPR>(a.greg_user + (size_t)bu * LPR * 4, f4_scale(ru, cu), sub, scr);
   if (same_i) {
     gp = f4_fma(cp, rp, gp);
     gn = f4_fma(cn, rn, gn);
   } else {
-    atomic_add_f4(a.greg_item + ((size_t)bi * LPR + sub) * 4, f4_scale(rp, cp));
-    if (a.reg_include_neg) atomic_add_f4(a.greg_item + ((size_t)bj * LPR + sub) * 4, f4_scale(rn, cn));
+    atomic_add_row<LPR>(a.greg_item + (size_t)bi * LPR * 4, f4_scale(rp, cp), sub, scr);
+    if (a.reg_include_neg) atomic_add_row<LPR>(a.greg_item + (size_t)bj * LPR * 4, f4_scale(rn, cn), sub, scr);
   }
-  atomic_add_f4(a.g_user + ((size_t)bu * LPR + sub) * 4, gu);
-  atomic_add_f4(a.g_item + ((size_t)bi * LPR + sub) * 4, gp);
-  atomic_add_f4(a.g_item + ((size_t)bj * LPR + sub) * 4, gn);
+  atomic_add_row<LPR>(a.g_user + (size_t)bu * LPR * 4, gu, sub, scr);
+  atomic_add_row<LPR>(a.g_item + (size_t)bi * LPR * 4, gp, sub, scr);
+  atomic_add_row<LPR>(a.g_item + (size_t)bj * LPR * 4, gn, sub, scr);
 }
 
 template <int LPR>
@@ -489,7 +500,7 @@ __device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, floa
 // gradients of both views through the normalisation and scatter them.  Returns the row's loss term
 // (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
 template <int LPR>
-__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub) {
+__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub, float4* scr) {
   const bool valid = i < n;
   const int ii = valid ? i : 0;
   const size_t at = (size_t)ii * LPR + sub;
@@ -527,12 +538,12 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   if (valid) {
     // atomic: BPR phase 2 shares this launch and adds to the same rows of g1.  g2 is a plain read-add-store
     // when the caller declares its rows exclusive (srh_infonce_problem_t::g2_exclusive)
-    atomic_add_f4(w.g1 + ((size_t)dst * LPR + sub) * 4, dv1);
+    atomic_add_row<LPR>(w.g1 + (size_t)dst * LPR * 4, dv1, sub, scr);
     if (w.g2_plain) {
       float4* p2 = reinterpret_cast<float4*>(w.g2) + (size_t)dst * LPR + sub;
       *p2 = f4_add(*p2, dv2);
     } else {
-      atomic_add_f4(w.g2 + ((size_t)dst * LPR + sub) * 4, dv2);
+      atomic_add_row<LPR>(w.g2 + (size_t)dst * LPR * 4, dv2, sub, scr);
     }
   }
   return (valid && sub == 0) ? (double)(lse - sii) : 0.0;
@@ -764,8 +775,9 @@ __global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs 
   }
   if (valid) {
     const int dst = w.idx ? w.idx[i] : i;
-    // atomic: the BPR scatter may be adding to the same rows on another stream of the captured step
-    atomic_add_f4((PASS2 ? w.g2 : w.g1) + ((size_t)dst * LPR + sub) * 4, dv);
+    // atomic: BPR's scatter adds to the same rows
+    __shared__ float4 s_scr[4][64];
+    atomic_add_row<LPR>((PASS2 ? w.g2 : w.g1) + (size_t)dst * LPR * 4, dv, sub, s_scr[threadIdx.x >> 6]);
   }
 }
 
@@ -784,7 +796,8 @@ __device__ __forceinline__ void nce_finish_both_body(const NceBatch& batch, cons
   const int n_waves = (int)(w.np / G);
   if (n <= 0 || wave >= n_waves) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub));
+  __shared__ float4 s_scr[4][64];
+  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub, s_scr[threadIdx.x >> 6]));
   // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
   __shared__ double wg_part[4];
   if (lane == 0) wg_part[threadIdx.x >> 6] = part;
