@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 18
+#define SRH_ABI_VERSION 19
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -417,23 +417,40 @@ srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n
  * arrays into fixed staging buffers and publishes its sizes (d_meta: int32[4] = {rows, n_uniq_u,
  * n_uniq_i, batch_no}); it only READS the cursor.  The cursor is advanced by the last kernel of the
  * step: srh_zero_rows(..., d_cursor_advance, ...) or srh_cursor_advance. */
-srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i,
-                             const int32_t* d_epoch_j, const int32_t* d_epoch_uniq_u,
-                             const int32_t* d_epoch_uniq_i, const int32_t* d_n_uniq_u,
-                             const int32_t* d_n_uniq_i, int64_t n_edges, int64_t batch_size,
-                             const int64_t* d_cursor /* [0]=batch no, [1]=adam step */,
-                             int32_t* d_stage_u, int32_t* d_stage_i, int32_t* d_stage_j,
-                             int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
-                             int32_t* d_meta,
-                             int32_t* d_row_mark /* optional: mark[u] = mark[off+i] = mark[off+j] = step */,
-                             int32_t mark_item_offset,
-                             double* d_zero4 /* optional: 4 loss accumulators cleared for the new step */,
-                             int32_t* d_stage_cat /* optional (2*batch_size): [uniq users ; uniq items + cat_item_offset] */,
-                             int32_t cat_item_offset, int32_t* d_n_cat /* optional: n_uniq_u + n_uniq_i */,
-                             int64_t* d_now /* optional int64[2]: copy of d_cursor taken by this launch -- what a kernel
-                                               that runs CONCURRENTLY with the cursor advance (Adam beside srh_zero_rows)
-                                               reads its step from */,
-                             void* stream);
+typedef struct {
+  const int32_t* d_epoch_u;        /* the epoch's sampled triples (srh_sampler_epoch, uploaded) */
+  const int32_t* d_epoch_i;
+  const int32_t* d_epoch_j;
+  const int32_t* d_epoch_uniq_u;   /* optional: per-batch sorted unique ids + counts (all five together) */
+  const int32_t* d_epoch_uniq_i;
+  const int32_t* d_n_uniq_u;
+  const int32_t* d_n_uniq_i;
+  int64_t n_edges;
+  int64_t batch_size;
+  const int64_t* d_cursor;         /* [0] = batch no, [1] = adam step */
+  int32_t* d_stage_u;
+  int32_t* d_stage_i;
+  int32_t* d_stage_j;
+  int32_t* d_stage_uniq_u;
+  int32_t* d_stage_uniq_i;
+  int32_t* d_meta;
+  int32_t* d_row_mark;             /* optional: mark[u] = mark[off+i] = mark[off+j] = step */
+  int32_t mark_item_offset;
+  int32_t cat_item_offset;
+  double* d_zero4;                 /* optional: 4 loss accumulators cleared for the new step */
+  int32_t* d_stage_cat;            /* optional (2*batch_size): [uniq users ; uniq items + cat_item_offset] */
+  int32_t* d_n_cat;                /* optional: n_uniq_u + n_uniq_i */
+  int64_t* d_now;                  /* optional int64[2]: copy of d_cursor taken by this launch -- what a kernel that runs
+                                      CONCURRENTLY with the cursor advance (Adam beside srh_zero_rows) reads its step from */
+} srh_batch_fetch_args_t;
+srh_status_t srh_batch_fetch(const srh_batch_fetch_args_t* args, void* stream);
+/* srh_spmm_f32 for d = 64, 128, 256 (no column marks) that ALSO performs srh_batch_fetch(fetch): eight more workgroups at
+ * the head of the same launch.  For a step whose first product does not depend on the batch (every model here: the
+ * batch only enters at the last forward layer's row marks and at the losses) this removes a 5 us launch from the
+ * step's critical path.  The product must not read anything the fetch writes (row marks, staged ids). */
+srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t* d_indptr, const int32_t* d_indices,
+                                     const float* d_vals, const float* d_x, float* d_y, int32_t d,
+                                     const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch, void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
  * d_counts[k] is NULL).  The sparse counterpart of a memset for gradient buffers that only

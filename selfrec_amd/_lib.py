@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -23,6 +23,17 @@ SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
 
 class SelfrecHipError(RuntimeError):
     pass
+
+
+class BatchFetchArgs(C.Structure):
+    """srh_batch_fetch_args_t (include/selfrec_hip.h)."""
+    _fields_ = [("d_epoch_u", C.c_void_p), ("d_epoch_i", C.c_void_p), ("d_epoch_j", C.c_void_p),
+                ("d_epoch_uniq_u", C.c_void_p), ("d_epoch_uniq_i", C.c_void_p), ("d_n_uniq_u", C.c_void_p),
+                ("d_n_uniq_i", C.c_void_p), ("n_edges", C.c_int64), ("batch_size", C.c_int64), ("d_cursor", C.c_void_p),
+                ("d_stage_u", C.c_void_p), ("d_stage_i", C.c_void_p), ("d_stage_j", C.c_void_p),
+                ("d_stage_uniq_u", C.c_void_p), ("d_stage_uniq_i", C.c_void_p), ("d_meta", C.c_void_p),
+                ("d_row_mark", C.c_void_p), ("mark_item_offset", C.c_int32), ("cat_item_offset", C.c_int32),
+                ("d_zero4", C.c_void_p), ("d_stage_cat", C.c_void_p), ("d_n_cat", C.c_void_p), ("d_now", C.c_void_p)]
 
 
 class InfonceProblem(C.Structure):
@@ -116,8 +127,8 @@ SIGNATURES = {
     "srh_topk_rows": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "srh_topk_hit_flags": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "srh_axpby": (_i32, [_f32, _vp, _f32, _vp, _i64, _vp]),
-    "srh_batch_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "srh_batch_fetch": (_i32, [_vp, _vp]),
+    "srh_spmm_f32_with_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "srh_zero_rows": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "srh_cursor_advance": (_i32, [_vp, _vp]),
     "srh_batch_pack": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),

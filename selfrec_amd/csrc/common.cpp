@@ -12,6 +12,20 @@ void set_error(const char* fmt, ...) {
   g_last_error = buf;
 }
 const std::string& last_error() { return g_last_error; }
+
+srh_status_t check_fetch_args(const srh_batch_fetch_args_t* in, srh_batch_fetch_args_t& out) {
+  SRH_REQUIRE(in, "batch_fetch: null argument");
+  SRH_REQUIRE(in->d_epoch_u && in->d_epoch_i && in->d_epoch_j && in->d_cursor && in->d_stage_u && in->d_stage_i &&
+                  in->d_stage_j && in->d_meta,
+              "batch_fetch: null argument");
+  const bool uq = in->d_epoch_uniq_u != nullptr;
+  SRH_REQUIRE(!uq || (in->d_epoch_uniq_i && in->d_n_uniq_u && in->d_n_uniq_i && in->d_stage_uniq_u && in->d_stage_uniq_i),
+              "batch_fetch: unique-id arrays must be given together");
+  SRH_REQUIRE(in->n_edges > 0 && in->batch_size > 0, "batch_fetch: bad sizes");
+  out = *in;
+  if (!uq) { out.d_stage_cat = nullptr; out.d_n_cat = nullptr; }
+  return SRH_OK;
+}
 }  // namespace srh
 
 extern "C" {

@@ -38,10 +38,54 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // lanes per embedding row when each lane owns one float4 of it
 inline bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
+// the checks srh_batch_fetch promises; `out` = the args as the kernels take them (optional groups normalised)
+srh_status_t check_fetch_args(const srh_batch_fetch_args_t* in, srh_batch_fetch_args_t& out);
+
 }  // namespace srh
 
 #ifdef __HIPCC__
 namespace srh {
+
+// Stages batch *cursor[0] of the epoch arrays into fixed buffers, publishes its sizes and stamps the
+// activity marks with the current optimiser step *cursor[1].  Read-only on the cursor, so any number of
+// workgroups can share the copy; the cursor is advanced at the END of the step (Adam's reset pass / zero_rows_kernel /
+// cursor_advance_kernel), after the last kernel that reads it.  `block` of `n_blocks` 256-thread workgroups: the body
+// of batch_fetch_kernel (optim.hip) and of the fetch workgroups riding on an SpMM launch (spmm.hip).
+constexpr int kFetchBlocks = 8;
+__device__ __forceinline__ void batch_fetch_body(const srh_batch_fetch_args_t& f, const int block, const int n_blocks) {
+  const int64_t b = f.d_cursor[0];
+  const int32_t stamp = (int32_t)f.d_cursor[1];
+  const int64_t bs = f.batch_size, ptr = b * bs;
+  const int64_t rows = (ptr >= f.n_edges) ? 0 : ((ptr + bs < f.n_edges) ? bs : f.n_edges - ptr);
+  const int64_t tid = (int64_t)block * 256 + threadIdx.x, nth = (int64_t)n_blocks * 256;
+  for (int64_t i = tid; i < rows; i += nth) {
+    const int32_t u = f.d_epoch_u[ptr + i], p = f.d_epoch_i[ptr + i], n = f.d_epoch_j[ptr + i];
+    f.d_stage_u[i] = u; f.d_stage_i[i] = p; f.d_stage_j[i] = n;
+    if (f.d_row_mark) {
+      f.d_row_mark[u] = stamp; f.d_row_mark[f.mark_item_offset + p] = stamp; f.d_row_mark[f.mark_item_offset + n] = stamp;
+    }
+  }
+  int32_t a = 0, c = 0;
+  if (f.d_epoch_uniq_u && rows > 0) {
+    a = f.d_n_uniq_u[b];
+    c = f.d_n_uniq_i[b];
+    for (int64_t i = tid; i < a; i += nth) f.d_stage_uniq_u[i] = f.d_epoch_uniq_u[b * bs + i];
+    for (int64_t i = tid; i < c; i += nth) f.d_stage_uniq_i[i] = f.d_epoch_uniq_i[b * bs + i];
+    if (f.d_stage_cat) {   // [unique users ; unique items] as one index list (SGL.py:120-125 concatenates the two sides)
+      for (int64_t i = tid; i < a; i += nth) f.d_stage_cat[i] = f.d_epoch_uniq_u[b * bs + i];
+      for (int64_t i = tid; i < c; i += nth) f.d_stage_cat[a + i] = f.d_epoch_uniq_i[b * bs + i] + f.cat_item_offset;
+    }
+  }
+  if (f.d_n_cat && tid == 0) *f.d_n_cat = a + c;
+  if (f.d_zero4 && tid < 4) f.d_zero4[tid] = 0.0;        // the step's loss accumulators
+  if (f.d_now && tid < 2) f.d_now[tid] = f.d_cursor[tid];
+  if (tid == 0) {
+    f.d_meta[0] = (int32_t)rows;
+    f.d_meta[1] = a;
+    f.d_meta[2] = c;
+    f.d_meta[3] = (int32_t)b;
+  }
+}
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {

@@ -66,48 +66,8 @@ __global__ __launch_bounds__(256) void axpby_kernel(float a, const float4* __res
   }
 }
 
-// Stages batch *cursor[0] of the epoch arrays into fixed buffers, publishes its sizes and stamps the
-// activity marks with the current optimiser step *cursor[1].  Read-only on the cursor, so any number of
-// workgroups can share the copy; the cursor is advanced at the END of the step (zero_rows_kernel /
-// cursor_advance_kernel), after the last kernel that reads it.
-constexpr int kFetchBlocks = 8;
-__global__ __launch_bounds__(256) void batch_fetch_kernel(
-    const int32_t* __restrict__ eu, const int32_t* __restrict__ ei, const int32_t* __restrict__ ej,
-    const int32_t* __restrict__ uu, const int32_t* __restrict__ ui, const int32_t* __restrict__ nuu,
-    const int32_t* __restrict__ nui, int64_t n_edges, int64_t bs, const int64_t* __restrict__ cursor, int32_t* su,
-    int32_t* si, int32_t* sj, int32_t* suu, int32_t* sui, int32_t* meta, int32_t* __restrict__ mark,
-    int32_t item_offset, double* __restrict__ zero4, int32_t* __restrict__ cat, int32_t cat_item_offset,
-    int32_t* __restrict__ n_cat, int64_t* __restrict__ now) {
-  const int64_t b = cursor[0];
-  const int32_t stamp = (int32_t)cursor[1];
-  const int64_t ptr = b * bs;
-  const int64_t rows = (ptr >= n_edges) ? 0 : ((ptr + bs < n_edges) ? bs : n_edges - ptr);
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
-  for (int64_t i = tid; i < rows; i += nth) {
-    const int32_t u = eu[ptr + i], p = ei[ptr + i], n = ej[ptr + i];
-    su[i] = u; si[i] = p; sj[i] = n;
-    if (mark) { mark[u] = stamp; mark[item_offset + p] = stamp; mark[item_offset + n] = stamp; }
-  }
-  int32_t a = 0, c = 0;
-  if (uu && rows > 0) {
-    a = nuu[b];
-    c = nui[b];
-    for (int64_t i = tid; i < a; i += nth) suu[i] = uu[b * bs + i];
-    for (int64_t i = tid; i < c; i += nth) sui[i] = ui[b * bs + i];
-    if (cat) {       // [unique users ; unique items] as one index list (SGL.py:120-125 concatenates the two sides)
-      for (int64_t i = tid; i < a; i += nth) cat[i] = uu[b * bs + i];
-      for (int64_t i = tid; i < c; i += nth) cat[a + i] = ui[b * bs + i] + cat_item_offset;
-    }
-  }
-  if (n_cat && tid == 0) *n_cat = a + c;
-  if (zero4 && tid < 4) zero4[tid] = 0.0;        // the step's loss accumulators
-  if (now && tid < 2) now[tid] = cursor[tid];
-  if (tid == 0) {
-    meta[0] = (int32_t)rows;
-    meta[1] = a;
-    meta[2] = c;
-    meta[3] = (int32_t)b;
-  }
+__global__ __launch_bounds__(256) void batch_fetch_kernel(srh_batch_fetch_args_t f) {
+  srh::batch_fetch_body(f, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ void cursor_advance_kernel(int64_t* cursor) {
@@ -194,24 +154,10 @@ srh_status_t srh_axpby(float a, const float* d_x, float b, float* d_y, int64_t n
   return SRH_OK;
 }
 
-srh_status_t srh_batch_fetch(const int32_t* d_epoch_u, const int32_t* d_epoch_i, const int32_t* d_epoch_j,
-                             const int32_t* d_epoch_uniq_u, const int32_t* d_epoch_uniq_i,
-                             const int32_t* d_n_uniq_u, const int32_t* d_n_uniq_i, int64_t n_edges,
-                             int64_t batch_size, const int64_t* d_cursor, int32_t* d_stage_u, int32_t* d_stage_i,
-                             int32_t* d_stage_j, int32_t* d_stage_uniq_u, int32_t* d_stage_uniq_i,
-                             int32_t* d_meta, int32_t* d_row_mark, int32_t mark_item_offset, double* d_zero4,
-                             int32_t* d_stage_cat, int32_t cat_item_offset, int32_t* d_n_cat, int64_t* d_now,
-                             void* stream) {
-  SRH_REQUIRE(d_epoch_u && d_epoch_i && d_epoch_j && d_cursor && d_stage_u && d_stage_i && d_stage_j && d_meta,
-              "batch_fetch: null argument");
-  const bool uq = d_epoch_uniq_u != nullptr;
-  SRH_REQUIRE(!uq || (d_epoch_uniq_i && d_n_uniq_u && d_n_uniq_i && d_stage_uniq_u && d_stage_uniq_i),
-              "batch_fetch: unique-id arrays must be given together");
-  SRH_REQUIRE(n_edges > 0 && batch_size > 0, "batch_fetch: bad sizes");
-  batch_fetch_kernel<<<kFetchBlocks, 256, 0, srh::as_stream(stream)>>>(
-      d_epoch_u, d_epoch_i, d_epoch_j, d_epoch_uniq_u, d_epoch_uniq_i, d_n_uniq_u, d_n_uniq_i, n_edges, batch_size,
-      d_cursor, d_stage_u, d_stage_i, d_stage_j, d_stage_uniq_u, d_stage_uniq_i, d_meta, d_row_mark,
-      mark_item_offset, d_zero4, uq ? d_stage_cat : nullptr, cat_item_offset, uq ? d_n_cat : nullptr, d_now);
+srh_status_t srh_batch_fetch(const srh_batch_fetch_args_t* args, void* stream) {
+  srh_batch_fetch_args_t f;
+  if (srh_status_t rc = srh::check_fetch_args(args, f)) return rc;
+  batch_fetch_kernel<<<srh::kFetchBlocks, 256, 0, srh::as_stream(stream)>>>(f);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

@@ -395,10 +395,17 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
                                                         float4* __restrict__ partial,
                                                         const Heavy* __restrict__ heavy,
                                                         const int32_t* __restrict__ slot_owner,
-                                                        int32_t* __restrict__ tickets, DevEpilogue ep) {
+                                                        int32_t* __restrict__ tickets, DevEpilogue ep,
+                                                        const int n_fetch, const srh_batch_fetch_args_t rider) {
   constexpr int G = 64 / LPR;          // row-groups per wave
   constexpr int CH = 16 * G;           // entries per coop chunk
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+  // srh_spmm_f32_with_fetch: the first n_fetch workgroups (a multiple of 8: every task keeps its XCD) stage the step's
+  // batch instead -- nothing in this product reads what they write
+  if ((int)blockIdx.x < n_fetch) {
+    srh::batch_fetch_body(rider, (int)blockIdx.x, n_fetch);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x - n_fetch) * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
@@ -1366,7 +1373,21 @@ srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices
 srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
                           const int32_t* d_indices, const float* d_vals, const float* d_x,
                           float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, void* stream) {
+  return srh_spmm_f32_with_fetch(plan, d_indptr, d_indices, d_vals, d_x, d_y, d, epi, nullptr, stream);
+}
+
+srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t* d_indptr, const int32_t* d_indices,
+                                     const float* d_vals, const float* d_x, float* d_y, int32_t d,
+                                     const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch, void* stream) {
   (void)d_indptr;  // the schedule in `plan` already encodes the row extents
+  srh_batch_fetch_args_t fetch_args{};
+  int n_fetch = 0;
+  if (fetch) {
+    SRH_REQUIRE(d >= 64 && !(epi && (epi->d_col_mark || epi->d_row_mark)),
+                "spmm_f32_with_fetch: d >= 64, and the product must not depend on the batch's marks");
+    if (srh_status_t rc = srh::check_fetch_args(fetch, fetch_args)) return rc;
+    n_fetch = srh::kFetchBlocks;
+  }
   SRH_REQUIRE(plan && d_indices && d_x && d_y, "spmm_f32: null argument");
   SRH_REQUIRE(d_vals || (d >= 64 && !(epi && epi->d_col_mark)),
               "spmm_f32: a pattern matrix (d_vals == NULL) needs d >= 64 and no column marks");
@@ -1392,10 +1413,10 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
       SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
                   (long long)plan->n_cols, d);
 #define SRH_LAUNCH_ROWS(LPRV, GI, CM)                                                                                \
-  spmm_rows_kernel<LPRV, CM><<<(plan->n_tasks[GI] + 3) / 4, 256, 0, st>>>(                                           \
+  spmm_rows_kernel<LPRV, CM><<<(plan->n_tasks[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(                                 \
       plan->d_tasks64[GI], plan->n_tasks[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),              \
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
-      plan->d_tickets, ep)
+      plan->d_tickets, ep, n_fetch, fetch_args)
       if (ep.col_mark) {
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, true);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true);

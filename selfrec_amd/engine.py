@@ -215,6 +215,10 @@ class FusedTrainer:
         self.vfree = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
                       and model in ("LightGCN", "XSimGCL", "SimGCL") and self.graph.weight is None)
         self.dinv = self.graph.dinv if self.vfree else None
+        # batch_fetch as a rider of the step's first product (see _step_front): models whose step starts with a plain
+        # srh_spmm_f32 launch of a layer that is not the last
+        self.ride_fetch = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
+                           and model in ("LightGCN", "XSimGCL"))
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -452,8 +456,11 @@ class FusedTrainer:
                 # layer 1 reads the true table E0 through the value array; later layers read pre-scaled tables through
                 # the pattern.  Every layer but the last stores its output pre-scaled.
                 kw.update(row_scale=self.dinv, scale_in=k > 0, scale_out=k < L - 1)
+            rider = {}
+            if getattr(self, "_rider", None) is not None:
+                rider, self._rider = {"fetch": self._rider}, None
             ops.spmm(adj, x, out=self._loc(Ys[k]), epilogue=ops.make_epilogue(**kw) if kw else None,
-                     **({"pattern": True} if vf and k > 0 else {}))
+                     **({"pattern": True} if vf and k > 0 else {}), **rider)
             if k < L - 1 or need_last:
                 self._allgather(Ys[k])          # the next layer (or the contrast view) reads every row
             x = Ys[k]
@@ -578,8 +585,16 @@ class FusedTrainer:
         adj = self.adj
         # the staged ids are table rows (items already offset / permuted): one table, one index space
         cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
-        ops.batch_fetch(self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta,
-                        row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now, **cat)
+        fetch = ((self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta),
+                 dict(row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now, **cat))
+        # The first product of the step does not depend on the batch (marks and staged ids enter at the last forward
+        # layer and at the losses), so the fetch rides on its launch as eight extra workgroups instead of being a 5 us
+        # launch of its own at the head of the step (srh_spmm_f32_with_fetch).
+        self._rider = None
+        if self.ride_fetch:
+            self._rider = ops.batch_fetch_args(*fetch[0], **fetch[1])
+        else:
+            ops.batch_fetch(*fetch[0], **fetch[1])
         self._noise_call = 0      # RNG counter = (adam step, perturbed-layer call no, row)
 
         include_ego = m in ("LightGCN", "SGL")

@@ -297,18 +297,22 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
 
 
 def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilogue: SpmmEpilogue | None = None,
-         pattern: bool = False):
+         pattern: bool = False, fetch=None):
     """out = csr @ x (+ fused epilogue).  x: (n_cols, d) fp32.  pattern=True: the structure with every stored entry 1
-    (no value stream; d >= 64) -- with row scaling in the epilogue this is the value-free form of D^-1/2 A D^-1/2."""
+    (no value stream; d >= 64) -- with row scaling in the epilogue this is the value-free form of D^-1/2 A D^-1/2.
+    fetch: a BatchFetchArgs (batch_fetch_args) -- the launch also stages the step's batch (srh_spmm_f32_with_fetch)."""
     if x.dim() != 2 or x.shape[0] != csr.shape[1]:
         raise SelfrecHipError(f"spmm: x has shape {tuple(x.shape)}, expected ({csr.shape[1]}, d)")
     d = int(x.shape[1])
     if out is None:
         out = torch.empty((csr.shape[0], d), dtype=torch.float32, device=x.device)
-    check(_lib.load().srh_spmm_f32(csr._plan, _p(csr.indptr, torch.int32), _p(csr.indices, torch.int32),
-                                   None if pattern else _p(csr.vals, torch.float32, "vals"), _p(x, torch.float32, "x"),
-                                   _p(out, torch.float32, "out"), d,
-                                   C.byref(epilogue) if epilogue is not None else None, _stream()), "srh_spmm_f32")
+    common = (csr._plan, _p(csr.indptr, torch.int32), _p(csr.indices, torch.int32),
+              None if pattern else _p(csr.vals, torch.float32, "vals"), _p(x, torch.float32, "x"),
+              _p(out, torch.float32, "out"), d, C.byref(epilogue) if epilogue is not None else None)
+    if fetch is not None:
+        check(_lib.load().srh_spmm_f32_with_fetch(*common, C.byref(fetch), _stream()), "srh_spmm_f32_with_fetch")
+    else:
+        check(_lib.load().srh_spmm_f32(*common, _stream()), "srh_spmm_f32")
     return out
 
 
@@ -567,18 +571,28 @@ def zero_rows(lists, d, cursor_advance=None):
                                     _stream()), "srh_zero_rows")
 
 
-def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
-                stage_cat=None, cat_item_offset=0, n_cat=None, now=None):
-    """ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
-    check(_lib.load().srh_batch_fetch(
-        _p(ep["u"], torch.int32), _p(ep["i"], torch.int32), _p(ep["j"], torch.int32),
-        _p(ep.get("uniq_u"), torch.int32), _p(ep.get("uniq_i"), torch.int32),
-        _p(ep.get("n_uniq_u"), torch.int32), _p(ep.get("n_uniq_i"), torch.int32), int(n_edges), int(batch_size),
-        _p(cursor, torch.int64), _p(stage["u"], torch.int32), _p(stage["i"], torch.int32),
-        _p(stage["j"], torch.int32), _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32),
-        _p(meta, torch.int32), _p(row_mark, torch.int32), int(mark_item_offset), _p(zero4, torch.float64),
-        _p(stage_cat, torch.int32), int(cat_item_offset), _p(n_cat, torch.int32), _p(now, torch.int64), _stream()),
-        "srh_batch_fetch")
+def batch_fetch_args(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
+                     stage_cat=None, cat_item_offset=0, n_cat=None, now=None):
+    """srh_batch_fetch_args_t.  ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
+    a = _lib.BatchFetchArgs()
+    a.d_epoch_u, a.d_epoch_i, a.d_epoch_j = (_p(ep[k], torch.int32) for k in ("u", "i", "j"))
+    a.d_epoch_uniq_u, a.d_epoch_uniq_i = _p(ep.get("uniq_u"), torch.int32), _p(ep.get("uniq_i"), torch.int32)
+    a.d_n_uniq_u, a.d_n_uniq_i = _p(ep.get("n_uniq_u"), torch.int32), _p(ep.get("n_uniq_i"), torch.int32)
+    a.n_edges, a.batch_size, a.d_cursor = int(n_edges), int(batch_size), _p(cursor, torch.int64)
+    a.d_stage_u, a.d_stage_i, a.d_stage_j = (_p(stage[k], torch.int32) for k in ("u", "i", "j"))
+    a.d_stage_uniq_u, a.d_stage_uniq_i = _p(stage.get("uniq_u"), torch.int32), _p(stage.get("uniq_i"), torch.int32)
+    a.d_meta, a.d_row_mark = _p(meta, torch.int32), _p(row_mark, torch.int32)
+    a.mark_item_offset, a.cat_item_offset = int(mark_item_offset), int(cat_item_offset)
+    a.d_zero4, a.d_stage_cat, a.d_n_cat = _p(zero4, torch.float64), _p(stage_cat, torch.int32), _p(n_cat, torch.int32)
+    a.d_now = _p(now, torch.int64)
+    a._keepalive = [ep, cursor, stage, meta, row_mark, zero4, stage_cat, n_cat, now]
+    return a
+
+
+def batch_fetch(*args, **kwargs):
+    """srh_batch_fetch: same arguments as batch_fetch_args (or one prebuilt BatchFetchArgs)."""
+    a = args[0] if len(args) == 1 and isinstance(args[0], _lib.BatchFetchArgs) else batch_fetch_args(*args, **kwargs)
+    check(_lib.load().srh_batch_fetch(C.byref(a), _stream()), "srh_batch_fetch")
 
 
 # ----------------------------------------------------------------------------------------

@@ -227,6 +227,46 @@ def test_value_free_product_with_row_scaling(tiny_data):
     assert rel_err(y.cpu().numpy(), dinv[:, None] * want) < 2e-6
 
 
+def test_product_with_batch_fetch_rider_equals_the_two_launches(tiny_data):
+    """srh_spmm_f32_with_fetch: the product and the staged batch are those of srh_spmm_f32 + srh_batch_fetch."""
+    g = tiny_data.device_graph()
+    N, d, B, E = g.n_nodes, 64, 32, 100
+    rng = np.random.default_rng(11)
+    U = g.n_users
+    ep = {"u": rng.integers(0, U, E), "i": rng.integers(U, N, E), "j": rng.integers(U, N, E),
+          "uniq_u": rng.integers(0, U, E), "uniq_i": rng.integers(U, N, E),
+          "n_uniq_u": rng.integers(1, B, (E + B - 1) // B), "n_uniq_i": rng.integers(1, B, (E + B - 1) // B)}
+    ep = {k: torch.from_numpy(v.astype(np.int32)).to(DEV) for k, v in ep.items()}
+    x = torch.from_numpy(rng.standard_normal((N, d)).astype(np.float32)).to(DEV)
+    cursor = torch.tensor([3, 17], dtype=torch.int64, device=DEV)          # the last, short batch: 4 of 32 rows
+
+    def buffers():
+        stage = {k: torch.full((B,), -1, dtype=torch.int32, device=DEV) for k in ("u", "i", "j", "uniq_u", "uniq_i")}
+        return dict(stage=stage, meta=torch.full((4,), -1, dtype=torch.int32, device=DEV),
+                    mark=torch.zeros(N, dtype=torch.int32, device=DEV), zero4=torch.ones(4, dtype=torch.float64, device=DEV),
+                    cat=torch.full((2 * B,), -1, dtype=torch.int32, device=DEV), n_cat=torch.zeros(1, dtype=torch.int32, device=DEV),
+                    now=torch.zeros(2, dtype=torch.int64, device=DEV))
+
+    def args(b):
+        return ops.batch_fetch_args(ep, E, B, cursor, b["stage"], b["meta"], row_mark=b["mark"], zero4=b["zero4"],
+                                    stage_cat=b["cat"], cat_item_offset=5, n_cat=b["n_cat"], now=b["now"])
+    one, two = buffers(), buffers()
+    epi = lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=3, rng_offset=0)      # noqa: E731
+    y1 = ops.spmm(g.adj, x, epilogue=epi(), fetch=args(one))
+    ops.batch_fetch(args(two))
+    y2 = ops.spmm(g.adj, x, epilogue=epi())
+    assert torch.equal(y1, y2)
+    assert int(one["meta"][0]) == E - 3 * B and torch.equal(one["now"], cursor) and float(one["zero4"].abs().sum()) == 0.0
+    assert int((one["mark"] == 17).sum()) > 0
+    for k in ("meta", "mark", "zero4", "cat", "n_cat", "now"):
+        assert torch.equal(one[k], two[k]), k
+    for k in one["stage"]:
+        assert torch.equal(one["stage"][k], two["stage"][k]), k
+    # the product may not depend on what the fetch writes
+    with pytest.raises(ops.SelfrecHipError):
+        ops.spmm(g.adj, x, epilogue=ops.make_epilogue(row_mark=one["mark"], mark_stamp=cursor[1:2]), fetch=args(one))
+
+
 # ------------------------------------------------------------------------------------------
 # (a-2) normalisation and edge-dropped views
 # ------------------------------------------------------------------------------------------
