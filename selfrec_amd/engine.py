@@ -218,7 +218,7 @@ class FusedTrainer:
         # batch_fetch as a rider of the step's first product (see _step_front): models whose step starts with a plain
         # srh_spmm_f32 launch of a layer that is not the last
         self.ride_fetch = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
-                           and model in ("LightGCN", "XSimGCL"))
+                           and model in ("LightGCN", "XSimGCL", "SimGCL"))
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -479,7 +479,10 @@ class FusedTrainer:
         # injected noise is drawn in the reference's order: view a layers 1..L, then view b
         na = [self._noise() for _ in range(L)] if self.noise_fn is not None else [None] * L
         nb = [self._noise() for _ in range(L)] if self.noise_fn is not None else [None] * L
-        ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), epilogue=ops.make_epilogue(
+        rider = {}
+        if getattr(self, "_rider", None) is not None:
+            rider, self._rider = {"fetch": self._rider}, None
+        ops.spmm(adj, self.E0, out=self._loc(self.Y[0]), **rider, epilogue=ops.make_epilogue(
             perturb_eps=self.eps, noise=None, rng_seed=self.rng_seed, rng_offset=0,
             rng_step=self.cursor[1:2] if self.noise_fn is None else None, rng_stride=self.P * self._rng_calls, main_clean=True,
             **self._slice_kw(), **(dict(row_scale=self.dinv, scale_out=True) if self.vfree and adj is self.adj else {}),
@@ -620,6 +623,8 @@ class FusedTrainer:
             for vi, v in enumerate(self.views):
                 self._forward_pass(self.view_adj[vi], v["Y"], v["F"], perturbed=False, include_ego=include_ego,
                                    batch_rows_only=True)
+        if self._rider is not None:
+            raise SelfrecHipError("internal: the batch fetch found no product to ride on")
         if self.cols:
             self._pack()
 

@@ -364,11 +364,6 @@ def section_M(out, meta):
                 if name == "SelfCF":
                     named0["u_target_his"], named0["i_target_his"] = enc.u_target_his.numpy().copy(), enc.i_target_his.numpy().copy()
                 # per-step losses: optimizer.zero_grad() follows each loss in every train() loop
-                real_adam = torch.optim.Adam
-
-                class SpyAdam(real_adam):
-                    def step(self, *a, **k):
-                        return super().step(*a, **k)
                 losses = []
                 real_backward = torch.Tensor.backward
 
