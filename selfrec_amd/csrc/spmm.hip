@@ -29,6 +29,16 @@
 
 #include "common.h"
 
+#ifndef SRH_EXP_SCALAR_R
+#define SRH_EXP_SCALAR_R 0
+#endif
+#ifndef SRH_EXP_HOIST_RNG
+#define SRH_EXP_HOIST_RNG 0
+#endif
+#ifndef SRH_ROWS_WAVES
+#define SRH_ROWS_WAVES 8      // waves per SIMD the row kernels are compiled for (<= 64 VGPRs)
+#endif
+
 namespace {
 
 using namespace srh;
@@ -108,17 +118,24 @@ __device__ __forceinline__ float4 load_f4_agent(const float4* p) {
 }
 
 // y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
+// rng_base: (*ep.rng_step) * ep.rng_stride when the caller fetched it up front (kRngLazy: read it here)
+constexpr uint64_t kRngLazy = ~0ull;
 template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
-                                              uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep) {
+                                              uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep,
+                                              uint64_t rng_base = kRngLazy) {
   float4 nu;
   float ss;
+  auto step_base = [&]() -> uint64_t {
+    if (rng_base != kRngLazy) return rng_base;
+    return ep.rng_step ? (uint64_t)(*ep.rng_step) * ep.rng_stride : 0ull;
+  };
   if (ep.noise_d_full != 4 * LPR) {
     // y is a column slice of noise_d_full-wide rows: the unit vector is normalised over the WHOLE row, whose
     // other columns are regenerated (counter RNG) or read (injected noise) by the group's lanes in turn
     const int nq = ep.noise_d_full >> 2, own = (ep.noise_col0 >> 2) + sub;
     uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
-    if (!noise && ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+    if (!noise) ctr += step_base();
     const float4* nr = reinterpret_cast<const float4*>(noise) + (size_t)row * nq;
     auto draw = [&](int q) {
       if (noise) return nr[q];
@@ -134,7 +151,7 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
       nu = reinterpret_cast<const float4*>(noise)[at];
     } else {
       uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
-      if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
+      ctr += step_base();
       uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
       nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
     }
@@ -153,7 +170,7 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
 // their chain of dependent round trips, and a load issued here would add one to every row
 template <int LPR>
 __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
-                                             const DevEpilogue& ep, const float r = 1.0f) {
+                                             const DevEpilogue& ep, const float r = 1.0f, uint64_t rng_base = kRngLazy) {
   const size_t at = (size_t)row * LPR + sub;
   if (ep.scale_flags & SRH_SCALE_IN) y = f4_scale(y, r);
   if (ep.flags & SRH_EPI_AXPY) {
@@ -170,9 +187,9 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   const bool out_scaled = (ep.scale_flags & SRH_SCALE_OUT) != 0;
   if (ep.flags & SRH_EPI_PERTURB) {
     const float4 raw = y;
-    if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep);
+    if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep, rng_base);
     for (int k = 0; k < ep.n_extra; ++k) {
-      const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
+      const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep, rng_base);
       if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = out_scaled ? f4_scale(yk, r) : yk;
     }
   }
@@ -309,6 +326,72 @@ __device__ __forceinline__ void gather8(unsigned cs, float v, unsigned sub16, co
   SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
 }
 
+// The same eight entries when only the first `nr` broadcast rounds carry live entries (the tail of a chunk).  A vector-
+// memory instruction costs the same whether 16 or 64 of its lanes are live (tools/microbench/gather_lds.hip, "halfmask":
+// half the row-groups predicated off, same time), so every round a chunk issues beyond the ones it needs is paid in
+// full: with whole eight-round halves the plan of the Yelp2018-shape graph issues 1.21 gather instructions per four
+// gathered rows (profiles/r02_h_*).  Here the loads are issued from round 7 DOWN to round 0 and a scalar branch skips the
+// rounds >= nr in steps of UNIT; the multiply-adds run in the same (issue) order with the usual vmcnt(7 .. 0) counts --
+// a skipped load only means fewer loads outstanding, so its wait passes at once, its destination keeps an older finite
+// x row and its value is 0 (no entry lives in a round >= nr) -- one asm block, the register allocation of gather8.
+#define SRH_PL(K) "v_cmpx_le_i32_e32 0, %[o" #K "]\n\tglobal_load_dwordx4 %[x" #K "], %[o" #K "], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+#define SRH_SK(N, L) "s_cmp_lt_i32 %[nr], " #N "\n\ts_cbranch_scc1 .Lsrh_skip" #L "_%=\n\t"
+#define SRH_LB(L) ".Lsrh_skip" #L "_%=:\n\t"
+#define SRH_PL_OPERANDS                                                                                                    \
+      : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),            \
+        [x7] "+v"(x7), [sv] "=&s"(save)                                                                                   \
+      : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),        \
+        [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X), [nr] "s"(nr)                                                       \
+      : "memory", "vcc", "scc"
+template <int UNIT>
+__device__ __forceinline__ void pred_load8_first(int nr, floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3,
+                                                 floatx4_t& x4, floatx4_t& x5, floatx4_t& x6, floatx4_t& x7,
+                                                 const unsigned (&off)[8], const void* X) {
+  unsigned long long save;
+  static_assert(UNIT == 1 || UNIT == 2 || UNIT == 4, "tail unit");
+  if (UNIT == 1) {
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 SRH_SK(8, 7) SRH_PL(7) SRH_LB(7) SRH_SK(7, 6) SRH_PL(6) SRH_LB(6) SRH_SK(6, 5) SRH_PL(5) SRH_LB(5)
+                 SRH_SK(5, 4) SRH_PL(4) SRH_LB(4) SRH_SK(4, 3) SRH_PL(3) SRH_LB(3) SRH_SK(3, 2) SRH_PL(2) SRH_LB(2)
+                 SRH_SK(2, 1) SRH_PL(1) SRH_LB(1) SRH_PL(0) "s_nop 4" SRH_PL_OPERANDS);
+  } else if (UNIT == 2) {
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 SRH_SK(7, 6) SRH_PL(7) SRH_PL(6) SRH_LB(6) SRH_SK(5, 4) SRH_PL(5) SRH_PL(4) SRH_LB(4)
+                 SRH_SK(3, 2) SRH_PL(3) SRH_PL(2) SRH_LB(2) SRH_PL(1) SRH_PL(0) "s_nop 4" SRH_PL_OPERANDS);
+  } else {
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 SRH_SK(5, 4) SRH_PL(7) SRH_PL(6) SRH_PL(5) SRH_PL(4) SRH_LB(4) SRH_PL(3) SRH_PL(2) SRH_PL(1) SRH_PL(0)
+                 "s_nop 4" SRH_PL_OPERANDS);
+  }
+}
+#undef SRH_PL
+#undef SRH_SK
+#undef SRH_LB
+#undef SRH_PL_OPERANDS
+
+// nr: broadcast rounds of THIS half (entries 0-7 or 8-15 of the DPP row) that carry a live entry somewhere in the wave
+template <bool HI, int UNIT>
+__device__ __forceinline__ void gather8_first(int nr, unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
+                                              Acc2& acc) {
+  unsigned off[8];
+  float vv[8];
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  if (!HI) {
+    SRH_DPP_OR(0); SRH_DPP_OR(1); SRH_DPP_OR(2); SRH_DPP_OR(3); SRH_DPP_OR(4); SRH_DPP_OR(5); SRH_DPP_OR(6); SRH_DPP_OR(7);
+  } else {
+    SRH_DPP_OR(8); SRH_DPP_OR(9); SRH_DPP_OR(10); SRH_DPP_OR(11); SRH_DPP_OR(12); SRH_DPP_OR(13); SRH_DPP_OR(14); SRH_DPP_OR(15);
+  }
+  pred_load8_first<UNIT>(nr, xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  if (!HI) {
+    SRH_DPP_MOV(0); SRH_DPP_MOV(1); SRH_DPP_MOV(2); SRH_DPP_MOV(3); SRH_DPP_MOV(4); SRH_DPP_MOV(5); SRH_DPP_MOV(6); SRH_DPP_MOV(7);
+  } else {
+    SRH_DPP_MOV(8); SRH_DPP_MOV(9); SRH_DPP_MOV(10); SRH_DPP_MOV(11); SRH_DPP_MOV(12); SRH_DPP_MOV(13); SRH_DPP_MOV(14); SRH_DPP_MOV(15);
+  }
+  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
+  SRH_FMA(7, 1, p3, xx[7]); SRH_FMA(6, 0, p3, xx[6]); SRH_FMA(5, 1, p2, xx[5]); SRH_FMA(4, 0, p2, xx[4]);
+  SRH_FMA(3, 1, p1, xx[3]); SRH_FMA(2, 0, p1, xx[2]); SRH_FMA(1, 1, p0, xx[1]); SRH_FMA(0, 0, p0, xx[0]);
+}
+
 // The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
 // entries are dead): the compiler's version branches over a gather whose whole wave is dead, where the asm form
 // still issues the exec = 0 load -- measured 34.2 against 38.1 us at the Yelp2018 shape (profiles/r02_a_spmm_lab.txt).
@@ -387,8 +470,12 @@ struct alignas(64) Task64 {
 // loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms the ticket).
 // COLMASK: the launch carries column activity marks (its own instantiation: the unmasked kernel then has no mark
 // code and always prefetches; a run-time switch between the two cost 2.5 us per launch).
-template <int LPR, bool COLMASK>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
+// UNIT: granularity of a chunk's LAST broadcast rounds (8 = whole halves only; 4 / 2 / 1: gather8_first).  With
+// UNIT < 8 a cooperative task also deals its entries to the row-groups round-robin (entry k of a chunk -> group k % G,
+// round k / G) instead of in blocks of 16, so a tail of R entries needs ceil(R / G) rounds with every group busy rather
+// than up to 16 rounds with one.
+template <int LPR, bool COLMASK, int UNIT = srh::kSpmmTailUnit>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WAVES, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,
@@ -411,6 +498,13 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
   const unsigned sub16 = (unsigned)sub * 16u;
   const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
+#if SRH_EXP_HOIST_RNG
+  // the step counter behind the perturbation's RNG: read here, where nothing this kernel stores can alias it (a scalar
+  // load under the task record's), instead of as a vector load at the end of every wave
+  const uint64_t rng_base = ep.rng_step ? (uint64_t)(*ep.rng_step) * ep.rng_stride : 0ull;
+#else
+  constexpr uint64_t rng_base = kRngLazy;
+#endif
   const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
   Acc2 acc = {{0.f, 0.f}, {0.f, 0.f}};
   floatx4_t xx[8];
@@ -420,13 +514,24 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   const Task64* tp = tasks + wave;       // uniform address: s_load
   const int kind = tp->kind, count = tp->count, slot = tp->slot;
   int row = tp->row[0], s = tp->start[0], e = tp->end[0];
+#if SRH_EXP_SCALAR_R
+  // the rows' scale factors by SCALAR loads (the row ids sit in SGPRs): no vector-memory instruction, no VGPR address
+  float rs = 1.0f;
+  if (ep.row_scale) rs = ep.row_scale[row];
+#endif
   if (kind == 1 && G > 1) {
     const int r1 = tp->row[1], s1 = tp->start[1], e1 = tp->end[1];
     if (g == 1) { row = r1; s = s1; e = e1; }
+#if SRH_EXP_SCALAR_R
+    if (ep.row_scale) { const float q1 = ep.row_scale[r1]; if (g == 1) rs = q1; }
+#endif
     if (G > 2) {
       const int r2 = tp->row[2], s2 = tp->start[2], e2 = tp->end[2], r3 = tp->row[3], s3 = tp->start[3], e3 = tp->end[3];
       if (g == 2) { row = r2; s = s2; e = e2; }
       if (g == 3) { row = r3; s = s3; e = e3; }
+#if SRH_EXP_SCALAR_R
+      if (ep.row_scale) { const float q2 = ep.row_scale[r2], q3 = ep.row_scale[r3]; if (g == 2) rs = q2; if (g == 3) rs = q3; }
+#endif
     }
   }
   // (col, val) of one entry as the gather wants them: the column pre-multiplied by the row bytes, the sign bit on
@@ -448,33 +553,45 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
   unsigned cs, csn = 0x80000000u;
   float v, vn = 0.f;
   float4 accm = f4_zero();                                // COLMASK accumulator
-  auto chunk = [&](int rem) {
+  constexpr bool INTER = !COLMASK && UNIT < 8;            // cooperative entries dealt round-robin to the groups
+  // nr: broadcast rounds the chunk needs (1 .. 16)
+  auto chunk = [&](int nr) {
     if (COLMASK) {
       gather16_compact<LPR>((int)cs, v, X, sub, accm);
-    } else {
+    } else if (UNIT == 8) {
       gather8<false>(cs, v, sub16, X, xx, acc);
-      if (rem > 8) gather8<true>(cs, v, sub16, X, xx, acc);
+      if (nr > 8) gather8<true>(cs, v, sub16, X, xx, acc);
+    } else {
+      constexpr int U = UNIT < 8 ? UNIT : 4;             // (UNIT == 8 never gets here)
+      gather8_first<false, U>(nr, cs, v, sub16, X, xx, acc);
+      if (nr > 8) gather8_first<true, U>(nr - 8, cs, v, sub16, X, xx, acc);
     }
   };
+  auto coop_at = [&](int base) { return INTER ? base + G * e16 + g : base + 16 * g + e16; };
+  auto coop_rounds = [&](int rem) { return INTER ? min(16, (rem + G - 1) / G) : rem; };
   auto total = [&]() { return COLMASK ? accm : make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y); };
 
   if (kind == 0) {
     row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
     if (ep.row_mark && ep.row_mark[row] != stamp) return;
+#if SRH_EXP_SCALAR_R
+    const float r = rs;
+#else
     const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
-    fetch(s + 16 * g + e16, e, cs, v);
+#endif
+    fetch(coop_at(s), e, cs, v);
     for (int base = s; base < e; base += CH) {
       const bool more = base + CH < e;
-      if (prefetch && more) fetch(base + CH + 16 * g + e16, e, csn, vn);
-      chunk(e - base);
+      if (prefetch && more) fetch(coop_at(base + CH), e, csn, vn);
+      chunk(coop_rounds(e - base));
       if (prefetch) { cs = csn; v = vn; }
-      else if (more) fetch(base + CH + 16 * g + e16, e, cs, v);
+      else if (more) fetch(coop_at(base + CH), e, cs, v);
     }
     float4 a4 = total();
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
-      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r);
+      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r, rng_base);
       return;
     }
     if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, a4);
@@ -492,13 +609,17 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
     for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
-    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
+    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r, rng_base);
     return;
   }
 
   // ---- one short row per row-group ----
   const bool live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
+#if SRH_EXP_SCALAR_R
+  const float r = rs;
+#else
   const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
+#endif
   if (!live) e = s;
   int maxlen = e - s;
 #pragma unroll
@@ -512,7 +633,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const Task64* __restrict
     if (prefetch) { cs = csn; v = vn; }
     else if (more) fetch(s + 16 * (q + 1) + e16, e, cs, v);
   }
-  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
+  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r, rng_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,8 +658,11 @@ __device__ __forceinline__ void gather8x3(int c, float v0, float v1, float v2, c
     xx[t] = f4_zero();
     if (a0[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // (views are sub-graphs: a0 == 0 only for padding)
   }
+  // (the summation order of spmm_rows_kernel, so that the three outputs equal three launches bit for bit: ascending
+  // rounds with whole-half units, descending inside each half when tails are skipped -- see gather8_first)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int u = 0; u < 8; ++u) {
+    const int t = srh::kSpmmTailUnit < 8 ? 7 - u : u;
     acc[0] = f4_fma(a0[t], xx[t], acc[0]);
     acc[1] = f4_fma(a1[t], xx[t], acc[1]);
     acc[2] = f4_fma(a2[t], xx[t], acc[2]);
@@ -576,7 +700,7 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
     const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
     const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
     for (int base = s; base < e; base += CH) {
-      const int j = base + 16 * g + e16;
+      const int j = srh::kSpmmTailUnit < 8 ? base + G * e16 + g : base + 16 * g + e16;     // (as spmm_rows_kernel deals them)
       int c = 0;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       if (j < e) { c = indices[j]; v0 = vals0[j]; v1 = vals1[j]; v2 = vals2[j]; }

@@ -32,6 +32,9 @@ using namespace srh;
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
+// MODE 60 (timing probe of MODE 2): per wave {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
+__device__ unsigned long long* g_probe = nullptr;
+
 #define LAB_DPP_OR(T)                                                                                          \
   asm volatile("v_or_b32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(off[T & 7]) : "v"(cs), "v"(sub16))
 #define LAB_DPP_MOV(T)                                                                                         \
@@ -240,6 +243,20 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
   floatx4_t xx[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) xx[t] = zero;
+  unsigned long long t_begin = 0;
+  unsigned xcc = 0;
+  if (MODE == 60) {
+    t_begin = wall_clock64();
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  }
+  auto stamp_end = [&](int what) {
+    if (MODE == 60 && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      g_probe[3 * (size_t)wave] = t_begin;
+      g_probe[3 * (size_t)wave + 1] = wall_clock64();
+      g_probe[3 * (size_t)wave + 2] = (xcc & 0xfu) | ((unsigned)what << 8);
+    }
+  };
 
   int kind, count, slot0;
   int row, s, e;              // this row-group's row / entry range (coop: the wave's segment)
@@ -306,8 +323,9 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
     float4 a4 = to_f4(acc);
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
-    if (slot < 0) { row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep); return; }
+    if (slot < 0) { row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep); stamp_end(0); return; }
     finish_split(a4, row, slot, lane, g, sub, Y, partial, heavy, slot_owner, tickets, ep);
+    stamp_end(1);
     return;
   }
 
@@ -336,6 +354,7 @@ __global__ __launch_bounds__(256) void rows_kernel(const Task* __restrict__ task
   }
   if (MODE == 20) { if (live) Y[(size_t)row * LPR + sub] = to_f4(acc); }
   else row_epilogue<LPR>(to_f4(acc), row, sub, live, Y, ep);
+  stamp_end(2);
 }
 
 // Second generation: K tasks per wave (tasks b, b + NB, ... of its workgroup column, so a wave keeps its XCD class),
@@ -793,6 +812,13 @@ void lab_destroy(void* h) {
   delete L;
 }
 
+// where variant 60 writes its 3 x n_tasks records (uint64: begin, end, xcd | exit << 8)
+int lab_set_probe(void* d_buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(d_buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(lab::g_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+int lab_n_tasks(void* h) { return reinterpret_cast<lab::Lab*>(h)->n_tasks; }
+
 // refresh the column bitmap from the epilogue's col_mark / stamp (not timed with the product: batch_fetch would write it)
 int lab_build_bits(void* h, const int32_t* d_mark, const int64_t* d_stamp, int n, void* stream) {
   lab::Lab* L = reinterpret_cast<lab::Lab*>(h);
@@ -826,6 +852,22 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
     case 23: LAB_LAUNCH(23, 0); break;
     case 21: LAB_LAUNCH(21, 0); break;
     case 22: LAB_LAUNCH(22, 0); break;
+    case 60: LAB_LAUNCH(60, 0); break;
+#define LAB_PRODUCT(UNITV, VALS)                                                                                      \
+  do {                                                                                                                \
+    if (ep.col_mark) return -6;                                                                                       \
+    srh_batch_fetch_args_t no_rider{};                                                                                \
+    spmm_rows_kernel<16, false, UNITV><<<blocks, 256, 0, st>>>(                                                       \
+        plan->d_tasks64[1], n, d_indices, VALS, reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), \
+        reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep, 0, no_rider); \
+  } while (0)
+    case 70: LAB_PRODUCT(4, d_vals); break;       /* product kernel, tails in units of 4 rounds, coop entries round-robin */
+    case 71: LAB_PRODUCT(2, d_vals); break;       /* ... units of 2 */
+    case 75: LAB_PRODUCT(1, d_vals); break;       /* ... single rounds */
+    case 72: LAB_PRODUCT(4, nullptr); break;      /* the same as pattern products (no value stream): vs all-ones values */
+    case 73: LAB_PRODUCT(2, nullptr); break;
+    case 76: LAB_PRODUCT(1, nullptr); break;
+    case 74: LAB_PRODUCT(8, nullptr); break;      /* the product's own pattern launch, for the same-table comparison */
 #define LAB_LAUNCH2(KK, DD, VV)                                                                                      \
   do {                                                                                                               \
     int nblk = (blocks + KK - 1) / KK;                                                                               \

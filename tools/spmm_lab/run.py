@@ -31,9 +31,15 @@ VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) pre
             40: "gen2 persistent: 2048 workgroups x 3 tasks, perturb-only epilogue",
             10: "gen2 K=1 depth 1", 11: "gen2 K=2 (next task's first chunk prefetched)", 12: "gen2 K=3", 13: "gen2 K=4",
             18: "gen2 K=6", 14: "gen2 K=1, 16 gathers in flight", 15: "gen2 K=2, 16 gathers in flight",
-            16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)"}
-VALUE_FREE = (3, 16, 17)
-SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14, 40)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
+            16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)",
+            70: "product kernel, chunk tails in units of 4 rounds, coop entries round-robin",
+            71: "product kernel, chunk tails in units of 2 rounds, coop entries round-robin",
+            75: "product kernel, chunk tails in single rounds, coop entries round-robin",
+            74: "product kernel as it is, pattern launch (vs all-ones)",
+            72: "70 as a pattern launch (vs all-ones)", 73: "71 as a pattern launch (vs all-ones)",
+            76: "75 as a pattern launch (vs all-ones)"}
+VALUE_FREE = (3, 16, 17, 72, 73, 74, 76)
+SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14, 40, 3, 4, 5, 23, 30, 50, 41, 10)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
 
 
 def timed(fn, iters):
@@ -49,12 +55,54 @@ def timed(fn, iters):
     return a.elapsed_time(b) / iters * 1e3          # us
 
 
+def probe(lab, h, adj, lab_call, flavours, y, dev):
+    """Where does the dense launch's time go across the chip?  Variant 60 = variant 2 + {begin, end} of every wave on the
+    chip-wide 100 MHz clock and the XCD it ran on.  Per XCD: waves, first begin, last begin, last end (us after the
+    launch's first wave began); per task kind: mean wave duration."""
+    vp = C.c_void_p
+    lab.lab_set_probe.argtypes = [vp]
+    lab.lab_n_tasks.argtypes = [vp]
+    n = lab.lab_n_tasks(h)
+    buf = torch.zeros(3 * n, dtype=torch.int64, device=dev)
+    assert lab.lab_set_probe(buf.data_ptr()) == 0
+    ep = flavours["dense"]()
+    for _ in range(5):
+        lab_call(adj, ep, 2, y)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        buf.zero_()
+        lab_call(adj, ep, 60, y)
+        torch.cuda.synchronize()
+        rec = buf.cpu().numpy().reshape(n, 3)
+        t0 = rec[:, 0].min()
+        b, e = (rec[:, 0] - t0) / 100.0, (rec[:, 1] - t0) / 100.0          # 100 MHz ticks -> us
+        xcd, what = rec[:, 2] & 0xff, rec[:, 2] >> 8
+        print(f"# probe run {rep}: {n} waves, launch spans {e.max():.2f} us from the first wave's begin")
+        print(f"{'xcd':>4}{'waves':>8}{'first begin':>13}{'last begin':>12}{'last end':>10}{'sum of wave us':>16}")
+        for x in range(8):
+            m = xcd == x
+            if m.any():
+                print(f"{x:>4}{int(m.sum()):>8}{b[m].min():>13.2f}{b[m].max():>12.2f}{e[m].max():>10.2f}{(e[m] - b[m]).sum():>16.1f}")
+        for w, label in ((0, "coop, whole row"), (1, "coop, split segment"), (2, "4 short rows")):
+            m = what == w
+            if m.any():
+                d = e[m] - b[m]
+                print(f"#   {label:<20} {int(m.sum()):>6} waves, duration mean {d.mean():.2f} us, p50 {np.median(d):.2f}, p99 {np.percentile(d, 99):.2f}, "
+                      f"begin range {b[m].min():.2f} .. {b[m].max():.2f}")
+        # how busy the chip is over time: waves in flight per 2 us bucket
+        edges = np.arange(0, e.max() + 2.0, 2.0)
+        infl = [int(((b < hi) & (e > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+        print("#   waves alive per 2 us bucket: " + " ".join(str(v) for v in infl))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="yelp2018")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--all", action="store_true")
+    ap.add_argument("--probe", action="store_true",
+                    help="variant 60 only: per-wave begin / end stamps of the dense launch, summarised per XCD")
     ap.add_argument("--no-colclass", action="store_true", help="plain row storage (no [even | odd] column classes)")
     ap.add_argument("--ids", default="raw", choices=["raw", "first-appearance"],
                     help="node labelling: the generator's ids, or ids in first-appearance order of the training list (what "
@@ -105,6 +153,8 @@ def main():
         assert rc == 0, (variant, rc)
 
     print(f"# ids: {args.ids}; column classes: {not args.no_colclass}")
+    if args.probe:
+        return probe(lab, h, adj, lab_call, flavours, y, dev)
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
@@ -118,7 +168,7 @@ def main():
         cells = []
         for name, mk in flavours.items():
             if (variant in (4, 5) and name != "col_masked") or (variant in (30, 50) and name == "col_masked") or \
-                    (variant in (40, 41) and name != "dense"):
+                    (variant in (40, 41) and name != "dense") or (variant in (70, 71, 72, 73, 74, 75, 76) and name == "col_masked"):
                 cells.append(f"{'-':>14}")
                 continue
             csr = ones if variant in VALUE_FREE else adj
