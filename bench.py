@@ -127,15 +127,17 @@ def time_spmm_kernel(trainer, iters=50):
                                                               row_mark=trainer.mark, mark_stamp=stamp, **sc)
         pattern = {"dense_value_free": True, "row_masked_value_free": True}
     out = {}
+    adj_cm = getattr(trainer, "adj_cm", None) or adj          # (the column-masked launch runs on its own plan: engine.py)
     for name, ep in flavours.items():
         kw = {"pattern": True} if pattern.get(name) else {}
+        m = adj_cm if name == "col_masked" else adj
         for _ in range(5):
-            ops.spmm(adj, x, out=y, epilogue=ep, **kw)
+            ops.spmm(m, x, out=y, epilogue=ep, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
         for _ in range(iters):
-            ops.spmm(adj, x, out=y, epilogue=ep, **kw)
+            ops.spmm(m, x, out=y, epilogue=ep, **kw)
         b.record()
         torch.cuda.synchronize()
         out[name] = a.elapsed_time(b) / iters * 1e-3

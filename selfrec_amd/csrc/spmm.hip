@@ -29,12 +29,6 @@
 
 #include "common.h"
 
-#ifndef SRH_EXP_SCALAR_R
-#define SRH_EXP_SCALAR_R 0
-#endif
-#ifndef SRH_EXP_HOIST_RNG
-#define SRH_EXP_HOIST_RNG 0
-#endif
 #ifndef SRH_ROWS_WAVES
 #define SRH_ROWS_WAVES 8      // waves per SIMD the row kernels are compiled for (<= 64 VGPRs)
 #endif
@@ -118,24 +112,17 @@ __device__ __forceinline__ float4 load_f4_agent(const float4* p) {
 }
 
 // y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
-// rng_base: (*ep.rng_step) * ep.rng_stride when the caller fetched it up front (kRngLazy: read it here)
-constexpr uint64_t kRngLazy = ~0ull;
 template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
-                                              uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep,
-                                              uint64_t rng_base = kRngLazy) {
+                                              uint32_t off_lo, uint32_t off_hi, const DevEpilogue& ep) {
   float4 nu;
   float ss;
-  auto step_base = [&]() -> uint64_t {
-    if (rng_base != kRngLazy) return rng_base;
-    return ep.rng_step ? (uint64_t)(*ep.rng_step) * ep.rng_stride : 0ull;
-  };
   if (ep.noise_d_full != 4 * LPR) {
     // y is a column slice of noise_d_full-wide rows: the unit vector is normalised over the WHOLE row, whose
     // other columns are regenerated (counter RNG) or read (injected noise) by the group's lanes in turn
     const int nq = ep.noise_d_full >> 2, own = (ep.noise_col0 >> 2) + sub;
     uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
-    if (!noise) ctr += step_base();
+    if (!noise && ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
     const float4* nr = reinterpret_cast<const float4*>(noise) + (size_t)row * nq;
     auto draw = [&](int q) {
       if (noise) return nr[q];
@@ -151,7 +138,7 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
       nu = reinterpret_cast<const float4*>(noise)[at];
     } else {
       uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
-      ctr += step_base();
+      if (ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
       uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
       nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
     }
@@ -170,7 +157,10 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
 // their chain of dependent round trips, and a load issued here would add one to every row
 template <int LPR>
 __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
-                                             const DevEpilogue& ep, const float r = 1.0f, uint64_t rng_base = kRngLazy) {
+                                             const DevEpilogue& ep, const float r = 1.0f) {
+  // (`store` is uniform over the row-group: a group that does not write -- groups 1.. of a cooperative task, the
+  // row-groups of dead rows on a row-masked launch -- leaves before the addend / layer-mean loads and the noise hash)
+  if (!store) return;
   const size_t at = (size_t)row * LPR + sub;
   if (ep.scale_flags & SRH_SCALE_IN) y = f4_scale(y, r);
   if (ep.flags & SRH_EPI_AXPY) {
@@ -187,9 +177,9 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   const bool out_scaled = (ep.scale_flags & SRH_SCALE_OUT) != 0;
   if (ep.flags & SRH_EPI_PERTURB) {
     const float4 raw = y;
-    if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep, rng_base);
+    if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep);
     for (int k = 0; k < ep.n_extra; ++k) {
-      const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep, rng_base);
+      const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
       if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = out_scaled ? f4_scale(yk, r) : yk;
     }
   }
@@ -326,53 +316,38 @@ __device__ __forceinline__ void gather8(unsigned cs, float v, unsigned sub16, co
   SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
 }
 
-// The same eight entries when only the first `nr` broadcast rounds carry live entries (the tail of a chunk).  A vector-
-// memory instruction costs the same whether 16 or 64 of its lanes are live (tools/microbench/gather_lds.hip, "halfmask":
-// half the row-groups predicated off, same time), so every round a chunk issues beyond the ones it needs is paid in
-// full: with whole eight-round halves the plan of the Yelp2018-shape graph issues 1.21 gather instructions per four
-// gathered rows (profiles/r02_h_*).  Here the loads are issued from round 7 DOWN to round 0 and a scalar branch skips the
-// rounds >= nr in steps of UNIT; the multiply-adds run in the same (issue) order with the usual vmcnt(7 .. 0) counts --
-// a skipped load only means fewer loads outstanding, so its wait passes at once, its destination keeps an older finite
-// x row and its value is 0 (no entry lives in a round >= nr) -- one asm block, the register allocation of gather8.
-#define SRH_PL(K) "v_cmpx_le_i32_e32 0, %[o" #K "]\n\tglobal_load_dwordx4 %[x" #K "], %[o" #K "], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-#define SRH_SK(N, L) "s_cmp_lt_i32 %[nr], " #N "\n\ts_cbranch_scc1 .Lsrh_skip" #L "_%=\n\t"
-#define SRH_LB(L) ".Lsrh_skip" #L "_%=:\n\t"
-#define SRH_PL_OPERANDS                                                                                                    \
-      : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),            \
-        [x7] "+v"(x7), [sv] "=&s"(save)                                                                                   \
-      : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),        \
-        [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X), [nr] "s"(nr)                                                       \
-      : "memory", "vcc", "scc"
-template <int UNIT>
-__device__ __forceinline__ void pred_load8_first(int nr, floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3,
-                                                 floatx4_t& x4, floatx4_t& x5, floatx4_t& x6, floatx4_t& x7,
-                                                 const unsigned (&off)[8], const void* X) {
+// The same eight entries when only `nr` of the eight broadcast rounds carry an entry (the tail of a chunk).  Every round a
+// chunk issues beyond the ones it needs is a vector-memory instruction paid for nothing: with whole eight-round halves
+// the plan of the Yelp2018-shape graph issues 762 k gathers per launch for 630 k x four rows (profiles/r02_h_*).  The
+// kernel therefore packs a tail's entries into the LAST nr lanes of the half (lanes 8 - nr .. 7, see lane_slot in
+// spmm_rows_kernel) and this form jumps over the first 8 - nr loads.  Everything else is gather8: loads issued in lane
+// order, multiply-adds in the same order with vmcnt(7 .. 0) -- a skipped load is an OLDER load that was never issued, so
+// the counts of the issued ones stand; its destination keeps an older finite x row and its value is 0.  Entries are
+// still summed in ascending order: the result equals the whole-half form bit for bit.
+#define SRH_PL(K) ".Lsrh_t" #K "_%=:\n\tv_cmpx_le_i32_e32 0, %[o" #K "]\n\tglobal_load_dwordx4 %[x" #K "], %[o" #K "], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
+#define SRH_GE(N, K) "s_cmp_ge_i32 %[nr], " #N "\n\ts_cbranch_scc1 .Lsrh_t" #K "_%=\n\t"
+__device__ __forceinline__ void pred_load8_tail(int nr, floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3,
+                                                floatx4_t& x4, floatx4_t& x5, floatx4_t& x6, floatx4_t& x7,
+                                                const unsigned (&off)[8], const void* X) {
   unsigned long long save;
-  static_assert(UNIT == 1 || UNIT == 2 || UNIT == 4, "tail unit");
-  if (UNIT == 1) {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 SRH_SK(8, 7) SRH_PL(7) SRH_LB(7) SRH_SK(7, 6) SRH_PL(6) SRH_LB(6) SRH_SK(6, 5) SRH_PL(5) SRH_LB(5)
-                 SRH_SK(5, 4) SRH_PL(4) SRH_LB(4) SRH_SK(4, 3) SRH_PL(3) SRH_LB(3) SRH_SK(3, 2) SRH_PL(2) SRH_LB(2)
-                 SRH_SK(2, 1) SRH_PL(1) SRH_LB(1) SRH_PL(0) "s_nop 4" SRH_PL_OPERANDS);
-  } else if (UNIT == 2) {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 SRH_SK(7, 6) SRH_PL(7) SRH_PL(6) SRH_LB(6) SRH_SK(5, 4) SRH_PL(5) SRH_PL(4) SRH_LB(4)
-                 SRH_SK(3, 2) SRH_PL(3) SRH_PL(2) SRH_LB(2) SRH_PL(1) SRH_PL(0) "s_nop 4" SRH_PL_OPERANDS);
-  } else {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 SRH_SK(5, 4) SRH_PL(7) SRH_PL(6) SRH_PL(5) SRH_PL(4) SRH_LB(4) SRH_PL(3) SRH_PL(2) SRH_PL(1) SRH_PL(0)
-                 "s_nop 4" SRH_PL_OPERANDS);
-  }
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               SRH_GE(8, 0) SRH_GE(7, 1) SRH_GE(6, 2) SRH_GE(5, 3) SRH_GE(4, 4) SRH_GE(3, 5) SRH_GE(2, 6)
+               "s_branch .Lsrh_t7_%=\n\t"
+               SRH_PL(0) SRH_PL(1) SRH_PL(2) SRH_PL(3) SRH_PL(4) SRH_PL(5) SRH_PL(6) SRH_PL(7)
+               "s_nop 4"
+               : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),
+                 [x7] "+v"(x7), [sv] "=&s"(save)
+               : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
+                 [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X), [nr] "s"(nr)
+               : "memory", "vcc", "scc");
 }
 #undef SRH_PL
-#undef SRH_SK
-#undef SRH_LB
-#undef SRH_PL_OPERANDS
+#undef SRH_GE
 
-// nr: broadcast rounds of THIS half (entries 0-7 or 8-15 of the DPP row) that carry a live entry somewhere in the wave
-template <bool HI, int UNIT>
-__device__ __forceinline__ void gather8_first(int nr, unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
-                                              Acc2& acc) {
+// nr (1 .. 8): rounds of THIS half (lanes 0-7 or 8-15 of the DPP row) that carry an entry somewhere in the wave: the last nr
+template <bool HI>
+__device__ __forceinline__ void gather8_tail(int nr, unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
+                                             Acc2& acc) {
   unsigned off[8];
   float vv[8];
   asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
@@ -381,15 +356,15 @@ __device__ __forceinline__ void gather8_first(int nr, unsigned cs, float v, unsi
   } else {
     SRH_DPP_OR(8); SRH_DPP_OR(9); SRH_DPP_OR(10); SRH_DPP_OR(11); SRH_DPP_OR(12); SRH_DPP_OR(13); SRH_DPP_OR(14); SRH_DPP_OR(15);
   }
-  pred_load8_first<UNIT>(nr, xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  pred_load8_tail(nr, xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
   if (!HI) {
     SRH_DPP_MOV(0); SRH_DPP_MOV(1); SRH_DPP_MOV(2); SRH_DPP_MOV(3); SRH_DPP_MOV(4); SRH_DPP_MOV(5); SRH_DPP_MOV(6); SRH_DPP_MOV(7);
   } else {
     SRH_DPP_MOV(8); SRH_DPP_MOV(9); SRH_DPP_MOV(10); SRH_DPP_MOV(11); SRH_DPP_MOV(12); SRH_DPP_MOV(13); SRH_DPP_MOV(14); SRH_DPP_MOV(15);
   }
   const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
-  SRH_FMA(7, 1, p3, xx[7]); SRH_FMA(6, 0, p3, xx[6]); SRH_FMA(5, 1, p2, xx[5]); SRH_FMA(4, 0, p2, xx[4]);
-  SRH_FMA(3, 1, p1, xx[3]); SRH_FMA(2, 0, p1, xx[2]); SRH_FMA(1, 1, p0, xx[1]); SRH_FMA(0, 0, p0, xx[0]);
+  SRH_FMA(7, 0, p0, xx[0]); SRH_FMA(6, 1, p0, xx[1]); SRH_FMA(5, 0, p1, xx[2]); SRH_FMA(4, 1, p1, xx[3]);
+  SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
 }
 
 // The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
@@ -470,10 +445,10 @@ struct alignas(64) Task64 {
 // loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms the ticket).
 // COLMASK: the launch carries column activity marks (its own instantiation: the unmasked kernel then has no mark
 // code and always prefetches; a run-time switch between the two cost 2.5 us per launch).
-// UNIT: granularity of a chunk's LAST broadcast rounds (8 = whole halves only; 4 / 2 / 1: gather8_first).  With
-// UNIT < 8 a cooperative task also deals its entries to the row-groups round-robin (entry k of a chunk -> group k % G,
-// round k / G) instead of in blocks of 16, so a tail of R entries needs ceil(R / G) rounds with every group busy rather
-// than up to 16 rounds with one.
+// UNIT (srh::kSpmmTailUnit): 8 = a chunk issues whole eight-round halves; 1 = a chunk's tail issues the rounds it needs
+// (gather8_tail) and a cooperative task deals its entries to the row-groups round-robin (entry k of a chunk -> group
+// k % G, round k / G) instead of in blocks of 16, so that a tail of R entries needs ceil(R / G) rounds with every group
+// busy rather than up to 16 rounds with one.
 template <int LPR, bool COLMASK, int UNIT = srh::kSpmmTailUnit>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WAVES, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
@@ -498,13 +473,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
   const unsigned sub16 = (unsigned)sub * 16u;
   const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
-#if SRH_EXP_HOIST_RNG
-  // the step counter behind the perturbation's RNG: read here, where nothing this kernel stores can alias it (a scalar
-  // load under the task record's), instead of as a vector load at the end of every wave
-  const uint64_t rng_base = ep.rng_step ? (uint64_t)(*ep.rng_step) * ep.rng_stride : 0ull;
-#else
-  constexpr uint64_t rng_base = kRngLazy;
-#endif
   const floatx4_t zero = {0.f, 0.f, 0.f, 0.f};
   Acc2 acc = {{0.f, 0.f}, {0.f, 0.f}};
   floatx4_t xx[8];
@@ -514,24 +482,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   const Task64* tp = tasks + wave;       // uniform address: s_load
   const int kind = tp->kind, count = tp->count, slot = tp->slot;
   int row = tp->row[0], s = tp->start[0], e = tp->end[0];
-#if SRH_EXP_SCALAR_R
-  // the rows' scale factors by SCALAR loads (the row ids sit in SGPRs): no vector-memory instruction, no VGPR address
-  float rs = 1.0f;
-  if (ep.row_scale) rs = ep.row_scale[row];
-#endif
   if (kind == 1 && G > 1) {
     const int r1 = tp->row[1], s1 = tp->start[1], e1 = tp->end[1];
     if (g == 1) { row = r1; s = s1; e = e1; }
-#if SRH_EXP_SCALAR_R
-    if (ep.row_scale) { const float q1 = ep.row_scale[r1]; if (g == 1) rs = q1; }
-#endif
     if (G > 2) {
       const int r2 = tp->row[2], s2 = tp->start[2], e2 = tp->end[2], r3 = tp->row[3], s3 = tp->start[3], e3 = tp->end[3];
       if (g == 2) { row = r2; s = s2; e = e2; }
       if (g == 3) { row = r3; s = s3; e = e3; }
-#if SRH_EXP_SCALAR_R
-      if (ep.row_scale) { const float q2 = ep.row_scale[r2], q3 = ep.row_scale[r3]; if (g == 2) rs = q2; if (g == 3) rs = q3; }
-#endif
     }
   }
   // (col, val) of one entry as the gather wants them: the column pre-multiplied by the row bytes, the sign bit on
@@ -553,32 +510,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   unsigned cs, csn = 0x80000000u;
   float v, vn = 0.f;
   float4 accm = f4_zero();                                // COLMASK accumulator
-  constexpr bool INTER = !COLMASK && UNIT < 8;            // cooperative entries dealt round-robin to the groups
-  // nr: broadcast rounds the chunk needs (1 .. 16)
+  constexpr bool TAIL = !COLMASK && UNIT < 8;             // tails issue only the rounds they need
+  constexpr bool INTER = TAIL;                            // cooperative entries dealt round-robin to the groups
+  // nr: broadcast rounds the chunk needs (>= 1; 16 and more = all)
   auto chunk = [&](int nr) {
     if (COLMASK) {
       gather16_compact<LPR>((int)cs, v, X, sub, accm);
-    } else if (UNIT == 8) {
+    } else if (!TAIL) {
       gather8<false>(cs, v, sub16, X, xx, acc);
       if (nr > 8) gather8<true>(cs, v, sub16, X, xx, acc);
     } else {
-      constexpr int U = UNIT < 8 ? UNIT : 4;             // (UNIT == 8 never gets here)
-      gather8_first<false, U>(nr, cs, v, sub16, X, xx, acc);
-      if (nr > 8) gather8_first<true, U>(nr - 8, cs, v, sub16, X, xx, acc);
+      // (two asm bodies per call site, not three: with a plain gather8 for whole first halves next to them the register
+      // allocator no longer finds eight aligned quads under the 64-VGPR cap and spills 160 bytes into the loop)
+      gather8_tail<false>(min(nr, 8), cs, v, sub16, X, xx, acc);
+      if (nr > 8) gather8_tail<true>(min(nr, 16) - 8, cs, v, sub16, X, xx, acc);
     }
   };
-  auto coop_at = [&](int base) { return INTER ? base + G * e16 + g : base + 16 * g + e16; };
+  // The entry slot (= broadcast round, 0 .. 15) this lane's DPP-row position holds in a chunk that needs nr rounds, or -1.
+  // A whole chunk: slot = lane.  A tail packs its nr slots into the LAST lanes of the half they end in (gather8_tail
+  // skips the leading loads): nr <= 8 -> lanes 8 - nr .. 7; 8 < nr < 16 -> lanes 0 .. 7 and 24 - nr .. 15.
+  auto lane_slot = [&](int nr) {
+    if (!TAIL) return e16;
+    const int shift = (e16 < 8) ? max(0, 8 - nr) : ((nr > 8) ? max(0, 16 - nr) : 16);
+    const int slot = e16 - shift;
+    return (slot >= (e16 & 8)) ? slot : -1;
+  };
   auto coop_rounds = [&](int rem) { return INTER ? min(16, (rem + G - 1) / G) : rem; };
+  // index of this lane's entry in a cooperative chunk starting at `base` / in chunk q of a short row (>= end: none)
+  auto coop_at = [&](int base) {
+    if (!INTER) return base + 16 * g + e16;
+    const int slot = lane_slot(coop_rounds(e - base));
+    return slot < 0 ? e : base + G * slot + g;
+  };
+  auto short_at = [&](int q, int maxlen_) {
+    const int slot = lane_slot(maxlen_ - 16 * q);
+    return slot < 0 ? e : s + 16 * q + slot;
+  };
   auto total = [&]() { return COLMASK ? accm : make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y); };
 
   if (kind == 0) {
     row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
     if (ep.row_mark && ep.row_mark[row] != stamp) return;
-#if SRH_EXP_SCALAR_R
-    const float r = rs;
-#else
     const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
-#endif
     fetch(coop_at(s), e, cs, v);
     for (int base = s; base < e; base += CH) {
       const bool more = base + CH < e;
@@ -591,7 +564,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
-      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r, rng_base);
+      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r);
       return;
     }
     if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, a4);
@@ -609,31 +582,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
     for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
-    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r, rng_base);
+    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
     return;
   }
 
   // ---- one short row per row-group ----
   const bool live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
-#if SRH_EXP_SCALAR_R
-  const float r = rs;
-#else
+  // row-masked launches (last forward layer): 92 % of the nodes are dead, and a wave of four dead rows used to run on
+  // through the scale load and the whole epilogue -- 3 us of a wave slot each (profiles/r02_i_*): leave at once
+  if (ep.row_mark && __ballot(live) == 0ull) return;
   const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
-#endif
   if (!live) e = s;
   int maxlen = e - s;
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-  fetch(s + e16, e, cs, v);
+  fetch(short_at(0, maxlen), e, cs, v);
   for (int q = 0; q * 16 < maxlen; ++q) {
     const bool more = (q + 1) * 16 < maxlen;
-    if (prefetch && more) fetch(s + 16 * (q + 1) + e16, e, csn, vn);
+    if (prefetch && more) fetch(short_at(q + 1, maxlen), e, csn, vn);
     chunk(maxlen - 16 * q);
     if (prefetch) { cs = csn; v = vn; }
-    else if (more) fetch(s + 16 * (q + 1) + e16, e, cs, v);
+    else if (more) fetch(short_at(q + 1, maxlen), e, cs, v);
   }
-  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r, rng_base);
+  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -658,11 +630,8 @@ __device__ __forceinline__ void gather8x3(int c, float v0, float v1, float v2, c
     xx[t] = f4_zero();
     if (a0[t] != 0.f) xx[t] = ld_x<LPR>(X, cc[t], sub);     // (views are sub-graphs: a0 == 0 only for padding)
   }
-  // (the summation order of spmm_rows_kernel, so that the three outputs equal three launches bit for bit: ascending
-  // rounds with whole-half units, descending inside each half when tails are skipped -- see gather8_first)
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int t = srh::kSpmmTailUnit < 8 ? 7 - u : u;
+  for (int t = 0; t < 8; ++t) {
     acc[0] = f4_fma(a0[t], xx[t], acc[0]);
     acc[1] = f4_fma(a1[t], xx[t], acc[1]);
     acc[2] = f4_fma(a2[t], xx[t], acc[2]);

@@ -215,6 +215,14 @@ class FusedTrainer:
         self.vfree = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
                       and model in ("LightGCN", "XSimGCL", "SimGCL") and self.graph.weight is None)
         self.dinv = self.graph.dinv if self.vfree else None
+        # The column-masked launch (first backward product: 3/4 of its entries are dead, its waves run on a latency chain)
+        # gains nothing from the L2 classes of the dense plan and loses to their imbalance -- the batch's item rows are the
+        # heavy ones: on a class-free plan of the same arrays (256-entry segments, tasks dealt to all XCDs alike) it takes
+        # 23.1 instead of 27.4 us at the Yelp2018 shape (profiles/r02_i_spmm_plans_by_flavour.txt; the dense launches lose
+        # 10 us without the classes, the row-masked one is indifferent).
+        self.adj_cm = None
+        if dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 1 and self.d >= 64:
+            self.adj_cm = self.adj.replanned(split_len=256)
         # batch_fetch as a rider of the step's first product (see _step_front): models whose step starts with a plain
         # srh_spmm_f32 launch of a layer that is not the last
         self.ride_fetch = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
@@ -530,6 +538,14 @@ class FusedTrainer:
         bufs = [self.Hb, self.Ha] if src is self.Ha else [self.Ha, self.Hb]
         first = True                               # the chain's first product reads true values (gF / H_L)
 
+        def plan_for(kw):
+            """the matrix under the plan its launch flavour wants: column-masked launches run on the class-free plan"""
+            if self.adj_cm is None or "col_mark" not in kw:
+                return adj
+            if adj is self.adj:
+                return self.adj_cm
+            return ops.DeviceCSR(None, None, adj.vals, adj.shape, structure_of=self.adj_cm)    # (SGL view: same arrays)
+
         def scale_kw(add, last):
             """value-free bookkeeping of one product: pattern + row scale on input unless it is the chain's first,
             pre-scaled store unless it is the chain's last."""
@@ -545,7 +561,7 @@ class FusedTrainer:
                 sc.append(1.0)
             dst = bufs[0]
             skw, pkw = scale_kw(add, last=False)
-            ops.spmm(adj, src, out=loc(dst),
+            ops.spmm(plan_for(sparse_src), src, out=loc(dst),
                      epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
                                                 **{**sparse_add(add), **sparse_src, **skw}), **pkw)
             self._allgather(dst)
@@ -566,7 +582,7 @@ class FusedTrainer:
                 raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
         skw, pkw = scale_kw(add, last=True)
-        ops.spmm(adj, src, out=loc(self.gE0),
+        ops.spmm(plan_for(sparse_src), src, out=loc(self.gE0),
                  epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
                                             **{**sparse_add(add), **sparse_src, **skw}), **pkw)
 

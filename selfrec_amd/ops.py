@@ -207,6 +207,23 @@ class DeviceCSR:
     def with_values(self, vals):
         return DeviceCSR(None, None, vals, self.shape, device=self.vals.device, structure_of=self)
 
+    def replanned(self, split_len: int = 0, xcd_split_row: int = 0, row_mid=None):
+        """The same matrix (the device arrays are shared) under ANOTHER SpMM schedule: its own segment length and
+        task-to-XCD dealing.  The engine runs the batch-masked launches of a step on a finer, class-free plan."""
+        other = DeviceCSR.__new__(DeviceCSR)
+        other._lib = self._lib
+        other.shape, other.h_indptr, other.indptr, other.indices = self.shape, self.h_indptr, self.indptr, self.indices
+        h = C.c_void_p()
+        h_mid = None if row_mid is None else np.ascontiguousarray(row_mid, dtype=np.int32)
+        check(self._lib.srh_spmm_plan_create(C.byref(h), self.shape[0], self.shape[1],
+                                             self.h_indptr.ctypes.data_as(C.c_void_p), int(split_len), int(xcd_split_row),
+                                             None if h_mid is None else h_mid.ctypes.data_as(C.c_void_p)),
+              "srh_spmm_plan_create")
+        other._plan, other._plan_owner = h, None
+        other.vals, other.nnz = self.vals, self.nnz
+        other._arrays_of = self                    # (keeps the shared tensors' owner alive)
+        return other
+
 
 def column_class_order(indptr, indices, min_len: int):
     """Host helper for DeviceCSR(row_mid=...): reorder the entries of every row with >= min_len non-zeros

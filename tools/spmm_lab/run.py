@@ -56,43 +56,80 @@ def timed(fn, iters):
 
 
 def probe(lab, h, adj, lab_call, flavours, y, dev):
-    """Where does the dense launch's time go across the chip?  Variant 60 = variant 2 + {begin, end} of every wave on the
+    """Where does a launch's time go across the chip?  Variant 60 = variant 2 + {begin, end} of every wave on the
     chip-wide 100 MHz clock and the XCD it ran on.  Per XCD: waves, first begin, last begin, last end (us after the
-    launch's first wave began); per task kind: mean wave duration."""
+    launch's first wave began); per task kind: wave durations; waves alive over time.  Dense and row-masked flavours
+    (a wave whose rows are all dead leaves before its stamp)."""
     vp = C.c_void_p
     lab.lab_set_probe.argtypes = [vp]
     lab.lab_n_tasks.argtypes = [vp]
     n = lab.lab_n_tasks(h)
     buf = torch.zeros(3 * n, dtype=torch.int64, device=dev)
     assert lab.lab_set_probe(buf.data_ptr()) == 0
-    ep = flavours["dense"]()
-    for _ in range(5):
-        lab_call(adj, ep, 2, y)
-    torch.cuda.synchronize()
-    for rep in range(3):
-        buf.zero_()
-        lab_call(adj, ep, 60, y)
+    for flavour in ("dense", "row_masked"):
+        print(f"## flavour: {flavour}")
+        ep = flavours[flavour]()
+        for _ in range(5):
+            lab_call(adj, ep, 2, y)
         torch.cuda.synchronize()
-        rec = buf.cpu().numpy().reshape(n, 3)
-        t0 = rec[:, 0].min()
-        b, e = (rec[:, 0] - t0) / 100.0, (rec[:, 1] - t0) / 100.0          # 100 MHz ticks -> us
-        xcd, what = rec[:, 2] & 0xff, rec[:, 2] >> 8
-        print(f"# probe run {rep}: {n} waves, launch spans {e.max():.2f} us from the first wave's begin")
-        print(f"{'xcd':>4}{'waves':>8}{'first begin':>13}{'last begin':>12}{'last end':>10}{'sum of wave us':>16}")
-        for x in range(8):
-            m = xcd == x
-            if m.any():
-                print(f"{x:>4}{int(m.sum()):>8}{b[m].min():>13.2f}{b[m].max():>12.2f}{e[m].max():>10.2f}{(e[m] - b[m]).sum():>16.1f}")
-        for w, label in ((0, "coop, whole row"), (1, "coop, split segment"), (2, "4 short rows")):
-            m = what == w
-            if m.any():
-                d = e[m] - b[m]
-                print(f"#   {label:<20} {int(m.sum()):>6} waves, duration mean {d.mean():.2f} us, p50 {np.median(d):.2f}, p99 {np.percentile(d, 99):.2f}, "
-                      f"begin range {b[m].min():.2f} .. {b[m].max():.2f}")
-        # how busy the chip is over time: waves in flight per 2 us bucket
-        edges = np.arange(0, e.max() + 2.0, 2.0)
-        infl = [int(((b < hi) & (e > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
-        print("#   waves alive per 2 us bucket: " + " ".join(str(v) for v in infl))
+        for rep in range(2):
+            buf.zero_()
+            lab_call(adj, ep, 60, y)
+            torch.cuda.synchronize()
+            rec = buf.cpu().numpy().reshape(n, 3)
+            wave = np.flatnonzero(rec[:, 1] != 0)                  # stamped waves (dispatch order = task order)
+            rec = rec[wave]
+            t0 = rec[:, 0].min()
+            b, e = (rec[:, 0] - t0) / 100.0, (rec[:, 1] - t0) / 100.0          # 100 MHz ticks -> us
+            xcd, what = rec[:, 2] & 0xff, rec[:, 2] >> 8
+            print(f"# probe run {rep}: {len(wave)} of {n} waves stamped, launch spans {e.max():.2f} us from the first wave's begin")
+            print(f"{'xcd':>4}{'waves':>8}{'first begin':>13}{'last begin':>12}{'last end':>10}{'sum of wave us':>16}")
+            for x in range(8):
+                m = xcd == x
+                if m.any():
+                    print(f"{x:>4}{int(m.sum()):>8}{b[m].min():>13.2f}{b[m].max():>12.2f}{e[m].max():>10.2f}{(e[m] - b[m]).sum():>16.1f}")
+            for w, label in ((0, "coop, whole row"), (1, "coop, split segment"), (2, "4 short rows")):
+                m = what == w
+                if m.any():
+                    d = e[m] - b[m]
+                    print(f"#   {label:<20} {int(m.sum()):>6} waves, duration mean {d.mean():.2f} us, p50 {np.median(d):.2f}, "
+                          f"p99 {np.percentile(d, 99):.2f}, max {d.max():.2f}, begin range {b[m].min():.2f} .. {b[m].max():.2f}, last end {e[m].max():.2f}")
+            edges = np.arange(0, e.max() + 2.0, 2.0)
+            infl = [int(((b < hi) & (e > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+            print("#   waves alive per 2 us bucket: " + " ".join(str(v) for v in infl))
+            idx = np.flatnonzero(what <= 1)
+            step = max(1, len(idx) // 8)
+            for lo in range(0, len(idx), step):
+                sel = idx[lo:lo + step]
+                print(f"#     coop waves {wave[sel[0]]:>6}..{wave[sel[-1]]:>6} ({len(sel)}): begin {b[sel].min():6.2f}..{b[sel].max():6.2f}  "
+                      f"duration mean {(e[sel] - b[sel]).mean():6.2f} max {(e[sel] - b[sel]).max():6.2f}  last end {e[sel].max():6.2f}")
+
+
+def plans(adj, g, x, y, flavours, iters):
+    """us per PRODUCT launch (ops.spmm) of every flavour under other plans of the same matrix: the engine's (512-entry
+    segments, row x column classes dealt to XCD pairs) against class-free plans with shorter segments."""
+    fl = dict(flavours)
+    fl["dense_pattern"] = flavours["dense"]
+    print(f"{'plan':<44}" + "".join(f"{k:>15}" for k in fl))
+    cands = [("engine: split 512, 4 XCD classes", adj)]
+    for sl in (512, 256, 128, 64):
+        cands.append((f"split {sl}, no classes", adj.replanned(split_len=sl)))
+    cands.append(("split 256, row classes only", adj.replanned(split_len=256, xcd_split_row=g.n_users)))
+    cands.append(("split 128, row classes only", adj.replanned(split_len=128, xcd_split_row=g.n_users)))
+    ref = {}
+    for label, csr in cands:
+        cells = []
+        for name, mk in fl.items():
+            ep = mk()
+            kw = {"pattern": True} if name == "dense_pattern" else {}
+            out = ops.spmm(csr, x, epilogue=ep, **kw)
+            if name not in ref:
+                ref[name] = out.clone()
+            # (row-masked launches write the marked rows only: `out` is uninitialised elsewhere -- not compared)
+            err = float((out - ref[name]).abs().max().item()) if name != "row_masked" else float("nan")
+            t = timed(lambda: ops.spmm(csr, x, out=y, epilogue=ep, **kw), iters)
+            cells.append(f"{t:>8.2f} {err:6.0e}")
+        print(f"{label:<44}" + "".join(cells))
 
 
 def main():
@@ -101,6 +138,9 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--all", action="store_true")
+    ap.add_argument("--plans", action="store_true",
+                    help="the PRODUCT launch under other schedules of the same matrix (segment length, with / without the "
+                         "XCD classes), every flavour")
     ap.add_argument("--probe", action="store_true",
                     help="variant 60 only: per-wave begin / end stamps of the dense launch, summarised per XCD")
     ap.add_argument("--no-colclass", action="store_true", help="plain row storage (no [even | odd] column classes)")
@@ -155,6 +195,8 @@ def main():
     print(f"# ids: {args.ids}; column classes: {not args.no_colclass}")
     if args.probe:
         return probe(lab, h, adj, lab_call, flavours, y, dev)
+    if args.plans:
+        return plans(adj, g, x, y, flavours, args.iters)
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
