@@ -209,7 +209,7 @@ class DeviceCSR:
 
     def replanned(self, split_len: int = 0, xcd_split_row: int = 0, row_mid=None):
         """The same matrix (the device arrays are shared) under ANOTHER SpMM schedule: its own segment length and
-        task-to-XCD dealing.  The engine runs the batch-masked launches of a step on a finer, class-free plan."""
+        task-to-XCD dealing.  The engine runs the column-masked launch of a step on a class-free plan."""
         other = DeviceCSR.__new__(DeviceCSR)
         other._lib = self._lib
         other.shape, other.h_indptr, other.indptr, other.indices = self.shape, self.h_indptr, self.indptr, self.indices
@@ -225,17 +225,18 @@ class DeviceCSR:
         return other
 
 
-def column_class_order(indptr, indices, min_len: int):
+def column_class_order(indptr, indices, min_len: int, bit: int = 0):
     """Host helper for DeviceCSR(row_mid=...): reorder the entries of every row with >= min_len non-zeros
-    as [even columns | odd columns] (stable), leave the others alone.  Returns (perm, row_mid): apply
-    perm to indices / values / anything aligned with them; row_mid[r] = number of even-column entries of
-    a reordered row, or -1 - c for a row left whole whose columns are mostly of parity c."""
+    as [class-0 columns | class-1 columns] (stable), leave the others alone; a column's class is bit `bit` of its
+    id (0: even / odd).  Returns (perm, row_mid): apply perm to indices / values / anything aligned with them;
+    row_mid[r] = number of class-0 entries of a reordered row, or -1 - c for a row left whole whose columns are
+    mostly of class c."""
     indptr = np.asarray(indptr, dtype=np.int64)
     indices = np.asarray(indices)
     n = indptr.size - 1
     lens = np.diff(indptr)
     row_of = np.repeat(np.arange(n, dtype=np.int64), lens)
-    odd = (indices & 1).astype(np.int64)
+    odd = ((indices >> int(bit)) & 1).astype(np.int64)
     split = lens >= int(min_len)
     key = row_of * 2 + np.where(split[row_of], odd, 0)
     perm = np.argsort(key, kind="stable")

@@ -94,6 +94,14 @@ def probe(lab, h, adj, lab_call, flavours, y, dev):
                     d = e[m] - b[m]
                     print(f"#   {label:<20} {int(m.sum()):>6} waves, duration mean {d.mean():.2f} us, p50 {np.median(d):.2f}, "
                           f"p99 {np.percentile(d, 99):.2f}, max {d.max():.2f}, begin range {b[m].min():.2f} .. {b[m].max():.2f}, last end {e[m].max():.2f}")
+            slot8 = (wave // 4) % 8                                   # the block's position in the dispatch round: b % 8
+            print("#   b % 8 -> XCC_ID: " + ", ".join(f"{k}->{sorted(set(xcd[slot8 == k].tolist()))}" for k in range(8)))
+            for k in range(8):
+                m = slot8 == k
+                if m.any():
+                    d = e[m] - b[m]
+                    print(f"#   blocks b % 8 == {k}: {int(m.sum())} waves, sum of wave us {d.sum():9.1f}, coop mean {d[what[m] <= 1].mean():6.2f}, "
+                          f"short mean {d[what[m] == 2].mean() if (what[m] == 2).any() else 0:6.2f}, last end {e[m].max():6.2f}")
             edges = np.arange(0, e.max() + 2.0, 2.0)
             infl = [int(((b < hi) & (e > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
             print("#   waves alive per 2 us bucket: " + " ".join(str(v) for v in infl))
@@ -110,12 +118,11 @@ def plans(adj, g, x, y, flavours, iters):
     segments, row x column classes dealt to XCD pairs) against class-free plans with shorter segments."""
     fl = dict(flavours)
     fl["dense_pattern"] = flavours["dense"]
-    print(f"{'plan':<44}" + "".join(f"{k:>15}" for k in fl))
+    print(f"{'plan':<52}" + "".join(f"{k:>15}" for k in fl))
     cands = [("engine: split 512, 4 XCD classes", adj)]
-    for sl in (512, 256, 128, 64):
+    for sl in (512, 256):
         cands.append((f"split {sl}, no classes", adj.replanned(split_len=sl)))
     cands.append(("split 256, row classes only", adj.replanned(split_len=256, xcd_split_row=g.n_users)))
-    cands.append(("split 128, row classes only", adj.replanned(split_len=128, xcd_split_row=g.n_users)))
     ref = {}
     for label, csr in cands:
         cells = []
@@ -129,7 +136,41 @@ def plans(adj, g, x, y, flavours, iters):
             err = float((out - ref[name]).abs().max().item()) if name != "row_masked" else float("nan")
             t = timed(lambda: ops.spmm(csr, x, out=y, epilogue=ep, **kw), iters)
             cells.append(f"{t:>8.2f} {err:6.0e}")
-        print(f"{label:<44}" + "".join(cells))
+        print(f"{label:<52}" + "".join(cells))
+
+
+def class_bits(data, dev, bits, iters, tu, ti, U, I):
+    """Which bit of the column id should split the long rows into their two column classes?  Parity (bit 0) is bit 8 of a
+    256-byte x row's address -- if the L2 picks its channel from that bit, an XCD that gathers one parity only uses half
+    of its channels.  Same matrix, same kernels, the class bit alone changes (ops.column_class_order)."""
+    from selfrec_amd.data import device_graph as dg
+    orig = ops.column_class_order
+    N, d = U + I, 64
+    gen = torch.Generator().manual_seed(1)
+    x = (torch.randn((N, d), generator=gen) * 0.1).to(dev)
+    y = torch.zeros((N, d), device=dev)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(len(tu), size=2048, replace=False)
+    marked = np.unique(np.concatenate([tu[pick], ti[pick] + U, rng.integers(0, I, 2048) + U]))
+    mark = torch.zeros(N, dtype=torch.int32, device=dev)
+    mark[torch.from_numpy(marked).to(dev)] = 7
+    stamp = torch.tensor([7], dtype=torch.int64, device=dev)
+    fl = {"dense": (lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=1, rng_offset=0), {}),
+          "dense_pattern": (lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=1, rng_offset=0), {"pattern": True}),
+          "row_masked": (lambda: ops.make_epilogue(perturb_eps=0.2, rng_seed=1, rng_offset=0, row_mark=mark, mark_stamp=stamp), {}),
+          "plain": (lambda: None, {})}
+    print(f"{'column class':<28}" + "".join(f"{k:>15}" for k in fl))
+    for b in bits:
+        ops.column_class_order = (lambda ip, ix, ml, _b=b: orig(ip, ix, ml, bit=_b))
+        dg.ops.column_class_order = ops.column_class_order
+        g = dg.DeviceGraph(data.interaction_mat, dev, column_classes=True)
+        cells = []
+        for name, (mk, kw) in fl.items():
+            ep = mk()
+            cells.append(f"{timed(lambda: ops.spmm(g.adj, x, out=y, epilogue=ep, **kw), iters):>15.2f}")
+        print(f"{'bit ' + str(b) + ' of the column id':<28}" + "".join(cells))
+        del g
+    ops.column_class_order = orig
 
 
 def main():
@@ -138,6 +179,9 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--all", action="store_true")
+    ap.add_argument("--class-bits", default="",
+                    help="comma-separated bits of the column id to try as the column class of long rows (0 = even / odd, the "
+                         "engine's): us per product launch of every flavour for each")
     ap.add_argument("--plans", action="store_true",
                     help="the PRODUCT launch under other schedules of the same matrix (segment length, with / without the "
                          "XCD classes), every flavour")
@@ -160,6 +204,8 @@ def main():
         Interaction({}, synth.as_triples(tu, ti), [])
     if args.ids != "raw":
         tu, ti = data.train_u.astype(np.int64), data.train_i.astype(np.int64)
+    if args.class_bits:
+        return class_bits(data, dev, [int(b) for b in args.class_bits.split(",")], args.iters, tu, ti, U, I)
     g = data.device_graph(dev, column_classes=not args.no_colclass)
     adj, N, d = g.adj, g.n_nodes, 64
     gen = torch.Generator().manual_seed(1)
