@@ -111,6 +111,33 @@ __device__ __forceinline__ float4 load_f4_agent(const float4* p) {
   return v;
 }
 
+// The partial sums of a split row, added in slot order by the segment that arrived last: partials t0, t0 + step, ...
+// (< hn) of this lane's 16 bytes.  Eight 16-byte agent-scope loads are in flight before the first add (one
+// global_load_dwordx4 sc1 each; 16-byte sc1 accesses are observed untorn on gfx950, MI355X_MICROARCH.md): the plain loop
+// -- four dword loads, wait, add, per partial -- put up to 30 dependent round trips at the end of the heaviest rows, which
+// is the critical path of the batch-masked launches (profiles/r02_i_wave_timeline_*).  Same order of additions.
+__device__ __forceinline__ float4 sum_partials_agent(const float4* base, int t0, int step, int hn, int stride4) {
+  typedef float fx4 __attribute__((ext_vector_type(4)));
+  float4 sum = f4_zero();
+  int t = t0;
+  for (; t + 7 * step < hn; t += 8 * step) {
+    fx4 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(p[k]) : "v"(base + (size_t)(t + k * step) * stride4) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])::"memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum = f4_add(sum, make_float4(p[k].x, p[k].y, p[k].z, p[k].w));
+  }
+  for (; t < hn; t += step) {
+    fx4 q;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(base + (size_t)t * stride4) : "memory");
+    sum = f4_add(sum, make_float4(q.x, q.y, q.z, q.w));
+  }
+  return sum;
+}
+
 // y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
 template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
@@ -578,8 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != hn - 1) return;
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    float4 sum = f4_zero();
-    for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
+    float4 sum = sum_partials_agent(partial + (size_t)hfirst * LPR + sub, g, G, hn, LPR);
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
     row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
