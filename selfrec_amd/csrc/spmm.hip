@@ -98,19 +98,9 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 // Epilogue on one full row held as float4 per lane of an LPR-lane group.  Executed by all
 // groups of the wave with identical data (they all hold the reduced row); `store` selects
 // the group that writes.
-// Agent-scope (sc1) load of a partial another XCD published with a write-through store: coherence per
-// access.  An acquire FENCE here (buffer_inv sc1) drops the whole XCD L2 -- thousands of them per launch
-// were costing the x rows their hit rate.
-__device__ __forceinline__ float4 load_f4_agent(const float4* p) {
-  const float* q = reinterpret_cast<const float*>(p);
-  float4 v;
-  v.x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return v;
-}
-
+// Partials another XCD published with a write-through store are read with agent-scope (sc1) loads: coherence per
+// access.  An acquire FENCE instead (buffer_inv sc1) drops the whole XCD L2 -- thousands of them per launch were
+// costing the x rows their hit rate.
 // The partial sums of a split row, added in slot order by the segment that arrived last: partials t0, t0 + step, ...
 // (< hn) of this lane's 16 bytes.  Eight 16-byte agent-scope loads are in flight before the first add (one
 // global_load_dwordx4 sc1 each; 16-byte sc1 accesses are observed untorn on gfx950, MI355X_MICROARCH.md): the plain loop
@@ -729,8 +719,7 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
-      float4 sum = f4_zero();
-      for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * 64 + v * LPR + sub));
+      float4 sum = sum_partials_agent(partial + (size_t)hfirst * 64 + v * LPR + sub, g, G, hn, 64);
 #pragma unroll
       for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
       if (g == 0) Y[v][(size_t)row * LPR + sub] = sum;
@@ -1157,8 +1146,7 @@ __global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict_
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != hn - 1) return;
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    float4 sum = f4_zero();
-    for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
+    float4 sum = sum_partials_agent(partial + (size_t)hfirst * LPR + sub, g, G, hn, LPR);
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
     row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);

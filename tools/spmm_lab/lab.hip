@@ -208,7 +208,7 @@ __device__ __forceinline__ void finish_split(float4 acc, int row, int slot, int 
   if (ticket != hn - 1) return;
   if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float4 sum = f4_zero();
-  for (int t = g; t < hn; t += G) sum = f4_add(sum, load_f4_agent(partial + (size_t)(hfirst + t) * LPR + sub));
+  sum = sum_partials_agent(partial + (size_t)hfirst * LPR + sub, g, G, hn, LPR);
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
   row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep);
