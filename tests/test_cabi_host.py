@@ -120,6 +120,29 @@ def test_seed_matches_cpython_for_wide_seeds():
         assert [s.next_u32() for _ in range(3)] == want
 
 
+def test_column_class_order_by_another_bit_of_the_column_id():
+    """`bit` picks which bit of the column id defines the two classes (0 = parity, the engine's): still a stable
+    partition of the long rows, short rows untouched, and row_mid counts the class-0 entries."""
+    import numpy as np
+    from selfrec_amd import ops
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 50, 150)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(4096, size=n, replace=False)) for n in lens]).astype(np.int32)
+    for bit in (1, 3, 7):
+        perm, row_mid = ops.column_class_order(indptr, indices, 16, bit=bit)
+        assert sorted(perm.tolist()) == list(range(indices.size))
+        new = indices[perm]
+        for r, n in enumerate(lens):
+            old_row, new_row = indices[indptr[r]:indptr[r + 1]], new[indptr[r]:indptr[r + 1]]
+            cls = (old_row >> bit) & 1
+            if n >= 16:
+                assert row_mid[r] == int((cls == 0).sum())
+                assert np.array_equal(new_row, np.concatenate([old_row[cls == 0], old_row[cls == 1]]))
+            else:
+                assert np.array_equal(new_row, old_row) and row_mid[r] == -1 - int((cls == 1).sum() > (cls == 0).sum())
+
+
 def test_column_class_order_is_a_stable_partition_of_long_rows():
     """ops.column_class_order (host side of srh_spmm_plan_create's h_row_mid): a permutation that leaves
     short rows alone and stores long rows [even columns | odd columns], each part in its old order."""

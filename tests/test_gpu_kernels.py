@@ -140,6 +140,42 @@ def test_spmm3_equals_three_launches():
         ops.spmm3(views, x128, [torch.empty((n, 128), device=DEV) for _ in range(3)])
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_spmm_under_another_plan_of_the_same_arrays(d):
+    """DeviceCSR.replanned: the same device arrays under a second schedule (the engine runs the column-masked launch of a
+    step on a class-free plan with shorter segments): same product in every flavour -- plain, pattern (no value stream),
+    row-masked, column-masked -- split heavy rows included, and the two objects share indices and values."""
+    n, U = 2600, 1000
+    m = powerlaw_csr(n, n, 52000, seed=31, heavy_rows=4, heavy_len=1700, empty_rows=9)
+    perm, row_mid = ops.column_class_order(m.indptr, m.indices, 64)
+    base = ops.DeviceCSR(m.indptr, m.indices[perm], m.data[perm], m.shape, xcd_split_row=U, row_mid=row_mid)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    tx = torch.from_numpy(x).to(DEV)
+    want = m.astype(np.float64) @ x.astype(np.float64)
+    ones = sp.csr_matrix((np.ones_like(m.data), m.indices, m.indptr), shape=m.shape)
+    want_pattern = ones.astype(np.float64) @ x.astype(np.float64)
+    live = rng.random(n) < 0.25
+    mark = torch.from_numpy(np.where(live, 7, 3).astype(np.int32)).to(DEV)
+    stamp = torch.tensor([7], dtype=torch.int64, device=DEV)
+    xz = x.copy(); xz[~live] = 0.0
+    want_cols = m.astype(np.float64) @ xz.astype(np.float64)
+    for split, split_row in ((256, 0), (128, 0), (512, U)):
+        other = base.replanned(split_len=split, xcd_split_row=split_row)
+        assert other.indices.data_ptr() == base.indices.data_ptr() and other.vals.data_ptr() == base.vals.data_ptr()
+        assert rel_err(ops.spmm(other, tx).cpu().numpy(), want) < 2e-6
+        assert rel_err(ops.spmm(other, tx, pattern=True).cpu().numpy(), want_pattern) < 2e-6
+        got = ops.spmm(other, tx, epilogue=ops.make_epilogue(col_mark=mark, mark_stamp=stamp))
+        assert rel_err(got.cpu().numpy(), want_cols) < 2e-6
+        out = torch.full((n, d), -5.0, device=DEV)
+        ops.spmm(other, tx, out=out, epilogue=ops.make_epilogue(row_mark=mark, mark_stamp=stamp))
+        out = out.cpu().numpy()
+        assert rel_err(out[live], want[live]) < 2e-6 and (out[~live] == -5.0).all()
+        assert torch.equal(ops.spmm(other, tx), ops.spmm(other, tx))          # fixed reduction order
+    del other
+    assert rel_err(ops.spmm(base, tx).cpu().numpy(), want) < 2e-6            # the first plan is untouched
+
+
 @pytest.mark.parametrize("d,min_len", [(64, 64), (64, 8), (128, 16), (32, 16)])
 def test_spmm_with_column_class_schedule_matches_scipy(d, min_len):
     """Rows of >= min_len non-zeros stored [even columns | odd columns] and scheduled as two segments on
