@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = a list of stages; everything lands in gpurun_out/.
-# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab bench benchquick refmodels prof pmc big cols
+# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab labprobe labplans labbits gatherlds bench benchquick refmodels prof pmc big cols
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -31,6 +31,14 @@ lab3)
   timeout 900 python tools/spmm_lab/run.py --ids first-appearance --no-colclass > $OUT/spmm_lab_nocc.log 2>&1; echo "lab3 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_nocc.log | tail -${LAB_TAIL:-20};;
 lab2)
   timeout 900 python tools/spmm_lab/run.py --ids first-appearance > $OUT/spmm_lab_fa.log 2>&1; echo "lab2 exit $?"; grep -v amdgpu.ids $OUT/spmm_lab_fa.log | tail -${LAB_TAIL:-20};;
+labprobe)
+  timeout 300 python tools/spmm_lab/run.py --ids first-appearance --probe > $OUT/lab_probe.txt 2>&1; echo "labprobe exit $?"; grep -v amdgpu.ids $OUT/lab_probe.txt | tail -${LAB_TAIL:-60};;
+labplans)
+  timeout 300 python tools/spmm_lab/run.py --ids first-appearance --plans > $OUT/lab_plans.txt 2>&1; echo "labplans exit $?"; grep -v amdgpu.ids $OUT/lab_plans.txt | tail -${LAB_TAIL:-14};;
+labbits)
+  timeout 400 python tools/spmm_lab/run.py --ids first-appearance --class-bits ${CLASS_BITS:-0,1,2,3,4,6,9} > $OUT/lab_classbits.txt 2>&1; echo "labbits exit $?"; grep -v amdgpu.ids $OUT/lab_classbits.txt | tail -12;;
+gatherlds)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_lds.hip -o /tmp/gather_lds.out && timeout 120 /tmp/gather_lds.out > $OUT/gather_lds.txt 2>&1; echo "gatherlds exit $?"; cat $OUT/gather_lds.txt;;
 evalprobe)
   timeout 600 python tools/eval_probe.py > $OUT/eval_probe.log 2>&1; echo "evalprobe exit $?"; grep -v amdgpu.ids $OUT/eval_probe.log | tail -3;;
 lossprobe)
