@@ -861,12 +861,9 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
         plan->d_tasks64[1], n, d_indices, VALS, reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), \
         reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep, 0, no_rider); \
   } while (0)
-    case 70: LAB_PRODUCT(4, d_vals); break;       /* product kernel, tails in units of 4 rounds, coop entries round-robin */
-    case 71: LAB_PRODUCT(2, d_vals); break;       /* ... units of 2 */
-    case 75: LAB_PRODUCT(1, d_vals); break;       /* ... single rounds */
-    case 72: LAB_PRODUCT(4, nullptr); break;      /* the same as pattern products (no value stream): vs all-ones values */
-    case 73: LAB_PRODUCT(2, nullptr); break;
-    case 76: LAB_PRODUCT(1, nullptr); break;
+    case 75: LAB_PRODUCT(1, d_vals); break;       /* product kernel, chunk tails issue only the rounds they need (the default) */
+    case 76: LAB_PRODUCT(1, nullptr); break;      /* ... as a pattern product (no value stream): vs all-ones values */
+    case 77: LAB_PRODUCT(8, d_vals); break;       /* product kernel with whole eight-round halves (SRH_SPMM_TAIL_UNIT = 8) */
     case 74: LAB_PRODUCT(8, nullptr); break;      /* the product's own pattern launch, for the same-table comparison */
 #define LAB_LAUNCH2(KK, DD, VV)                                                                                      \
   do {                                                                                                               \
