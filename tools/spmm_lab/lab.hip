@@ -819,6 +819,43 @@ int lab_set_probe(void* d_buf) {
 }
 int lab_n_tasks(void* h) { return reinterpret_cast<lab::Lab*>(h)->n_tasks; }
 
+// ---- custom task lists (run.py --balance): the plan's Task64 records on the host, and launches over a caller's list ----
+// The plan binds task k to block k / 4 and the hardware binds block b to XCD b % 8, so every XCD gets the same NUMBER of
+// blocks; the XCDs do not take the same TIME over them (profiles/r02_i_wave_timeline_*: 3.5 us between the first and the
+// last to finish).  A list in which a slow XCD's last blocks are EMPTY records (kind 1, count 0: the wave leaves at once)
+// and their tasks sit in extra blocks of a fast XCD gives unequal shares without touching the kernel.
+int lab_get_tasks64(const srh_spmm_plan_t* plan, void* host_out, int max_n) {
+  const int n = plan->n_tasks[1];
+  if (n > max_n) return -n;
+  return hipMemcpy(host_out, plan->d_tasks64[1], sizeof(Task64) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? n : -1;
+}
+// probe = 0: the PRODUCT kernel over d_tasks (n_tasks records, a multiple of 4);  probe = 1: the stamping kernel
+// (rows_kernel<60>: begin / end / XCD of every wave into the buffer set by lab_set_probe, 3 x n_tasks uint64)
+int lab_spmm_custom(void* h, const srh_spmm_plan_t* plan, const void* d_tasks, int n_tasks, const int32_t* d_indices,
+                    const float* d_vals, const float* d_x, float* d_y, const srh_spmm_epilogue_t* epi, void* stream, int probe) {
+  using namespace lab;
+  Lab* L = reinterpret_cast<Lab*>(h);
+  DevEpilogue ep{};
+  if (translate_epilogue(epi, 64, d_x, d_y, ep) != SRH_OK) return -2;
+  if (ep.col_mark) return -6;
+  hipStream_t st = srh::as_stream(stream);
+  const Task64* tasks = reinterpret_cast<const Task64*>(d_tasks);
+  const int blocks = (n_tasks + 3) / 4;
+  if (probe) {
+    if (!d_vals) return -7;
+    rows_kernel<60><<<blocks, 256, 0, st>>>(plan->d_tasks[1], tasks, n_tasks, plan->d_tsegs, d_indices, d_vals,
+                                            reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
+                                            reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner,
+                                            plan->d_tickets, L->d_bits, L->n_bit_words, (int)plan->n_cols, ep);
+  } else {
+    srh_batch_fetch_args_t no_rider{};
+    spmm_rows_kernel<16, false, srh::kSpmmTailUnit><<<blocks, 256, 0, st>>>(
+        tasks, n_tasks, d_indices, d_vals, reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
+        reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep, 0, no_rider);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // refresh the column bitmap from the epilogue's col_mark / stamp (not timed with the product: batch_fetch would write it)
 int lab_build_bits(void* h, const int32_t* d_mark, const int64_t* d_stamp, int n, void* stream) {
   lab::Lab* L = reinterpret_cast<lab::Lab*>(h);

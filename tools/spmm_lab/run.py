@@ -170,6 +170,81 @@ def class_bits(data, dev, bits, iters, tu, ti, U, I):
     ops.column_class_order = orig
 
 
+def balance(lab, h, adj, x, y, flavours, iters, dev, st):
+    """Do unequal XCD shares of the task list pay?  (the XCDs finish a dense launch 3.5 us apart although the
+    plan deals every one of them the same number of blocks; block b runs on XCD b % 8.)  The plan's Task64 list is read back,
+    cut into per-XCD queues, and in each round the probe kernel's per-XCD finish times move the LAST blocks of the late XCDs
+    to the ends of the early ones' queues; vacated positions become empty records.  Prints, per round, the product kernel's
+    time over that list (dense flavour, with values) next to the finish times.  Not in the library: an experiment."""
+    vp, i32 = C.c_void_p, C.c_int32
+    lab.lab_get_tasks64.argtypes = [vp, vp, i32]
+    lab.lab_spmm_custom.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, C.POINTER(_lib.SpmmEpilogue), vp, i32]
+    lab.lab_set_probe.argtypes = [vp]
+    lab.lab_n_tasks.argtypes = [vp]
+    n = lab.lab_n_tasks(h)
+    host = np.zeros((n, 16), dtype=np.int32)
+    assert lab.lab_get_tasks64(adj._plan, host.ctypes.data_as(vp), n) == n
+    pad = (-n) % 4
+    empty = np.zeros((1, 16), dtype=np.int32)
+    empty[0, 0] = 1                                             # kind 1, count 0: a wave with nothing to do
+    blocks = np.concatenate([host, np.repeat(empty, pad, axis=0)]).reshape(-1, 4, 16)
+    queues = [[blocks[b] for b in range(k, len(blocks), 8)] for k in range(8)]
+    ep = flavours["dense"]()
+    y2 = torch.zeros_like(y)
+    ops.spmm(adj, x, out=y2, epilogue=ep)                       # what every list must reproduce
+
+    def assemble(qs):
+        depth = max(len(q) for q in qs)
+        out = np.repeat(empty[None], depth * 8 * 4, axis=0).reshape(depth * 8, 4, 16).copy()
+        for k, q in enumerate(qs):
+            for pos, blk in enumerate(q):
+                out[pos * 8 + k] = blk
+        return torch.from_numpy(out.reshape(-1, 16)).to(dev)
+
+    def run(tasks, probe):
+        rc = lab.lab_spmm_custom(h, adj._plan, tasks.data_ptr(), int(tasks.shape[0]), adj.indices.data_ptr(), adj.vals.data_ptr(),
+                                 x.data_ptr(), y.data_ptr(), C.byref(ep), st, probe)
+        assert rc == 0, rc
+
+    print(f"{'round':<7}{'product us':>11}{'max |err|':>11}   per-XCD finish (us) of the probe kernel / real blocks per XCD")
+    for rnd in range(5):
+        tasks = assemble(queues)
+        y.fill_(float("nan"))
+        run(tasks, 0)
+        torch.cuda.synchronize()
+        err = float((y - y2).abs().max().item())
+        t = timed(lambda: run(tasks, 0), iters)
+        buf = torch.zeros(3 * int(tasks.shape[0]), dtype=torch.int64, device=dev)
+        assert lab.lab_set_probe(buf.data_ptr()) == 0
+        fin = np.zeros(8)
+        for _ in range(3):                                       # (median of three probe launches)
+            buf.zero_()
+            run(tasks, 1)
+            torch.cuda.synchronize()
+            rec = buf.cpu().numpy().reshape(-1, 3)
+            rec = rec[rec[:, 1] != 0]
+            t0 = rec[:, 0].min()
+            e, xcd = (rec[:, 1] - t0) / 100.0, rec[:, 2] & 0xff
+            fin += np.array([e[xcd == k].max() for k in range(8)]) / 3
+        print(f"{rnd:<7}{t:>11.2f}{err:>11.1e}   " + " ".join(f"{v:6.2f}" for v in fin) + "  /  " + " ".join(str(len(q)) for q in queues))
+        # move blocks: about 0.035 us of finish time per tail block (9 us x 4 waves over 1,024 slots); gain 0.7
+        want = np.round(0.7 * (fin - fin.mean()) / 0.035).astype(int)
+        givers = [k for k in range(8) if want[k] > 0]
+        takers = sorted((k for k in range(8) if want[k] < 0), key=lambda k: want[k])
+        pool = []
+        for k in givers:
+            m = min(int(want[k]), len(queues[k]) // 4)
+            pool += queues[k][len(queues[k]) - m:]
+            del queues[k][len(queues[k]) - m:]
+        need = np.array([-want[k] for k in takers], dtype=float)
+        if pool and need.sum() > 0:
+            share = np.floor(need / need.sum() * len(pool)).astype(int)
+            share[0] += len(pool) - share.sum()
+            for k, m in zip(takers, share):
+                queues[k] += pool[:m]
+                pool = pool[m:]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="yelp2018")
@@ -179,6 +254,9 @@ def main():
     ap.add_argument("--class-bits", default="",
                     help="comma-separated bits of the column id to try as the column class of long rows (0 = even / odd, the "
                          "engine's): us per product launch of every flavour for each")
+    ap.add_argument("--balance", action="store_true",
+                    help="closed-loop experiment: unequal shares of the task list per XCD (empty blocks at the end of a slow "
+                         "XCD's queue, its last tasks appended to a fast XCD's), driven by the per-XCD finish times of the probe")
     ap.add_argument("--plans", action="store_true",
                     help="the PRODUCT launch under other schedules of the same matrix (segment length, with / without the "
                          "XCD classes), every flavour")
@@ -240,6 +318,8 @@ def main():
         return probe(lab, h, adj, lab_call, flavours, y, dev)
     if args.plans:
         return plans(adj, g, x, y, flavours, args.iters)
+    if args.balance:
+        return balance(lab, h, adj, x, y, flavours, args.iters, dev, st)
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
