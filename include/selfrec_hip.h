@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 19
+#define SRH_ABI_VERSION 20
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -144,6 +144,19 @@ typedef struct srh_spmm_plan srh_spmm_plan_t;
 srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t n_cols,
                                   const int32_t* h_indptr, int32_t split_len /* 0 = default */,
                                   int64_t xcd_split_row, const int32_t* h_row_mid);
+
+/* Unequal XCD shares of a plan's task list (tables of d = 64 / 128 / 256 columns).  A task list binds task k to
+ * workgroup k / 4 and the hardware runs workgroup b on XCD b % 8 (observed, performance only), so every XCD gets the same
+ * NUMBER of workgroups -- but not the same time over them: at the Yelp2018 shape the XCDs finish a propagation launch
+ * 3.5 us apart.  h_blocks_per_xcd[8] (>= 0, adding up to ceil(srh_spmm_plan_run_tasks() / 4) of the canonical list)
+ * says how many workgroups of real tasks each XCD runs; queues above their share give up their last workgroups (the
+ * shortest rows), the others append them, and empty records pad the list.  NULL restores the canonical list.  Same
+ * tasks, same sums bit for bit; locality / balance only.  Synchronises the device: not inside a stream capture, and a
+ * captured launch of this plan must be re-captured afterwards.  The engine calibrates the shares once at start-up
+ * from srh_spmm_f32_probe (engine.py). */
+srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_blocks_per_xcd);
+/* records in the list a launch on d-column tables runs now (a multiple of 32 once shares are set); -1: no such list */
+int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d);
 void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
 
 enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };
@@ -451,6 +464,14 @@ srh_status_t srh_batch_fetch(const srh_batch_fetch_args_t* args, void* stream);
 srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t* d_indptr, const int32_t* d_indices,
                                      const float* d_vals, const float* d_x, float* d_y, int32_t d,
                                      const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch, void* stream);
+
+/* srh_spmm_f32 (no column marks, d = 64 / 128 / 256) that also leaves, for task k of the list, d_stamps[3k .. 3k+2] =
+ * {begin, end} of its wave on the chip-wide 100 MHz clock and the XCD (0 .. 7) it ran on; records of tasks that do not
+ * exist in the list stay untouched.  d_stamps: 3 * srh_spmm_plan_run_tasks(plan, d) uint64 of device memory.  What the
+ * calibration of srh_spmm_plan_set_xcd_shares reads; tools/spmm_lab/run.py --probe draws timelines from it. */
+srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals,
+                                const float* d_x, float* d_y, int32_t d, const srh_spmm_epilogue_t* epi,
+                                uint64_t* d_stamps, void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
  * d_counts[k] is NULL).  The sparse counterpart of a memset for gradient buffers that only

@@ -75,6 +75,7 @@ struct DevEpilogue {
   // row scaling (value-free products: include/selfrec_hip.h)
   const float* row_scale;
   int32_t scale_flags, prev_unscale, add_rowscale;
+  unsigned long long* stamps;    // srh_spmm_f32_probe: {begin, end, XCD} per wave (PROBE instantiations only)
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -466,7 +467,9 @@ struct alignas(64) Task64 {
 // (gather8_tail) and a cooperative task deals its entries to the row-groups round-robin (entry k of a chunk -> group
 // k % G, round k / G) instead of in blocks of 16, so that a tail of R entries needs ceil(R / G) rounds with every group
 // busy rather than up to 16 rounds with one.
-template <int LPR, bool COLMASK, int UNIT = srh::kSpmmTailUnit>
+// PROBE (srh_spmm_f32_probe): every wave also leaves {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
+// in stamps[3 * wave ..] -- what the engine's start-up calibration of the plan's XCD shares reads (engine.py).
+template <int LPR, bool COLMASK, int UNIT = srh::kSpmmTailUnit, bool PROBE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WAVES, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
@@ -487,6 +490,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   const int wave = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x - n_fetch) * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
+  unsigned long long t_begin = 0;
+  unsigned xcc = 0;
+  if constexpr (PROBE) {
+    t_begin = wall_clock64();
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  }
+  auto leave = [&]() {
+    if constexpr (PROBE) if (lane == 0) {
+      ep.stamps[3 * (size_t)wave] = t_begin;
+      ep.stamps[3 * (size_t)wave + 1] = wall_clock64();
+      ep.stamps[3 * (size_t)wave + 2] = xcc & 0xfu;
+    }
+  };
   const int g = lane / LPR, sub = lane % LPR, e16 = lane & 15;
   const unsigned sub16 = (unsigned)sub * 16u;
   const int stamp = ep.mark_stamp ? (int)(*ep.mark_stamp) : 0;
@@ -567,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
 
   if (kind == 0) {
     row = __builtin_amdgcn_readfirstlane(row); s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
-    if (ep.row_mark && ep.row_mark[row] != stamp) return;
+    if (ep.row_mark && ep.row_mark[row] != stamp) { leave(); return; }
     const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
     fetch(coop_at(s), e, cs, v);
     for (int base = s; base < e; base += CH) {
@@ -582,6 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
       row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r);
+      leave();
       return;
     }
     if (g == 0) store_f4_sc1(partial + (size_t)slot * LPR + sub, a4);
@@ -593,12 +610,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
     int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + hid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != hn - 1) return;
+    if (ticket != hn - 1) { leave(); return; }
     if (lane == 0) __hip_atomic_store(tickets + hid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     float4 sum = sum_partials_agent(partial + (size_t)hfirst * LPR + sub, g, G, hn, LPR);
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
     row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
+    leave();
     return;
   }
 
@@ -606,7 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   const bool live = g < count && (!ep.row_mark || ep.row_mark[row] == stamp);
   // row-masked launches (last forward layer): 92 % of the nodes are dead, and a wave of four dead rows used to run on
   // through the scale load and the whole epilogue -- 3 us of a wave slot each (profiles/r02_i_*): leave at once
-  if (ep.row_mark && __ballot(live) == 0ull) return;
+  if (ep.row_mark && __ballot(live) == 0ull) { leave(); return; }
   const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
   if (!live) e = s;
   int maxlen = e - s;
@@ -622,6 +640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
     else if (more) fetch(short_at(q + 1, maxlen), e, cs, v);
   }
   row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
+  leave();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1201,6 +1220,11 @@ struct srh_spmm_plan {
   Task* d_tasks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Seg* d_tsegs = nullptr;          // segments in task order (+ 16 padding records: a short-row task may read past its count)
   Task64* d_tasks64[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // spmm_rows_kernel's records (index 1..3)
+  // srh_spmm_plan_set_xcd_shares: the list a launch runs may deal the XCDs unequal numbers of blocks (empty records
+  // pad the shorter queues); the canonical list stays on the host
+  std::vector<Task64> h_tasks64[5];
+  int32_t n_run[5] = {0, 0, 0, 0, 0};       // records in d_tasks64[gi] (a multiple of 32 once shares are set)
+  size_t cap64[5] = {0, 0, 0, 0, 0};        // records d_tasks64[gi] has room for
   Heavy* d_heavy = nullptr;
   int32_t* d_slot_owner = nullptr;
   int32_t* d_tickets = nullptr;    // one arrival counter per split row, self re-arming
@@ -1426,6 +1450,9 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
     err = hipMalloc(&p->d_tasks64[gi], sizeof(Task64) * std::max<size_t>(1, t64.size()));
     if (err == hipSuccess && !t64.empty())
       err = hipMemcpy(p->d_tasks64[gi], t64.data(), sizeof(Task64) * t64.size(), hipMemcpyHostToDevice);
+    p->n_run[gi] = (int32_t)t64.size();
+    p->cap64[gi] = std::max<size_t>(1, t64.size());
+    p->h_tasks64[gi] = std::move(t64);
   }
   if (err == hipSuccess && !heavy.empty()) {
     err = hipMalloc(&p->d_heavy, sizeof(Heavy) * heavy.size());
@@ -1483,10 +1510,84 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
   return srh_spmm_f32_with_fetch(plan, d_indptr, d_indices, d_vals, d_x, d_y, d, epi, nullptr, stream);
 }
 
+static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
+                                float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch,
+                                unsigned long long* d_stamps, void* stream);
+
 srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t* d_indptr, const int32_t* d_indices,
                                      const float* d_vals, const float* d_x, float* d_y, int32_t d,
                                      const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch, void* stream) {
   (void)d_indptr;  // the schedule in `plan` already encodes the row extents
+  return spmm_launch(plan, d_indices, d_vals, d_x, d_y, d, epi, fetch, nullptr, stream);
+}
+
+srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
+                                float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, uint64_t* d_stamps, void* stream) {
+  SRH_REQUIRE(d_stamps, "spmm_f32_probe: null stamp buffer");
+  SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_f32_probe: d=%d unsupported (64, 128 or 256)", d);
+  return spmm_launch(plan, d_indices, d_vals, d_x, d_y, d, epi, nullptr, reinterpret_cast<unsigned long long*>(d_stamps), stream);
+}
+
+int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d) {
+  if (!plan) return -1;
+  return d == 64 ? plan->n_run[1] : d == 128 ? plan->n_run[2] : d == 256 ? plan->n_run[3] : -1;
+}
+
+srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_blocks_per_xcd) {
+  SRH_REQUIRE(plan, "spmm_plan_set_xcd_shares: null plan");
+  SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_plan_set_xcd_shares: d=%d unsupported (64, 128 or 256)", d);
+  const int gi = d == 64 ? 1 : d == 128 ? 2 : 3;
+  const std::vector<Task64>& canon = plan->h_tasks64[gi];
+  const size_t nb = (canon.size() + 3) / 4;                 // canonical blocks (4 records each)
+  Task64 empty{};
+  empty.kind = 1; empty.count = 0; empty.slot = -1;
+  auto block = [&](size_t b, int w) -> const Task64& { return b * 4 + w < canon.size() ? canon[b * 4 + w] : empty; };
+  std::vector<Task64> list;
+  if (!h_blocks_per_xcd) {
+    list = canon;                                            // back to the canonical list
+  } else {
+    int64_t total = 0;
+    for (int k = 0; k < 8; ++k) {
+      SRH_REQUIRE(h_blocks_per_xcd[k] >= 0, "spmm_plan_set_xcd_shares: negative share");
+      total += h_blocks_per_xcd[k];
+    }
+    SRH_REQUIRE((size_t)total == nb, "spmm_plan_set_xcd_shares: shares add up to %lld blocks, the plan has %lld",
+                (long long)total, (long long)nb);
+    // canonical queues: block b runs on XCD b % 8.  Queues above their share give up their LAST blocks (the short rows of
+    // the tail: locality matters least there), queues below theirs append them in that order.
+    std::vector<size_t> q[8], pool;
+    for (size_t b = 0; b < nb; ++b) q[b % 8].push_back(b);
+    for (int k = 0; k < 8; ++k)
+      while ((int64_t)q[k].size() > h_blocks_per_xcd[k]) { pool.push_back(q[k].back()); q[k].pop_back(); }
+    std::reverse(pool.begin(), pool.end());
+    for (int k = 0; k < 8; ++k)
+      while ((int64_t)q[k].size() < h_blocks_per_xcd[k]) { q[k].push_back(pool.back()); pool.pop_back(); }
+    size_t depth = 0;
+    for (int k = 0; k < 8; ++k) depth = std::max(depth, q[k].size());
+    list.assign(depth * 8 * 4, empty);
+    for (int k = 0; k < 8; ++k)
+      for (size_t pos = 0; pos < q[k].size(); ++pos)
+        for (int w = 0; w < 4; ++w) list[(pos * 8 + k) * 4 + w] = block(q[k][pos], w);
+  }
+  if (list.size() > plan->cap64[gi]) {                       // (hipFree synchronises: never inside a stream capture)
+    Task64* fresh = nullptr;
+    hipError_t err = hipMalloc(&fresh, sizeof(Task64) * list.size());
+    if (err != hipSuccess) { srh::set_error("spmm_plan_set_xcd_shares: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+    (void)hipFree(plan->d_tasks64[gi]);
+    plan->d_tasks64[gi] = fresh;
+    plan->cap64[gi] = list.size();
+  }
+  hipError_t err = hipDeviceSynchronize();                   // no launch may still be reading the old list
+  if (err == hipSuccess && !list.empty())
+    err = hipMemcpy(plan->d_tasks64[gi], list.data(), sizeof(Task64) * list.size(), hipMemcpyHostToDevice);
+  if (err != hipSuccess) { srh::set_error("spmm_plan_set_xcd_shares: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+  plan->n_run[gi] = (int32_t)list.size();
+  return SRH_OK;
+}
+
+static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
+                                float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch,
+                                unsigned long long* d_stamps, void* stream) {
   srh_batch_fetch_args_t fetch_args{};
   int n_fetch = 0;
   if (fetch) {
@@ -1519,19 +1620,25 @@ srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t*
       // (the gather offsets carry "no gather" in their sign bit: the table must stay below 2 GiB)
       SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
                   (long long)plan->n_cols, d);
-#define SRH_LAUNCH_ROWS(LPRV, GI, CM)                                                                                \
-  spmm_rows_kernel<LPRV, CM><<<(plan->n_tasks[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(                                 \
-      plan->d_tasks64[GI], plan->n_tasks[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),              \
+#define SRH_LAUNCH_ROWS(LPRV, GI, CM, PR)                                                                            \
+  spmm_rows_kernel<LPRV, CM, srh::kSpmmTailUnit, PR><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
+      plan->d_tasks64[GI], plan->n_run[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),                \
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)
-      if (ep.col_mark) {
-        if (d == 64) SRH_LAUNCH_ROWS(16, 1, true);
-        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true);
-        else SRH_LAUNCH_ROWS(64, 3, true);
+      ep.stamps = d_stamps;
+      if (d_stamps) {
+        SRH_REQUIRE(!ep.col_mark, "spmm_f32_probe: no column marks");
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, true);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, true);
+        else SRH_LAUNCH_ROWS(64, 3, false, true);
+      } else if (ep.col_mark) {
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, true, false);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true, false);
+        else SRH_LAUNCH_ROWS(64, 3, true, false);
       } else {
-        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false);
-        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false);
-        else SRH_LAUNCH_ROWS(64, 3, false);
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, false);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, false);
+        else SRH_LAUNCH_ROWS(64, 3, false, false);
       }
 #undef SRH_LAUNCH_ROWS
     }

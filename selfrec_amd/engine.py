@@ -257,6 +257,59 @@ class FusedTrainer:
         self._rng_calls = max(16, 2 * self.L)
         if self.cols:
             self._init_exchange()
+        self.xcd_shares = self._calibrate_xcd_shares()
+
+    # ------------------------------------------------------------------------------------
+    # start-up calibration of the dense plan's XCD shares
+    # ------------------------------------------------------------------------------------
+    def _calibrate_xcd_shares(self, rounds=5):
+        """The plan deals every XCD the same number of workgroups, but the XCDs do not take the same time over them (at the
+        Yelp2018 shape they finish a propagation launch 3.5 us apart: the odd column classes run 15 % slower for the same
+        non-zeros).  A few probe launches of the step's dominant product (srh_spmm_f32_probe: per-XCD finish times) move the
+        last workgroups of the late XCDs' queues to the early ones' (srh_spmm_plan_set_xcd_shares) until they finish
+        together: 45.1 -> 42.7 us per dense launch in the lab (profiles/r02_j_xcd_balance_closed_loop.txt).  Same tasks, same
+        sums -- placement only.  Once per (plan, table width), before anything captures a launch of the plan;
+        SRH_XCD_CALIBRATE=0 keeps the equal dealing.  Returns the shares, or None."""
+        if os.environ.get("SRH_XCD_CALIBRATE", "1") == "0" or self.dev.type != "cuda" or self.sharded or self.cols:
+            return None
+        if self.L < 1 or self.d not in (64, 128, 256):
+            return None
+        done = self.adj.__dict__.setdefault("_xcd_calibrated", {})
+        if self.d in done:
+            return done[self.d]
+        nb = (ops.spmm_plan_run_tasks(self.adj, self.d) + 3) // 4
+        if nb < 4096:                                   # nothing to balance on a small graph
+            done[self.d] = None
+            return None
+        kw = dict(perturb_eps=self.eps, rng_seed=1, rng_offset=0) if self.model == "XSimGCL" else {}
+        if self.vfree:
+            kw.update(row_scale=self.dinv, scale_in=True, scale_out=True)
+        ep = ops.make_epilogue(**kw) if kw else None
+        canon = np.array([len(range(k, nb, 8)) for k in range(8)], dtype=np.int64)
+        shares, best = canon.copy(), (float("inf"), canon.copy())
+
+        def finish_times():
+            runs = [ops.spmm_probe(self.adj, self.E0, self.Ha, epilogue=ep, pattern=bool(self.vfree))[0] for _ in range(3)]
+            return np.median(np.stack(runs), axis=0)
+        finish_times()                                  # warm-up (module load, caches)
+        for rnd in range(rounds):
+            fin = finish_times()
+            if fin.max() < best[0]:
+                best = (float(fin.max()), shares.copy())
+            if fin.max() - fin.min() < 0.4 or rnd == rounds - 1:
+                break
+            per_block = fin.mean() / (nb / 8.0)         # us of an XCD's finish time per workgroup of its queue
+            new = shares - np.round((fin - fin.mean()) / per_block).astype(np.int64)
+            new = np.clip(new, (canon * 6) // 10, (canon * 14) // 10)
+            new[int(np.argmin(fin))] += nb - int(new.sum())
+            if new.min() < 0 or int(new.sum()) != nb:
+                break
+            shares = new
+            ops.spmm_set_xcd_shares(self.adj, self.d, shares)
+        if not np.array_equal(best[1], shares):
+            ops.spmm_set_xcd_shares(self.adj, self.d, None if np.array_equal(best[1], canon) else best[1])
+        done[self.d] = best[1]
+        return best[1]
 
     # ------------------------------------------------------------------------------------
     # column-sharded layout: the batch-row exchange (csrc/exchange.hip)

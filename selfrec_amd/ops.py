@@ -20,7 +20,7 @@ require_gpu = _lib.require_gpu
 def gpu_available() -> bool:
     return torch.cuda.is_available()
 
-__all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
+__all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "spmm_probe", "spmm_set_xcd_shares", "spmm_plan_run_tasks", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",
            "SelfrecHipError"]
@@ -332,6 +332,49 @@ def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilo
     else:
         check(_lib.load().srh_spmm_f32(*common, _stream()), "srh_spmm_f32")
     return out
+
+
+def spmm_plan_run_tasks(csr: DeviceCSR, d: int) -> int:
+    """Records in the task list a launch of `csr` on d-column tables runs now (srh_spmm_plan_run_tasks)."""
+    n = int(_lib.load().srh_spmm_plan_run_tasks(csr._plan, int(d)))
+    if n < 0:
+        raise SelfrecHipError(f"spmm_plan_run_tasks: no task list for d = {d}")
+    return n
+
+
+def spmm_set_xcd_shares(csr: DeviceCSR, d: int, blocks_per_xcd=None):
+    """Deal the plan's workgroups of real tasks to the 8 XCDs in these numbers (srh_spmm_plan_set_xcd_shares; None: the
+    canonical equal dealing).  Same tasks, same sums; synchronises the device -- never inside a stream capture, and a
+    captured launch of this plan must be re-captured afterwards."""
+    if blocks_per_xcd is None:
+        check(_lib.load().srh_spmm_plan_set_xcd_shares(csr._plan, int(d), None), "srh_spmm_plan_set_xcd_shares")
+        return
+    h = np.ascontiguousarray(blocks_per_xcd, dtype=np.int32)
+    if h.shape != (8,):
+        raise SelfrecHipError("spmm_set_xcd_shares: eight shares, one per XCD")
+    check(_lib.load().srh_spmm_plan_set_xcd_shares(csr._plan, int(d), h.ctypes.data_as(C.c_void_p)),
+          "srh_spmm_plan_set_xcd_shares")
+
+
+def spmm_probe(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor, epilogue: SpmmEpilogue | None = None, pattern: bool = False):
+    """One srh_spmm_f32_probe launch (no column marks, d = 64 / 128 / 256).  Returns (finish, begin, end, xcd): finish[k]
+    = when XCD k's last wave left, in us after the launch's first wave began; begin / end / xcd per stamped wave (us, us,
+    0 .. 7) in task order.  A device-to-host sync: calibration and lab work, not the step."""
+    d = int(x.shape[1])
+    n = spmm_plan_run_tasks(csr, d)
+    stamps = torch.zeros(3 * n, dtype=torch.int64, device=x.device)
+    check(_lib.load().srh_spmm_f32_probe(csr._plan, _p(csr.indices, torch.int32), None if pattern else _p(csr.vals, torch.float32, "vals"),
+                                         _p(x, torch.float32, "x"), _p(out, torch.float32, "out"), d,
+                                         C.byref(epilogue) if epilogue is not None else None, stamps.data_ptr(), _stream()),
+          "srh_spmm_f32_probe")
+    rec = stamps.cpu().numpy().reshape(n, 3)
+    rec = rec[rec[:, 1] != 0]
+    if rec.shape[0] == 0:
+        raise SelfrecHipError("spmm_probe: no wave left a stamp")
+    t0 = rec[:, 0].min()
+    begin, end, xcd = (rec[:, 0] - t0) / 100.0, (rec[:, 1] - t0) / 100.0, (rec[:, 2] & 0xff).astype(np.int64)
+    finish = np.array([end[xcd == k].max() if (xcd == k).any() else 0.0 for k in range(8)])
+    return finish, begin, end, xcd
 
 
 def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None,

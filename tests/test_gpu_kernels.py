@@ -141,6 +141,46 @@ def test_spmm3_equals_three_launches():
 
 
 @pytest.mark.parametrize("d", [64, 128])
+def test_spmm_xcd_shares_and_probe(d):
+    """srh_spmm_plan_set_xcd_shares / srh_spmm_f32_probe: unequal numbers of workgroups per XCD (empty records pad the
+    list) change where tasks run, never what they compute -- same product bit for bit, also with split heavy rows, the
+    pattern form and row marks -- and the probe launch computes the product too and stamps every task once."""
+    n, U = 3000, 1200
+    m = powerlaw_csr(n, n, 60000, seed=37, heavy_rows=4, heavy_len=1800, empty_rows=11)
+    perm, row_mid = ops.column_class_order(m.indptr, m.indices, 64)
+    csr = ops.DeviceCSR(m.indptr, m.indices[perm], m.data[perm], m.shape, xcd_split_row=U, row_mid=row_mid)
+    rng = np.random.default_rng(8)
+    tx = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    mark = torch.from_numpy(np.where(rng.random(n) < 0.2, 7, 1).astype(np.int32)).to(DEV)
+    stamp = torch.tensor([7], dtype=torch.int64, device=DEV)
+    ep_rows = lambda: ops.make_epilogue(row_mark=mark, mark_stamp=stamp)          # noqa: E731
+    ep_cols = lambda: ops.make_epilogue(col_mark=mark, mark_stamp=stamp)          # noqa: E731
+    ref, ref_pat = ops.spmm(csr, tx), ops.spmm(csr, tx, pattern=True)
+    ref_cols = ops.spmm(csr, tx, epilogue=ep_cols())
+    ref_rows = torch.zeros((n, d), device=DEV); ops.spmm(csr, tx, out=ref_rows, epilogue=ep_rows())
+    n_canon = ops.spmm_plan_run_tasks(csr, d)
+    nb = (n_canon + 3) // 4
+    canon = np.array([len(range(k, nb, 8)) for k in range(8)])
+    a, b, few = int(canon.min()) // 2, int(canon.min()) // 3, max(1, int(canon.min()) // 4)
+    for shares in (canon, canon + np.array([a, -a, b, -b, 0, 0, 1, -1]), np.array([nb - 7 * few] + [few] * 7)):
+        ops.spmm_set_xcd_shares(csr, d, shares)
+        assert ops.spmm_plan_run_tasks(csr, d) == int(shares.max()) * 32
+        assert torch.equal(ops.spmm(csr, tx), ref) and torch.equal(ops.spmm(csr, tx, pattern=True), ref_pat)
+        assert torch.equal(ops.spmm(csr, tx, epilogue=ep_cols()), ref_cols)
+        out = torch.zeros((n, d), device=DEV); ops.spmm(csr, tx, out=out, epilogue=ep_rows())
+        assert torch.equal(out, ref_rows)
+        got = torch.empty((n, d), device=DEV)
+        finish, begin, end, xcd = ops.spmm_probe(csr, tx, got)
+        assert torch.equal(got, ref)
+        assert begin.size == int(shares.max()) * 32 and (end >= begin).all() and set(np.unique(xcd)) <= set(range(8))
+        assert finish.shape == (8,) and finish.max() < 1e4                         # us: a sane clock
+    with pytest.raises(ops.SelfrecHipError):
+        ops.spmm_set_xcd_shares(csr, d, canon + 1)                                 # does not add up
+    ops.spmm_set_xcd_shares(csr, d, None)
+    assert ops.spmm_plan_run_tasks(csr, d) == n_canon and torch.equal(ops.spmm(csr, tx), ref)
+
+
+@pytest.mark.parametrize("d", [64, 128])
 def test_spmm_under_another_plan_of_the_same_arrays(d):
     """DeviceCSR.replanned: the same device arrays under a second schedule (the engine runs the column-masked launch of a
     step on a class-free plan with shorter segments): same product in every flavour -- plain, pattern (no value stream),

@@ -160,6 +160,37 @@ def first_appearance_ids(raw):
     return rank[raw]
 
 
+def test_xcd_share_calibration_changes_placement_not_results(yelp_data):
+    """engine.FusedTrainer calibrates the dense plan's XCD shares at start-up (probe launches -> unequal numbers of
+    workgroups per XCD).  At the Yelp2018 shape it does move workgroups, and a trainer on the calibrated list takes the
+    same steps as one on the canonical list: same batches, same losses, same embeddings (to the order of the loss
+    section's atomics)."""
+    kw = dict(model="XSimGCL", n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048)
+
+    def run(tr):
+        tr.sampler.seed(11)
+        tr.begin_epoch()
+        out = []
+        for _ in range(3):
+            tr.step()
+            out.append(tr.read_losses())
+        return np.asarray(out), [t.cpu().numpy() for t in tr.embeddings()]
+    torch.manual_seed(5)
+    a = FusedTrainer(yelp_data, 64, **kw)
+    assert a.xcd_shares is not None
+    shares = np.asarray(a.xcd_shares)
+    assert shares.shape == (8,) and shares.min() > 0
+    la, ea = run(a)
+    ops.spmm_set_xcd_shares(a.adj, 64, None)                    # back to the equal dealing (a is not used again)
+    torch.manual_seed(5)
+    b = FusedTrainer(yelp_data, 64, **kw)                       # (the plan is marked calibrated: b does not probe again)
+    lb, eb = run(b)
+    np.testing.assert_allclose(la, lb, rtol=2e-6)
+    for x, y in zip(ea, eb):
+        assert rel_err(x, y) < 2e-6
+    ops.spmm_set_xcd_shares(a.adj, 64, shares)                  # leave the module's shared graph as the engine set it
+
+
 def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
     """BASELINE.json configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions) --
     one step of the reference (8 torch threads, ~25 GB of python objects) against the fused engine on one MI355X.
