@@ -436,7 +436,11 @@ def main():
                                f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
                                f"(see steady_state for a region that always spans >= 1)",
                    "global_batch": args.batch, "parallelism": f"{layout} x{world}" if sharded else "single",
-                   "launch": "hipGraph replay" if trainer.use_graph else "eager"},
+                   "launch": "hipGraph replay" if trainer.use_graph else "eager",
+                   # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration
+                   # (engine._calibrate_xcd_shares; null: equal dealing)
+                   "xcd_shares": (None if getattr(trainer, "xcd_shares", None) is None
+                                  else [int(v) for v in trainer.xcd_shares])},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
     # ---- steady state: >= 2 epochs (>= 1 epoch boundary: sampler hand-over + 25 MB index upload inside the region)
