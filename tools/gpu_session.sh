@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = a list of stages; everything lands in gpurun_out/.
-# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab labprobe labplans labbalance labbits gatherlds bench benchquick refmodels prof pmc big cols
+# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab labprobe labplans labbalance labgap labbits gatherlds bench benchquick refmodels prof pmc big cols
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -36,7 +36,9 @@ labprobe)
 labplans)
   timeout 300 python tools/spmm_lab/run.py --ids first-appearance --plans > $OUT/lab_plans.txt 2>&1; echo "labplans exit $?"; grep -v amdgpu.ids $OUT/lab_plans.txt | tail -${LAB_TAIL:-14};;
 labbalance)
-  timeout 300 python tools/spmm_lab/run.py --ids first-appearance --balance > $OUT/lab_balance.txt 2>&1; echo "labbalance exit $?"; grep -v amdgpu.ids $OUT/lab_balance.txt | tail -10;;
+  timeout 300 python tools/spmm_lab/run.py --ids first-appearance --balance --balance-flavour ${BALANCE_FLAVOUR:-dense} > $OUT/lab_balance.txt 2>&1; echo "labbalance exit $?"; grep -v amdgpu.ids $OUT/lab_balance.txt | tail -10;;
+labgap)
+  timeout 300 python tools/spmm_lab/run.py --ids first-appearance --gap > $OUT/lab_gap.txt 2>&1; echo "labgap exit $?"; grep -v amdgpu.ids $OUT/lab_gap.txt | tail -8;;
 labbits)
   timeout 400 python tools/spmm_lab/run.py --ids first-appearance --class-bits ${CLASS_BITS:-0,1,2,3,4,6,9} > $OUT/lab_classbits.txt 2>&1; echo "labbits exit $?"; grep -v amdgpu.ids $OUT/lab_classbits.txt | tail -12;;
 gatherlds)

@@ -170,7 +170,7 @@ def class_bits(data, dev, bits, iters, tu, ti, U, I):
     ops.column_class_order = orig
 
 
-def balance(lab, h, adj, x, y, flavours, iters, dev, st):
+def balance(lab, h, adj, x, y, flavours, iters, dev, st, flavour="dense"):
     """Do unequal XCD shares of the task list pay?  (the XCDs finish a dense launch 3.5 us apart although the
     plan deals every one of them the same number of blocks; block b runs on XCD b % 8.)  The plan's Task64 list is read back,
     cut into per-XCD queues, and in each round the probe kernel's per-XCD finish times move the LAST blocks of the late XCDs
@@ -189,7 +189,8 @@ def balance(lab, h, adj, x, y, flavours, iters, dev, st):
     empty[0, 0] = 1                                             # kind 1, count 0: a wave with nothing to do
     blocks = np.concatenate([host, np.repeat(empty, pad, axis=0)]).reshape(-1, 4, 16)
     queues = [[blocks[b] for b in range(k, len(blocks), 8)] for k in range(8)]
-    ep = flavours["dense"]()
+    ep = flavours[flavour]()
+    print(f"# flavour: {flavour}")
     y2 = torch.zeros_like(y)
     ops.spmm(adj, x, out=y2, epilogue=ep)                       # what every list must reproduce
 
@@ -209,7 +210,7 @@ def balance(lab, h, adj, x, y, flavours, iters, dev, st):
     print(f"{'round':<7}{'product us':>11}{'max |err|':>11}   per-XCD finish (us) of the probe kernel / real blocks per XCD")
     for rnd in range(5):
         tasks = assemble(queues)
-        y.fill_(float("nan"))
+        y.zero_()                                              # (row-masked launches write the marked rows only)
         run(tasks, 0)
         torch.cuda.synchronize()
         err = float((y - y2).abs().max().item())
@@ -245,6 +246,33 @@ def balance(lab, h, adj, x, y, flavours, iters, dev, st):
                 pool = pool[m:]
 
 
+def gap(adj, x, y, flavours, dev):
+    """Two PRODUCT probe launches (srh_spmm_f32_probe) issued back to back on one stream, stamps read afterwards: the chip-
+    wide clock places the second launch's waves relative to the first's.  Prints, per pair: span of each launch (first
+    begin .. last end), the gap between launch 1's last end and launch 2's first begin (negative: they overlap), and the
+    period first-begin to first-begin -- what a launch costs in a chain of launches."""
+    lib = _lib.load()
+    n = ops.spmm_plan_run_tasks(adj, 64)
+    ep = flavours["dense"]()
+    y2 = torch.zeros_like(y)
+    sa, sb = (torch.zeros(3 * n, dtype=torch.int64, device=dev) for _ in range(2))
+    st = torch.cuda.current_stream().cuda_stream
+    for rep in range(6):
+        sa.zero_(); sb.zero_()
+        torch.cuda.synchronize()
+        for stamps, out in ((sa, y), (sb, y2)):
+            rc = lib.srh_spmm_f32_probe(adj._plan, adj.indices.data_ptr(), adj.vals.data_ptr(), x.data_ptr(), out.data_ptr(), 64,
+                                        C.byref(ep), stamps.data_ptr(), st)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        ra, rb = (t.cpu().numpy().reshape(n, 3) for t in (sa, sb))
+        ra, rb = ra[ra[:, 1] != 0], rb[rb[:, 1] != 0]
+        t0 = ra[:, 0].min()
+        a0, a1, b0, b1 = 0.0, (ra[:, 1].max() - t0) / 100.0, (rb[:, 0].min() - t0) / 100.0, (rb[:, 1].max() - t0) / 100.0
+        print(f"pair {rep}: launch 1 span {a1 - a0:6.2f} us, launch 2 span {b1 - b0:6.2f} us, gap end(1) -> begin(2) {b0 - a1:6.2f} us, "
+              f"period begin(1) -> begin(2) {b0 - a0:6.2f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="yelp2018")
@@ -254,6 +282,12 @@ def main():
     ap.add_argument("--class-bits", default="",
                     help="comma-separated bits of the column id to try as the column class of long rows (0 = even / odd, the "
                          "engine's): us per product launch of every flavour for each")
+    ap.add_argument("--balance-flavour", default="dense", choices=["dense", "row_masked", "plain"],
+                    help="the launch flavour --balance equalises (row_masked: the last forward layer's own imbalance -- its "
+                         "live work sits 70 %% on the item side)")
+    ap.add_argument("--gap", action="store_true",
+                    help="two product probe launches back to back: where the second launch's first waves begin relative to "
+                         "the first launch's last waves (what a launch costs beyond its own first-begin .. last-end span)")
     ap.add_argument("--balance", action="store_true",
                     help="closed-loop experiment: unequal shares of the task list per XCD (empty blocks at the end of a slow "
                          "XCD's queue, its last tasks appended to a fast XCD's), driven by the per-XCD finish times of the probe")
@@ -319,7 +353,9 @@ def main():
     if args.plans:
         return plans(adj, g, x, y, flavours, args.iters)
     if args.balance:
-        return balance(lab, h, adj, x, y, flavours, args.iters, dev, st)
+        return balance(lab, h, adj, x, y, flavours, args.iters, dev, st, args.balance_flavour)
+    if args.gap:
+        return gap(adj, x, y, flavours, dev)
     print(f"# {args.shape}: N = {N}, nnz = {adj.nnz}, d = {d}; {len(marked)} marked nodes; us per launch, {args.iters} iters")
     print(f"{'variant':<58}" + "".join(f"{k:>14}" for k in flavours))
     base = {}
