@@ -1,6 +1,8 @@
 #!/bin/bash
 # One gpurun call = a list of stages; everything lands in gpurun_out/.
 # usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab labprobe labplans labbalance labgap labbits gatherlds bench benchquick refmodels prof pmc big cols
+# (budget note from round 2: a call is charged for getting the box as well as for the run -- 20 s when a warm box is at hand,
+#  3-5 min when not, whatever the command: batch stages into one call, and keep the last minutes for a final check)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
