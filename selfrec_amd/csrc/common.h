@@ -8,11 +8,6 @@
 
 namespace srh {
 
-// Granularity of the last broadcast rounds of an SpMM chunk (csrc/spmm.hip, spmm_rows_kernel): 8, 4, 2 or 1.
-#ifndef SRH_SPMM_TAIL_UNIT
-#define SRH_SPMM_TAIL_UNIT 1
-#endif
-constexpr int kSpmmTailUnit = SRH_SPMM_TAIL_UNIT;
 
 void set_error(const char* fmt, ...);
 

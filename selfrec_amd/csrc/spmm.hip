@@ -289,59 +289,14 @@ struct Acc2 { floatx2_t lo, hi; };       // columns 0-1 / 2-3 of this lane's flo
                : [lo] "+v"(acc.lo), [hi] "+v"(acc.hi)                                                           \
                : [vp] "v"(VP), [xlo] "v"(__builtin_shufflevector(XR, XR, 0, 1)), [xhi] "v"(__builtin_shufflevector(XR, XR, 2, 3)))
 
-__device__ __forceinline__ void pred_load8(floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3, floatx4_t& x4,
-                                           floatx4_t& x5, floatx4_t& x6, floatx4_t& x7, const unsigned (&off)[8],
-                                           const void* X) {
-  unsigned long long save;
-  asm volatile(
-      "s_mov_b64 %[sv], exec\n\t"
-      "v_cmpx_le_i32_e32 0, %[o0]\n\tglobal_load_dwordx4 %[x0], %[o0], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o1]\n\tglobal_load_dwordx4 %[x1], %[o1], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o2]\n\tglobal_load_dwordx4 %[x2], %[o2], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o3]\n\tglobal_load_dwordx4 %[x3], %[o3], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o4]\n\tglobal_load_dwordx4 %[x4], %[o4], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o5]\n\tglobal_load_dwordx4 %[x5], %[o5], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o6]\n\tglobal_load_dwordx4 %[x6], %[o6], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "v_cmpx_le_i32_e32 0, %[o7]\n\tglobal_load_dwordx4 %[x7], %[o7], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
-      "s_nop 4"
-      : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),
-        [x7] "+v"(x7), [sv] "=&s"(save)
-      : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
-        [o6] "v"(off[6]), [o7] "v"(off[7]), [b] "s"(X)
-      : "memory", "vcc");
-}
-
-// entries 0-7 (HI false) or 8-15 (HI true) of the 16 this lane's DPP row holds.  cs = column * row bytes (sign bit:
-// no gather), v = value, sub16 = this lane's byte offset inside an x row; xx[] persists across calls.
-template <bool HI>
-__device__ __forceinline__ void gather8(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8], Acc2& acc) {
-  unsigned off[8];
-  float vv[8];
-  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
-  if (!HI) {
-    SRH_DPP_OR(0); SRH_DPP_OR(1); SRH_DPP_OR(2); SRH_DPP_OR(3); SRH_DPP_OR(4); SRH_DPP_OR(5); SRH_DPP_OR(6); SRH_DPP_OR(7);
-  } else {
-    SRH_DPP_OR(8); SRH_DPP_OR(9); SRH_DPP_OR(10); SRH_DPP_OR(11); SRH_DPP_OR(12); SRH_DPP_OR(13); SRH_DPP_OR(14); SRH_DPP_OR(15);
-  }
-  pred_load8(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
-  if (!HI) {
-    SRH_DPP_MOV(0); SRH_DPP_MOV(1); SRH_DPP_MOV(2); SRH_DPP_MOV(3); SRH_DPP_MOV(4); SRH_DPP_MOV(5); SRH_DPP_MOV(6); SRH_DPP_MOV(7);
-  } else {
-    SRH_DPP_MOV(8); SRH_DPP_MOV(9); SRH_DPP_MOV(10); SRH_DPP_MOV(11); SRH_DPP_MOV(12); SRH_DPP_MOV(13); SRH_DPP_MOV(14); SRH_DPP_MOV(15);
-  }
-  const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
-  SRH_FMA(7, 0, p0, xx[0]); SRH_FMA(6, 1, p0, xx[1]); SRH_FMA(5, 0, p1, xx[2]); SRH_FMA(4, 1, p1, xx[3]);
-  SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
-}
-
-// The same eight entries when only `nr` of the eight broadcast rounds carry an entry (the tail of a chunk).  Every round a
-// chunk issues beyond the ones it needs is a vector-memory instruction paid for nothing: with whole eight-round halves
-// the plan of the Yelp2018-shape graph issues 762 k gathers per launch for 630 k x four rows (profiles/r02_h_*).  The
-// kernel therefore packs a tail's entries into the LAST nr lanes of the half (lanes 8 - nr .. 7, see lane_slot in
-// spmm_rows_kernel) and this form jumps over the first 8 - nr loads.  Everything else is gather8: loads issued in lane
-// order, multiply-adds in the same order with vmcnt(7 .. 0) -- a skipped load is an OLDER load that was never issued, so
-// the counts of the issued ones stand; its destination keeps an older finite x row and its value is 0.  Entries are
-// still summed in ascending order: the result equals the whole-half form bit for bit.
+// Eight entries of the DPP row (lanes 0-7 or 8-15), of which only the LAST `nr` carry an entry (nr = 8: a whole half).
+// Every round a chunk issues beyond the ones it needs is a vector-memory instruction paid for nothing: with whole
+// eight-round halves only, the plan of the Yelp2018-shape graph issued 762 k gathers per launch for 630 k x four rows
+// (profiles/r02_h_*).  The kernel therefore packs a tail's entries into the last nr lanes of the half (lanes 8 - nr .. 7,
+// see lane_slot in spmm_rows_kernel) and the load block jumps over the first 8 - nr loads.  Loads are issued in lane
+// order, multiply-adds follow in the same order with vmcnt(7 .. 0) -- a skipped load is an OLDER load that was never
+// issued, so the counts of the issued ones stand; its destination keeps an older finite x row and its value is 0.
+// Entries are summed in ascending order (the whole-half form this replaced gave the same sums bit for bit).
 #define SRH_PL(K) ".Lsrh_t" #K "_%=:\n\tv_cmpx_le_i32_e32 0, %[o" #K "]\n\tglobal_load_dwordx4 %[x" #K "], %[o" #K "], %[b]\n\ts_mov_b64 exec, %[sv]\n\t"
 #define SRH_GE(N, K) "s_cmp_ge_i32 %[nr], " #N "\n\ts_cbranch_scc1 .Lsrh_t" #K "_%=\n\t"
 __device__ __forceinline__ void pred_load8_tail(int nr, floatx4_t& x0, floatx4_t& x1, floatx4_t& x2, floatx4_t& x3,
@@ -463,13 +418,12 @@ struct alignas(64) Task64 {
 // loads, adds them in slot order -- bitwise reproducible -- runs the epilogue and re-arms the ticket).
 // COLMASK: the launch carries column activity marks (its own instantiation: the unmasked kernel then has no mark
 // code and always prefetches; a run-time switch between the two cost 2.5 us per launch).
-// UNIT (srh::kSpmmTailUnit): 8 = a chunk issues whole eight-round halves; 1 = a chunk's tail issues the rounds it needs
-// (gather8_tail) and a cooperative task deals its entries to the row-groups round-robin (entry k of a chunk -> group
-// k % G, round k / G) instead of in blocks of 16, so that a tail of R entries needs ceil(R / G) rounds with every group
-// busy rather than up to 16 rounds with one.
+// A chunk's tail issues only the rounds it needs (gather8_tail), and a cooperative task deals its entries to the row-
+// groups round-robin (entry k of a chunk -> group k % G, round k / G), so that a tail of R entries needs ceil(R / G) rounds
+// with every group busy rather than up to 16 rounds with one.
 // PROBE (srh_spmm_f32_probe): every wave also leaves {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
 // in stamps[3 * wave ..] -- what the engine's start-up calibration of the plan's XCD shares reads (engine.py).
-template <int LPR, bool COLMASK, int UNIT = srh::kSpmmTailUnit, bool PROBE = false>
+template <int LPR, bool COLMASK, bool PROBE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WAVES, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
@@ -543,15 +497,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WA
   unsigned cs, csn = 0x80000000u;
   float v, vn = 0.f;
   float4 accm = f4_zero();                                // COLMASK accumulator
-  constexpr bool TAIL = !COLMASK && UNIT < 8;             // tails issue only the rounds they need
+  constexpr bool TAIL = !COLMASK;                         // tails issue only the rounds they need
   constexpr bool INTER = TAIL;                            // cooperative entries dealt round-robin to the groups
   // nr: broadcast rounds the chunk needs (>= 1; 16 and more = all)
   auto chunk = [&](int nr) {
     if (COLMASK) {
       gather16_compact<LPR>((int)cs, v, X, sub, accm);
-    } else if (!TAIL) {
-      gather8<false>(cs, v, sub16, X, xx, acc);
-      if (nr > 8) gather8<true>(cs, v, sub16, X, xx, acc);
     } else {
       // (two asm bodies per call site, not three: with a plain gather8 for whole first halves next to them the register
       // allocator no longer finds eight aligned quads under the 64-VGPR cap and spills 160 bytes into the loop)
@@ -704,7 +655,7 @@ __global__ __launch_bounds__(256) void spmm_rows3_kernel(const Task* __restrict_
     const int row = __builtin_amdgcn_readfirstlane(sg.row), s = __builtin_amdgcn_readfirstlane(sg.start);
     const int e = __builtin_amdgcn_readfirstlane(sg.end), slot = __builtin_amdgcn_readfirstlane(sg.slot);
     for (int base = s; base < e; base += CH) {
-      const int j = srh::kSpmmTailUnit < 8 ? base + G * e16 + g : base + 16 * g + e16;     // (as spmm_rows_kernel deals them)
+      const int j = base + G * e16 + g;                  // (dealt round-robin to the groups, as spmm_rows_kernel does)
       int c = 0;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       if (j < e) { c = indices[j]; v0 = vals0[j]; v1 = vals1[j]; v2 = vals2[j]; }
@@ -1621,7 +1572,7 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
       SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
                   (long long)plan->n_cols, d);
 #define SRH_LAUNCH_ROWS(LPRV, GI, CM, PR)                                                                            \
-  spmm_rows_kernel<LPRV, CM, srh::kSpmmTailUnit, PR><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
+  spmm_rows_kernel<LPRV, CM, PR><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
       plan->d_tasks64[GI], plan->n_run[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),                \
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)

@@ -2,7 +2,7 @@
 # The product library rebuilt with other compile-time switches of csrc/spmm.hip, for a file-level A/B of bench.py on
 # the GPU box (no run-time knob ships in the library):
 #   tools/spmm_lab/build_alt.sh <name> "<flags>" ...   ->  tools/spmm_lab/alt/libselfrec_hip_<name>.so
-#   e.g.  build_alt.sh u8 "-DSRH_SPMM_TAIL_UNIT=8" sr "-DSRH_EXP_SCALAR_R=1"
+#   e.g.  build_alt.sh w7 "-DSRH_ROWS_WAVES=7"
 # (cp the file over selfrec_amd/lib/libselfrec_hip.so to use it; tools/spmm_lab/ab_libs.sh does that in a loop)
 set -e
 cd "$(dirname "$0")/../.."

@@ -849,7 +849,7 @@ int lab_spmm_custom(void* h, const srh_spmm_plan_t* plan, const void* d_tasks, i
                                             plan->d_tickets, L->d_bits, L->n_bit_words, (int)plan->n_cols, ep);
   } else {
     srh_batch_fetch_args_t no_rider{};
-    spmm_rows_kernel<16, false, srh::kSpmmTailUnit><<<blocks, 256, 0, st>>>(
+    spmm_rows_kernel<16, false><<<blocks, 256, 0, st>>>(
         tasks, n_tasks, d_indices, d_vals, reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y),
         reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep, 0, no_rider);
   }
@@ -890,18 +890,16 @@ int lab_spmm(void* h, const srh_spmm_plan_t* plan, const int32_t* d_indices, con
     case 21: LAB_LAUNCH(21, 0); break;
     case 22: LAB_LAUNCH(22, 0); break;
     case 60: LAB_LAUNCH(60, 0); break;
-#define LAB_PRODUCT(UNITV, VALS)                                                                                      \
+#define LAB_PRODUCT(VALS)                                                                                             \
   do {                                                                                                                \
     if (ep.col_mark) return -6;                                                                                       \
     srh_batch_fetch_args_t no_rider{};                                                                                \
-    spmm_rows_kernel<16, false, UNITV><<<blocks, 256, 0, st>>>(                                                       \
+    spmm_rows_kernel<16, false><<<blocks, 256, 0, st>>>(                                                              \
         plan->d_tasks64[1], n, d_indices, VALS, reinterpret_cast<const float4*>(d_x), reinterpret_cast<float4*>(d_y), \
         reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, plan->d_tickets, ep, 0, no_rider); \
   } while (0)
-    case 75: LAB_PRODUCT(1, d_vals); break;       /* product kernel, chunk tails issue only the rounds they need (the default) */
-    case 76: LAB_PRODUCT(1, nullptr); break;      /* ... as a pattern product (no value stream): vs all-ones values */
-    case 77: LAB_PRODUCT(8, d_vals); break;       /* product kernel with whole eight-round halves (SRH_SPMM_TAIL_UNIT = 8) */
-    case 74: LAB_PRODUCT(8, nullptr); break;      /* the product's own pattern launch, for the same-table comparison */
+    case 75: LAB_PRODUCT(d_vals); break;          /* the product kernel launched from here (canonical task list) */
+    case 76: LAB_PRODUCT(nullptr); break;         /* ... as a pattern product (no value stream): vs all-ones values */
 #define LAB_LAUNCH2(KK, DD, VV)                                                                                      \
   do {                                                                                                               \
     int nblk = (blocks + KK - 1) / KK;                                                                               \

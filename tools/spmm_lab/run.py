@@ -32,10 +32,9 @@ VARIANTS = {1: "asm inner loop", 2: "asm + Task64 scalar records + (col,val) pre
             10: "gen2 K=1 depth 1", 11: "gen2 K=2 (next task's first chunk prefetched)", 12: "gen2 K=3", 13: "gen2 K=4",
             18: "gen2 K=6", 14: "gen2 K=1, 16 gathers in flight", 15: "gen2 K=2, 16 gathers in flight",
             16: "gen2 K=2 value-free (vs all-ones)", 17: "gen2 K=3 value-free (vs all-ones)",
-            75: "product kernel, chunk tails issue only the rounds they need (the default)",
-            77: "product kernel, whole eight-round halves (SRH_SPMM_TAIL_UNIT = 8)",
-            74: "77 as a pattern launch (vs all-ones)", 76: "75 as a pattern launch (vs all-ones)"}
-VALUE_FREE = (3, 16, 17, 74, 76)
+            75: "the product kernel launched from the lab (canonical task list)",
+            76: "75 as a pattern launch (vs all-ones)"}
+VALUE_FREE = (3, 16, 17, 76)
 SKIP = (11, 12, 13, 18, 15, 16, 17, 1, 6, 20, 21, 22, 14, 40, 3, 4, 5, 23, 30, 50, 41, 10)          # measured and lost (profiles/r02_a_spmm_lab.txt): not re-run by default
 
 
@@ -369,7 +368,7 @@ def main():
         cells = []
         for name, mk in flavours.items():
             if (variant in (4, 5) and name != "col_masked") or (variant in (30, 50) and name == "col_masked") or \
-                    (variant in (40, 41) and name != "dense") or (variant in (74, 75, 76, 77) and name == "col_masked"):
+                    (variant in (40, 41) and name != "dense") or (variant in (75, 76) and name == "col_masked"):
                 cells.append(f"{'-':>14}")
                 continue
             csr = ones if variant in VALUE_FREE else adj
