@@ -164,3 +164,58 @@ def test_ranked_lists_reads_like_the_dict_and_reports_the_same_strings():
     # without flags (or against another test set) it goes through the loops like any mapping
     plain = evaluation.RankedLists(users, names, ids, scores)
     assert evaluation.ranking_evaluation(origin, plain, [10, 20]) == evaluation.ranking_evaluation(origin, as_dict, [10, 20])
+
+
+def test_xcd_share_calibration_controller(monkeypatch):
+    """engine.FusedTrainer._calibrate_xcd_shares against a simulated chip: XCD k takes speed[k] us per workgroup of its
+    queue.  The controller must move workgroups from the late XCDs to the early ones until they finish together, keep the
+    total, stay inside its clip range, remember the result on the plan, and do nothing when told not to."""
+    import types
+
+    import numpy as np
+    from selfrec_amd import engine, ops
+
+    nb = 7140
+    canon = np.array([len(range(k, nb, 8)) for k in range(8)])
+    speed = 43.0 / 893 * np.array([0.97, 0.95, 1.06, 1.03, 0.99, 0.97, 1.04, 1.00])      # (the shape measured on an MI355X)
+    state = {"shares": canon.copy(), "probes": 0, "sets": []}
+
+    def fake_probe(csr, x, out, epilogue=None, pattern=False):
+        state["probes"] += 1
+        rng = np.random.default_rng(state["probes"])
+        return state["shares"] * speed + rng.normal(0, 0.05, 8), None, None, None
+
+    def fake_set(csr, d, blocks=None):
+        state["shares"] = canon.copy() if blocks is None else np.asarray(blocks).copy()
+        state["sets"].append(None if blocks is None else list(map(int, blocks)))
+    monkeypatch.setattr(ops, "spmm_probe", fake_probe)
+    monkeypatch.setattr(ops, "spmm_set_xcd_shares", fake_set)
+    monkeypatch.setattr(ops, "spmm_plan_run_tasks", lambda csr, d: nb * 4 - 1)
+    monkeypatch.delenv("SRH_XCD_CALIBRATE", raising=False)
+
+    def trainer(**over):
+        t = types.SimpleNamespace(dev=types.SimpleNamespace(type="cuda"), sharded=False, cols=False, L=3, d=64, model="LightGCN",
+                                  vfree=False, eps=0.2, dinv=None, E0=None, Ha=None, adj=types.SimpleNamespace())
+        t.__dict__.update(over)
+        return t
+    before = (canon * speed).max() - (canon * speed).min()
+    t = trainer()
+    got = engine.FusedTrainer._calibrate_xcd_shares(t)
+    fin = state["shares"] * speed
+    assert got is not None and np.array_equal(got, state["shares"]) and int(got.sum()) == nb
+    assert fin.max() - fin.min() < 0.8 < before and fin.max() < (canon * speed).max() - 1.0
+    assert (got >= canon * 6 // 10).all() and (got <= canon * 14 // 10 + 8).all()
+    assert got[2] < canon[2] and got[1] > canon[1]                        # the slow XCD gave, the fast one took
+    # the plan remembers: a second trainer on the same matrix does not probe again
+    n = state["probes"]
+    again = engine.FusedTrainer._calibrate_xcd_shares(trainer(adj=t.adj))
+    assert state["probes"] == n and np.array_equal(again, got)
+    # switched off, sharded layouts, unsupported widths, small graphs: nothing happens
+    monkeypatch.setenv("SRH_XCD_CALIBRATE", "0")
+    assert engine.FusedTrainer._calibrate_xcd_shares(trainer()) is None and state["probes"] == n
+    monkeypatch.delenv("SRH_XCD_CALIBRATE")
+    for over in (dict(sharded=True), dict(cols=True), dict(d=32), dict(L=0), dict(dev=types.SimpleNamespace(type="cpu"))):
+        assert engine.FusedTrainer._calibrate_xcd_shares(trainer(**over)) is None and state["probes"] == n
+    monkeypatch.setattr(ops, "spmm_plan_run_tasks", lambda csr, d: 4000)
+    assert engine.FusedTrainer._calibrate_xcd_shares(trainer()) is None and state["probes"] == n
+
