@@ -29,10 +29,6 @@
 
 #include "common.h"
 
-#ifndef SRH_ROWS_WAVES
-#define SRH_ROWS_WAVES 8      // waves per SIMD the row kernels are compiled for (<= 64 VGPRs)
-#endif
-
 namespace {
 
 using namespace srh;
@@ -424,7 +420,7 @@ struct alignas(64) Task64 {
 // PROBE (srh_spmm_f32_probe): every wave also leaves {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
 // in stamps[3 * wave ..] -- what the engine's start-up calibration of the plan's XCD shares reads (engine.py).
 template <int LPR, bool COLMASK, bool PROBE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_ROWS_WAVES, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,

@@ -2,7 +2,7 @@
 # The product library rebuilt with other compile-time switches of csrc/spmm.hip, for a file-level A/B of bench.py on
 # the GPU box (no run-time knob ships in the library):
 #   tools/spmm_lab/build_alt.sh <name> "<flags>" ...   ->  tools/spmm_lab/alt/libselfrec_hip_<name>.so
-#   e.g.  build_alt.sh w7 "-DSRH_ROWS_WAVES=7"
+#   e.g.  build_alt.sh exp "-DSRH_EXP_SOMETHING=1"   (a switch the experiment adds to csrc/spmm.hip for its duration)
 # (cp the file over selfrec_amd/lib/libselfrec_hip.so to use it; tools/spmm_lab/ab_libs.sh does that in a loop)
 set -e
 cd "$(dirname "$0")/../.."
