@@ -344,19 +344,55 @@ def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
             "note": f"test users dealt over {world} ranks, item table replicated, ranked ids all-gathered; slowest rank's time"}
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` (no launcher, the way the driver's single-GPU command line is spelled): start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` -- one rank per GPU over
+    RCCL -- and hand its exit code back.  Rank 0 of the child job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool's hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU of this node)
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    sharded = world > 1 or bool(os.environ.get("SRH_FORCE_SHARDED"))     # (knob: exercise the N>1 path on one GPU)
+    backend = os.environ.get("SRH_DIST_BACKEND", "nccl")                  # ("gloo": the CPU test of the launch path)
+    if sharded and backend != "nccl":
+        # launch-path check without GPUs (tests/test_dist_cpu.py): rendezvous, one collective, the layout this world
+        # size would take -- then stop; everything after this point needs the HIP library and a device
+        import torch.distributed as dist
+        from selfrec_amd.dist import describe_layout
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "backend": backend, "world": world, "rank_sum": float(t.item()),
+                              "parallelism": describe_layout(args.emb, world)}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from selfrec_amd import _lib
     _lib.require_gpu()
     torch.cuda.set_device(local)
-    sharded = world > 1 or bool(os.environ.get("SRH_FORCE_SHARDED"))     # (knob: exercise the N>1 path on one GPU)
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -418,7 +454,11 @@ def main():
     losses = trainer.read_losses()
 
     # Sharded or not, the global batch is fixed at B pairs per step for every N (strong scaling).
-    layout = "column-sharded tables" if getattr(trainer, "cols", False) else "row-sharded graph + tables"
+    if sharded:
+        from selfrec_amd.dist import describe_layout
+        layout = (describe_layout(args.emb, world, str(trainer.layout) if world > 1 else
+                                  ("cols" if trainer.cols else "rows"), 2 * trainer.graph.n_edges)
+                  + f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU")
     pairs = args.steps * args.batch
     value = pairs / elapsed
     g = trainer.graph
@@ -435,7 +475,7 @@ def main():
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; epochs are sampled by a host thread one epoch ahead and "
                                f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
                                f"(see steady_state for a region that always spans >= 1)",
-                   "global_batch": args.batch, "parallelism": f"{layout} x{world}" if sharded else "single",
+                   "global_batch": args.batch, "parallelism": layout if sharded else "single",
                    "launch": "hipGraph replay" if trainer.use_graph else "eager",
                    # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration
                    # (engine._calibrate_xcd_shares; null: equal dealing)

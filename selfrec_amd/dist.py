@@ -47,19 +47,47 @@ import os
 
 import torch.distributed as _dist
 
-from .engine import SLICE_WIDTHS, FusedTrainer, shard_adjacency  # noqa: F401  (shard_adjacency: public helper)
+from .engine import SLICE_WIDTHS, FusedTrainer, parse_grid, shard_adjacency  # noqa: F401  (public helpers)
+
+# Above this many stored non-zeros a rank's propagation launch is bound by its GATHERS (one 128-byte line per
+# non-zero whatever the slice width: DESIGN.md 6.2, measured at 80.5 M), and column blocks narrower than 32
+# columns stop paying: "auto" then takes the 2-D grid with 32-column blocks.
+GATHER_BOUND_NNZ = 30_000_000
 
 
-def pick_layout(emb_size: int, world: int, layout: str | None = None) -> str:
-    """"cols" whenever the column slice d / world is a width the SpMM kernels serve, else "rows".
-    ``layout`` / ``SRH_SHARD_LAYOUT`` = rows | cols | auto overrides."""
+def pick_layout(emb_size: int, world: int, layout: str | None = None, nnz: int | None = None) -> str:
+    """"cols" whenever the column slice d / world is a width the SpMM kernels serve, else "rows"; "2d:GCxGR" for
+    gather-bound graphs (``nnz`` stored non-zeros of the (N x N) adjacency) once d / world < 32.
+    ``layout`` / ``SRH_SHARD_LAYOUT`` = rows | cols | 2d | 2d:GCxGR | auto overrides."""
     layout = (layout or os.environ.get("SRH_SHARD_LAYOUT") or "auto").lower()
     if layout in ("rows", "cols"):
         return layout
+    if layout.startswith("2d"):
+        gc, gr = parse_grid(layout, world, emb_size)
+        return f"2d:{gc}x{gr}"
     if layout != "auto":
-        raise ValueError(f"shard layout {layout!r}: rows, cols or auto")
+        raise ValueError(f"shard layout {layout!r}: rows, cols, 2d[:GCxGR] or auto")
     # (a single rank has nothing to split: "auto" keeps it on the row layout's code path, "cols" can still be asked for)
-    return "cols" if world > 1 and emb_size % world == 0 and emb_size // world in SLICE_WIDTHS else "rows"
+    cols_ok = world > 1 and emb_size % world == 0 and emb_size // world in SLICE_WIDTHS
+    if cols_ok and nnz is not None and nnz >= GATHER_BOUND_NNZ and emb_size // world < 32 and world % 2 == 0:
+        gc = max(1, emb_size // 32)
+        if world % gc == 0 and gc < world:
+            return f"2d:{gc}x{world // gc}"
+    return "cols" if cols_ok else "rows"
+
+
+def describe_layout(emb_size: int, world: int, layout: str | None = None, nnz: int | None = None) -> str:
+    """One line for bench.py's ``config.parallelism``: the layout this world size takes and what it exchanges."""
+    lay = pick_layout(emb_size, world, layout, nnz)
+    if lay == "cols":
+        return (f"column-sharded tables x{world} (w = {emb_size // max(world, 1)} columns per rank, graph replicated, "
+                f"one all-gather of the batch rows per step)")
+    if lay == "rows":
+        return f"row-sharded graph + tables x{world} (an all-gather of (N, d) after every product)"
+    gc, gr = parse_grid(lay, world, emb_size)
+    return (f"2-D grid x{world}: {gc} column blocks (w = {emb_size // gc}) x {gr} row parts (per product: an all-gather "
+            f"of (N, w) over the {gr} ranks of a column block; per step: one all-gather of the batch rows over the "
+            f"{gc} ranks of a row part)")
 
 
 class ShardedTrainer(FusedTrainer):
@@ -68,8 +96,13 @@ class ShardedTrainer(FusedTrainer):
 
     def __init__(self, data, emb_size, layout=None, **kw):
         kw.pop("backend", None)
-        world = kw["comm"].world if kw.get("comm") is not None else _dist.get_world_size()
-        super().__init__(data, emb_size, shard=pick_layout(int(emb_size), int(world), layout), **kw)
+        comm = kw.get("comm")
+        if isinstance(comm, tuple):                      # (2-D stand-in communicators: (batch-row comm, table-row comm))
+            world = comm[0].world * comm[1].world
+        else:
+            world = comm.world if comm is not None else _dist.get_world_size()
+        nnz = 2 * int(data.interaction_mat.nnz) if hasattr(data, "interaction_mat") else None
+        super().__init__(data, emb_size, shard=pick_layout(int(emb_size), int(world), layout, nnz), **kw)
 
     def parameters_full(self):
         return self.user_emb, self.item_emb

@@ -48,16 +48,47 @@ SLICE_WIDTHS = (8, 16, 32, 64, 128)   # column slices the SpMM kernels serve (cs
 
 
 class TorchComm:
-    """The default process group as the two things the trainer needs from it."""
+    """A process group (the default one, or a sub-group of it) as the two things the trainer needs from it."""
 
-    def __init__(self):
+    def __init__(self, group=None, ranks=None):
         if not _dist.is_initialized():
             raise SelfrecHipError("sharded training needs an initialised torch.distributed process group")
-        self.world, self.rank = _dist.get_world_size(), _dist.get_rank()
+        self.group = group
+        if group is None:
+            self.world, self.rank = _dist.get_world_size(), _dist.get_rank()
+        else:
+            self.world, self.rank = len(ranks), list(ranks).index(_dist.get_rank())
+
+    @classmethod
+    def grid(cls, n_col_groups, n_row_parts):
+        """The two communicators of the 2-D layout on the default group of G = Gc * Gr ranks.  Rank q holds column
+        block q // Gr and row part q % Gr; it exchanges BATCH rows with the ranks of its row part (one per column
+        block: `cols`) and TABLE rows with the ranks of its column block (`rows`).  Every rank creates every group,
+        in the same order (torch.distributed's rule)."""
+        world, me = _dist.get_world_size(), _dist.get_rank()
+        if world != n_col_groups * n_row_parts:
+            raise SelfrecHipError(f"2-D layout {n_col_groups} x {n_row_parts} needs {n_col_groups * n_row_parts} ranks, not {world}")
+        mine = {}
+        for r in range(n_row_parts):
+            ranks = [c * n_row_parts + r for c in range(n_col_groups)]
+            g = _dist.new_group(ranks)
+            if me in ranks:
+                mine["cols"] = cls(g, ranks)
+        for c in range(n_col_groups):
+            ranks = [c * n_row_parts + r for r in range(n_row_parts)]
+            g = _dist.new_group(ranks)
+            if me in ranks:
+                mine["rows"] = cls(g, ranks)
+        how = os.environ.get("SRH_2D_EXCHANGE", "twohop").lower()
+        if how not in ("twohop", "direct"):
+            raise SelfrecHipError(f"SRH_2D_EXCHANGE={how!r}: twohop or direct")
+        if how == "twohop" and n_col_groups > 1 and n_row_parts > 1:
+            mine["rows"] = TwoHopRows(mine["rows"], n_col_groups, n_row_parts)
+        return mine["cols"], mine["rows"]
 
     def all_gather(self, out, inp):
         # (flat views: rank r's contribution is the r-th equal piece of `out`, whatever the shapes)
-        _dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
+        _dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
     def assert_replicated(self, what, values, device):
         """Every rank must hold the same `values` (a short list of floats: checksums of state the step code
@@ -65,12 +96,92 @@ class TorchComm:
         from rank 0 AND on rank 0, so a mis-seeded job stops instead of training on different batches."""
         mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
         everyone = torch.empty((self.world, mine.numel()), dtype=torch.float64, device=device)
-        _dist.all_gather_into_tensor(everyone.view(-1), mine)
+        _dist.all_gather_into_tensor(everyone.view(-1), mine, group=self.group)
         bad = [r for r in range(self.world) if not torch.equal(everyone[r], everyone[0])]
         if bad:
             raise SelfrecHipError(f"{what} differs between ranks (rank 0 vs ranks {bad}): every rank must be seeded "
                                   f"identically (torch.manual_seed for the tables, the sampler seed / python `random` "
                                   f"state for the batches); this rank is {self.rank}")
+
+
+class TwoHopRows:
+    """The table-row all-gather of the 2-D layout, moved over EVERY xGMI link instead of the Gr - 1 direct ones.
+
+    xGMI is a full mesh of point-to-point links (7 per GPU, ~75 GB/s per direction each).  A column block's all-gather
+    over its Gr ranks uses Gr - 1 of a rank's links and leaves the others idle: at Gr = 2 one link carries the whole
+    (N / 2, w) slab (96 MB at the 1 M x 500 k, d = 128 shape on a 4 x 2 grid: ~1.3 ms per layer).
+    Two all-to-alls over ALL G ranks move the same slab through every link at once:
+
+        hop 1   rank q cuts its slab into G pieces and sends piece k to rank k          (1/G of the slab per link)
+        hop 2   rank k forwards piece k of rank q's slab to q's partner(s)              (again 1/G per link)
+
+    so a rank's link carries 2/G of a slab per partner instead of a whole one (Gr = 2, G = 8: 4x less time on the wire).
+    With Gr > 2 hop 2 runs once per partner offset j = 1 .. Gr - 1 (rank k sends to rank t the piece it holds of the
+    slab of t's j-th partner).  Pieces are padded to equal size; the slab's own piece never leaves the rank.
+    Same interface and same result as the direct group all-gather (tests/test_dist_cpu.py)."""
+
+    def __init__(self, direct, n_col_groups, n_row_parts):
+        self.direct = direct                              # (tiny messages -- checksums, the D^-1/2 vector -- go direct)
+        self.world, self.rank, self.group = direct.world, direct.rank, direct.group
+        self.Gc, self.Gr = int(n_col_groups), int(n_row_parts)
+        self.G, self.me = self.Gc * self.Gr, _dist.get_rank()
+        self._buf = {}
+        self.min_bytes = int(os.environ.get("SRH_2D_TWOHOP_MIN_BYTES", 1 << 20))
+
+    def assert_replicated(self, what, values, device):
+        self.direct.assert_replicated(what, values, device)
+
+    def _scratch(self, piece, dtype, device):
+        key = (piece, dtype, str(device))
+        if key not in self._buf:
+            self._buf[key] = tuple(torch.empty(self.G * piece, dtype=dtype, device=device) for _ in range(3))
+        return self._buf[key]
+
+    def all_gather(self, out, inp):
+        out, inp = out.view(-1), inp.reshape(-1)
+        n = inp.numel()
+        if n * inp.element_size() < self.min_bytes or out.numel() != self.Gr * n:
+            return self.direct.all_gather(out, inp)
+        G, Gr = self.G, self.Gr
+        piece = (n + G - 1) // G
+        send, held, fwd = self._scratch(piece, inp.dtype, inp.device)
+        send[:n].copy_(inp)                               # (inp may alias out's own piece: read it before anything lands)
+        _dist.all_to_all_single(held, send)               # hop 1: held[q] = piece `me` of rank q's slab
+        c, r = self.me // Gr, self.me % Gr
+        pieces = held.view(G, piece)
+        for j in range(1, Gr):
+            # hop 2, partner offset j: destination t receives the piece of t's j-th partner's slab that this rank holds
+            key = (j, str(inp.device))
+            if key not in self._buf:
+                self._buf[key] = torch.tensor([(t // Gr) * Gr + (t % Gr + j) % Gr for t in range(G)], device=inp.device)
+            src = self._buf[key]
+            torch.index_select(pieces, 0, src, out=fwd.view(G, piece))
+            _dist.all_to_all_single(send, fwd)            # send[k] = piece k of my j-th partner's slab
+            part = (r + j) % Gr
+            out[part * n:(part + 1) * n].copy_(send[:n])
+        if out.data_ptr() + r * n * out.element_size() != inp.data_ptr():
+            out[r * n:(r + 1) * n].copy_(inp)
+
+
+def parse_grid(spec, world, emb_size):
+    """"2d" or "2d:GCxGR" -> (column blocks, row parts) with GC * GR = world.  Unspecified: two row parts (the exchange a
+    rank waits for per layer is (Gr - 1) / Gr of an (N, w) slice -- DESIGN.md 6.2 -- so rows are split as little as
+    the column widths allow), more only while d / GC would fall below the narrowest slice the kernels serve."""
+    world, d = int(world), int(emb_size)
+    if ":" in str(spec):
+        try:
+            gc, gr = (int(v) for v in str(spec).split(":", 1)[1].lower().split("x"))
+        except ValueError:
+            raise SelfrecHipError(f"shard layout {spec!r}: expected 2d:GCxGR, e.g. 2d:4x2") from None
+        if gc * gr != world:
+            raise SelfrecHipError(f"shard layout {spec!r}: {gc} x {gr} != world size {world}")
+        return gc, gr
+    gr = 2 if world % 2 == 0 else 1
+    while world % gr or d % (world // gr) or (world // gr > 1 and d // (world // gr) not in SLICE_WIDTHS):
+        gr += 1
+        if gr > world:
+            raise SelfrecHipError(f"no 2-D grid for {world} ranks at d = {d}")
+    return world // gr, gr
 
 
 def shard_adjacency(norm_adj_csr, rank, world):
@@ -125,37 +236,63 @@ class FusedTrainer:
         # independent per column, so the 2L + 1 products of a step need NO exchange; the losses read
         # whole rows, but only the O(batch) rows the staged lists name: those are all-gathered once per
         # step into compact (5B, d) tables (csrc/exchange.hip) on which the unchanged loss kernels run.
-        if shard not in (False, True, None, "rows", "cols"):
-            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows' or 'cols')")
+        #
+        # shard="2d" (or "2d:GCxGR"): both at once on G = Gc * Gr ranks -- rank q keeps column block q // Gr of every
+        # table and computes row part q % Gr of every product: the column layout's one batch-row exchange over the Gc
+        # ranks of its row part, the row layout's per-layer all-gather over the Gr ranks of its column block, on
+        # (N / Gr, d / Gc) slices.  For graphs whose products are bound by the GATHERS (1 M x 500 k: a rank's launch
+        # costs one line fetch per non-zero whatever its width), where more column blocks stop paying.
+        grid = None
+        if isinstance(shard, str) and shard.startswith("2d"):
+            grid, shard = shard, "2d"
+        if shard not in (False, True, None, "rows", "cols", "2d"):
+            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows', 'cols' or '2d[:GCxGR]')")
         self.G, self.rank = 1, 0
-        self.sharded = shard in (True, "rows")          # row-sharded layout
-        self.cols = shard == "cols"                      # column-sharded layout
-        self.comm = None
-        if self.sharded or self.cols:
+        self.sharded = shard in (True, "rows", "2d")    # rows of the graph / tables dealt over Gr ranks
+        self.cols = shard in ("cols", "2d")              # columns of the tables split over Gc ranks
+        self.layout = {True: "rows", None: False}.get(shard, shard)
+        self.comm = self.comm_rows = None                # comm: the batch-row exchange (cols); comm_rows: table rows
+        self.Gc = self.Gr = 1
+        self.cr = self.rr = 0                            # this rank's column block / row part
+        if shard == "2d":
+            if comm is None:
+                world = _dist.get_world_size() if _dist.is_initialized() else 1
+                gc, gr = parse_grid(grid, world, int(emb_size))
+                comm = TorchComm.grid(gc, gr)
+            self.comm, self.comm_rows = comm
+            self.Gc, self.cr = int(self.comm.world), int(self.comm.rank)
+            self.Gr, self.rr = int(self.comm_rows.world), int(self.comm_rows.rank)
+            self.G, self.rank = self.Gc * self.Gr, self.cr * self.Gr + self.rr
+            self.layout = f"2d:{self.Gc}x{self.Gr}"
+        elif self.sharded or self.cols:
             self.comm = comm if comm is not None else TorchComm()
             self.G, self.rank = int(self.comm.world), int(self.comm.rank)
+            if self.cols:
+                self.Gc, self.cr = self.G, self.rank
+            else:
+                self.Gr, self.rr, self.comm_rows = self.G, self.rank, self.comm
         N, d, B = self.N, self.d, self.B
         self.w = d                                       # width of this rank's tables
         if self.cols:
             # (a single rank keeps whole rows: the layout then only adds the batch-row exchange -- a way to run
             # this code path, collective included, on one GPU)
-            if d % self.G or ((d // self.G) not in SLICE_WIDTHS and self.G > 1):
-                raise SelfrecHipError(f"column-sharded layout: d / world = {d}/{self.G} must be one of {SLICE_WIDTHS}")
-            self.w = d // self.G
-        self.col0 = self.rank * self.w if self.cols else 0
-        G = self.G if self.sharded else 1                # ranks the ROWS are dealt over
+            if d % self.Gc or ((d // self.Gc) not in SLICE_WIDTHS and self.Gc > 1):
+                raise SelfrecHipError(f"column-sharded layout: d / column blocks = {d}/{self.Gc} must be one of {SLICE_WIDTHS}")
+            self.w = d // self.Gc
+        self.col0 = self.cr * self.w if self.cols else 0
+        G = self.Gr                                      # ranks the ROWS are dealt over
         self.n_pad = (N + G - 1) // G
         self.P = G * self.n_pad
         nodes = np.arange(N, dtype=np.int64)
         self._pos = ((nodes % G) * self.n_pad + nodes // G).astype(np.int32)
         self._pos_dev = torch.from_numpy(self._pos.astype(np.int64)).to(dev)
-        self.loc = slice(self.rank * self.n_pad, (self.rank + 1) * self.n_pad) if self.sharded else slice(0, self.P)
+        self.loc = slice(self.rr * self.n_pad, (self.rr + 1) * self.n_pad) if self.sharded else slice(0, self.P)
         if not self.sharded:
             self.graph = data.device_graph(dev, column_classes=not self.cols)
             self.adj = self.graph.adj
         else:
             from .data import device_graph as _dg
-            self.graph = _dg.ShardedDeviceGraph(data.interaction_mat, self.rank, G, dev, self._allgather)
+            self.graph = _dg.ShardedDeviceGraph(data.interaction_mat, self.rr, G, dev, self._allgather)
             self.adj = self.graph.adj
         g = self.graph
         P = self.P
@@ -249,7 +386,8 @@ class FusedTrainer:
         # SRH_SHARDED_GRAPH=0 launches eagerly.  The row-sharded step has a collective after every product: it
         # launches eagerly unless SRH_SHARDED_GRAPH=1 asks for RCCL inside the capture.
         env = os.environ.get("SRH_SHARDED_GRAPH")
-        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols) or env == "1" or (self.cols and env != "0"))
+        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols) or env == "1"
+                                              or (self.cols and not self.sharded and env != "0"))
         self._graph = None
         self._noise_call = 0
         # counter RNG layout: (optimiser step) * rng_stride + (perturbed-layer call of the step) * P + row; SimGCL makes
@@ -337,7 +475,7 @@ class FusedTrainer:
         self._x_cgrad = {id(g): compact() for g in grads}
         self._x_pairs = [(self._x_cgrad[id(g)], g) for g in grads]
         self._x_send = torch.zeros((len(tables), rows, self.w), dtype=torch.float32, device=dev)
-        self._x_recv = torch.zeros((self.G, len(tables), rows, self.w), dtype=torch.float32, device=dev)
+        self._x_recv = torch.zeros((self.Gc, len(tables), rows, self.w), dtype=torch.float32, device=dev)
         slots = torch.arange(rows, dtype=torch.int32, device=dev)
         self._x_idx = {k: slots[s * B:(s + 1) * B] for s, k in enumerate(("u", "i", "j", "uniq_u", "uniq_i"))}
         self._x_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev) if m == "SGL" else None
@@ -351,19 +489,20 @@ class FusedTrainer:
         self.comm.all_gather(self._x_recv, self._x_send)
 
     def _unpack(self):
-        ops.batch_unpack(self._x_lists, self._x_recv, self.G, self.w, [self._x_compact[id(t)] for t in self._x_tables],
+        ops.batch_unpack(self._x_lists, self._x_recv, self.Gc, self.w, [self._x_compact[id(t)] for t in self._x_tables],
                          [c for c, _ in self._x_pairs])
 
     def _assert_replicated(self, what, values):
-        check = getattr(self.comm, "assert_replicated", None)      # (test stand-in communicators may not have it)
-        if check is not None and self.G > 1:
-            check(what, values, self.dev)
+        for comm in {id(c): c for c in (self.comm, self.comm_rows) if c is not None}.values():
+            check = getattr(comm, "assert_replicated", None)       # (test stand-in communicators may not have it)
+            if check is not None and comm.world > 1:
+                check(what, values, self.dev)                      # (2-D: row part + column block span the grid)
 
     def _full(self, t):
         """(rows, w) slice on every rank -> the whole (rows, d) table (a collective; plumbing, not per step)."""
         if not self.cols:
             return t
-        recv = torch.empty((self.G,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        recv = torch.empty((self.Gc,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         self.comm.all_gather(recv, t.contiguous())
         return recv.permute(1, 0, 2).reshape(t.shape[0], self.d).contiguous()
 
@@ -372,15 +511,13 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------
     @property
     def user_emb(self):
-        if self.cols:
-            return self._full(self.E0)[:self.U]         # (a collective: every rank must ask)
-        return self.E0[:self.U] if not self.sharded else self.E0[self._pos_dev[:self.U]]
+        t = self._full(self.E0)                          # (column-sharded: a collective -- every rank must ask)
+        return t[:self.U] if not self.sharded else t[self._pos_dev[:self.U]]
 
     @property
     def item_emb(self):
-        if self.cols:
-            return self._full(self.E0)[self.U:]
-        return self.E0[self.U:] if not self.sharded else self.E0[self._pos_dev[self.U:]]
+        t = self._full(self.E0)
+        return t[self.U:] if not self.sharded else t[self._pos_dev[self.U:]]
 
     def _loc(self, t):
         """The rows of a table this rank owns (the whole table on one GPU)."""
@@ -390,7 +527,7 @@ class FusedTrainer:
         """Make a table whose owned rows were just written whole again on every rank."""
         if self.sharded:
             mine = t[self.loc]
-            self.comm.all_gather(t, mine if self.dev.type == "cuda" else mine.clone())
+            self.comm_rows.all_gather(t, mine if self.dev.type == "cuda" else mine.clone())
 
     # ------------------------------------------------------------------------------------
     # sampling
@@ -479,7 +616,7 @@ class FusedTrainer:
 
     def _rng_offset(self, call):
         """Counter offset of perturbed-layer call number `call` of this step (rows of all ranks)."""
-        return (call * self.P + (self.rank * self.n_pad if self.sharded else 0)) & ((1 << 62) - 1)
+        return (call * self.P + (self.rr * self.n_pad if self.sharded else 0)) & ((1 << 62) - 1)
 
     def _slice_kw(self):
         """PERTURB on a column slice: tell the kernel where the slice sits in the whole row."""

@@ -23,7 +23,8 @@ def _free_port():
 def _worker(rank, world, port, model, layout, out_path, d=64):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SRH_2D_TWOHOP_MIN_BYTES="0")           # (2-D: even these small tables take the two-hop exchange)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from selfrec_amd import engine, synth
@@ -43,6 +44,11 @@ def _worker(rank, world, port, model, layout, out_path, d=64):
     assert tr.G == world
     if layout == "rows":
         assert tr.sharded and tr.P == world * tr.n_pad
+    elif layout.startswith("2d"):
+        # column blocks x row parts: (N / Gr, d / Gc) slices, tables kept whole in all-gather order of the row parts
+        assert tr.sharded and tr.cols and tr.Gc * tr.Gr == world and tr.Gr >= 2
+        assert tr.w == d // tr.Gc and tr.E0.shape == (tr.Gr * tr.n_pad, tr.w) and tr.m.shape == (tr.n_pad, tr.w)
+        assert (tr.cr, tr.rr) == (rank // tr.Gr, rank % tr.Gr)
     else:
         assert tr.cols and tr.w == d // world and tr.E0.shape == (U + I, d // world)
     import random
@@ -66,14 +72,17 @@ def _worker(rank, world, port, model, layout, out_path, d=64):
 CASES = [("XSimGCL", 2, "rows"), ("LightGCN", 2, "rows"), ("MF", 2, "rows"), ("XSimGCL", 3, "rows"), ("SimGCL", 2, "rows"),
          ("SGL", 2, "rows"),
          ("XSimGCL", 2, "cols"), ("XSimGCL", 4, "cols"), ("XSimGCL", 8, "cols"), ("LightGCN", 2, "cols"), ("MF", 4, "cols"),
-         ("SimGCL", 2, "cols"), ("SGL", 2, "cols")]
+         ("SimGCL", 2, "cols"), ("SGL", 2, "cols"),
+         # the 2-D grid: 4 x 2 at d = 128 is the layout BASELINE configs[3] takes on 8 GPUs
+         ("XSimGCL", 8, "2d@128"), ("XSimGCL", 4, "2d"), ("LightGCN", 4, "2d"), ("SGL", 4, "2d"), ("SimGCL", 4, "2d:1x4"),
+         ("MF", 4, "2d")]
 
 
-@pytest.mark.parametrize("model,world,layout", CASES + [("XSimGCL", 2, "cols128")])
+@pytest.mark.parametrize("model,world,layout", CASES + [("XSimGCL", 2, "cols@128")])
 def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
     out = str(tmp_path / "res.npz")
-    d = 128 if layout == "cols128" else 64              # (d = 128 over 2 ranks: 64-column slices)
-    layout = layout[:4]
+    layout, _, dd = layout.partition("@")               # (d = 128 over 2 ranks: 64-column slices)
+    d = int(dd or 64)
     mp.spawn(_worker, args=(world, _free_port(), model, layout, out, d), nprocs=world, join=True)
     r = np.load(out)
     gen = torch.Generator().manual_seed(7)
@@ -94,6 +103,44 @@ def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
     fu, fi = ref.embeddings()
     np.testing.assert_allclose(r["fu"], fu, rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(r["fi"], fi, rtol=1e-4, atol=2e-6)
+
+
+def _twohop_worker(rank, world, port, gc, gr, flag_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SRH_2D_TWOHOP_MIN_BYTES="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from selfrec_amd.engine import TorchComm, TwoHopRows
+    cols, rows = TorchComm.grid(gc, gr)
+    assert isinstance(rows, TwoHopRows) and (cols.world, rows.world) == (gc, gr)
+    assert (cols.rank, rows.rank) == (rank // gr, rank % gr)
+    for n in (world * 5, 1003, 7):                           # divisible by G, ragged (padded pieces), smaller than G
+        table = torch.full((gr * n,), -1.0)
+        mine = table[rows.rank * n:(rows.rank + 1) * n]      # in place, as the engine calls it
+        mine.copy_(torch.arange(n, dtype=torch.float32) + 1000.0 * rank)
+        rows.all_gather(table, mine)
+        want = torch.cat([torch.arange(n, dtype=torch.float32) + 1000.0 * ((rank // gr) * gr + r) for r in range(gr)])
+        assert torch.equal(table, want), (rank, n)
+        direct = torch.empty_like(table)
+        rows.direct.all_gather(direct, mine.clone())
+        assert torch.equal(direct, want)
+    # the batch-row communicator: ranks of the same row part, one per column block
+    got = torch.empty(gc)
+    cols.all_gather(got, torch.tensor([float(rank)]))
+    assert got.tolist() == [float(c * gr + rank % gr) for c in range(gc)]
+    open(os.path.join(flag_dir, f"ok{rank}"), "w").close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gc,gr", [(4, 2), (2, 4), (2, 3)])
+def test_two_hop_row_exchange_equals_direct_all_gather(tmp_path, gc, gr):
+    """the per-layer all-gather of a column block moved as two all-to-alls over all G ranks (every xGMI
+    link carries 1/G of the slab per hop) leaves exactly what the direct group all-gather leaves."""
+    world = gc * gr
+    mp.spawn(_twohop_worker, args=(world, _free_port(), gc, gr, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
 def test_shard_adjacency_layout():
@@ -122,6 +169,12 @@ def test_layout_choice():
     assert [pick_layout(64, w) for w in (1, 2, 3, 4, 8, 16)] == ["rows", "cols", "rows", "cols", "cols", "rows"]
     assert pick_layout(128, 8) == "cols" and pick_layout(128, 2) == "cols" and pick_layout(64, 2, "rows") == "rows"
     assert pick_layout(256, 8) == "cols" and pick_layout(128, 3) == "rows"
+    # the 2-D grid: on request, and by itself for gather-bound graphs once the column blocks would fall below 32
+    assert pick_layout(128, 8, "2d") == "2d:4x2" and pick_layout(64, 4, "2d") == "2d:2x2" and pick_layout(64, 8, "2d:2x4") == "2d:2x4"
+    assert pick_layout(128, 8, nnz=80_600_000) == "2d:4x2" and pick_layout(128, 4, nnz=80_600_000) == "cols"
+    assert pick_layout(64, 8, nnz=2_521_586) == "cols" and pick_layout(64, 8, nnz=80_600_000) == "2d:2x4"
+    with pytest.raises(Exception):
+        pick_layout(128, 8, "2d:3x2")
 
 
 def _eval_worker(rank, world, port, out_path):
@@ -202,3 +255,23 @@ def test_unequal_seeds_across_ranks_are_detected(tmp_path):
     stops the job with an error instead of silently training on different data."""
     mp.spawn(_seed_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bench_gpus_n_launches_itself_under_torchrun():
+    """`python bench.py --gpus 2` -- no launcher, the way the driver spells the single-GPU command --
+    must start one rank per GPU itself (torch.distributed.run) instead of exiting.  Here: gloo instead of RCCL, and the
+    ranks stop after the rendezvous + one collective (everything later needs a GPU)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SRH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0
+    assert rec["parallelism"].startswith("column-sharded tables x2")
+    assert "torch.distributed.run" in p.stderr
