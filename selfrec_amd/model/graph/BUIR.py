@@ -71,18 +71,26 @@ class _TwoTowerScores(OpLevelRecommender):
     (2d) vectors [p(u) ; u] . [i ; p(i)]."""
     verbose_every = 1
 
-    def snapshot(self):
-        self.p_u_online, self.u_online, self.p_i_online, self.i_online = self.model.get_embedding()
+    def _set_towers(self, p_u, u, p_i, i):
+        """The four tables predict() scores with AND their concatenation, which test() ranks with on the device -- always
+        set together, so the final 'Testing...' pass after train() ranks the tables restore_best() put back (BUIR.py:
+        36-37 reports the best epoch), not the last epoch's concatenation."""
+        self.p_u_online, self.u_online, self.p_i_online, self.i_online = p_u, u, p_i, i
         if 2 * self.emb_size in (64, 128, 256):                  # widths the scoring GEMM serves
-            self.user_emb = torch.cat([self.p_u_online, self.u_online], 1)
-            self.item_emb = torch.cat([self.i_online, self.p_i_online], 1)
+            self.user_emb = torch.cat([p_u, u], 1)
+            self.item_emb = torch.cat([i, p_i], 1)
+        else:                                                    # test() then falls back to predict()
+            self.user_emb = self.item_emb = None
+
+    def snapshot(self):
+        self._set_towers(*self.model.get_embedding())
 
     def save(self):
         self.best_p_u, self.best_u, self.best_p_i, self.best_i = self.model.get_embedding()
 
     def restore_best(self):
         if hasattr(self, 'best_p_u'):
-            self.p_u_online, self.u_online, self.p_i_online, self.i_online = self.best_p_u, self.best_u, self.best_p_i, self.best_i
+            self._set_towers(self.best_p_u, self.best_u, self.best_p_i, self.best_i)
 
     def predict(self, u):
         uid = self.data.get_user_id(u)

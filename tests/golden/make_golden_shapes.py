@@ -83,8 +83,14 @@ def make_conf(tmp, model, extra, emb=None, batch=2048, topn="[10,20]"):
 
 
 def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2718, 4242), eval_users=0,
-              full_rank=False, sample_rows=True):
-    """n_steps reference training steps of `name`; everything recorded under the prefix `tag`."""
+              full_rank=False, sample_rows=True, capture=0):
+    """n_steps reference training steps of `name`; everything recorded under the prefix `tag`.
+
+    capture = K > 0 (VERDICT r02 "next" #2): also keep, from the FIRST step, sampled rows of the first K sparse-product
+    outputs as the model appends them to its layer list (XSimGCL.py:88-92 / SimGCL.py:86-90 perturb the product's output
+    in place, so the kept tensor IS the layer output; LightGCN.py:72-73 / SGL.py:106-107 append it as it is) and of
+    embedding_dict[*].grad after the first backward(), BEFORE Adam -- quantities that summation order moves by 1e-7,
+    not by the fraction of an Adam step that 1 / (sqrt(v) + 1e-8) makes of it."""
     init_seed, sampler_seed, noise_seed = seeds
     mod = importlib.import_module(f"model.graph.{name}")
     rec = {"batches": [], "bpr": [], "reg": [], "nce": []}
@@ -115,6 +121,22 @@ def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2
                 mod.InfoNCE = wrap(ref_loss.InfoNCE, "nce")
             noise_gen = torch.Generator().manual_seed(noise_seed)
             torch.rand_like = lambda t, **k: torch.rand(t.shape, generator=noise_gen)
+            kept, grads = [], {}
+            real_mm, real_adam_step = torch.sparse.mm, torch.optim.Adam.step
+            if capture:
+                def mm(a, b):
+                    y = real_mm(a, b)
+                    if len(kept) < capture:
+                        kept.append(y)
+                    return y
+
+                def adam_step(self, *a, **k):
+                    if not grads:
+                        for group in self.param_groups:
+                            for q in group["params"]:
+                                grads[tuple(q.shape)] = q.grad.detach().clone()
+                    return real_adam_step(self, *a, **k)
+                torch.sparse.mm, torch.optim.Adam.step = mm, adam_step
             torch.manual_seed(init_seed)
             random.seed(sampler_seed)
             t0 = time.time()
@@ -129,6 +151,8 @@ def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2
                 model.train()
             except AttributeError as e:                          # best_user_emb is only set by fast_evaluation
                 assert "best_user_emb" in str(e), e
+            finally:
+                torch.sparse.mm, torch.optim.Adam.step = real_mm, real_adam_step
             with torch.no_grad():
                 model.user_emb, model.item_emb = model.model()
             t2 = time.time()
@@ -159,6 +183,26 @@ def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2
                     "n_users": U, "n_items": I, "n_train": len(d.training_data),
                     "init_sha_user": sha(init_u, np.float32), "init_sha_item": sha(init_i, np.float32),
                     "build_s": round(t1 - t0, 1), "train_s": round(t2 - t1, 1)}
+            if capture:
+                assert len(kept) == capture and len(grads) == 2, (len(kept), list(grads))
+                # rows: the random sample + the first 256 distinct users / items of batch 1 (where the gradient lives)
+                bu = np.unique(np.asarray(rec["batches"][0][0], dtype=np.int64))[:256]
+                bi = np.unique(np.asarray(rec["batches"][0][1] + rec["batches"][0][2], dtype=np.int64))[:256]
+                g_rows_u = np.concatenate([ru, bu]).astype(np.int32)
+                g_rows_i = np.concatenate([ri, bi]).astype(np.int32)
+                out[f"{tag}_pre_rows_user"], out[f"{tag}_pre_rows_item"] = g_rows_u, g_rows_i
+                for k, y in enumerate(kept):
+                    y = y.detach().numpy()
+                    out[f"{tag}_pre_layer{k}_user"] = y[:U][g_rows_u].copy()
+                    out[f"{tag}_pre_layer{k}_item"] = y[U:][g_rows_i].copy()
+                gu, gi = grads[(U, pu.shape[1])].numpy(), grads[(I, pi.shape[1])].numpy()
+                out[f"{tag}_pre_grad_user"], out[f"{tag}_pre_grad_item"] = gu[g_rows_u].copy(), gi[g_rows_i].copy()
+                info["pre_adam"] = {"captured_products": capture, "grad_absmax_user": float(np.abs(gu).max()),
+                                    "grad_absmax_item": float(np.abs(gi).max()),
+                                    "grad_l2_user": float(np.sqrt((gu.astype(np.float64) ** 2).sum())),
+                                    "grad_l2_item": float(np.sqrt((gi.astype(np.float64) ** 2).sum()))}
+                del kept[:]
+                grads.clear()
             if eval_users:
                 # graph_recommender.py:46-53 for a sample of the test users: predict, mask, heap top-K
                 users = list(d.test_set.keys())
@@ -215,9 +259,12 @@ def section_Y(out, meta):
     meta["Y_graph"] = {"shape": "yelp2018", "seed": SEED_GRAPH, "n_users": U, "n_items": I, "n_train": len(tu), "n_test": len(su)}
     stream_hashes(train, 2048, 2, 20240924, meta, "Y_sampler")
     run_model("XSimGCL", {"n_layer": 3, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2},
-              [list(t) for t in train], [list(t) for t in test], 2, "Y_XSimGCL", out, meta, eval_users=64)
+              [list(t) for t in train], [list(t) for t in test], 2, "Y_XSimGCL", out, meta, eval_users=64, capture=3)
     run_model("LightGCN", {"n_layer": 3}, [list(t) for t in train], [list(t) for t in test], 2, "Y_LightGCN", out, meta,
-              eval_users=64)
+              eval_users=64, capture=3)
+    # SimGCL.py:21-50: one clean pass + two perturbed views per step (tau = 0.2 is hard-coded there)
+    run_model("SimGCL", {"n_layer": 3, "lambda": 0.5, "eps": 0.1}, [list(t) for t in train], [list(t) for t in test], 2,
+              "Y_SimGCL", out, meta, capture=9)
 
 
 def section_F(out, meta):
@@ -225,7 +272,7 @@ def section_F(out, meta):
     train, test = synth.as_triples(tu, ti), synth.as_triples(su, si)
     meta["F_graph"] = {"shape": "ifashion", "seed": SEED_GRAPH, "n_users": U, "n_items": I, "n_train": len(tu), "n_test": len(su)}
     extra = {"n_layer": 2, "lambda": 0.1, "drop_rate": 0.1, "aug_type": 1, "temp": 0.2}
-    model, state0 = run_model("SGL", extra, [list(t) for t in train], [list(t) for t in test], 1, "F_SGL", out, meta)
+    model, state0 = run_model("SGL", extra, [list(t) for t in train], [list(t) for t in test], 1, "F_SGL", out, meta, capture=6)
     # the epoch's two keep-sets, replayed from the state train() started with (SGL.py:28-29, augmentor.py:34)
     random.setstate(state0)
     e = model.data.interaction_mat.count_nonzero()
@@ -233,6 +280,10 @@ def section_F(out, meta):
     keeps = [random.sample(range(e), k) for _ in range(2)]
     meta["F_SGL"].update(n_edges=int(e), n_keep=k, keep_sha=[sha(x, np.int64) for x in keeps],
                          keep_sorted_sha=[sha(np.sort(np.asarray(x, dtype=np.int64)), np.int64) for x in keeps])
+    # BASELINE.json configs[4] and the README's model matrix run SGL with THREE layers (the shipped yaml has 2)
+    extra3 = dict(extra, n_layer=3)
+    run_model("SGL", extra3, [list(t) for t in train], [list(t) for t in test], 1, "F_SGL3", out, meta, capture=9)
+    meta["F_SGL3"].update(n_edges=int(e), n_keep=k)
 
 
 def section_B(out, meta):
@@ -248,7 +299,7 @@ def section_B(out, meta):
         meta["B_graph"] = {"shape": "1m-500k", "seed": SEED_GRAPH, "n_users": U, "n_items": I, "n_train": len(tu),
                            "n_test_used": 200000}
         run_model("XSimGCL", {"n_layer": 3, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, train, test, 1, "B_XSimGCL",
-                  out, meta, eval_users=16)
+                  out, meta, eval_users=16, capture=3)
     finally:
         torch.set_num_threads(1)
         EMB["default"] = 64

@@ -355,3 +355,115 @@ def test_bench_helpers_accept_a_column_sharded_trainer(golden_models, golden_met
     assert trainers[1].w == 16 and traffic > 0 and "pmc" in note
     alg = bench.spmm_alg_bytes(trainers[1].adj.nnz, trainers[1].adj.shape[0], trainers[1].adj.shape[1], trainers[1].w)
     assert alg > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the 2-D grid (column blocks x row parts) on ONE GPU: Gc * Gr virtual ranks, one python THREAD each
+# (the row all-gathers sit inside the step's halves, so the ranks cannot be driven phase by phase), their two
+# communicators stood in by barriers + device copies on the shared stream
+# ---------------------------------------------------------------------------------------------------
+class ThreadGrid:
+    class _Shared:
+        def __init__(self, n):
+            import threading
+            self.n, self.slots, self.barrier = n, [None] * n, threading.Barrier(n, timeout=120)
+
+    class _Comm:
+        def __init__(self, shared, rank):
+            self.shared, self.rank, self.world = shared, rank, shared.n
+
+        def all_gather(self, out, inp):
+            sh = self.shared
+            sh.slots[self.rank] = inp
+            sh.barrier.wait()
+            flat, n = out.view(-1), inp.numel()
+            for r, t in enumerate(sh.slots):
+                piece = flat[r * n:(r + 1) * n]
+                if piece.data_ptr() != t.data_ptr():
+                    piece.copy_(t.reshape(-1))
+            sh.barrier.wait()
+
+    def __init__(self, gc, gr):
+        self.gc, self.gr = gc, gr
+        self.col_groups = [self._Shared(gc) for _ in range(gr)]      # one per row part: its Gc ranks trade batch rows
+        self.row_groups = [self._Shared(gr) for _ in range(gc)]      # one per column block: its Gr ranks trade table rows
+
+    def comms(self, q):
+        c, r = q // self.gr, q % self.gr
+        return self._Comm(self.col_groups[r], c), self._Comm(self.row_groups[c], r)
+
+    def run(self, body):
+        """body(q, comms) on one thread per virtual rank; returns their results in rank order, re-raises a failure."""
+        import threading
+        res, err = [None] * (self.gc * self.gr), []
+
+        def work(q):
+            try:
+                torch.cuda.set_device(0)
+                res[q] = body(q, self.comms(q))
+            except BaseException as e:       # noqa: BLE001  (a dead rank would leave the others at a barrier)
+                err.append(e)
+                for g in self.col_groups + self.row_groups:
+                    g.barrier.abort()
+        threads = [threading.Thread(target=work, args=(q,)) for q in range(self.gc * self.gr)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise next((e for e in err if not isinstance(e, __import__("threading").BrokenBarrierError)), err[0])
+        return res
+
+
+def whole_table_2d(results, gc, gr):
+    """[(E0 of rank q in all-gather order, pos)] -> the (N, d) table in node order (row part 0 of every column block)."""
+    blocks = [results[c * gr][0][results[c * gr][1]] for c in range(gc)]
+    return torch.cat(blocks, dim=1)
+
+
+@pytest.mark.parametrize("name,grid", [("XSimGCL", (2, 2)), ("XSimGCL", (4, 2)), ("LightGCN", (2, 2)), ("SGL", (2, 4)),
+                                       ("SimGCL", (2, 2)), ("MF", (2, 2))])
+def test_virtual_ranks_2d_match_reference_run(golden_models, golden_meta, tiny_data, name, grid):
+    """The 2-D layout over Gc x Gr virtual ranks == the reference's own 3 training steps (noise injected): slice
+    kernels on row parts of the graph, per-layer row all-gathers inside a column block, the batch-row exchange inside a
+    row part, Adam on (N / Gr, d / Gc) slices."""
+    gm, meta = golden_models, golden_meta
+    gc, gr = grid
+    d = meta[name]["emb"]
+    if d % gc or d // gc not in WIDTHS + (64,):
+        pytest.skip(f"d / Gc = {d}/{gc} is not a slice width")
+    tiny_data.interaction_mat                                  # (lazy attribute: build it before the threads race for it)
+
+    def body(q, comms):
+        kw = make_kw(name, gm, meta)
+        gen = torch.Generator().manual_seed(kw.pop("noise_seed"))      # every rank draws the same noise stream
+        tr = ShardedTrainer(tiny_data, d, layout=f"2d:{gc}x{gr}", comm=comms,
+                            noise_fn=lambda shape: torch.rand(shape, generator=gen), **kw)
+        assert tr.cols and tr.sharded and (tr.Gc, tr.Gr, tr.cr, tr.rr) == (gc, gr, q // gr, q % gr)
+        assert tr.E0.shape == (gr * tr.n_pad, d // gc) and tr.adj.shape == (tr.n_pad, gr * tr.n_pad)
+        rnd = random.Random(meta[name]["sampler_seed"])                # (threads: no shared global `random` state)
+        tr.sampler.set_state_from_python(rnd.getstate())
+        nb = tr.begin_epoch()
+        losses = []
+        for _ in range(nb):
+            tr.step()
+            losses.append(tr.read_losses())
+        return tr.E0.clone(), tr._pos_dev, losses, tr.cl_rate
+
+    res = ThreadGrid(gc, gr).run(body)
+    for other in res[1:]:
+        np.testing.assert_allclose(other[2], res[0][2], rtol=1e-6)        # replicated loss section
+    bpr, cl = [l[0] for l in res[0][2]], [l[2] for l in res[0][2]]
+    np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+    nb = len(bpr)
+    if name in ("XSimGCL", "SimGCL"):
+        np.testing.assert_allclose(cl, gm[f"{name}_loss_nce"].reshape(nb, 2).sum(1) * res[0][3], rtol=2e-5)
+    elif name == "SGL":
+        np.testing.assert_allclose(cl, gm[f"{name}_loss_nce"] * res[0][3], rtol=2e-5)
+    E0 = whole_table_2d(res, gc, gr).cpu().numpy()
+    U = gm[f"{name}_param_user"].shape[0]
+    assert rel_err(E0[:U], gm[f"{name}_param_user"]) < 1e-4 and rel_err(E0[U:], gm[f"{name}_param_item"]) < 1e-4
+    # every row part of a column block ends with the same table (the all-gather after Adam)
+    for c in range(gc):
+        for r in range(1, gr):
+            assert torch.equal(res[c * gr + r][0], res[c * gr][0])

@@ -126,3 +126,47 @@ def test_handle_dropout_is_a_value_array_with_a_mirrored_transpose(fresh_tiny_da
     (torch.sparse.mm(want, x2) * w).sum().backward()
     assert rel_err(torch.sparse.mm(dropped, x).detach().cpu().numpy(), torch.sparse.mm(want, x2).detach().cpu().numpy()) < 2e-6
     assert rel_err(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["BUIR", "SelfCF"])
+def test_final_test_ranks_the_best_epoch_not_the_last(smeta, fresh_tiny_data, name, monkeypatch, tmp_path):
+    """after train() the two-tower models report the BEST epoch (BUIR.py:36-37, SelfCF.py:33-34
+    copy best_* back) -- test()'s device path ranks the concatenated tables, so restore_best() must rebuild those too.
+    Three epochs whose best is the first: the final ranking equals predict() on the best tables, row by row."""
+    from selfrec_amd.util.conf import ModelConf
+    monkeypatch.chdir(tmp_path)
+    m = smeta[f"M_{name}"]
+    conf = ModelConf({"model": {"name": name, "type": "graph"}, "item.ranking.topN": [10, 20], "embedding.size": m["emb"],
+                      "max.epoch": 3, "batch.size": m["batch"], "learning.rate": 0.05, "reg.lambda": m["reg"],
+                      "output": "./results/", "training.set": "x", "test.set": "y", name: m["conf"]})
+    torch.manual_seed(1); np.random.seed(2); random.seed(3)
+    data = fresh_tiny_data
+    cls = getattr(importlib.import_module(f"selfrec_amd.model.graph.{name}"), name)
+    model = cls(conf, data.training_data, data.test_data)
+    kept = {}
+
+    def fast_evaluation(epoch):                     # the first epoch is "the best": save() there only
+        if epoch == 0:
+            model.bestPerformance = [1, {"Recall": 1.0, "NDCG": 1.0}]
+            model.save()
+            kept["best"] = [t.clone() for t in (model.best_p_u, model.best_u, model.best_p_i, model.best_i)]
+        kept["last"] = [t.clone() for t in model.model.get_embedding()]
+    model.fast_evaluation = fast_evaluation
+    model.train()
+    best, last = kept["best"], kept["last"]
+    assert not torch.equal(best[1], last[1])        # (lr = 0.05: the tables did move after the first epoch)
+    for got, want in zip((model.p_u_online, model.u_online, model.p_i_online, model.i_online), best):
+        assert torch.equal(got, want)
+    assert torch.equal(model.user_emb, torch.cat([best[0], best[1]], 1))
+    assert torch.equal(model.item_emb, torch.cat([best[3], best[2]], 1))
+    rec = model.test()                              # the final 'Testing...' pass: device ranking of the concatenation
+    from selfrec_amd.util.algorithm import find_k_largest
+    same = total = 0
+    for user in list(data.test_set)[:40]:
+        cand = model.predict(user)                  # the reference's path on the best tables
+        for item in data.user_rated(user)[0]:
+            cand[data.item[item]] = -10e8
+        ids, _ = find_k_largest(20, cand)
+        got = [data.item[it] for it, _ in rec[user]]
+        same += sum(int(a == b) for a, b in zip(got, ids)); total += 20
+    assert same / total > 0.99
