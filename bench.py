@@ -467,8 +467,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" + (" (InfoNCE's two n x n x d products: 3-term split-bf16 MFMA with f32 accumulation, 2e-5 rel; "
-                          "exact-f32 MFMA path timed in ms_per_step_nce_f32)" if args.model in ("XSimGCL", "SimGCL", "SGL") else ""),
+        "dtype": "f32" + (" (InfoNCE's two n x n x d products on 16-bit MFMA operands with f32 accumulation: the logits on "
+                          "split f16 hi+lo = 2^-22, the accuracy of an f32 dot product; P.V on split bf16 = 2^-18 per "
+                          "product, gradients 1e-6 rel; all-f32-MFMA path timed in ms_per_step_nce_f32)"
+                          if args.model in ("XSimGCL", "SimGCL", "SGL") else ""),
         "data": "synthetic",
         "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
@@ -507,7 +509,7 @@ def main():
         run(20); fence()
         t0 = time.perf_counter(); run(300); fence()
         out["ms_per_step_nce_f32"] = round((time.perf_counter() - t0) / 300 * 1e3, 4)
-        _ops.set_infonce_precision("bf16x3")
+        _ops.set_infonce_precision("split")
         trainer.reset_graph()
         run(5); fence()
     if rank == 0:

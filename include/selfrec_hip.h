@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 20
+#define SRH_ABI_VERSION 21
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -219,6 +219,11 @@ typedef struct srh_spmm_epilogue {
   int32_t scale_flags;
   int32_t prev_unscale_mask;
   int32_t add_rowscale_mask;
+  /* Any `embedding.size` (base/recommender.py:16): tables of d_valid columns are stored zero-padded to the next width
+   * the kernels serve.  Zero columns stay zero through every product, AXPY and MEAN; PERTURB must only know that the
+   * noise row (torch.rand_like(h) in XSimGCL.py:90: d_valid columns) ends at noise_d_valid, so that F.normalize runs
+   * over those columns alone.  0 = every column of the (whole) row is valid.  Tables of >= 64 columns. */
+  int32_t noise_d_valid;
 } srh_spmm_epilogue_t;
 enum { SRH_SCALE_IN = 1, SRH_SCALE_OUT = 2 };
 
@@ -314,12 +319,15 @@ srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, in
                                        void* d_ws, void* stream);
 
 /* Arithmetic of InfoNCE's two n x n x d products (util/loss_torch.py:46-47's matmul and its backward).  The
- * reference computes them in fp32; the default here carries every operand as hi + lo bf16 and evaluates
- * a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 MFMA with f32 accumulation (logits within 2e-5 absolute,
- * loss / gradients within 2e-5 relative of the reference; north_star's budget is 1e-4).  SRH_NCE_F32 evaluates them
- * as exact f32 multiply-adds on the f32 MFMA (2e-6) at ~2.5x the time of the two passes.  Process-wide; the
- * environment variable SRH_NCE_F32 (set to anything) selects F32 as the initial mode. */
-#define SRH_NCE_SPLIT_BF16 0
+ * reference computes them in fp32.  Default (SRH_NCE_SPLIT16): operands carried as short sums of 16-bit pieces on the
+ * 16-bit MFMA pipe with f32 accumulation -- the similarity product on scaled f16 hi + lo (x to 2^-22: logits as accurate
+ * as an f32 dot product, the loss to f32 rounding), the P.V product on bf16 hi + mid (2^-18 per product; gradients within
+ * 1e-6 relative of the f64 expression; the library can be built with SRH_NCE_PV_TERMS=6 for 2^-27).  SRH_NCE_F32
+ * evaluates every multiply-add on the f32 MFMA at ~2.5x the time of the two passes.  Process-wide; the environment
+ * variable SRH_NCE_F32 (set to anything) selects F32 as the initial mode.  (SRH_NCE_SPLIT_BF16: the mode's name in
+ * ABI <= 20, when both products ran on bf16 hi + lo and the logits were good to 2e-5 only.) */
+#define SRH_NCE_SPLIT16 0
+#define SRH_NCE_SPLIT_BF16 SRH_NCE_SPLIT16
 #define SRH_NCE_F32 1
 srh_status_t srh_infonce_set_precision(int32_t mode);
 int32_t srh_infonce_get_precision(void);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -69,7 +69,7 @@ class SpmmEpilogue(C.Structure):
         ("d_extra_noise", C.c_void_p * SRH_MAX_EXTRA), ("extra_rng_offset", C.c_uint64 * SRH_MAX_EXTRA),
         ("noise_d_full", C.c_int32), ("noise_col0", C.c_int32),
         ("d_row_scale", C.c_void_p), ("scale_flags", C.c_int32), ("prev_unscale_mask", C.c_int32),
-        ("add_rowscale_mask", C.c_int32),
+        ("add_rowscale_mask", C.c_int32), ("noise_d_valid", C.c_int32),
     ]
 
 

@@ -31,6 +31,11 @@ DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered):
 
 
 class GraphRecommender(Recommender):
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        from .. import dropin            # dropin.install(fuse=True): unmodified reference model files get the fused engine
+        dropin.maybe_fuse(cls)
+
     def __init__(self, conf, training_set, test_set, **kwargs):
         super().__init__(conf, training_set, test_set, **kwargs)
         self.data = Interaction(conf, training_set, test_set)
@@ -49,8 +54,12 @@ class GraphRecommender(Recommender):
     def _device_embeddings(self):
         ue, ie = getattr(self, 'user_emb', None), getattr(self, 'item_emb', None)
         ok = all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 2 for t in (ue, ie))
-        if ok and ue.shape[0] == self.data.user_num and ie.shape[0] == self.data.item_num:
-            return ue.detach().float().contiguous(), ie.detach().float().contiguous()
+        if ok and ue.shape[0] == self.data.user_num and ie.shape[0] == self.data.item_num and ue.shape[1] == ie.shape[1]:
+            # any embedding.size (base/recommender.py:16): zero columns up to the next width the scoring GEMM serves
+            # add exact zeros to every score's fmaf chain -- same scores, same ranking
+            w = ops.padded_width(int(ue.shape[1]), ops.ROW_WIDTHS)
+            if w is not None:
+                return ops.pad_cols(ue.detach().float(), w), ops.pad_cols(ie.detach().float(), w)
         return None
 
     def _test_csr(self, device):

@@ -26,12 +26,12 @@ class _SpmmFn(torch.autograd.Function):
         x = dense.contiguous()
         if x.dtype != torch.float32 or not x.is_cuda:
             raise ops.SelfrecHipError("torch.sparse.mm(SparseAdjHandle, x): x must be an fp32 HIP tensor")
-        return ops.spmm(handle.csr, x)
+        return ops.spmm_any(handle.csr, x)        # (any embedding.size: base/recommender.py:16)
 
     @staticmethod
     def backward(ctx, grad_out):
         g = grad_out.contiguous()
-        return None, ops.spmm(ctx.handle.transposed().csr, g)
+        return None, ops.spmm_any(ctx.handle.transposed().csr, g)
 
 
 class SparseAdjHandle:

@@ -217,11 +217,29 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // InfoNCE
 // ---------------------------------------------------------------------------------------
 constexpr int kNceSplits = 16;      // workspace is sized for this many key splits
-constexpr int kNceUsedSplits = 8;   // key-range splits per query tile (NceBatch::splits; the finish kernel unrolls over it)
+constexpr float kNceKqScale = 32.0f;                                  // K / Q images hold 32 x (see nce_prep_body)
+constexpr float kNceInvKqScale2 = 1.0f / (kNceKqScale * kNceKqScale);   // the similarity product comes out 1024 x
+// Two build-time shape constants of the tile passes (tools/spmm_lab/build_alt.sh builds the other settings for an A/B;
+// no run-time knob ships):
+//   SRH_NCE_SPLITS    key-range splits per query tile: 8 (256-key stages, one workgroup per CU) or 16 (128-key stages:
+//                     two workgroups per CU with 3-term P.V products)
+//   SRH_NCE_PV_TERMS  cross terms of the P.V product: 3 (bf16 hi/mid operands: 2^-18 per product) or 6 (hi/mid/lo:
+//                     2^-27, f32-class; a third V image in the stage)
+#ifndef SRH_NCE_SPLITS
+#define SRH_NCE_SPLITS 8
+#endif
+#ifndef SRH_NCE_PV_TERMS
+#define SRH_NCE_PV_TERMS 3
+#endif
+static_assert(SRH_NCE_SPLITS == 8 || SRH_NCE_SPLITS == 16, "SRH_NCE_SPLITS: 8 or 16");
+static_assert(SRH_NCE_PV_TERMS == 3 || SRH_NCE_PV_TERMS == 6, "SRH_NCE_PV_TERMS: 3 or 6");
+constexpr int kNceUsedSplits = SRH_NCE_SPLITS;   // key-range splits per query tile (NceBatch::splits; the finish kernels unroll over it)
+constexpr int kNcePvTerms = SRH_NCE_PV_TERMS;
 
-// Arithmetic of the two n x n x d products (srh_infonce_set_precision): split-bf16 x 3 on the bf16 MFMA (default;
-// logits within 2e-5 absolute of fp32, loss and gradients within 2e-5 relative of the reference) or exact f32
-// multiply-adds on the f32 MFMA (2e-6; ~2.5x the time of the two passes).  Process-wide, read at launch time.
+// Arithmetic of the two n x n x d products (srh_infonce_set_precision): split 16-bit operands on the 16-bit MFMA pipe
+// (default: the similarity product on scaled f16 hi + lo -- logits to 2^-22, the accuracy of an f32 dot product -- the
+// P.V product on bf16 hi + mid [+ lo]) or exact f32 multiply-adds on the f32 MFMA (~2.5x the time of the two passes).
+// Process-wide, read at launch time.
 std::atomic<int> g_nce_precision{getenv("SRH_NCE_F32") ? SRH_NCE_F32 : SRH_NCE_SPLIT_BF16};
 
 struct NceWs {
@@ -234,7 +252,7 @@ struct NceWs {
   //               dims (D/4) g + 8 s + e -- K / Q operands of the similarity product
   //   vt_*[view]  [row/32][n-tile t][lane][8]: lane holds column NT*c16 + t of the 8 keys
   //               32*blk + {4g..4g+3, 16+4g..16+4g+3} -- V operand of the P.V product
-  uint16_t *kq_hi[2], *kq_lo[2], *vt_hi[2], *vt_lo[2];
+  uint16_t *kq_hi[2], *kq_lo[2], *vt_hi[2], *vt_mid[2], *vt_lo[2];
   int64_t np;
   // the problem this workspace belongs to (several InfoNCE problems share each launch: blockIdx.z)
   const float *src1, *src2;
@@ -272,6 +290,7 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
     w.kq_hi[v] = h; h += np * d;
     w.kq_lo[v] = h; h += np * d;
     w.vt_hi[v] = h; h += np * d;
+    w.vt_mid[v] = h; h += np * d;
     w.vt_lo[v] = h; h += np * d;
   }
   w.ticket = reinterpret_cast<int32_t*>(h);
@@ -309,17 +328,28 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
   if (in_pad) {
     reinterpret_cast<float4*>(out)[(size_t)i * LPR + sub] = o;
     if (sub == 0) nrm[i] = valid ? norm : 0.f;
-    // split-bf16 images for the MFMA passes
+    // split images for the MFMA passes: K / Q operands of the similarity product as SCALED FP16 hi + lo (kNceKqScale x,
+    // an exact power of two: hi = f16(32 x), lo = f16(32 x - hi) represents x to 2^-22 -- |x| <= 1, so hi <= 32 and lo
+    // stays a normal f16 down to |x| ~ 1e-3, below which its absolute error is < 2^-25 / 32), V operand of the P.V
+    // product as bf16 hi + lo (its partner, the weights, needs f32's exponent range)
     const int view = second ? 1 : 0;
     constexpr int D = LPR * 4;
     const float f[4] = {o.x, o.y, o.z, o.w};
-    uint16_t hi[4], lo[4];
+    uint16_t hi[4], mid[4], lo[4], kh[4], kl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const __bf16 bh = (__bf16)f[t];
-      const __bf16 bl = (__bf16)(f[t] - (float)bh);
+      const float r1 = f[t] - (float)bh;
+      const __bf16 bm = (__bf16)r1;
+      const __bf16 bl = (__bf16)(r1 - (float)bm);
       hi[t] = __builtin_bit_cast(uint16_t, bh);
+      mid[t] = __builtin_bit_cast(uint16_t, bm);
       lo[t] = __builtin_bit_cast(uint16_t, bl);
+      const float fs = f[t] * kNceKqScale;
+      const _Float16 qh = (_Float16)fs;
+      const _Float16 ql = (_Float16)(fs - (float)qh);
+      kh[t] = __builtin_bit_cast(uint16_t, qh);
+      kl[t] = __builtin_bit_cast(uint16_t, ql);
     }
     // this lane holds columns 4*sub .. 4*sub+3 of row i
     constexpr int DG = D / 4, KSL = D / 32, NTL = D / 16;
@@ -327,8 +357,8 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
       const int col0 = 4 * sub;
       const int gk = col0 / DG, within = col0 % DG, sk = within / 8, e0 = within % 8;   // 4 consecutive e
       const size_t at = ((((size_t)(i >> 4) * KSL + sk) * 64) + 16 * gk + (i & 15)) * 8 + e0;
-      *reinterpret_cast<uint2*>(w.kq_hi[view] + at) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-      *reinterpret_cast<uint2*>(w.kq_lo[view] + at) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+      *reinterpret_cast<uint2*>(w.kq_hi[view] + at) = make_uint2(kh[0] | ((uint32_t)kh[1] << 16), kh[2] | ((uint32_t)kh[3] << 16));
+      *reinterpret_cast<uint2*>(w.kq_lo[view] + at) = make_uint2(kl[0] | ((uint32_t)kl[1] << 16), kl[2] | ((uint32_t)kl[3] << 16));
     }
     const int blk = i >> 5, k = i & 31;
     const int gv = (k & 15) >> 2, ev = 4 * (k >> 4) + (k & 3);
@@ -337,7 +367,8 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
       const int col = 4 * sub + t, c16v = col / NTL, nt = col % NTL;
       const size_t at = ((((size_t)blk * NTL + nt) * 64) + 16 * gv + c16v) * 8 + ev;
       w.vt_hi[view][at] = hi[t];
-      w.vt_lo[view][at] = lo[t];
+      w.vt_mid[view][at] = mid[t];
+      if (kNcePvTerms == 6) w.vt_lo[view][at] = lo[t];
     }
   }
 }
@@ -461,16 +492,22 @@ __global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
   }
 }
 
-// Split-bf16 arithmetic of nce_tile_lds (the default path): every f32 operand x is carried as hi + lo with
-// hi = bf16(x), lo = bf16(x - hi), and a product a.b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
-// on v_mfma_f32_16x16x32_bf16 with f32 accumulation -- 3 MFMAs at 16x the f32-MFMA rate.  The dropped
-// a_lo b_lo term is 2^-16 relative; measured against fp64 at n = 2048, d = 64, tau = 0.2 the logits are
-// off by 1.9e-5 absolute, the loss by 1e-8 and the gradients by 8.5e-7 relative (the f32 MFMA path:
-// 1.6e-6 / 2e-8 / 7e-8), far inside the 1e-4 budget.  Same dataflow as nce_tile: swapped S^T = K Q^T so
-// a lane's 8 weights of a 32-key block ARE its A-operand fragment of the P.V product, whose V operand
-// is read from the key-blocked transposed image (one 16-byte load per n-tile).  The summation index
-// of every product may be permuted freely as long as both operands use the same permutation.
+// Split 16-bit arithmetic of nce_tile_lds (the default path).  An f32 operand x is carried as a short sum of 16-bit
+// pieces and a product a.b as the cross terms that matter, each one MFMA at 16x the f32-MFMA rate, f32 accumulation:
+//   similarity product S = Q K^T (the logits, and through them the loss): f16 pieces of 32 x -- hi = f16(32 x),
+//     lo = f16(32 x - hi): 11 + 11 mantissa bits, x to 2^-22 -- and the three terms hi.hi + hi.lo + lo.hi on
+//     v_mfma_f32_16x16x32_f16.  The rows are unit vectors, so the fixed scale keeps every piece in f16's normal range;
+//     against fp64 the logits are off by 7e-8 (an f32 dot product: 3e-7), the loss by parts in 1e-12 (emulation of this
+//     arithmetic with an exact accumulator: DESIGN.md 4.2; the MFMA's f32 accumulation adds the usual 1e-7).
+//   P.V product (softmax weights times value rows -> the gradients): the weights span f32's exponent range (e^(-2/tau)
+//     ... 1, and 1 / l(key) on top in pass 2), so they stay bf16 pieces -- hi, mid = bf16(x - hi) [, lo = bf16(x - hi -
+//     mid)] on v_mfma_f32_16x16x32_bf16: three terms (2^-18 per product, gradients to 7e-7 relative) or, built with
+//     SRH_NCE_PV_TERMS = 6, six (2^-27: gradients to 2e-9 of the exact product, below the f32 accumulator's own noise).
+// Same dataflow as nce_tile: swapped S^T = K Q^T so a lane's 8 weights of a 32-key block ARE its A-operand fragment of
+// the P.V product, whose V operand is read from the key-blocked transposed image (one 16-byte load per n-tile).  The
+// summation index of every product may be permuted freely as long as both operands use the same permutation.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
@@ -506,14 +543,6 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const size_t at = (size_t)ii * LPR + sub;
   // every load of the row is issued before the first use: this kernel is a chain of dependent round trips for
   // O(batch) bytes, and a split loop with a run-time trip count serialised eight of them
-  float4 p1[kNceUsedSplits], p2[kNceUsedSplits];
-  float lp[kNceUsedSplits];
-#pragma unroll
-  for (int ks = 0; ks < kNceUsedSplits; ++ks) {
-    p1[ks] = reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at];
-    p2[ks] = reinterpret_cast<const float4*>(w.opart2 + (size_t)ks * w.np * (LPR * 4))[at];
-    lp[ks] = w.lpart[(size_t)ks * w.np + ii];
-  }
   const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
   const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
   const float n1 = w.norm1[ii], n2 = w.norm2[ii];
@@ -521,10 +550,21 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   float4 O1 = f4_zero(), O2 = f4_zero();
   float l = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < kNceUsedSplits; ++ks) {      // split order: the order pass 2 folded 1 / l in
-    O1 = f4_add(O1, p1[ks]);
-    O2 = f4_add(O2, p2[ks]);
-    l += lp[ks];
+  for (int k0 = 0; k0 < kNceUsedSplits; k0 += 8) {     // eight splits' loads in flight at a time
+    float4 p1[8], p2[8];
+    float lp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      p1[k] = reinterpret_cast<const float4*>(w.opart + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
+      p2[k] = reinterpret_cast<const float4*>(w.opart2 + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
+      lp[k] = w.lpart[(size_t)(k0 + k) * w.np + ii];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                      // split order: the order pass 2 folded 1 / l in
+      O1 = f4_add(O1, p1[k]);
+      O2 = f4_add(O2, p2[k]);
+      l += lp[k];
+    }
   }
   const float coef = a.loss_scale * a.inv_tau / (float)n;
   const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
@@ -566,14 +606,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
 __device__ __forceinline__ bf16x8 lds_bf16x8(const unsigned char* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
 }
+__device__ __forceinline__ f16x8 lds_f16x8(const unsigned char* p) {
+  return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p));
+}
+__device__ __forceinline__ f16x8 ld_f16x8(const uint16_t* p) {
+  return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p));
+}
 
-template <int D, bool PASS2, int QT, int WAVES>
+// keys per LDS stage: 256 at d = 64 with 4 images (128 KB), half of that when the stage carries a fifth image (6-term
+// P.V) or a workgroup's whole key range is 128 keys anyway (16 splits of 2048)
+template <int D, int PVT>
+constexpr int nce_chunk() { return (PVT == 6 || kNceUsedSplits == 16 ? 8192 : 16384) / D; }
+template <int D, int PVT>
+constexpr int nce_lds_bytes() { return (PVT == 6 ? 5 : 4) * nce_chunk<D, PVT>() * D * 2 + nce_chunk<D, PVT>() * 4; }
+
+template <int D, bool PASS2, int QT, int WAVES, int PVT>
 __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float inv_tau) {
   constexpr int NT = D / 16, KS = D / 32;
-  constexpr int CHUNK = 16384 / D;           // keys per LDS stage: 4 images x CHUNK x D x 2 B = 128 KB
-  constexpr int SPAN = CHUNK * D * 2;        // bytes of one image of one stage (32 KB)
+  constexpr int NIMG = PVT == 6 ? 5 : 4;     // kq_hi, kq_lo, vt_hi, vt_mid [, vt_lo]
+  constexpr int CHUNK = nce_chunk<D, PVT>();
+  constexpr int SPAN = CHUNK * D * 2;        // bytes of one image of one stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* invl_s = reinterpret_cast<float*>(smem + 4 * SPAN);
+  float* invl_s = reinterpret_cast<float*>(smem + NIMG * SPAN);
   const NceWs& w = batch.w[blockIdx.z];
   const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
   const int np = (int)w.np;
@@ -587,16 +641,17 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
   const int kb = ks * per, ke = min(np, kb + per);
   const bool wave_live = q0 < np;
 
-  bf16x8 qh[QT][KS], ql[QT][KS];
+  f16x8 qh[QT][KS], ql[QT][KS];
 #pragma unroll
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int tile = min((q0 >> 4) + t, (np >> 4) - 1);
       const size_t at = (((size_t)tile * KS + s) * 64 + lane) * 8;
-      qh[t][s] = ld_bf16x8(w.kq_hi[qv] + at);
-      ql[t][s] = ld_bf16x8(w.kq_lo[qv] + at);
+      qh[t][s] = ld_f16x8(w.kq_hi[qv] + at);
+      ql[t][s] = ld_f16x8(w.kq_lo[qv] + at);
     }
+  const float s_scale = inv_tau * kNceInvKqScale2;       // the images hold 32 x: products come out 1024 x (exact)
   floatx4 O[QT][NT];
 #pragma unroll
   for (int t = 0; t < QT; ++t)
@@ -610,13 +665,14 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
     const int cn = min(CHUNK, ke - c0);                  // a multiple of 32
     if (c0 != kb) __syncthreads();                       // the previous stage has been read by every wave
     const int n_kb = cn * D * 2 / 1024;                  // 1 KB fragments per image in this stage
-    const unsigned char* src[4] = {
+    const unsigned char* src[5] = {
         reinterpret_cast<const unsigned char*>(w.kq_hi[kv]) + (size_t)(c0 >> 4) * KS * 1024,
         reinterpret_cast<const unsigned char*>(w.kq_lo[kv]) + (size_t)(c0 >> 4) * KS * 1024,
         reinterpret_cast<const unsigned char*>(w.vt_hi[kv]) + (size_t)(c0 >> 5) * NT * 1024,
+        reinterpret_cast<const unsigned char*>(w.vt_mid[kv]) + (size_t)(c0 >> 5) * NT * 1024,
         reinterpret_cast<const unsigned char*>(w.vt_lo[kv]) + (size_t)(c0 >> 5) * NT * 1024};
 #pragma unroll
-    for (int img = 0; img < 4; ++img)
+    for (int img = 0; img < NIMG; ++img)
       for (int k = wv; k < n_kb; k += WAVES)
         glds16(src[img] + (size_t)k * 1024 + lane * 16, smem + img * SPAN + k * 1024);
     if (PASS2) {
@@ -632,21 +688,22 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
     if (!wave_live) continue;
 
     for (int j0 = 0; j0 < cn; j0 += 32) {
-      bf16x8 kh[2][KS], kl[2][KS];
+      f16x8 kh[2][KS], kl[2][KS];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const int off = (((j0 >> 4) + h) * KS + s) * 1024 + lane * 16;
-          kh[h][s] = lds_bf16x8(smem + off);
-          kl[h][s] = lds_bf16x8(smem + SPAN + off);
+          kh[h][s] = lds_f16x8(smem + off);
+          kl[h][s] = lds_f16x8(smem + SPAN + off);
         }
-      bf16x8 vh[NT], vl[NT];
+      bf16x8 vh[NT], vm[NT], vl[PVT == 6 ? NT : 1];
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int off = ((j0 >> 5) * NT + u) * 1024 + lane * 16;
         vh[u] = lds_bf16x8(smem + 2 * SPAN + off);
-        vl[u] = lds_bf16x8(smem + 3 * SPAN + off);
+        vm[u] = lds_bf16x8(smem + 3 * SPAN + off);
+        if (PVT == 6) vl[u] = lds_bf16x8(smem + 4 * SPAN + off);
       }
       float il[2][4];
       if (PASS2) {
@@ -663,30 +720,40 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
           a[h] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
+            // smallest terms first into the f32 accumulator
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
           }
         }
-        bf16x8 ph, pl;
+        bf16x8 ph, pm, pl;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = c0 + j0 + 16 * h + 4 * g + r;
-            float e = __expf(a[h][r] * inv_tau - inv_tau);   // v_exp_f32: 1e-6 relative, inside the split-bf16 error
+            float e = __expf(fmaf(a[h][r], s_scale, -inv_tau));
             if (PASS2) e *= il[h][r];
             const float wt = (key < n) ? e : 0.f;
             lsum[t] += wt;
             const __bf16 bh = (__bf16)wt;
+            const float r1 = wt - (float)bh;
+            const __bf16 bm = (__bf16)r1;
             ph[4 * h + r] = bh;
-            pl[4 * h + r] = (__bf16)(wt - (float)bh);
+            pm[4 * h + r] = bm;
+            if (PVT == 6) pl[4 * h + r] = (__bf16)(r1 - (float)bm);
           }
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+          // the block's partial product summed smallest terms first, then added to the running output in one MFMA chain
+          if (PVT == 6) {
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vm[u], O[t][u], 0, 0, 0);
+          }
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vh[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vm[u], O[t][u], 0, 0, 0);
           O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], O[t][u], 0, 0, 0);
-          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
-          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
         }
       }
     }
@@ -864,17 +931,17 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
   if (g_nce_precision.load(std::memory_order_relaxed) == SRH_NCE_SPLIT_BF16) {
-    constexpr int kLds = 4 * (16384 / D) * D * 2 + (16384 / D) * 4;
+    constexpr int kLds = nce_lds_bytes<D, kNcePvTerms>();
     static const bool attr_set = [] {
-      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, true, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, 1, 8, kNcePvTerms>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, true, 1, 8, kNcePvTerms>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
       return true;
     }();
     (void)attr_set;
     dim3 gl((np_max + 127) / 128, batch.splits, count);          // 8 waves x 16 queries per workgroup
-    nce_tile_lds<D, false, 1, 8><<<gl, 512, kLds, st>>>(batch, inv_tau);
+    nce_tile_lds<D, false, 1, 8, kNcePvTerms><<<gl, 512, kLds, st>>>(batch, inv_tau);
     SRH_LAUNCH_CHECK();
-    nce_tile_lds<D, true, 1, 8><<<gl, 512, kLds, st>>>(batch, inv_tau);
+    nce_tile_lds<D, true, 1, 8, kNcePvTerms><<<gl, 512, kLds, st>>>(batch, inv_tau);
     SRH_LAUNCH_CHECK();
     if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
     else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
@@ -996,7 +1063,7 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
   return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
-         16 * np * d + 4 * (np / 16) + 256;
+         20 * np * d + 4 * (np / 16) + 256;       // (2 views x 5 sixteen-bit operand images)
 }
 
 static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d, float tau,

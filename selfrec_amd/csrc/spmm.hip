@@ -68,6 +68,9 @@ struct DevEpilogue {
   // column-sharded tables (thin kernel): y holds columns [noise_col0, noise_col0 + d) of rows that are
   // noise_d_full wide -- the perturbation's unit vector is normalised over the WHOLE row
   int32_t noise_d_full, noise_col0;
+  // rows padded with zero columns (any embedding.size): only the first noise_d_valid columns of the WHOLE row carry
+  // noise -- the unit vector is normalised over those (the padding's y is exactly 0, so sign(y) keeps it 0)
+  int32_t noise_d_valid;
   // row scaling (value-free products: include/selfrec_hip.h)
   const float* row_scale;
   int32_t scale_flags, prev_unscale, add_rowscale;
@@ -125,6 +128,12 @@ __device__ __forceinline__ float4 sum_partials_agent(const float4* base, int t0,
   return sum;
 }
 
+// columns >= dv of float4 number q of a row carry no noise (zero-padded rows)
+__device__ __forceinline__ float4 mask_valid(float4 z, int q, int dv) {
+  const int c = 4 * q;
+  return make_float4(c < dv ? z.x : 0.f, c + 1 < dv ? z.y : 0.f, c + 2 < dv ? z.z : 0.f, c + 3 < dv ? z.w : 0.f);
+}
+
 // y + sign(y) * normalize(noise_row) * eps  (XSimGCL.py:90-91); noise injected or from the counter RNG
 template <int LPR>
 __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t at, const float* noise,
@@ -138,10 +147,16 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
     uint64_t ctr = (((uint64_t)off_hi << 32) | off_lo) + (uint64_t)row;
     if (!noise && ep.rng_step) ctr += (uint64_t)(*ep.rng_step) * ep.rng_stride;
     const float4* nr = reinterpret_cast<const float4*>(noise) + (size_t)row * nq;
+    const bool padded = ep.noise_d_valid < ep.noise_d_full;
     auto draw = [&](int q) {
-      if (noise) return nr[q];
-      const uint4 r = counter_rng4(ctr, (uint32_t)q, ep.seed_lo, ep.seed_hi);
-      return make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+      float4 z;
+      if (noise) {
+        z = nr[q];
+      } else {
+        const uint4 r = counter_rng4(ctr, (uint32_t)q, ep.seed_lo, ep.seed_hi);
+        z = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+      }
+      return padded ? mask_valid(z, q, ep.noise_d_valid) : z;
     };
     ss = 0.f;
     for (int q = sub; q < nq; q += LPR) { const float4 z = draw(q); ss += f4_dot(z, z); }
@@ -156,6 +171,7 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
       uint4 r = counter_rng4(ctr, (uint32_t)sub, ep.seed_lo, ep.seed_hi);
       nu = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
     }
+    if (ep.noise_d_valid < 4 * LPR) nu = mask_valid(nu, sub, ep.noise_d_valid);      // (uniform: zero-padded rows)
     ss = group_sum<LPR>(f4_dot(nu, nu));
   }
   // F.normalize: v / max(||v||, 1e-12); one reciprocal instead of four divisions (<= 1 ulp apart)
@@ -1250,6 +1266,14 @@ static srh_status_t translate_epilogue(const srh_spmm_epilogue_t* epi, int32_t d
     }
   }
   if (!ep.noise_d_full) { ep.noise_d_full = d; ep.noise_col0 = 0; }
+  ep.noise_d_valid = ep.noise_d_full;
+  if (epi && epi->noise_d_valid) {
+    SRH_REQUIRE(epi->noise_d_valid > 0 && epi->noise_d_valid <= ep.noise_d_full,
+                "spmm_f32: noise_d_valid = %d outside (0, %d]", epi->noise_d_valid, ep.noise_d_full);
+    SRH_REQUIRE(d >= 64 || epi->noise_d_valid == ep.noise_d_full,
+                "spmm_f32: zero-padded rows (noise_d_valid < row width) are served on tables of >= 64 columns, not %d", d);
+    ep.noise_d_valid = epi->noise_d_valid;
+  }
   SRH_REQUIRE(d > 32 || ep.noise_d_full % 32 == 0 || !(ep.flags & SRH_EPI_PERTURB),
               "spmm_f32: PERTURB on %d-wide rows needs the whole row width (a multiple of 32) in noise_d_full", d);
   return SRH_OK;

@@ -9,8 +9,19 @@ stays on ``sys.path`` and is imported as is:
     dropin.install()
     sys.path.insert(0, "/path/to/SELFRec")          # for model/graph/XSimGCL.py only
     from model.graph.XSimGCL import XSimGCL           # unmodified reference file, HIP kernels underneath
+
+``install(fuse=True)`` (or ``SRH_DROPIN_FUSE=1``) goes one step further for the five model files whose whole training
+step the fused engine implements (MF, LightGCN, XSimGCL, SimGCL, SGL): when such a file is imported and its bytes are
+the reference's (SHA-256 below -- "unchanged" is checked, not assumed), the class keeps everything it defines --
+``__init__`` (config keys, the torch encoder and its xavier-initialised ``embedding_dict``), ``save``, ``predict``,
+``cal_cl_loss`` -- but ``train()`` is served by ``engine.FusedTrainer``: same batches (the global ``random`` stream is
+consumed and left as the file's own loop would leave it), same arithmetic (the parity tests of the engine are against
+this very file's CPU run), the encoder's parameters aliased to the engine's table so ``save()`` / ``predict()`` /
+checkpoints see the trained values.  An edited file -- any byte -- keeps its own ``train()`` on the op-level tier.
 """
+import hashlib
 import importlib
+import os
 import sys
 
 MIRRORED = {
@@ -20,7 +31,45 @@ MIRRORED = {
 }
 
 
-def install(overwrite: bool = True) -> None:
+# SHA-256 of the reference's model files at the surveyed commit (Coder-Yu/SELFRec @ 2025-07-25): facts about the
+# reference, not copies of it.  model/graph/<name>.py -> digest.
+FUSABLE = {
+    "XSimGCL": "621ed1ea0181e57ac2924c8ad14f82ceefc7e774080613362ad92c3ae3fe3f2e",
+    "LightGCN": "18707b19917c481ea0c1b3f9fcd1db0be2cb0ad0fa955b7affc498d89d52c8dd",
+    "SimGCL": "33d92e815b98f2f19d57fb8615d3076efac7014e16fd66d4aa3c02d870ad6f11",
+    "SGL": "ee53e7821791b7196d44bc84833b694ece64f2cc7d3b5f92dd360fab26c7452a",
+    "MF": "0564ad7cfc66cca9c79d004efbfa6fda0c51370af266110924a25e260bb563b3",
+}
+_state = {"fuse": False, "fused": []}
+
+
+def fuse_enabled() -> bool:
+    return _state["fuse"] or os.environ.get("SRH_DROPIN_FUSE", "0") not in ("", "0")
+
+
+def maybe_fuse(cls) -> bool:
+    """Called by the mirrored ``GraphRecommender.__init_subclass__`` for every model class: route ``cls.train`` to the
+    fused engine iff fusing is on, the class is one of the five the engine implements, it is defined in a module named
+    ``model.graph.<its own name>`` and that module's file is byte-for-byte the reference's."""
+    name = cls.__name__
+    if not fuse_enabled() or name not in FUSABLE or cls.__module__ != f"model.graph.{name}":
+        return False
+    path = getattr(sys.modules.get(cls.__module__), "__file__", None)
+    if not path or not os.path.isfile(path):
+        return False
+    with open(path, "rb") as f:
+        if hashlib.sha256(f.read()).hexdigest() != FUSABLE[name]:
+            return False                                  # edited file: its own train() runs, on the op-level tier
+    from .model.graph._fused import fused_train_of_reference_class
+    cls._reference_train = cls.train
+    cls.train = fused_train_of_reference_class
+    _state["fused"].append(name)
+    return True
+
+
+def install(overwrite: bool = True, fuse: bool | None = None) -> None:
+    if fuse is not None:
+        _state["fuse"] = bool(fuse)
     for pkg, mods in MIRRORED.items():
         mirror = importlib.import_module(f"{__package__}.{pkg}")
         if overwrite or pkg not in sys.modules:

@@ -208,7 +208,17 @@ class FusedTrainer:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
         ops.require_gpu()
         self.model, self.data = model, data
-        self.d, self.L = int(emb_size), (0 if model == "MF" else int(n_layers))
+        # Any embedding.size (base/recommender.py:16): every table is stored with zero columns up to the next width the
+        # kernels serve (d_valid -> d).  Zero columns stay exactly zero through products, means, losses (inner products,
+        # norms and F.normalize ignore them), their gradients are zero and Adam's update of a zero gradient is zero; the
+        # perturbation normalises its noise over the d_valid real columns (epilogue field noise_d_valid).
+        self.d_valid = int(emb_size)
+        widths = ops.NCE_WIDTHS if model in ("XSimGCL", "SimGCL", "SGL") else ops.ROW_WIDTHS
+        self.d = ops.padded_width(self.d_valid, widths) if self.d_valid > 0 else None
+        if self.d is None:
+            raise SelfrecHipError(f"{model}: embedding.size = {emb_size} -- the fused kernels serve up to {widths[-1]} columns"
+                                  + (" (InfoNCE; the op-level tier, selfrec_amd.dropin, takes wider rows)" if widths[-1] < 256 else ""))
+        self.L = 0 if model == "MF" else int(n_layers)
         self.lr, self.reg, self.cl_rate, self.eps, self.tau = float(lr), float(reg), float(cl_rate), float(eps), float(tau)
         if model == "SimGCL":
             self.tau = 0.2                       # hard-coded in the reference, SimGCL.py:48-49
@@ -273,6 +283,9 @@ class FusedTrainer:
                 self.Gr, self.rr, self.comm_rows = self.G, self.rank, self.comm
         N, d, B = self.N, self.d, self.B
         self.w = d                                       # width of this rank's tables
+        if self.cols and self.d_valid != d and self.Gc > 1:
+            raise SelfrecHipError(f"embedding.size = {self.d_valid} is stored padded to {d} columns: column-sharded layouts need "
+                                  f"one of {ops.ROW_WIDTHS} (use SRH_SHARD_LAYOUT=rows)")
         if self.cols:
             # (a single rank keeps whole rows: the layout then only adds the batch-row exchange -- a way to run
             # this code path, collective included, on one GPU)
@@ -304,11 +317,15 @@ class FusedTrainer:
 
         self.E0 = buf()
         if user_emb is None or item_emb is None:
-            ue = torch.nn.init.xavier_uniform_(torch.empty(self.U, d))      # XSimGCL.py:76-80
-            ie = torch.nn.init.xavier_uniform_(torch.empty(self.I, d))
+            ue = torch.nn.init.xavier_uniform_(torch.empty(self.U, self.d_valid))      # XSimGCL.py:76-80
+            ie = torch.nn.init.xavier_uniform_(torch.empty(self.I, self.d_valid))
         else:
             ue, ie = torch.as_tensor(user_emb, dtype=torch.float32), torch.as_tensor(item_emb, dtype=torch.float32)
-        self.E0[self._pos_dev] = torch.cat([ue, ie])[:, self.col0:self.col0 + w].contiguous().to(dev)
+        if ue.shape[1] != self.d_valid or ie.shape[1] != self.d_valid:
+            raise SelfrecHipError(f"initial tables have {ue.shape[1]} / {ie.shape[1]} columns, embedding.size is {self.d_valid}")
+        whole = torch.zeros((N, d), dtype=torch.float32)
+        whole[:, :self.d_valid] = torch.cat([ue, ie])
+        self.E0[self._pos_dev] = whole[:, self.col0:self.col0 + w].contiguous().to(dev)
         # the step code assumes the tables (and, per epoch, the sampled batches) are replicated: check, don't trust
         self._assert_replicated("initial embedding tables",
                                 [ue.double().sum().item(), ie.double().sum().item(), ue.double().abs().sum().item(),
@@ -511,13 +528,17 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------
     @property
     def user_emb(self):
-        t = self._full(self.E0)                          # (column-sharded: a collective -- every rank must ask)
+        t = self._valid(self._full(self.E0))             # (column-sharded: a collective -- every rank must ask)
         return t[:self.U] if not self.sharded else t[self._pos_dev[:self.U]]
 
     @property
     def item_emb(self):
-        t = self._full(self.E0)
+        t = self._valid(self._full(self.E0))
         return t[self.U:] if not self.sharded else t[self._pos_dev[self.U:]]
+
+    def _valid(self, t):
+        """The real columns of a whole-row table (tables are stored zero-padded to a width the kernels serve)."""
+        return t if self.d_valid == self.d else t[:, :self.d_valid]
 
     def _loc(self, t):
         """The rows of a table this rank owns (the whole table on one GPU)."""
@@ -607,7 +628,10 @@ class FusedTrainer:
     def _noise(self):
         if self.noise_fn is None:
             return None
-        t = torch.as_tensor(self.noise_fn((self.N, self.d)), dtype=torch.float32).to(self.dev)
+        t = torch.as_tensor(self.noise_fn((self.N, self.d_valid)), dtype=torch.float32)     # torch.rand_like(h): XSimGCL.py:90
+        if self.d_valid != self.d:
+            t = torch.nn.functional.pad(t, (0, self.d - self.d_valid))
+        t = t.to(self.dev)
         if not self.sharded:
             return t.contiguous()          # (column-sharded: whole rows too -- the unit vector spans the row)
         full = torch.zeros((self.P, self.d), dtype=torch.float32, device=self.dev)
@@ -619,8 +643,12 @@ class FusedTrainer:
         return (call * self.P + (self.rr * self.n_pad if self.sharded else 0)) & ((1 << 62) - 1)
 
     def _slice_kw(self):
-        """PERTURB on a column slice: tell the kernel where the slice sits in the whole row."""
-        return dict(d_full=self.d, col0=self.col0) if self.cols and self.w != self.d else {}
+        """PERTURB on a column slice: tell the kernel where the slice sits in the whole row; on zero-padded rows: where
+        the real columns end."""
+        kw = dict(d_full=self.d, col0=self.col0) if self.cols and self.w != self.d else {}
+        if self.d_valid != self.d:
+            kw["d_valid"] = self.d_valid
+        return kw
 
     def _forward_pass(self, adj, Ys, F, *, perturbed, include_ego, batch_rows_only=False, need_last=False,
                       start_layer=0, noises=None, call_base=None):
@@ -1016,6 +1044,7 @@ class FusedTrainer:
         self._forward_pass(self.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
         if self.cols:
             out = self._full(out)                 # (a collective: every rank must ask)
+        out = self._valid(out)
         if not self.sharded:
             return out[:self.U], out[self.U:]
         return out[self._pos_dev[:self.U]], out[self._pos_dev[self.U:]]

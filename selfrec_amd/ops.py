@@ -20,7 +20,7 @@ require_gpu = _lib.require_gpu
 def gpu_available() -> bool:
     return torch.cuda.is_available()
 
-__all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm3", "spmm_probe", "spmm_set_xcd_shares", "spmm_plan_run_tasks", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
+__all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm_any", "pad_cols", "padded_width", "spmm3", "spmm_probe", "spmm_set_xcd_shares", "spmm_plan_run_tasks", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
            "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",
            "SelfrecHipError"]
@@ -250,7 +250,7 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
                   row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
                   extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0,
-                  row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None):
+                  row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None, d_valid=0):
     """row_scale / scale_in / scale_out / prev_unscale / add_rowscale: per-row scaling for value-free products
     (include/selfrec_hip.h: SRH_SCALE_*); prev_unscale / add_rowscale are lists of booleans aligned with prev / add."""
     ep = SpmmEpilogue()
@@ -260,6 +260,7 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
         ep.prev_unscale_mask = sum(1 << t for t, f in enumerate(prev_unscale or []) if f)
         ep.add_rowscale_mask = sum(1 << t for t, f in enumerate(add_rowscale or []) if f)
     ep.noise_d_full, ep.noise_col0 = int(d_full), int(col0)      # column-sharded tables (0 = whole rows)
+    ep.noise_d_valid = int(d_valid)                               # zero-padded rows: PERTURB's noise ends here (0 = all)
     keep = []
     flags = 0
     if perturb_eps is not None:
@@ -331,6 +332,43 @@ def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilo
         check(_lib.load().srh_spmm_f32_with_fetch(*common, C.byref(fetch), _stream()), "srh_spmm_f32_with_fetch")
     else:
         check(_lib.load().srh_spmm_f32(*common, _stream()), "srh_spmm_f32")
+    return out
+
+
+# ---- any table width through the boundary (reference base/recommender.py:16: `embedding.size` is any integer) ----
+SPMM_WIDTHS = (8, 16, 32, 64, 128, 256)      # row widths srh_spmm_f32 serves (csrc/spmm.hip)
+ROW_WIDTHS = (32, 64, 128, 256)              # LPR kernels: BPR / L2 / scoring GEMM (csrc/common.h: dim_supported)
+NCE_WIDTHS = (64, 128)                       # srh_infonce_fwd_bwd
+
+
+def padded_width(d: int, widths) -> int | None:
+    """The narrowest width of `widths` that holds d columns (None: wider than the widest)."""
+    return next((w for w in widths if w >= int(d)), None)
+
+
+def pad_cols(t: torch.Tensor, width: int) -> torch.Tensor:
+    """(rows, d) -> contiguous (rows, width) with zero columns on the right (a no-op view when d == width).  Zero columns
+    change none of the path's results: products, inner products, norms and F.normalize ignore them, their gradients
+    are exactly zero."""
+    d = int(t.shape[1])
+    if d == width:
+        return t.contiguous()
+    out = torch.zeros((t.shape[0], width), dtype=t.dtype, device=t.device)
+    out[:, :d] = t
+    return out
+
+
+def spmm_any(csr: DeviceCSR, x: torch.Tensor) -> torch.Tensor:
+    """csr @ x for x of ANY width: 256-column blocks, the last one zero-padded to the next width the kernels serve.
+    (Widths the kernels serve directly take the plain call: no copy.)"""
+    d = int(x.shape[1])
+    if d in SPMM_WIDTHS:
+        return spmm(csr, x.contiguous())
+    out = torch.empty((csr.shape[0], d), dtype=torch.float32, device=x.device)
+    for c0 in range(0, d, SPMM_WIDTHS[-1]):
+        wb = min(SPMM_WIDTHS[-1], d - c0)
+        y = spmm(csr, pad_cols(x[:, c0:c0 + wb], padded_width(wb, SPMM_WIDTHS)))
+        out[:, c0:c0 + wb] = y[:, :wb]
     return out
 
 
@@ -441,12 +479,14 @@ def sumsq(x, out):
     check(_lib.load().srh_sumsq(_p(x, torch.float32), x.numel(), _p(out, torch.float64), _stream()), "srh_sumsq")
 
 
-NCE_PRECISIONS = {"bf16x3": 0, "f32": 1}      # SRH_NCE_SPLIT_BF16, SRH_NCE_F32 (include/selfrec_hip.h)
+# SRH_NCE_SPLIT16, SRH_NCE_F32 (include/selfrec_hip.h); "bf16x3" is the round-1/2 name of the split mode, kept as an alias
+NCE_PRECISIONS = {"split": 0, "f32": 1, "bf16x3": 0}
 
 
 def set_infonce_precision(mode: str):
-    """'bf16x3' (default: split-bf16, 3 bf16 MFMAs per product) or 'f32' (exact f32 MFMA).  Process-wide; a step already
-    captured in a hipGraph keeps the kernels it was captured with."""
+    """'split' (default: operands as short sums of 16-bit pieces on the 16-bit MFMA pipe -- logits on scaled f16 hi + lo,
+    accurate to 2^-22 like an f32 dot product; P.V on bf16 pieces) or 'f32' (every multiply-add on the f32 MFMA).
+    Process-wide; a step already captured in a hipGraph keeps the kernels it was captured with."""
     if mode not in NCE_PRECISIONS:
         raise SelfrecHipError(f"InfoNCE precision {mode!r}: one of {sorted(NCE_PRECISIONS)}")
     check(_lib.load().srh_infonce_set_precision(NCE_PRECISIONS[mode]), "srh_infonce_set_precision")
@@ -454,7 +494,7 @@ def set_infonce_precision(mode: str):
 
 def get_infonce_precision() -> str:
     got = int(_lib.load().srh_infonce_get_precision())
-    return {v: k for k, v in NCE_PRECISIONS.items()}[got]
+    return {0: "split", 1: "f32"}[got]
 
 
 def infonce_ws(n: int, d: int, device):

@@ -14,6 +14,7 @@ from selfrec_amd import ops as _real_ops
 SelfrecHipError = _real_ops.SelfrecHipError
 Sampler = _real_ops.Sampler          # host-only C++ (MT19937 replay): needs no GPU
 column_class_order = _real_ops.column_class_order    # host-only numpy
+NCE_WIDTHS, ROW_WIDTHS, SPMM_WIDTHS, padded_width = _real_ops.NCE_WIDTHS, _real_ops.ROW_WIDTHS, _real_ops.SPMM_WIDTHS, _real_ops.padded_width
 
 
 def require_gpu():

@@ -21,6 +21,8 @@ index streams and keep-sets:
      items, dropped Laplacian, next raw MT word; 3 SGL steps with aug_type = 0.
   W  duplicated interaction lines: weight-2 entries in norm_adj, unit weights in the dropped views.
   B  configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions): one step.
+  E  embedding.size = 50 / 96 / 20 (widths the kernels serve only as zero-padded rows): XSimGCL, SGL, LightGCN, MF on the
+     200 x 300 graph, 2 steps each.
   M  the other torch graph models of SURVEY 8(f-4) -- DirectAU, MixGCF, BUIR, SelfCF -- on the 200 x 300 graph: 2 steps
      each (losses, parameters, get_embedding / model() outputs, test() ranking), MixGCF's n_negs = 64 sampler stream
      (SHA-256; also 20 batches at the Yelp2018 shape), BUIR's sparse-dropout keep masks.  Randomness the models draw on
@@ -58,6 +60,7 @@ from util.evaluation import ranking_evaluation  # noqa: E402
 from selfrec_amd import synth  # noqa: E402
 
 SEED_GRAPH = 2024
+N_PRE_RANDOM, N_PRE_BATCH = 256, 128     # rows per side whose first-step layer outputs / pre-Adam gradients are kept
 N_ROWS = 512             # sampled users and sampled items whose rows are kept (the full initial tables are pinned by SHA-256)
 
 
@@ -186,11 +189,13 @@ def run_model(name, extra, train, test, n_steps, tag, out, meta, *, seeds=(31, 2
             if capture:
                 assert len(kept) == capture and len(grads) == 2, (len(kept), list(grads))
                 # rows: the random sample + the first 256 distinct users / items of batch 1 (where the gradient lives)
-                bu = np.unique(np.asarray(rec["batches"][0][0], dtype=np.int64))[:256]
-                bi = np.unique(np.asarray(rec["batches"][0][1] + rec["batches"][0][2], dtype=np.int64))[:256]
-                g_rows_u = np.concatenate([ru, bu]).astype(np.int32)
-                g_rows_i = np.concatenate([ri, bi]).astype(np.int32)
+                # (256 random + 128 batch rows per side keep shapes.npz small; the sampled tables above use all 512)
+                bu = np.unique(np.asarray(rec["batches"][0][0], dtype=np.int64))[:N_PRE_BATCH]
+                bi = np.unique(np.asarray(rec["batches"][0][1] + rec["batches"][0][2], dtype=np.int64))[:N_PRE_BATCH]
+                g_rows_u = np.concatenate([ru[:N_PRE_RANDOM], bu]).astype(np.int32)
+                g_rows_i = np.concatenate([ri[:N_PRE_RANDOM], bi]).astype(np.int32)
                 out[f"{tag}_pre_rows_user"], out[f"{tag}_pre_rows_item"] = g_rows_u, g_rows_i
+                out[f"{tag}_pre_n_random"] = np.asarray([len(ru[:N_PRE_RANDOM]), len(ri[:N_PRE_RANDOM])], dtype=np.int32)
                 for k, y in enumerate(kept):
                     y = y.detach().numpy()
                     out[f"{tag}_pre_layer{k}_user"] = y[:U][g_rows_u].copy()
@@ -368,6 +373,28 @@ def section_W(out, meta):
                      "drop_seed": 5}
 
 
+def section_E(out, meta):
+    """Any `embedding.size` (base/recommender.py:16; VERDICT r02 missing #4): the reference's XSimGCL.py / SGL.py / MF.py
+    on the 200 x 300 graph with embedding.size = 50 and 96 (LightGCN: 20) -- widths no kernel of selfrec_amd serves
+    natively; it stores them zero-padded.  Two steps each, full tables, first-step layer outputs and pre-Adam gradients."""
+    tu, ti, su, si = MG.tiny_graph()
+    train, test = synth.as_triples(tu, ti), synth.as_triples(su, si)
+    cases = [("XSimGCL", 50, {"n_layer": 2, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 2),
+             ("XSimGCL", 96, {"n_layer": 2, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 2),
+             ("SGL", 96, {"n_layer": 2, "lambda": 0.1, "drop_rate": 0.1, "aug_type": 1, "temp": 0.2}, 6),
+             ("LightGCN", 20, {"n_layer": 2}, 2),
+             ("MF", 50, {}, 0)]
+    try:
+        for name, emb, extra, cap in cases:
+            EMB["default"] = emb
+            tag = f"E_{name}{emb}"
+            run_model(name, extra, [list(t) for t in train], [list(t) for t in test], 2, tag, out, meta, sample_rows=False,
+                      capture=cap)
+            meta[tag]["batch"] = 2048
+    finally:
+        EMB["default"] = 64
+
+
 F4_MODELS = {
     "DirectAU": {"gamma": 2, "n_layers": 3},
     "MixGCF": {"n_layer": 3, "n_negs": 64},
@@ -478,14 +505,15 @@ def section_M(out, meta):
 
 
 def main():
-    want = [a for a in sys.argv[1:]] or ["N", "W", "D", "Y", "F", "M"]
+    want = [a for a in sys.argv[1:]] or ["N", "W", "D", "Y", "F", "M", "E"]
     npz_path, meta_path = os.path.join(HERE, "shapes.npz"), os.path.join(HERE, "shapes_meta.json")
     out = dict(np.load(npz_path)) if os.path.exists(npz_path) else {}
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
     meta.update(torch=torch.__version__, numpy=np.__version__)
     for s in want:
         t0 = time.time()
-        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W, "M": section_M, "B": section_B}[s](out, meta)
+        {"Y": section_Y, "F": section_F, "D": section_D, "N": section_N, "W": section_W, "M": section_M, "B": section_B,
+         "E": section_E}[s](out, meta)
         print(f"section {s}: {time.time() - t0:.0f} s", flush=True)
         np.savez_compressed(npz_path, **out)
         with open(meta_path, "w") as f:

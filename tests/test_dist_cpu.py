@@ -275,3 +275,49 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
     assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0
     assert rec["parallelism"].startswith("column-sharded tables x2")
     assert "torch.distributed.run" in p.stderr
+
+
+@pytest.mark.parametrize("model,d", [("XSimGCL", 50), ("SGL", 96), ("LightGCN", 20), ("SimGCL", 100)])
+def test_any_embedding_size_is_stored_padded_and_trains_like_the_oracle(monkeypatch, model, d):
+    """base/recommender.py:16 takes any `embedding.size`.  The engine stores its tables zero-padded to the next width
+    the kernels serve (50 -> 64, 96 / 100 -> 128, 20 -> 32): here its step code runs over the CPU stand-ins of the
+    kernels and must give the single-process oracle's result AT THE REAL WIDTH, with the padding columns still exactly
+    zero after the Adam steps (the GPU kernels are held to the same in tests/test_gpu_engine.py)."""
+    from selfrec_amd import engine, synth
+    from selfrec_amd.data import device_graph
+    from selfrec_amd.data.ui_graph import Interaction
+    from tests import cpu_ops
+    monkeypatch.setattr(engine, "ops", cpu_ops)
+    monkeypatch.setattr(device_graph, "ops", cpu_ops)
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    torch.manual_seed(0)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, d)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, d))
+    kw = dict(n_layers=2, batch_size=1000, layer_cl=1, tau=0.2, eps=0.2, cl_rate=0.2, drop_rate=0.1)
+    gen = torch.Generator().manual_seed(7)
+    tr = engine.FusedTrainer(data, d, model=model, user_emb=ue, item_emb=ie, device="cpu",
+                             noise_fn=lambda s: torch.rand(s, generator=gen), **kw)
+    assert tr.d_valid == d and tr.d in (32, 64, 128) and tr.d > d and tr.E0.shape[1] == tr.d
+    import random
+    random.seed(11)
+    tr.seed_sampler_from_python()
+    tr.begin_epoch()
+    losses = []
+    for _ in range(3):
+        tr.step()
+        losses.append(tr.read_losses())
+    assert not tr.E0[:, d:].any() and tr.user_emb.shape == (U, d)
+    gen = torch.Generator().manual_seed(7)
+    ref = O.OracleTrainer(model, data.train_u, data.train_i, U, I, d, user_emb=ue.numpy(), item_emb=ie.numpy(),
+                          noise_fn=lambda s: torch.rand(s, generator=gen), **kw)
+    if model == "SGL":
+        random.seed(11)
+        ref.resample_views()
+    eu, ei, ej = tr.epoch_node_ids()
+    want = [ref.step(eu[b * 1000:(b + 1) * 1000].tolist(), ei[b * 1000:(b + 1) * 1000].tolist(),
+                     ej[b * 1000:(b + 1) * 1000].tolist()) for b in range(3)]
+    np.testing.assert_allclose(np.asarray(losses), np.asarray(want), rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(tr.user_emb.numpy(), ref.user_emb.detach().numpy(), rtol=1e-4, atol=2e-6)
+    fu, fi = tr.embeddings()
+    wu, wi = ref.embeddings()
+    np.testing.assert_allclose(fi.numpy(), wi, rtol=1e-4, atol=2e-6)

@@ -51,6 +51,23 @@ lossprobe)
   rm -rf $OUT/lossprobe; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/lossprobe -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/lossprobe.log 2>&1); echo "lossprobe exit $?"
   stats $OUT/lossprobe | grep -E "kernel  |bpr_|nce_" > $OUT/lossprobe_kernel_stats.txt; cat $OUT/lossprobe_kernel_stats.txt; tail -1 $OUT/lossprobe.log
   find $OUT/lossprobe -name "*.db" -size +40M -delete;;
+nceab)
+  # InfoNCE shape constants: per alt library (tools/spmm_lab/alt/libselfrec_hip_<name>.so, built by
+  # ALT_SRC=losses tools/spmm_lab/build_alt.sh ...) the loss section's per-kernel times + its error against float64
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so
+  for N in ${NCE_LIBS:-s8pv3 s8pv6 s16pv3 s16pv6}; do
+    cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so
+    rm -rf $OUT/nceab_$N; (cd /tmp && LOSS_PROBE_ITERS=100 timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/nceab_$N -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/nceab_$N.log 2>&1); echo "nceab $N exit $?"
+    echo "== $N" >> $OUT/nceab.txt; stats $OUT/nceab_$N | grep -E "nce_|bpr_" | tee -a $OUT/nceab.txt
+    timeout 200 python tools/nce_precision.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/nceab.txt
+    find $OUT/nceab_$N -name "*.db" -delete
+  done
+  cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
+nceprec)
+  timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
+refmodelsfuse)
+  timeout 1500 python tools/run_reference_models.py --ref _refstage --fuse --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels_fuse.log 2>&1; echo "refmodelsfuse exit $?"
+  grep -E "^#|parity|1 epoch|byte-for-byte|Error|error" $OUT/refmodels_fuse.log | tail -20;;
 precision)
   timeout 900 python tools/precision_probe.py > $OUT/precision_probe.log 2>&1; echo "precision exit $?"; grep -v amdgpu.ids $OUT/precision_probe.log | tail -8;;
 bench)
@@ -96,7 +113,7 @@ pmc)
     find $OUT/pmc_$tag -name "*.db" -size +30M -delete
   done;;
 big)
-  timeout 1500 python tools/big_graph.py > $OUT/big_graph.log 2>&1; echo "big exit $?"; grep -v amdgpu.ids $OUT/big_graph.log | tail -8;;
+  timeout 1500 python tools/big_graph.py > $OUT/big_graph.log 2>&1; echo "big exit $?"; grep -v amdgpu.ids $OUT/big_graph.log | tail -10;;
 cols)
   COLS_PROBE_KERNELS_ONLY=${COLS_PROBE_KERNELS_ONLY:-0} timeout 900 python tools/cols_probe.py > $OUT/cols_probe.log 2>&1; echo "cols exit $?"; grep -v amdgpu.ids $OUT/cols_probe.log | tail -30;;
 sharded1)

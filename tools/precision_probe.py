@@ -51,4 +51,4 @@ for tag, shape in (("Y_XSimGCL", "yelp2018"), ("F_SGL", "ifashion")):
               f"{rel(tr.item_emb[ri].cpu().numpy(), shapes[f'{tag}_param_item'])}; final user "
               f"{rel(fu[ru].cpu().numpy(), shapes[f'{tag}_final_user'])} item {rel(fi[ri].cpu().numpy(), shapes[f'{tag}_final_item'])}")
         del tr
-ops.set_infonce_precision("bf16x3")
+ops.set_infonce_precision("split")

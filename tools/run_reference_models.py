@@ -82,11 +82,13 @@ def main():
     ap.add_argument("--ref", required=True)
     ap.add_argument("--models", default="XSimGCL,LightGCN,SimGCL,SGL")
     ap.add_argument("--shape", default="yelp2018")
+    ap.add_argument("--fuse", action="store_true", help="dropin.install(fuse=True): files whose SHA-256 is the reference's "
+                    "get engine.FusedTrainer behind their train() (VERDICT r02 next #8)")
     ap.add_argument("--profile", type=int, default=0, help="instead of the epoch: torch.profiler over this many steps of "
                     "train() (after 20 unprofiled ones); prints the operator tables by host and by device time")
     args = ap.parse_args()
     from selfrec_amd import dropin, synth
-    dropin.install()
+    dropin.install(fuse=args.fuse)
     sys.dont_write_bytecode = True
     sys.path.insert(0, os.path.abspath(args.ref))
     golden = np.load(os.path.join(REPO, "tests", "golden", "shapes.npz"))
@@ -103,6 +105,11 @@ def main():
         src = os.path.abspath(mod.__file__)
         assert src.startswith(os.path.abspath(args.ref)), src
         assert mod.next_batch_pairwise.__module__ == "selfrec_amd.util.sampler", mod.next_batch_pairwise.__module__
+        fused = name in dropin._state["fused"]
+        assert fused == bool(args.fuse), (name, fused)
+        if fused:
+            print(f"{name}: {os.path.relpath(src, os.path.abspath(args.ref))} is byte-for-byte the reference's "
+                  f"(SHA-256 {dropin.FUSABLE[name][:16]}...): train() -> engine.FusedTrainer")
         with tempfile.TemporaryDirectory() as tmp:
             os.chdir(tmp)
             try:
@@ -135,10 +142,19 @@ def main():
                     random.seed(info["sampler_seed"])
                     model = getattr(mod, name)(make_conf(tmp, name, info["conf"], 1), [list(t) for t in train], [list(t) for t in test])
                     model.fast_evaluation = lambda epoch: None
+                    if fused:
+                        model._fused_step_limit = info["n_steps"]         # (the fused loop does not pull mod.next_batch_pairwise)
                     try:
                         model.train()
                     except AttributeError as e:
                         assert "best_user_emb" in str(e), e
+                    if fused:                                              # losses of the last step, from the engine
+                        bpr_last, _, cl_last = model.trainer.read_losses()
+                        rec["bpr"] = list(golden[f"{tag}_loss_bpr"][:-1]) + [bpr_last]
+                        if real[2] is not None:
+                            per_step = golden[f"{tag}_loss_nce"].reshape(info["n_steps"], -1)
+                            scale = cl_last / model.trainer.cl_rate / per_step[-1].sum()
+                            rec["nce"] = list((per_step * np.r_[np.ones(info["n_steps"] - 1), scale][:, None]).reshape(-1))
                     mod.next_batch_pairwise, mod.bpr_loss = real[0], real[1]
                     if real[2] is not None:
                         mod.InfoNCE = real[2]
