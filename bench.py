@@ -58,7 +58,12 @@ def build_data(shape, seed):
     from selfrec_amd import synth
     from selfrec_amd.data.ui_graph import Interaction
     tu, ti, su, si, U, I = synth.make_dataset(shape, seed=seed)
-    data = Interaction({}, synth.as_triples(tu, ti), synth.as_triples(su, si))
+    if len(tu) > 5_000_000:
+        # (the 1 M x 500 k graph: 40 M python triples would be 25 GB of host objects -- what the reference needs for it;
+        # the id arrays go straight in, with a bounded test set)
+        data = Interaction.from_id_arrays({}, tu, ti, su[:200_000], si[:200_000], U, I)
+    else:
+        data = Interaction({}, synth.as_triples(tu, ti), synth.as_triples(su, si))
     return data, (tu, ti, su, si, U, I)
 
 
@@ -74,15 +79,31 @@ def step_alg_bytes(model, nnz, N, d, L, B):
     return spmm + 7 * N * d * 4 + N * d * 4 + 2 * 3 * B * d * 4 + 4 * 2 * B * d * 4
 
 
+def git_blob_hash(path):
+    """`git hash-object path` without git: the id of the file's contents."""
+    import hashlib
+    with open(path, "rb") as f:
+        body = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(body) + body).hexdigest()
+
+
 def pmc_traffic(args):
-    """HBM-side bytes per dense SpMM launch from the committed PMC passes (bench.py cannot run under
-    rocprofv3 --pmc itself): profiles/spmm_dense_traffic.json, valid for the default workload only."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "spmm_dense_traffic.json")
+    """HBM-side bytes per dense SpMM launch from the committed PMC passes (bench.py cannot run under rocprofv3 --pmc
+    itself): profiles/spmm_dense_traffic[_<shape>_d<emb>].json, written by tools/pmc_to_json.py from a counter session
+    over tools/spmm_pmc.py.  The record carries the git blob id of the csrc/spmm.hip it was measured on: a record taken
+    from another kernel source is REFUSED (traffic = null, with the reason), not quoted."""
+    here = os.path.dirname(os.path.abspath(__file__))
     default = args.shape == "yelp2018" and args.emb == 64
-    if not default or not os.path.exists(path):
-        return None, "no PMC pass committed for this workload"
+    name = "spmm_dense_traffic.json" if default else f"spmm_dense_traffic_{args.shape}_d{args.emb}.json"
+    path = os.path.join(here, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"no PMC pass committed for this workload (profiles/{name})"
     with open(path) as f:
         rec = json.load(f)
+    want, have = rec.get("spmm_hip_blob"), git_blob_hash(os.path.join(here, "selfrec_amd", "csrc", "spmm.hip"))
+    if want != have:
+        return None, (f"profiles/{name} was measured on csrc/spmm.hip blob {str(want)[:12]}, this tree has {have[:12]}: stale "
+                      f"record refused (re-run tools/gpu_session.sh pmc)")
     return rec["traffic_bytes_per_launch"], f"{rec['summary']}: {rec['how']}"
 
 
@@ -310,9 +331,32 @@ def eval_throughput(trainer, data, k=20):
     t_e2e = time.time() - t0
     assert len(report) == 5
     flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
+    # the scoring GEMM alone (srh_gemm_nt_f32: the same MFMA kernel without the filter epilogue, one 4096-user chunk
+    # into a slab): its rate against the fp32 MFMA peak is the kernel-quality figure; `achieved` below is the whole
+    # ranking pipeline (bound pass + filter GEMM + candidate ranking + D2H of ids and scores) against the same peak
+    from selfrec_amd import ops
+    q = rec.user_emb[torch.as_tensor(uid[:4096], device=rec.user_emb.device, dtype=torch.long)].contiguous()
+    slab = torch.empty((q.shape[0], data.item_num), dtype=torch.float32, device=q.device)
+    for _ in range(3):
+        ops.gemm_nt(q, rec.item_emb, out=slab)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(10):
+        ops.gemm_nt(q, rec.item_emb, out=slab)
+    b.record(); torch.cuda.synchronize()
+    gemm_tflops = 2.0 * q.shape[0] * data.item_num * q.shape[1] * 10 / (a.elapsed_time(b) * 1e-3) / 1e12
+    del slab
     return {"users": len(uid), "k": k, "device_users_per_s": round(len(uid) / t_kernel, 1),
             "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
-            "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS}
+            "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
+                         "achieved": round(flops / t_kernel / 1e12, 2),
+                         "frac": round(flops / t_kernel / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "what": "2 * users * items * d flops of full-catalogue scoring / the whole device-side ranking "
+                                 "(exact-f32 MFMA chain, masks, top-K, ids + scores to the host)",
+                         "gemm_alone_tflops": round(gemm_tflops, 2),
+                         "gemm_alone_frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                         "mfma_busy": "profiles/r03_*_eval_pmc.txt (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"}}
 
 
 def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
@@ -547,6 +591,18 @@ def main():
                                "traffic_source": traffic_note,
                                "traffic_GBps": round(traffic / t_spmm["dominant"] / 1e9, 1) if traffic else None,
                                "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dominant"] * 1e6, 2),
+                               # the value-free launch streams no value array -- the same launch priced by the
+                               # bytes ITS formulation has to move (indices + indptr + D^-1/2 + x + y), next to SURVEY
+                               # 8(d)'s figure for the problem (CSR with values) that `achieved` / `frac` use
+                               **({"value_free_byte_model": {
+                                   "bytes_per_launch": alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4,
+                                   "achieved": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9, 1),
+                                   "frac": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9 / HBM_PEAK_GBS, 4)}}
+                                  if dom == "dense_value_free" else {}),
+                               "with_values": ({"launch_us": round(t_spmm["dense"] * 1e6, 2),
+                                                "achieved": round(alg / t_spmm["dense"] / 1e9, 1),
+                                                "frac": round(alg / t_spmm["dense"] / 1e9 / HBM_PEAK_GBS, 4)}
+                                               if "dense" in t_spmm else None),
                                "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
                                "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
                                        "launch_us_by_flavour.step_mix (profiles/)",

@@ -244,6 +244,8 @@ std::atomic<int> g_nce_precision{getenv("SRH_NCE_F32") ? SRH_NCE_F32 : SRH_NCE_S
 
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
+  float* ediag;         // split path: exp(s_ii / tau - 1 / tau) as pass 1's MFMA saw it (the pair's own weight is kept out of
+                        // the accumulated sums: see nce_tile_lds)
   double* losspart;     // one partial per finish wave
   int32_t* ticket;      // np/16 + 1 arrival counters (zeroed by nce_prep, re-armed by the last arriver)
   // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
@@ -284,6 +286,7 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
   w.norm2 = p; p += np;
   w.lpart = p; p += (int64_t)kNceSplits * np;
   w.invl = p; p += np;
+  w.ediag = p; p += np;
   w.losspart = reinterpret_cast<double*>(p);     // np doubles (np is a multiple of 64: 8-byte aligned)
   uint16_t* h = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(p) + np);
   for (int v = 0; v < 2; ++v) {
@@ -566,13 +569,20 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
       l += lp[k];
     }
   }
+  // l, O1, O2 are OFF-DIAGONAL sums (nce_tile_lds keeps the pair's own weight out); the diagonal enters here, exactly:
+  //   e_ii = exp(s_ii / tau - 1 / tau) from the f32 dot product of the two rows,  L = l + e_ii,
+  //   loss_i = log(L) - (s_ii / tau - 1 / tau) = log1p(l / e_ii),
+  //   d/dn1_i = (O1 + e_ii v2_i) / L - v2_i = (O1 - l v2_i) / L,     d/dn2_i = O2 + (e_ii / L) v1_i - v1_i = O2 - (l / L) v1_i
+  // -- no difference of nearly equal numbers anywhere, however sharp the softmax.
   const float coef = a.loss_scale * a.inv_tau / (float)n;
   const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
-  const float lse = a.inv_tau + logf(l);
-  const float il = 1.0f / l;
-  const float4 dn1 = make_float4(coef * (O1.x * il - vb.x), coef * (O1.y * il - vb.y), coef * (O1.z * il - vb.z),
-                                 coef * (O1.w * il - vb.w));
-  const float4 dn2 = make_float4(coef * (O2.x - va.x), coef * (O2.y - va.y), coef * (O2.z - va.z), coef * (O2.w - va.w));
+  const float eii = expf(sii - a.inv_tau);
+  const float il = 1.0f / (l + eii);
+  const float off = l * il;                      // 1 - p_ii
+  const float4 dn1 = make_float4(coef * (O1.x * il - off * vb.x), coef * (O1.y * il - off * vb.y),
+                                 coef * (O1.z * il - off * vb.z), coef * (O1.w * il - off * vb.w));
+  const float4 dn2 = make_float4(coef * (O2.x - off * va.x), coef * (O2.y - off * va.y), coef * (O2.z - off * va.z),
+                                 coef * (O2.w - off * va.w));
   const float4 dv1 = nce_norm_backward<LPR>(va, dn1, n1);
   const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, n2);
   if (valid) {
@@ -586,7 +596,7 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
       atomic_add_row<LPR>(w.g2 + (size_t)dst * LPR * 4, dv2, sub, scr);
     }
   }
-  return (valid && sub == 0) ? (double)(lse - sii) : 0.0;
+  return (valid && sub == 0) ? (double)log1pf(l / eii) : 0.0;
 }
 
 // LDS-staged form of nce_tile_bf16 (the default).  The register version is latency-bound: a workgroup's
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
       for (int t = threadIdx.x; t < cn; t += 64 * WAVES) {
         float l = 0.f;
         for (int sp = 0; sp < batch.splits; ++sp) l += w.lpart[(size_t)sp * np + c0 + t];
-        invl_s[t] = 1.0f / l;
+        invl_s[t] = 1.0f / (l + w.ediag[c0 + t]);       // (lpart holds the off-diagonal sums; rows >= n: unused)
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -727,14 +737,22 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
           }
         }
         bf16x8 ph, pm, pl;
+        const int qrow = q0 + 16 * t + c16;              // the query whose weights this lane holds
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = c0 + j0 + 16 * h + 4 * g + r;
             float e = __expf(fmaf(a[h][r], s_scale, -inv_tau));
+            // The pair's OWN weight (key == query: the positive of InfoNCE) stays out of the accumulated sums.  Its part
+            // of the gradient, p_ii v_i - v_i, is a cancellation -- the closer p_ii is to 1 (small tau, a trained model)
+            // the more of the sum's rounding error it exposes (measured with it inside the sums: gradient errors of
+            // 3e-3 ... 8e-2 at tau = 0.05 on correlated views, all-f32 path included) -- so the finish kernel forms
+            // -(1 - p_ii) v_i = -(l' / l) v_i from the off-diagonal sum l' directly, and the loss as log1p(l' / e_ii).
+            const bool own = key == qrow;
+            if (!PASS2 && own && key < n) w.ediag[qrow] = e;
             if (PASS2) e *= il[h][r];
-            const float wt = (key < n) ? e : 0.f;
+            const float wt = (key < n && !own) ? e : 0.f;
             lsum[t] += wt;
             const __bf16 bh = (__bf16)wt;
             const float r1 = wt - (float)bh;
@@ -1062,7 +1080,7 @@ srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* st
 int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
-  return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 3 * np + (int64_t)kNceSplits * np) + 8 * np +
+  return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 4 * np + (int64_t)kNceSplits * np) + 8 * np +
          20 * np * d + 4 * (np / 16) + 256;       // (2 views x 5 sixteen-bit operand images)
 }
 

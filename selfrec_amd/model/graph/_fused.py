@@ -43,13 +43,19 @@ class FusedGraphModel(GraphRecommender):
                                     reg=self.reg, batch_size=self.batch_size, rng_seed=rng_seed,
                                     use_graph=_as_bool(get('engine.hipgraph', True)), **self.engine_kwargs())
         self.exact_sampling = _as_bool(get('sampler.python_state', True))
-        precision = get('engine.nce_precision', None)          # "f32" | "split" (process-wide; default split)
-        if precision is not None:
-            from ... import ops
-            ops.set_infonce_precision(str(precision))
+        # "f32" | "split".  The library's setting is process-wide, so every model states its own -- the default
+        # included (a model must not inherit the arithmetic an earlier model in the process asked for) --
+        # and train() re-asserts it before the step is captured
+        self.nce_precision = str(get('engine.nce_precision', 'split'))
+        from ... import ops
+        ops.set_infonce_precision(self.nce_precision)
 
     def train(self):
         tr = self.trainer
+        from ... import ops
+        if ops.NCE_PRECISIONS[ops.get_infonce_precision()] != ops.NCE_PRECISIONS[self.nce_precision]:
+            ops.set_infonce_precision(self.nce_precision)
+            tr.reset_graph()                   # (a captured step keeps the kernels it was captured with)
         if self.exact_sampling:           # consume the global `random` stream like the reference
             tr.seed_sampler_from_python()
         else:

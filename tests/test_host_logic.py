@@ -300,3 +300,36 @@ def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, m
         dropin.uninstall()
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             del sys.modules[k]
+
+
+def test_reordered_training_list_rebuilds_the_sampler(golden_ops):
+    """`data.training_data` edited or re-ordered by the caller between epochs -- anywhere, not only at the
+    64 probed positions -- must be noticed (full identity fingerprint of the records), and the next epoch must read
+    the list as the reference's generator would."""
+    from tests.conftest import _tiny_interaction
+    from selfrec_amd.util import sampler as S
+    data = _tiny_interaction(golden_ops)
+    random.seed(5)
+    first = [b for b in next_batch_pairwise(data, 512)]
+    smp0 = data._srh_sampler[0]
+    random.seed(6)
+    list(next_batch_pairwise(data, 512))
+    assert data._srh_sampler[0] is smp0                       # untouched list: the sampler is reused
+    td = data.training_data
+    n = len(td)
+    probed = set(np.unique(np.linspace(0, n - 1, num=64).astype(np.int64)).tolist())
+    a, b = [k for k in range(n) if k not in probed and k + 1 not in probed][:2]
+    b += 7
+    assert a not in probed and b not in probed and td[a][:2] != td[b][:2]
+    td[a], td[b] = td[b], td[a]                               # a swap the value probes cannot see
+    want_u = [data.user[r[0]] for r in td]
+    random.seed(7)
+    gen = next_batch_pairwise(data, 512)
+    u0, i0, j0 = next(gen)
+    assert data._srh_sampler[0] is not smp0                   # noticed: rebuilt from the list
+    # ... and the epoch is what the reference's generator yields for this list: shuffle(list) then slices of it
+    import copy
+    ref = copy.deepcopy([r for r in data.training_data])      # (already shuffled in place by the generator)
+    assert u0 == [data.user[r[0]] for r in ref[:512]] and i0 == [data.item[r[1]] for r in ref[:512]]
+    assert sorted(want_u) == sorted(data.user[r[0]] for r in data.training_data)
+    assert len(first) == (n + 511) // 512

@@ -67,7 +67,7 @@ nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
 refmodelsfuse)
   timeout 1500 python tools/run_reference_models.py --ref _refstage --fuse --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels_fuse.log 2>&1; echo "refmodelsfuse exit $?"
-  grep -E "^#|parity|1 epoch|byte-for-byte|Error|error" $OUT/refmodels_fuse.log | tail -20;;
+  grep -E "^#|parity|epoch\(s\)|byte-for-byte|Error|error" $OUT/refmodels_fuse.log | tail -20;;
 precision)
   timeout 900 python tools/precision_probe.py > $OUT/precision_probe.log 2>&1; echo "precision exit $?"; grep -v amdgpu.ids $OUT/precision_probe.log | tail -8;;
 bench)
@@ -108,10 +108,22 @@ pmc)
   # HBM-side traffic + L2 hit rate + issue counters of the dense SpMM launch (separate passes, counters only)
   for c in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     tag=$(echo $c | tr ' ' '_' | cut -c1-40); rm -rf $OUT/pmc_$tag
-    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmc_$tag -o pmc -- python $OLDPWD/tools/spmm_pmc.py > $OLDPWD/$OUT/pmc_$tag.log 2>&1); echo "pmc [$c] exit $?"
-    f=$(find $OUT/pmc_$tag -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" --tail 40 | grep -E "spmm_rows" | tee -a $OUT/pmc_summary.txt
-    find $OUT/pmc_$tag -name "*.db" -size +30M -delete
-  done;;
+    (cd /tmp && timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/$OUT/pmc_$tag -o pmc -- python $OLDPWD/tools/spmm_pmc.py ${PMC_ARGS:-} > $OLDPWD/$OUT/pmc_$tag.log 2>&1); echo "pmc [$c] exit $?"
+    f=$(find $OUT/pmc_$tag -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" --tail ${PMC_TAIL:-40} | grep -E "spmm_rows" | tee -a $OUT/pmc_summary${PMC_NAME:-}.txt
+  done
+  # the record bench.py quotes as roofline.traffic, stamped with the blob id of the spmm.hip it was measured on
+  python tools/pmc_to_json.py $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE_TCC_HIT_sum_TCC_MISS_sum $OUT/pmc_SQ_WAVES* -name "*.db") \
+    --tail ${PMC_TAIL:-40} --out $OUT/spmm_dense_traffic${PMC_NAME:-}.json --summary "${PMC_SUMMARY:-profiles/r03_pmc_dense_spmm.txt}" \
+    --what "${PMC_WHAT:-spmm_rows_kernel<16,false>, dominant launch of the step: dense value-free flavour, yelp2018-shape graph, d=64}" > /dev/null && echo "wrote $OUT/spmm_dense_traffic${PMC_NAME:-}.json"
+  find $OUT/pmc_* -name "*.db" -size +30M -delete;;
+evalpmc)
+  # MFMA utilisation of the scoring GEMM (double-buffered gemm_nt_kernel<64, 8, filter>) + per-kernel times of the ranking
+  rm -rf $OUT/evalpmc $OUT/evalprof
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d $OLDPWD/$OUT/evalpmc -o pmc -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalpmc.log 2>&1); echo "evalpmc exit $?"
+  f=$(find $OUT/evalpmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "gemm_nt|topk|cand_|mask_kernel|hit_flags" | tee $OUT/eval_pmc.txt
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/evalprof -o trace -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalprof.log 2>&1); echo "evalprof exit $?"
+  stats $OUT/evalprof | grep -E "kernel  |gemm_nt|topk|mask_kernel|cand_|hit_flags" | tee $OUT/eval_kernel_stats.txt; grep -v amdgpu.ids $OUT/evalprof.log | tail -1
+  find $OUT/evalpmc $OUT/evalprof -name "*.db" -size +30M -delete;;
 big)
   timeout 1500 python tools/big_graph.py > $OUT/big_graph.log 2>&1; echo "big exit $?"; grep -v amdgpu.ids $OUT/big_graph.log | tail -10;;
 cols)
