@@ -403,11 +403,15 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
  *      >= t_u -- a few hundred (item, score) pairs per user, appended to a list of `cap` slots;
  *   3. training items of u are dropped from its list (binary search in the mask CSR) and the rest is
  *      put in exact (score desc, id asc) order.
+ *   d = 64 / 128 (round 3): pass 2 only has to DECIDE, so it runs on split-bf16 operands (3 bf16 MFMAs per 16
+ *   dimensions, 5.3x the f32 MFMA's rate) against t_u lowered by a rigorous error margin (4e-5 |u| max|i|) and keeps ids
+ *   only; pass 3 re-scores the survivors with the exact-f32 instruction sequence of pass 1 before ranking them.
  * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
  * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
  * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with
  * srh_score_mask_topk.  d_ws: srh_score_mask_topk_filtered_ws_bytes(chunk_rows, ...) bytes. */
-int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap);
+int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
+                                              int64_t n_items, int32_t d);
 srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
                                           const float* d_item_emb, int64_t n_items, int32_t d,
                                           const int32_t* d_r_indptr, const int32_t* d_r_indices, int32_t k,

@@ -123,7 +123,7 @@ SIGNATURES = {
     "srh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _f32, _f32, _f32, _f32, _vp]),
     "srh_adam_step_reset": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp]),
     "srh_score_mask_topk": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
-    "srh_score_mask_topk_filtered_ws_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "srh_score_mask_topk_filtered_ws_bytes": (_i64, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "srh_score_mask_topk_filtered": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp,
                                             _vp, _vp, _vp]),
     "srh_gemm_nt_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),

@@ -202,6 +202,241 @@ __global__ __launch_bounds__(256) void cand_topk_kernel(const int32_t* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The FILTER pass on the bf16 pipe (round 3).  The filter only has to decide "can this score reach the row's
+// bound?" -- it never has to report a score -- so it runs on split-bf16 operands (x = hi + lo, three MFMAs of
+// v_mfma_f32_32x32x16_bf16 per 16 dimensions: 5.3x the f32 MFMA's rate) against a bound lowered by a rigorous margin;
+// the few hundred survivors per user are then RE-SCORED with the very instruction sequence of gemm_nt_kernel (so
+// ids and scores stay bit-identical to the plain pipeline) and ranked.
+//   |s~ - s| <= 3 * 2^-18 * sum_k |u_k i_k| (dropped lo.lo, two operand representations) + f32 accumulation of either
+//   side (d * 2^-24 * sum |u_k i_k|) <= 4e-5 * |u| * max_i |i| for d <= 128 =: delta_u  (kFilterMargin)
+// A true top-K item has s >= t_u, hence s~ >= t_u - delta_u: it survives.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float kFilterMargin = 4e-5f;
+
+// rows of an f32 table as bf16 hi / lo images (row-major) + the row's L2 norm; the table's largest norm in *max_norm
+// (float bits compare like unsigned ints for non-negative floats)
+template <int LPR>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, const int32_t* __restrict__ rows, int n,
+                                                         uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                         float* __restrict__ norm, unsigned int* __restrict__ max_norm) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int r = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool valid = r < n;
+  const int src = valid ? (rows ? rows[r] : r) : 0;
+  const float4 v = reinterpret_cast<const float4*>(X)[(size_t)src * LPR + sub];
+  const float ss = group_sum<LPR>(f4_dot(v, v));
+  if (!valid) return;
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  uint16_t h[4], l[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const __bf16 bh = (__bf16)f[t];
+    h[t] = __builtin_bit_cast(uint16_t, bh);
+    l[t] = __builtin_bit_cast(uint16_t, (__bf16)(f[t] - (float)bh));
+  }
+  const size_t at = ((size_t)r * LPR + sub) * 4;
+  *reinterpret_cast<uint2*>(hi + at) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+  *reinterpret_cast<uint2*>(lo + at) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+  if (sub == 0) {
+    const float nr = sqrtf(ss);
+    if (norm) norm[r] = nr;
+    if (max_norm) atomicMax(max_norm, __float_as_uint(nr));
+  }
+}
+
+struct Filter16Args {
+  const float* thr;            // row r's exact bound = thr[r * thr_stride]
+  int thr_stride;
+  const float* u_norm;         // |u_r|
+  const unsigned int* max_item_norm;
+  int32_t* cnt;
+  int32_t* cand_id;
+  int cap;
+};
+
+// One wave: 64 query rows (two 32-row MFMA blocks, operands resident) x a stream of 32-item tiles.  Operand layout of
+// v_mfma_f32_32x32x16_bf16: lane l gives A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31]; k is
+// a free summation index, so MFMA step s takes dimensions [16 s + 8 h, 16 s + 8 h + 8) from lane half h -- one 16-byte
+// load per operand, image and step.  Two row blocks per B tile halve the bytes per MFMA: with one, four SIMDs of a CU
+// would ask the vector L1 for 85 B/clk (it delivers 64).
+template <int D, int TILES_PER_WAVE>
+__global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
+                                                       const uint16_t* __restrict__ Ihi, const uint16_t* __restrict__ Ilo,
+                                                       int m, int n, Filter16Args f) {
+  constexpr int KS = D / 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 64;
+  const int tile0 = (blockIdx.x * 4 + wv) * TILES_PER_WAVE;
+  const int n_tiles = (n + 31) / 32;
+  if (tile0 >= n_tiles) return;
+  auto ld8 = [](const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); };
+  bf16x8 ah[2][KS], al[2][KS];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    const int ar = min(m0 + 32 * ub + r32, m - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      ah[ub][s] = ld8(Uhi + (size_t)ar * D + 16 * s + 8 * h);
+      al[ub][s] = ld8(Ulo + (size_t)ar * D + 16 * s + 8 * h);
+    }
+  }
+  __shared__ short s_stage_row[4 * kStageCap];
+  __shared__ int s_stage_col[4 * kStageCap];
+  short* stage_row = s_stage_row + wv * kStageCap;
+  int* stage_col = s_stage_col + wv * kStageCap;
+  int staged = 0;                // wave-uniform
+  float thr[2][16];              // lowered bounds of the rows this lane holds results for
+  {
+    const float item_norm = __uint_as_float(*f.max_item_norm);
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
+        thr[ub][t] = (row < m) ? f.thr[(size_t)row * f.thr_stride] - kFilterMargin * f.u_norm[row] * item_norm : INFINITY;
+      }
+  }
+  auto flush = [&]() {
+    for (int e = lane; e < staged; e += 64) {
+      const int row = m0 + stage_row[e];
+      const int slot = atomicAdd(f.cnt + row, 1);
+      if (slot < f.cap) f.cand_id[(size_t)row * f.cap + slot] = stage_col[e];
+    }
+    staged = 0;
+  };
+  bf16x8 bhn[KS], bln[KS];
+  auto load_b = [&](int tile) {
+    const int br = min(tile * 32 + r32, n - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bhn[s] = ld8(Ihi + (size_t)br * D + 16 * s + 8 * h);
+      bln[s] = ld8(Ilo + (size_t)br * D + 16 * s + 8 * h);
+    }
+  };
+  load_b(tile0);
+  for (int tt = 0; tt < TILES_PER_WAVE; ++tt) {
+    const int tile = tile0 + tt;
+    if (tile >= n_tiles) break;
+    bf16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { bh[s] = bhn[s]; bl[s] = bln[s]; }
+    if (tt + 1 < TILES_PER_WAVE && tile + 1 < n_tiles) load_b(tile + 1);      // in flight under this tile's MFMAs
+    const int col = tile * 32 + r32;
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+      floatx16 acc;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bool pass = (col < n) && (acc[t] >= thr[ub][t]);            // (rows >= m carry +inf)
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+        if (bal == 0) continue;                                            // wave-uniform
+        if (pass) {
+          const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+          stage_row[at] = (short)(32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h);
+          stage_col[at] = col;
+        }
+        staged += __builtin_popcountll(bal);
+        if (staged > kStageCap - 64) flush();
+      }
+    }
+  }
+  if (staged > 0) flush();
+}
+
+// Survivors of filter16_kernel: exact scores by the instruction sequence of gemm_nt_kernel (the user row replicated over
+// the 32 A rows of the tile, 32 candidates as the B columns: every output row is the chain gemm_nt_kernel runs for that
+// (user, item) -- same operands per MFMA, same order, same zero start, hence the same bits), training items dropped,
+// exact (score desc, id asc) order.  One workgroup per query row; rows whose list overflowed are left alone.
+template <int D>
+__global__ __launch_bounds__(256) void rescore_topk_kernel(const float* __restrict__ U, const int32_t* __restrict__ user_ids,
+                                                           int user_base, const float* __restrict__ I,
+                                                           const int32_t* __restrict__ cnt, const int32_t* __restrict__ cand_id,
+                                                           int cap, int k, const int32_t* __restrict__ r_indptr,
+                                                           const int32_t* __restrict__ r_indices,
+                                                           int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  constexpr int DH = D / 2;
+  extern __shared__ unsigned char cand_smem[];
+  float* s_val = reinterpret_cast<float*>(cand_smem);
+  int* s_idx = reinterpret_cast<int*>(cand_smem) + cap;
+  __shared__ int s_n;
+  const int row = blockIdx.x;
+  const int c = cnt[row];
+  if (c > cap) return;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  // U: the table user_ids index into, or the chunk's own rows (the caller passes the chunk base)
+  const int u = user_ids ? user_ids[row] : user_base + row;          // the user's id: mask CSR row
+  const int urow = user_ids ? u : row;
+  float a[DH];
+  {
+    const float4* ap = reinterpret_cast<const float4*>(U + (size_t)urow * D + h * DH);
+#pragma unroll
+    for (int t = 0; t < DH / 4; ++t) {
+      const float4 v = ap[t];
+      a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
+    }
+  }
+  const int rs = r_indptr ? r_indptr[u] : 0, re = r_indptr ? r_indptr[u + 1] : 0;
+  for (int t0 = wv * 32; t0 < c; t0 += 128) {
+    const int ci = t0 + r32;
+    const int id = cand_id[(size_t)row * cap + min(ci, c - 1)];
+    float b[DH];
+    {
+      const float4* bp = reinterpret_cast<const float4*>(I + (size_t)id * D + h * DH);
+#pragma unroll
+      for (int t = 0; t < DH / 4; ++t) {
+        const float4 v = bp[t];
+        b[4 * t] = v.x; b[4 * t + 1] = v.y; b[4 * t + 2] = v.z; b[4 * t + 3] = v.w;
+      }
+    }
+    floatx16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    if (h == 0 && ci < c) {
+      // training items of the user are dropped here (graph_recommender.py:49-50 masks them to -10e8)
+      int lo = rs, hi = re;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (r_indices[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      if (!(lo < re && r_indices[lo] == id)) {
+        const int at = atomicAdd(&s_n, 1);
+        s_val[at] = acc[0];                         // (every row of the tile holds this user's score of column r32)
+        s_idx[at] = id;
+      }
+    }
+  }
+  __syncthreads();
+  const int nv = s_n;
+  for (int t = threadIdx.x; t < nv; t += 256) {
+    const float v = s_val[t];
+    const int id = s_idx[t];
+    int rank = 0;
+    for (int j = 0; j < nv; ++j) rank += (s_val[j] > v) || (s_val[j] == v && s_idx[j] < id);
+    if (rank < k) {
+      out_ids[(size_t)row * k + rank] = id;
+      out_scores[(size_t)row * k + rank] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // top-K of one row per workgroup.  Ordering: score descending, then id ascending.
 //   pass A: every thread's running maximum; the K-th largest of those 256 maxima is a lower
@@ -417,10 +652,17 @@ static inline int64_t filt_align(int64_t b) { return (b + 255) / 256 * 256; }
 static int64_t filt_chunk_bytes(int64_t rows, int64_t sample, int32_t k, int32_t cap) {
   return filt_align(rows * sample * 4) + 2 * filt_align(rows * k * 4) + filt_align(rows * 4) + 2 * filt_align(rows * (int64_t)cap * 4);
 }
+// the split-bf16 filter's share: hi / lo images of the item table and of one chunk of query rows, their norms
+static bool filt_split_served(int32_t d) { return d == 64 || d == 128; }
+static int64_t filt_split_bytes(int64_t rows, int64_t n_items, int32_t d) {
+  if (!filt_split_served(d)) return 0;
+  return 2 * filt_align(n_items * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + 256;
+}
 
-int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap) {
-  if (chunk_rows <= 0 || sample_items <= 0 || k <= 0 || cap <= 0) return 0;
-  return filt_chunk_bytes(chunk_rows, sample_items, k, cap);
+int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
+                                              int64_t n_items, int32_t d) {
+  if (chunk_rows <= 0 || sample_items <= 0 || k <= 0 || cap <= 0 || n_items <= 0 || d <= 0) return 0;
+  return filt_chunk_bytes(chunk_rows, sample_items, k, cap) + filt_split_bytes(chunk_rows, n_items, d);
 }
 
 srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
@@ -439,7 +681,28 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
   int32_t* s_ids = reinterpret_cast<int32_t*>(ws); ws += filt_align(chunk_rows * k * 4);
   float* s_sc = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * k * 4);
   int32_t* cand_id = reinterpret_cast<int32_t*>(ws); ws += filt_align(chunk_rows * (int64_t)cap * 4);
-  float* cand_sc = reinterpret_cast<float*>(ws);
+  float* cand_sc = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * (int64_t)cap * 4);
+  // split-bf16 filter (d = 64 / 128): operand images of the whole item table once, of each chunk's query rows per chunk
+  const bool split = filt_split_served(d);
+  uint16_t *i_hi = nullptr, *i_lo = nullptr, *u_hi = nullptr, *u_lo = nullptr;
+  float* u_norm = nullptr;
+  unsigned int* max_norm = nullptr;
+  if (split) {
+    ws += filt_align(chunk_rows * 4);            // (the chunk layout's counter slot: counts live in d_out_counts)
+    i_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(n_items * d * 2);
+    i_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(n_items * d * 2);
+    u_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
+    u_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
+    u_norm = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * 4);
+    max_norm = reinterpret_cast<unsigned int*>(ws);
+    hipError_t err = hipMemsetAsync(max_norm, 0, sizeof(unsigned int), st);
+    if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+    const int lpr = d / 4, g = 64 / lpr;
+    const int blocks = (int)(((n_items + g - 1) / g + 3) / 4);
+    if (d == 64) split_rows_kernel<16><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
+    else split_rows_kernel<32><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
+    SRH_LAUNCH_CHECK();
+  }
   for (int64_t lo = 0; lo < n_query; lo += chunk_rows) {
     const int64_t m = std::min(chunk_rows, n_query - lo);
     const float* emb = d_user_ids ? d_user_emb : d_user_emb + lo * d;
@@ -458,6 +721,32 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     // 2. all scores again, never stored: only those reaching the bound and not masked are kept
     hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int32_t) * m, st);
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+    if (split) {
+      // 2'. the filter on split-bf16 operands against the bound lowered by its error margin (ids only) ...
+      const int lpr = d / 4, g = 64 / lpr;
+      const int sb = (int)(((m + g - 1) / g + 3) / 4);
+      constexpr int TPW = 8;
+      const int n_tiles = (int)((n_items + 31) / 32);
+      dim3 grid((n_tiles + 4 * TPW - 1) / (4 * TPW), (unsigned)((m + 63) / 64));
+      Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cap};
+      if (d == 64) {
+        split_rows_kernel<16><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<64, TPW><<<grid, 256, 0, st>>>(u_hi, u_lo, i_hi, i_lo, (int)m, (int)n_items, f16);
+      } else {
+        split_rows_kernel<32><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<128, TPW><<<grid, 256, 0, st>>>(u_hi, u_lo, i_hi, i_lo, (int)m, (int)n_items, f16);
+      }
+      SRH_LAUNCH_CHECK();
+      // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
+      if (d == 64)
+        rescore_topk_kernel<64><<<(int)m, 256, (size_t)cap * 8, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cap, k,
+                                                                      d_r_indptr, d_r_indices, d_out_ids + lo * k, d_out_scores + lo * k);
+      else
+        rescore_topk_kernel<128><<<(int)m, 256, (size_t)cap * 8, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cap, k,
+                                                                       d_r_indptr, d_r_indices, d_out_ids + lo * k, d_out_scores + lo * k);
+      SRH_LAUNCH_CHECK();
+      continue;
+    }
     FilterArgs fa{s_sc + (k - 1), k, cnt, cand_id, cand_sc, cap};
     rc = gemm_dispatch(emb, ids, d_item_emb, nullptr, m, n_items, d, st, &fa);
     if (rc) return rc;

@@ -606,7 +606,7 @@ def score_mask_topk_filtered(user_emb, user_ids, item_emb, r_indptr, r_indices, 
     dev = item_emb.device
     sample_items = max(int(k), min(int(sample_items), n_items))
     chunk_rows = max(1, min(int(chunk_rows), nq))
-    need = int(lib.srh_score_mask_topk_filtered_ws_bytes(chunk_rows, sample_items, int(k), int(cap)))
+    need = int(lib.srh_score_mask_topk_filtered_ws_bytes(chunk_rows, sample_items, int(k), int(cap), n_items, d))
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev)

@@ -528,6 +528,32 @@ def test_filtered_ranking_equals_exact_ranking(d):
         assert torch.equal(ids[ok], want_ids[ok]) and torch.equal(sc[ok], want_sc[ok])
 
 
+@pytest.mark.parametrize("d,scale", [(64, 30.0), (64, 1e-3), (128, 5.0)])
+def test_split_bf16_filter_never_loses_a_top_k_item(d, scale):
+    """Round 3: at d = 64 / 128 the filter pass of srh_score_mask_topk_filtered decides on split-bf16 products against a
+    bound lowered by 4e-5 |u| max|i|, and the survivors are re-scored exactly.  Stress for that margin: large and tiny
+    magnitudes, a catalogue of near-duplicates (thousands of items within 1e-6 relative of each other, i.e. inside the
+    bf16 products' error of the bound), items of very unequal norms -- ids AND scores must still be bit-identical to the
+    plain pipeline's on every row that fits."""
+    rng = np.random.default_rng(7 + d)
+    U, I, K = 700, 12000, 20
+    ue = torch.from_numpy((rng.standard_normal((U, d)) * scale).astype(np.float32)).to(DEV)
+    base = (rng.standard_normal((40, d)) * scale).astype(np.float32)
+    items = base[rng.integers(0, 40, I)] * (1.0 + 1e-6 * rng.standard_normal((I, 1))).astype(np.float32)   # near-duplicates
+    items[::7] = (rng.standard_normal((len(items[::7]), d)) * scale * 0.05).astype(np.float32)             # small-norm items
+    items[5] *= 20.0                                                                                        # one huge item
+    ie = torch.from_numpy(items.astype(np.float32)).to(DEV)
+    r_indptr = torch.zeros(U + 1, dtype=torch.int32, device=DEV)
+    r_indices = torch.zeros(1, dtype=torch.int32, device=DEV)
+    users = torch.arange(U, dtype=torch.int32, device=DEV)
+    want_ids, want_sc = ops.score_mask_topk(ue, users, ie, r_indptr, r_indices, K)
+    ids, sc, counts, _ = ops.score_mask_topk_filtered(ue, users, ie, r_indptr, r_indices, K, sample_items=2048, cap=1024,
+                                                      chunk_rows=512)
+    ok = counts <= 1024
+    assert ok.float().mean() > 0.5 and (counts[ok] >= K).all()
+    assert torch.equal(ids[ok], want_ids[ok]) and torch.equal(sc[ok], want_sc[ok])
+
+
 # ------------------------------------------------------------------------------------------
 # (a-9) Adam
 # ------------------------------------------------------------------------------------------

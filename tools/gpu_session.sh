@@ -63,6 +63,8 @@ nceab)
     find $OUT/nceab_$N -name "*.db" -delete
   done
   cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
+determinism)
+  timeout 600 python tools/determinism_probe.py > $OUT/determinism.txt 2>&1; echo "determinism exit $?"; grep -v amdgpu.ids $OUT/determinism.txt | tail -12;;
 nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
 refmodelsfuse)
