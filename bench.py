@@ -288,6 +288,60 @@ def dropin_throughput(args, raw, steps=60, warmup=8):
             "final_loss": float(loss.item())}
 
 
+def dropin_fused_throughput(args, raw, epochs=3):
+    """pairs/s of the THIRD tier: the reference's own, unmodified model/graph/XSimGCL.py with dropin.install(fuse=True)
+    -- the file's SHA-256 is checked and its train() is served by engine.FusedTrainer (selfrec_amd/dropin.py).  Needs
+    the reference's model/ directory: it is staged untracked under _refstage/ for a GPU session (reference sources are
+    never committed; /root/reference does not exist on the bench box) -- without it this returns the committed
+    measurement's location instead of a number."""
+    import importlib
+    import random
+    import tempfile
+    stage = os.path.join(REPO, "_refstage")
+    if not os.path.isfile(os.path.join(stage, "model", "graph", "XSimGCL.py")):
+        return {"pairs_per_s": None, "note": "no staged reference checkout on this box (_refstage/model/graph/XSimGCL.py); "
+                "measured in a gpurun session: profiles/r03_b_dropin_fused_reference_models.txt (6.31 M pairs/s over 5 epochs)"}
+    from selfrec_amd import dropin, synth
+    from selfrec_amd.util.conf import ModelConf
+    tu, ti, su, si, U, I = raw
+    dropin.install(fuse=True)
+    sys.path.insert(0, stage)
+    cwd = os.getcwd()
+    try:
+        mod = importlib.import_module("model.graph.XSimGCL")
+        if "XSimGCL" not in dropin._state["fused"]:
+            return {"pairs_per_s": None, "note": "the staged XSimGCL.py is not byte-for-byte the reference's: not fused"}
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            conf = ModelConf({"model": {"name": "XSimGCL", "type": "graph"}, "item.ranking.topN": [10, 20],
+                              "embedding.size": args.emb, "max.epoch": epochs, "batch.size": args.batch, "learning.rate": 0.001,
+                              "reg.lambda": 0.0001, "output": "./results/", "training.set": "x", "test.set": "y",
+                              "XSimGCL": {"n_layer": args.layers, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": args.tau}})
+            torch.manual_seed(args.seed); random.seed(args.seed)
+            model = mod.XSimGCL(conf, [list(t) for t in synth.as_triples(tu, ti)], [list(t) for t in synth.as_triples(su, si)])
+            t_eval = [0.0]
+            real_eval = model.fast_evaluation
+
+            def timed_eval(epoch):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r = real_eval(epoch)
+                torch.cuda.synchronize(); t_eval[0] += time.perf_counter() - t0
+                return r
+            model.fast_evaluation = timed_eval
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.train()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0 - t_eval[0]
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(stage)
+        dropin.uninstall()
+    return {"pairs_per_s": round(epochs * len(tu) / dt, 1), "epochs": epochs, "seconds": round(dt, 3),
+            "fast_evaluation_seconds": round(t_eval[0], 3),
+            "what": "model/graph/XSimGCL.py of the reference, unmodified (SHA-256 checked), dropin.install(fuse=True): "
+                    "train() on engine.FusedTrainer; engine construction, XCD calibration, graph capture, sampling included"}
+
+
 def stream_bandwidth(dev):
     """Measured streaming rates of this GPU with the library's own elementwise kernel, y = a*x + b*y
     (srh_axpby: 2 reads + 1 write per element): arrays that stay in the 256 MiB Infinity Cache (the regime
@@ -614,6 +668,8 @@ def main():
         if not sharded and not args.no_dropin and args.model == "XSimGCL":
             out["dropin"] = dropin_throughput(args, raw)
             out["dropin_pairs_per_s"] = out["dropin"]["pairs_per_s"]
+            out["dropin_fused"] = dropin_fused_throughput(args, raw)
+            out["dropin_fused_pairs_per_s"] = out["dropin_fused"]["pairs_per_s"]
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
             if out.get("eval"):

@@ -216,19 +216,33 @@ __global__ __launch_bounds__(256) void cand_topk_kernel(const int32_t* __restric
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr float kFilterMargin = 4e-5f;
 
-// rows of an f32 table as bf16 hi / lo images (row-major) + the row's L2 norm; the table's largest norm in *max_norm
-// (float bits compare like unsigned ints for non-negative floats)
-template <int LPR>
+// rows of an f32 table as bf16 hi / lo images + the row's L2 norm; the table's largest norm in *max_norm (float bits
+// compare like unsigned ints for non-negative floats).  FRAG = false: row-major images (the query rows: each wave loads
+// its A operands once).  FRAG = true: FRAGMENT-LINEAR images of the item table -- per 32-row tile, per image, per MFMA
+// step s one contiguous 1 KB fragment whose lane l = 32 h + r holds row 32 tile + r, dimensions [16 s + 8 h, + 8): exactly
+// what lane l feeds v_mfma_f32_32x32x16_bf16 as its B operand, so a workgroup copies whole tiles into LDS with direct
+// global -> LDS loads and every wave reads its operand with one conflict-free ds_read_b128.
+template <int LPR, bool FRAG>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, const int32_t* __restrict__ rows, int n,
                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                                          float* __restrict__ norm, unsigned int* __restrict__ max_norm) {
-  constexpr int G = 64 / LPR;
+  constexpr int G = 64 / LPR, D = 4 * LPR, KS = D / 16;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int r = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
   const bool valid = r < n;
   const int src = valid ? (rows ? rows[r] : r) : 0;
   const float4 v = reinterpret_cast<const float4*>(X)[(size_t)src * LPR + sub];
   const float ss = group_sum<LPR>(f4_dot(v, v));
+  if (max_norm) {
+    // one atomic per workgroup: same-address atomics serialise at ~11 ns each on this chip (one per row: 111 us for
+    // 38 k items)
+    __shared__ float s_mx[4];
+    float mx = valid ? sqrtf(ss) : 0.f;
+    for (int msk = 1; msk < 64; msk <<= 1) mx = fmaxf(mx, __shfl_xor(mx, msk));
+    if (lane == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(max_norm, __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+  }
   if (!valid) return;
   const float f[4] = {v.x, v.y, v.z, v.w};
   uint16_t h[4], l[4];
@@ -238,13 +252,23 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     h[t] = __builtin_bit_cast(uint16_t, bh);
     l[t] = __builtin_bit_cast(uint16_t, (__bf16)(f[t] - (float)bh));
   }
-  const size_t at = ((size_t)r * LPR + sub) * 4;
-  *reinterpret_cast<uint2*>(hi + at) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-  *reinterpret_cast<uint2*>(lo + at) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+  const uint2 ph = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+  const uint2 pl = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+  if (FRAG) {
+    const int col0 = 4 * sub, st = col0 >> 4, hh = (col0 >> 3) & 1, e0 = col0 & 7;
+    const size_t tile = (size_t)(r >> 5);
+    const size_t at_hi = ((tile * 2 + 0) * KS + st) * 512 + (size_t)(hh * 32 + (r & 31)) * 8 + e0;
+    const size_t at_lo = ((tile * 2 + 1) * KS + st) * 512 + (size_t)(hh * 32 + (r & 31)) * 8 + e0;
+    *reinterpret_cast<uint2*>(hi + at_hi) = ph;            // (hi: the base of the interleaved image; lo unused)
+    *reinterpret_cast<uint2*>(hi + at_lo) = pl;
+  } else {
+    const size_t at = ((size_t)r * LPR + sub) * 4;
+    *reinterpret_cast<uint2*>(hi + at) = ph;
+    *reinterpret_cast<uint2*>(lo + at) = pl;
+  }
   if (sub == 0) {
     const float nr = sqrtf(ss);
     if (norm) norm[r] = nr;
-    if (max_norm) atomicMax(max_norm, __float_as_uint(nr));
   }
 }
 
@@ -255,181 +279,244 @@ struct Filter16Args {
   const unsigned int* max_item_norm;
   int32_t* cnt;
   int32_t* cand_id;
+  float* cand_sc;              // the split-bf16 score of the candidate (within delta_u of the exact one)
   int cap;
 };
 
-// One wave: 64 query rows (two 32-row MFMA blocks, operands resident) x a stream of 32-item tiles.  Operand layout of
-// v_mfma_f32_32x32x16_bf16: lane l gives A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31]; k is
-// a free summation index, so MFMA step s takes dimensions [16 s + 8 h, 16 s + 8 h + 8) from lane half h -- one 16-byte
-// load per operand, image and step.  Two row blocks per B tile halve the bytes per MFMA: with one, four SIMDs of a CU
-// would ask the vector L1 for 85 B/clk (it delivers 64).
-template <int D, int TILES_PER_WAVE>
+__device__ __forceinline__ void glds16_b(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+constexpr int kF16StageCap = 384;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
+constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two stages + the four waves' survivor lists
+
+// One workgroup: 256 query rows (four waves x 64 rows = two 32-row MFMA blocks, operands resident in registers) against a
+// contiguous range of 32-item tiles, which it copies into LDS a stage of ST tiles at a time (double-buffered: the copy
+// of stage k + 1 runs under the MFMAs of stage k) -- one L2 read of the item images per 256 query rows instead of one
+// per 64, and no wave ever waits for a global round trip per tile (the first version, every wave streaming its own B
+// tiles from L2 with one tile of prefetch, ran at 217 us per 4096 x 38048 chunk for 24 us of MFMA work).
+// Operand layout of v_mfma_f32_32x32x16_bf16: lane l gives A[i = l & 31][k = 8 (l >> 5) .. +7], B[k ..][j = l & 31]; k is a
+// free summation index: MFMA step s takes dimensions [16 s + 8 h, + 8) from lane half h.
+template <int D>
 __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
-                                                       const uint16_t* __restrict__ Ihi, const uint16_t* __restrict__ Ilo,
-                                                       int m, int n, Filter16Args f) {
+                                                       const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
+                                                       Filter16Args f) {
   constexpr int KS = D / 16;
+  constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile
+  constexpr int ST = 32768 / TILE_BYTES;             // tiles per stage: 4 (d = 64), 2 (d = 128)
+  extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
+  constexpr int STAGE_BYTES = ST * TILE_BYTES;       // 32 KB
+  int* s_col = reinterpret_cast<int*>(f16_smem + 2 * ST * TILE_BYTES);
+  float* s_sc = reinterpret_cast<float*>(s_col + 4 * kF16StageCap);
+  short* s_row = reinterpret_cast<short*>(s_sc + 4 * kF16StageCap);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 64;
-  const int tile0 = (blockIdx.x * 4 + wv) * TILES_PER_WAVE;
+  const int m0 = blockIdx.y * 256 + wv * 64;
   const int n_tiles = (n + 31) / 32;
-  if (tile0 >= n_tiles) return;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  const bool live = m0 < m;                          // (a wave beyond the chunk's rows still copies and synchronises)
   auto ld8 = [](const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); };
   bf16x8 ah[2][KS], al[2][KS];
-#pragma unroll
-  for (int ub = 0; ub < 2; ++ub) {
-    const int ar = min(m0 + 32 * ub + r32, m - 1);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      ah[ub][s] = ld8(Uhi + (size_t)ar * D + 16 * s + 8 * h);
-      al[ub][s] = ld8(Ulo + (size_t)ar * D + 16 * s + 8 * h);
-    }
-  }
-  __shared__ short s_stage_row[4 * kStageCap];
-  __shared__ int s_stage_col[4 * kStageCap];
-  short* stage_row = s_stage_row + wv * kStageCap;
-  int* stage_col = s_stage_col + wv * kStageCap;
-  int staged = 0;                // wave-uniform
   float thr[2][16];              // lowered bounds of the rows this lane holds results for
   {
     const float item_norm = __uint_as_float(*f.max_item_norm);
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
+    for (int ub = 0; ub < 2; ++ub) {
+      const int ar = min(m0 + 32 * ub + r32, m - 1);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        ah[ub][s] = ld8(Uhi + (size_t)ar * D + 16 * s + 8 * h);
+        al[ub][s] = ld8(Ulo + (size_t)ar * D + 16 * s + 8 * h);
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
         thr[ub][t] = (row < m) ? f.thr[(size_t)row * f.thr_stride] - kFilterMargin * f.u_norm[row] * item_norm : INFINITY;
       }
+    }
   }
+  int* stage_col = s_col + wv * kF16StageCap;
+  float* stage_sc = s_sc + wv * kF16StageCap;
+  short* stage_row = s_row + wv * kF16StageCap;
+  int staged = 0;                // wave-uniform
   auto flush = [&]() {
     for (int e = lane; e < staged; e += 64) {
       const int row = m0 + stage_row[e];
       const int slot = atomicAdd(f.cnt + row, 1);
-      if (slot < f.cap) f.cand_id[(size_t)row * f.cap + slot] = stage_col[e];
+      if (slot < f.cap) {
+        f.cand_id[(size_t)row * f.cap + slot] = stage_col[e];
+        f.cand_sc[(size_t)row * f.cap + slot] = stage_sc[e];
+      }
     }
     staged = 0;
   };
-  bf16x8 bhn[KS], bln[KS];
-  auto load_b = [&](int tile) {
-    const int br = min(tile * 32 + r32, n - 1);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bhn[s] = ld8(Ihi + (size_t)br * D + 16 * s + 8 * h);
-      bln[s] = ld8(Ilo + (size_t)br * D + 16 * s + 8 * h);
-    }
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(Ifrag);
+  auto copy_stage = [&](int t0, unsigned char* dst) {           // tiles [t0, min(t0 + ST, t_end)) -> dst
+    const int frags = min(ST, t_end - t0) * 2 * KS;
+    const unsigned char* src = img + (size_t)t0 * TILE_BYTES;
+    for (int k = wv; k < frags; k += 4) glds16_b(src + (size_t)k * 1024 + lane * 16, dst + k * 1024);
   };
-  load_b(tile0);
-  for (int tt = 0; tt < TILES_PER_WAVE; ++tt) {
-    const int tile = tile0 + tt;
-    if (tile >= n_tiles) break;
-    bf16x8 bh[KS], bl[KS];
+  copy_stage(t_begin, f16_smem);
+  int cur = 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += ST, cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of stage t0 (and its flush) landed
+    __syncthreads();                                             // ... everyone's; and the other buffer has been read
+    if (t0 + ST < t_end) copy_stage(t0 + ST, f16_smem + (cur ^ 1) * STAGE_BYTES);   // in flight under this stage's MFMAs
+    if (live) {
+      const unsigned char* buf = f16_smem + cur * STAGE_BYTES;
+      const int nt = min(ST, t_end - t0);
+      for (int tt = 0; tt < nt; ++tt) {
+        bf16x8 bh[KS], bl[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { bh[s] = bhn[s]; bl[s] = bln[s]; }
-    if (tt + 1 < TILES_PER_WAVE && tile + 1 < n_tiles) load_b(tile + 1);      // in flight under this tile's MFMAs
-    const int col = tile * 32 + r32;
-#pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
-      floatx16 acc;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const bool pass = (col < n) && (acc[t] >= thr[ub][t]);            // (rows >= m carry +inf)
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
-        if (bal == 0) continue;                                            // wave-uniform
-        if (pass) {
-          const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-          stage_row[at] = (short)(32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h);
-          stage_col[at] = col;
+        for (int s = 0; s < KS; ++s) {
+          bh[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + s) * 1024 + lane * 16));
+          bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + KS + s) * 1024 + lane * 16));
         }
-        staged += __builtin_popcountll(bal);
-        if (staged > kStageCap - 64) flush();
+        const int col = (t0 + tt) * 32 + r32;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+          floatx16 acc;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const bool pass = (col < n) && (acc[t] >= thr[ub][t]);          // (rows >= m carry +inf)
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+            if (bal == 0) continue;                                          // wave-uniform
+            if (pass) {
+              const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+              stage_row[at] = (short)(32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h);
+              stage_col[at] = col;
+              stage_sc[at] = acc[t];
+            }
+            staged += __builtin_popcountll(bal);
+            if (staged > kF16StageCap - 64) flush();                        // (rare: a tie-heavy block)
+          }
+        }
       }
+      if (staged > 0) flush();      // once per stage, right before the wait the pipeline makes anyway
     }
   }
-  if (staged > 0) flush();
 }
 
-// Survivors of filter16_kernel: exact scores by the instruction sequence of gemm_nt_kernel (the user row replicated over
-// the 32 A rows of the tile, 32 candidates as the B columns: every output row is the chain gemm_nt_kernel runs for that
-// (user, item) -- same operands per MFMA, same order, same zero start, hence the same bits), training items dropped,
-// exact (score desc, id asc) order.  One workgroup per query row; rows whose list overflowed are left alone.
+// Survivors of filter16_kernel -> the row's exact top-K.  The survivors carry their split-bf16 scores s~ (|s~ - s| <=
+// delta_u); only the few that can still be in the exact top-K are re-scored:
+//   tau~ = K-th largest s~ of the unmasked survivors.  The K survivors above it have s >= tau~ - delta, so the exact K-th
+//   score is >= tau~ - delta, and an exact top-K item has s~ >= s - delta >= tau~ - 2 delta: the candidates of the second
+//   round (K ... a few dozen per user instead of a few hundred -- their item rows are the only ones gathered again).
+// The exact score is the fma chain  acc = fma(u[s], i[s], acc); acc = fma(u[D/2 + s], i[D/2 + s], acc), s = 0 .. D/2 - 1 --
+// BIT-IDENTICAL to what v_mfma_f32_32x32x2_f32 accumulates in gemm_nt_kernel with its operand assignment (measured on
+// gfx950: tools/microbench/mfma_chain.hip, 40 / 40 tiles; every other order, 0 / 40), so ids and scores equal the plain
+// pipeline's bit for bit (tests/test_gpu_kernels.py compares them).  One workgroup per query row; rows whose list
+// overflowed are left alone.
 template <int D>
-__global__ __launch_bounds__(256) void rescore_topk_kernel(const float* __restrict__ U, const int32_t* __restrict__ user_ids,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rescore_topk_kernel(const float* __restrict__ U, const int32_t* __restrict__ user_ids,
                                                            int user_base, const float* __restrict__ I,
                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ cand_id,
+                                                           const float* __restrict__ cand_sc, const float* __restrict__ u_norm,
+                                                           const unsigned int* __restrict__ max_item_norm,
                                                            int cap, int k, const int32_t* __restrict__ r_indptr,
                                                            const int32_t* __restrict__ r_indices,
                                                            int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
   constexpr int DH = D / 2;
   extern __shared__ unsigned char cand_smem[];
-  float* s_val = reinterpret_cast<float*>(cand_smem);
+  float* s_val = reinterpret_cast<float*>(cand_smem);         // approximate scores, then exact ones of the second round
   int* s_idx = reinterpret_cast<int*>(cand_smem) + cap;
-  __shared__ int s_n;
+  int* s_sel = s_idx + cap;                                    // second-round candidates (positions in s_idx)
+  __shared__ float s_u[D];
+  __shared__ int s_n, s_m;
+  __shared__ float s_tau;
   const int row = blockIdx.x;
   const int c = cnt[row];
   if (c > cap) return;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r32 = lane & 31, h = lane >> 5;
-  // U: the table user_ids index into, or the chunk's own rows (the caller passes the chunk base)
+  if (threadIdx.x == 0) { s_n = 0; s_m = 0; s_tau = -INFINITY; }
   const int u = user_ids ? user_ids[row] : user_base + row;          // the user's id: mask CSR row
   const int urow = user_ids ? u : row;
-  float a[DH];
-  {
-    const float4* ap = reinterpret_cast<const float4*>(U + (size_t)urow * D + h * DH);
-#pragma unroll
-    for (int t = 0; t < DH / 4; ++t) {
-      const float4 v = ap[t];
-      a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
-    }
-  }
+  if (threadIdx.x < D) s_u[threadIdx.x] = U[(size_t)urow * D + threadIdx.x];
+  __syncthreads();
+  // training items of the user are dropped here (graph_recommender.py:49-50 masks them to -10e8)
   const int rs = r_indptr ? r_indptr[u] : 0, re = r_indptr ? r_indptr[u + 1] : 0;
-  for (int t0 = wv * 32; t0 < c; t0 += 128) {
-    const int ci = t0 + r32;
-    const int id = cand_id[(size_t)row * cap + min(ci, c - 1)];
-    float b[DH];
-    {
-      const float4* bp = reinterpret_cast<const float4*>(I + (size_t)id * D + h * DH);
-#pragma unroll
-      for (int t = 0; t < DH / 4; ++t) {
-        const float4 v = bp[t];
-        b[4 * t] = v.x; b[4 * t + 1] = v.y; b[4 * t + 2] = v.z; b[4 * t + 3] = v.w;
-      }
-    }
-    floatx16 acc;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-#pragma unroll
-    for (int s = 0; s < DH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-    if (h == 0 && ci < c) {
-      // training items of the user are dropped here (graph_recommender.py:49-50 masks them to -10e8)
+  // (compaction by wave ballot: one LDS atomic per wave and round -- 370 same-address LDS atomics per row, one per
+  // candidate, were a third of this kernel's time)
+  const int lane = threadIdx.x & 63;
+  for (int t0 = 0; t0 < c; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    bool keep = t < c;
+    int id = 0;
+    if (keep) {
+      id = cand_id[(size_t)row * cap + t];
       int lo = rs, hi = re;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (r_indices[mid] < id) lo = mid + 1; else hi = mid;
       }
-      if (!(lo < re && r_indices[lo] == id)) {
-        const int at = atomicAdd(&s_n, 1);
-        s_val[at] = acc[0];                         // (every row of the tile holds this user's score of column r32)
-        s_idx[at] = id;
-      }
+      keep = !(lo < re && r_indices[lo] == id);
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&s_n, __builtin_popcountll(bal));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) {
+      const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      s_val[at] = cand_sc[(size_t)row * cap + t];
+      s_idx[at] = id;
     }
   }
   __syncthreads();
   const int nv = s_n;
+  // tau~: the approximate score of rank min(K, nv) - 1
   for (int t = threadIdx.x; t < nv; t += 256) {
     const float v = s_val[t];
     const int id = s_idx[t];
     int rank = 0;
     for (int j = 0; j < nv; ++j) rank += (s_val[j] > v) || (s_val[j] == v && s_idx[j] < id);
+    if (rank == min(k, nv) - 1) s_tau = v;
+  }
+  __syncthreads();
+  const float floor2 = s_tau - 2.0f * kFilterMargin * u_norm[row] * __uint_as_float(*max_item_norm);
+  for (int t0 = 0; t0 < nv; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool keep = t < nv && s_val[t] >= floor2;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&s_m, __builtin_popcountll(bal));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) s_sel[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = t;
+  }
+  __syncthreads();
+  const int ns = s_m;
+  // exact scores of the second round, in place
+  for (int e = threadIdx.x; e < ns; e += 256) {
+    const int t = s_sel[e];
+    const float4* ip = reinterpret_cast<const float4*>(I + (size_t)s_idx[t] * D);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < DH / 4; ++q) {
+      const float4 x0 = ip[q], x1 = ip[DH / 4 + q];
+      acc = __builtin_fmaf(s_u[4 * q + 0], x0.x, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 0], x1.x, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 1], x0.y, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 1], x1.y, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 2], x0.z, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 2], x1.z, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 3], x0.w, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 3], x1.w, acc);
+    }
+    s_val[t] = acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ns; e += 256) {
+    const int t = s_sel[e];
+    const float v = s_val[t];
+    const int id = s_idx[t];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j) {
+      const int tj = s_sel[j];
+      rank += (s_val[tj] > v) || (s_val[tj] == v && s_idx[tj] < id);
+    }
     if (rank < k) {
       out_ids[(size_t)row * k + rank] = id;
       out_scores[(size_t)row * k + rank] = v;
@@ -656,7 +743,8 @@ static int64_t filt_chunk_bytes(int64_t rows, int64_t sample, int32_t k, int32_t
 static bool filt_split_served(int32_t d) { return d == 64 || d == 128; }
 static int64_t filt_split_bytes(int64_t rows, int64_t n_items, int32_t d) {
   if (!filt_split_served(d)) return 0;
-  return 2 * filt_align(n_items * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + 256;
+  const int64_t padded = (n_items + 31) / 32 * 32;               // the item images are whole 32-row tiles
+  return 2 * filt_align(padded * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + 256;
 }
 
 int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
@@ -689,8 +777,9 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
   unsigned int* max_norm = nullptr;
   if (split) {
     ws += filt_align(chunk_rows * 4);            // (the chunk layout's counter slot: counts live in d_out_counts)
-    i_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(n_items * d * 2);
-    i_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(n_items * d * 2);
+    const int64_t padded = (n_items + 31) / 32 * 32;
+    i_hi = reinterpret_cast<uint16_t*>(ws); ws += 2 * filt_align(padded * d * 2);      // hi and lo fragments, tile by tile
+    i_lo = nullptr;
     u_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_norm = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * 4);
@@ -699,9 +788,15 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
     const int lpr = d / 4, g = 64 / lpr;
     const int blocks = (int)(((n_items + g - 1) / g + 3) / 4);
-    if (d == 64) split_rows_kernel<16><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
-    else split_rows_kernel<32><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
+    if (d == 64) split_rows_kernel<16, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
+    else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
     SRH_LAUNCH_CHECK();
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      return true;
+    }();
+    (void)attr_set;
   }
   for (int64_t lo = 0; lo < n_query; lo += chunk_rows) {
     const int64_t m = std::min(chunk_rows, n_query - lo);
@@ -725,25 +820,30 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       // 2'. the filter on split-bf16 operands against the bound lowered by its error margin (ids only) ...
       const int lpr = d / 4, g = 64 / lpr;
       const int sb = (int)(((m + g - 1) / g + 3) / 4);
-      constexpr int TPW = 8;
+      // 256 query rows per workgroup; the item tiles are dealt over enough workgroups to give every CU two
       const int n_tiles = (int)((n_items + 31) / 32);
-      dim3 grid((n_tiles + 4 * TPW - 1) / (4 * TPW), (unsigned)((m + 63) / 64));
-      Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cap};
+      const int gy = (int)((m + 255) / 256);
+      const int gx = std::max(1, std::min(n_tiles, (512 + gy - 1) / gy));
+      const int tiles_per_wg = (n_tiles + gx - 1) / gx;
+      dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
+      Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cand_sc, cap};
       if (d == 64) {
-        split_rows_kernel<16><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<64, TPW><<<grid, 256, 0, st>>>(u_hi, u_lo, i_hi, i_lo, (int)m, (int)n_items, f16);
+        split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<64><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       } else {
-        split_rows_kernel<32><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<128, TPW><<<grid, 256, 0, st>>>(u_hi, u_lo, i_hi, i_lo, (int)m, (int)n_items, f16);
+        split_rows_kernel<32, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<128><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       }
       SRH_LAUNCH_CHECK();
       // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
       if (d == 64)
-        rescore_topk_kernel<64><<<(int)m, 256, (size_t)cap * 8, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cap, k,
-                                                                      d_r_indptr, d_r_indices, d_out_ids + lo * k, d_out_scores + lo * k);
+        rescore_topk_kernel<64><<<(int)m, 256, (size_t)cap * 12, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
+                                                                       max_norm, cap, k, d_r_indptr, d_r_indices,
+                                                                       d_out_ids + lo * k, d_out_scores + lo * k);
       else
-        rescore_topk_kernel<128><<<(int)m, 256, (size_t)cap * 8, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cap, k,
-                                                                       d_r_indptr, d_r_indices, d_out_ids + lo * k, d_out_scores + lo * k);
+        rescore_topk_kernel<128><<<(int)m, 256, (size_t)cap * 12, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
+                                                                        max_norm, cap, k, d_r_indptr, d_r_indices,
+                                                                        d_out_ids + lo * k, d_out_scores + lo * k);
       SRH_LAUNCH_CHECK();
       continue;
     }

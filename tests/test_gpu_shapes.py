@@ -302,8 +302,15 @@ def test_xcd_share_calibration_changes_placement_not_results(yelp_data):
     b = FusedTrainer(yelp_data, 64, **kw)                       # (the plan is marked calibrated: b does not probe again)
     lb, eb = run(b)
     np.testing.assert_allclose(la, lb, rtol=2e-6)
+    # Two runs of ONE trainer configuration already differ (tools/determinism_probe.py, profiles/r03_c_determinism.txt:
+    # the loss section scatters with atomics -- 12 % of the gradient elements differ in their last bits, 5e-8 relative --
+    # and three Adam steps later the embeddings by 2.5e-7).  And once in a few runs such a last-bit difference lands on a
+    # layer-output element within rounding of zero, where XSimGCL.py:90's sign(h) turns it into a 2 eps |unit| jump of
+    # one element and its neighbours (observed: one run at 1.8e-4).  So: all but 1e-5 of the elements within 2e-6, every
+    # element within 2e-3 -- a placement bug (a task dropped or run twice) moves whole rows by O(1).
     for x, y in zip(ea, eb):
-        assert rel_err(x, y) < 2e-6
+        err = np.abs(x.astype(np.float64) - y) / np.abs(y).max()
+        assert (err > 2e-6).mean() < 1e-5 and err.max() < 2e-3, ((err > 2e-6).mean(), err.max())
     ops.spmm_set_xcd_shares(a.adj, 64, shares)                  # leave the module's shared graph as the engine set it
 
 
