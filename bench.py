@@ -373,7 +373,7 @@ def eval_throughput(trainer, data, k=20):
     rec.data, rec.max_N = data, k
     rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())
     uid = [data.user[u] for u in users]
-    rec.rank_on_device(uid[:256])                                         # warm-up
+    rec.rank_on_device(uid)                                               # warm-up at the measured shape (workspace, module load)
     torch.cuda.synchronize(); t0 = time.time()
     ids, sc = rec.rank_on_device(uid)
     torch.cuda.synchronize(); t_kernel = time.time() - t0
@@ -428,7 +428,7 @@ def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
     from selfrec_amd.dist import deal_users, gather_ranked
     uid = [data.user[u] for u in users]
     mine, n_max = deal_users(uid, rank, world)
-    rec.rank_on_device(mine[:256])                                                   # warm-up
+    rec.rank_on_device(mine)                                                         # warm-up at the measured shape
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.time()
     ids, _ = rec.rank_on_device(mine)

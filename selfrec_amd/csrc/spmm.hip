@@ -330,9 +330,10 @@ __device__ __forceinline__ void pred_load8_tail(int nr, floatx4_t& x0, floatx4_t
 #undef SRH_GE
 
 // nr (1 .. 8): rounds of THIS half (lanes 0-7 or 8-15 of the DPP row) that carry an entry somewhere in the wave: the last nr
-template <bool HI>
+struct NoIssue { __device__ __forceinline__ void operator()() const {} };
+template <bool HI, bool PF = false, class F = NoIssue>
 __device__ __forceinline__ void gather8_tail(int nr, unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xx)[8],
-                                             Acc2& acc) {
+                                             Acc2& acc, F issue_next = F()) {
   unsigned off[8];
   float vv[8];
   asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
@@ -342,14 +343,23 @@ __device__ __forceinline__ void gather8_tail(int nr, unsigned cs, float v, unsig
     SRH_DPP_OR(8); SRH_DPP_OR(9); SRH_DPP_OR(10); SRH_DPP_OR(11); SRH_DPP_OR(12); SRH_DPP_OR(13); SRH_DPP_OR(14); SRH_DPP_OR(15);
   }
   pred_load8_tail(nr, xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], xx[6], xx[7], off, X);
+  if (PF) {
+    issue_next();                       // the next chunk's raw (col [, val]): YOUNGER than this batch's gathers
+    asm volatile("s_nop 4" ::: "memory");
+  }
   if (!HI) {
     SRH_DPP_MOV(0); SRH_DPP_MOV(1); SRH_DPP_MOV(2); SRH_DPP_MOV(3); SRH_DPP_MOV(4); SRH_DPP_MOV(5); SRH_DPP_MOV(6); SRH_DPP_MOV(7);
   } else {
     SRH_DPP_MOV(8); SRH_DPP_MOV(9); SRH_DPP_MOV(10); SRH_DPP_MOV(11); SRH_DPP_MOV(12); SRH_DPP_MOV(13); SRH_DPP_MOV(14); SRH_DPP_MOV(15);
   }
   const floatx2_t p0 = {vv[0], vv[1]}, p1 = {vv[2], vv[3]}, p2 = {vv[4], vv[5]}, p3 = {vv[6], vv[7]};
-  SRH_FMA(7, 0, p0, xx[0]); SRH_FMA(6, 1, p0, xx[1]); SRH_FMA(5, 0, p1, xx[2]); SRH_FMA(4, 1, p1, xx[3]);
-  SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
+  if (PF) {
+    SRH_FMA(8, 0, p0, xx[0]); SRH_FMA(7, 1, p0, xx[1]); SRH_FMA(6, 0, p1, xx[2]); SRH_FMA(5, 1, p1, xx[3]);
+    SRH_FMA(4, 0, p2, xx[4]); SRH_FMA(3, 1, p2, xx[5]); SRH_FMA(2, 0, p3, xx[6]); SRH_FMA(1, 1, p3, xx[7]);
+  } else {
+    SRH_FMA(7, 0, p0, xx[0]); SRH_FMA(6, 1, p0, xx[1]); SRH_FMA(5, 0, p1, xx[2]); SRH_FMA(4, 1, p1, xx[3]);
+    SRH_FMA(3, 0, p2, xx[4]); SRH_FMA(2, 1, p2, xx[5]); SRH_FMA(1, 0, p3, xx[6]); SRH_FMA(0, 1, p3, xx[7]);
+  }
 }
 
 // The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
@@ -435,7 +445,11 @@ struct alignas(64) Task64 {
 // with every group busy rather than up to 16 rounds with one.
 // PROBE (srh_spmm_f32_probe): every wave also leaves {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
 // in stamps[3 * wave ..] -- what the engine's start-up calibration of the plan's XCD shares reads (engine.py).
-template <int LPR, bool COLMASK, bool PROBE = false>
+// LATEPF (round 3): the next chunk's (col, val) are issued AFTER the current chunk's gathers instead of before them.  An
+// A/B of the whole library settled where it belongs (profiles/r03_b_late_prefetch_ab.txt): the dense launches lose 0.4-0.6
+// us with it (their waves overlap enough for the early prefetch to be free), the ROW-MASKED launch -- a few thousand live
+// cooperative waves on a chain of dependent gather batches -- gains 1.5-1.8 us: instantiated for that flavour only.
+template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
@@ -531,6 +545,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int slot = e16 - shift;
     return (slot >= (e16 & 8)) ? slot : -1;
   };
+  // LATE: the next chunk's (col, val) are issued after the current chunk's last gathers (second half, always: a clamped
+  // valid position on a task's last chunk), so that the gathers' returns do not queue behind that miss
+  constexpr bool LATE = TAIL && LATEPF;
+  int c_raw = 0;
+  float v_raw = 0.f;
+  auto chunk_late = [&](int nr, int jn, int end) {
+    auto issue = [&]() {
+      const int jj = max(min(jn, end - 1), 0);
+      c_raw = indices[jj];
+      v_raw = vals ? vals[jj] : 1.0f;
+    };
+    gather8_tail<false>(min(nr, 8), cs, v, sub16, X, xx, acc);
+    if (nr > 8) {
+      gather8_tail<true, true>(min(nr, 16) - 8, cs, v, sub16, X, xx, acc, issue);
+      asm volatile("" : "+v"(c_raw), "+v"(v_raw));      // first use of the prefetched pair: after the last multiply-add
+      v = jn < end ? v_raw : 0.f;
+      cs = (v == 0.f) ? 0x80000000u : (unsigned)c_raw * (unsigned)(LPR * 16);
+    }
+  };
   auto coop_rounds = [&](int rem) { return INTER ? min(16, (rem + G - 1) / G) : rem; };
   // index of this lane's entry in a cooperative chunk starting at `base` / in chunk q of a short row (>= end: none)
   auto coop_at = [&](int base) {
@@ -549,6 +582,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (ep.row_mark && ep.row_mark[row] != stamp) { leave(); return; }
     const float r = ep.row_scale ? ep.row_scale[row] : 1.0f;
     fetch(coop_at(s), e, cs, v);
+    if (LATE) {
+      for (int base = s; base < e; base += CH) chunk_late(coop_rounds(e - base), coop_at(base + CH), e);
+    } else
     for (int base = s; base < e; base += CH) {
       const bool more = base + CH < e;
       if (prefetch && more) fetch(coop_at(base + CH), e, csn, vn);
@@ -595,6 +631,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   for (int m = LPR; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
   fetch(short_at(0, maxlen), e, cs, v);
+  if (LATE) {
+    for (int q = 0; q * 16 < maxlen; ++q) chunk_late(maxlen - 16 * q, short_at(q + 1, maxlen), e);
+  } else
   for (int q = 0; q * 16 < maxlen; ++q) {
     const bool more = (q + 1) * 16 < maxlen;
     if (prefetch && more) fetch(short_at(q + 1, maxlen), e, csn, vn);
@@ -1591,8 +1630,8 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
       // (the gather offsets carry "no gather" in their sign bit: the table must stay below 2 GiB)
       SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
                   (long long)plan->n_cols, d);
-#define SRH_LAUNCH_ROWS(LPRV, GI, CM, PR)                                                                            \
-  spmm_rows_kernel<LPRV, CM, PR><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
+#define SRH_LAUNCH_ROWS(LPRV, GI, CM, PR, ...)                                                                       \
+  spmm_rows_kernel<LPRV, CM, PR, ##__VA_ARGS__><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
       plan->d_tasks64[GI], plan->n_run[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),                \
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)
@@ -1606,6 +1645,8 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, true, false);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true, false);
         else SRH_LAUNCH_ROWS(64, 3, true, false);
+      } else if (ep.row_mark && d == 64) {
+        SRH_LAUNCH_ROWS(16, 1, false, false, true);              // row-masked launch: late prefetch (measured at d = 64)
       } else {
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, false);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, false);
