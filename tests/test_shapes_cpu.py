@@ -122,6 +122,17 @@ def oracle_for(info, data, **over):
     return O.OracleTrainer(info["model"], data.train_u, data.train_i, data.user_num, data.item_num, info["emb"], **kw)
 
 
+def oracle_for_tables(info, data, ue, ie):
+    """oracle_for with explicit initial tables (goldens that store them whole)"""
+    c = info["conf"]
+    gen = torch.Generator().manual_seed(info["noise_seed"])
+    return O.OracleTrainer(info["model"], data.train_u, data.train_i, data.user_num, data.item_num, info["emb"],
+                           n_layers=int(c.get("n_layer", 0)), lr=info["lr"], reg=info["reg"], cl_rate=float(c.get("lambda", 0.0)),
+                           eps=float(c.get("eps", 0.0)), tau=float(c.get("tau", c.get("temp", 0.2))), layer_cl=int(c.get("l_star", 1)),
+                           drop_rate=float(c.get("drop_rate", 0.1)), aug_type=int(c.get("aug_type", 1)), batch_size=info["batch"],
+                           user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen))
+
+
 def check_oracle_run(tag, shapes, info, ref, rows=True):
     sizes = shapes[f"{tag}_batch_sizes"]
     off = np.concatenate([[0], np.cumsum(sizes)])
@@ -130,6 +141,13 @@ def check_oracle_run(tag, shapes, info, ref, rows=True):
         sl = slice(off[b], off[b + 1])
         got.append(ref.step(shapes[f"{tag}_batch_u"][sl].tolist(), shapes[f"{tag}_batch_i"][sl].tolist(),
                             shapes[f"{tag}_batch_j"][sl].tolist()))
+        if b == 0 and f"{tag}_pre_grad_user" in shapes:
+            # round 3: the gradient that enters Adam in the first step (embedding_dict[*].grad of the reference run) --
+            # the oracle restates the reference's torch expressions, so it is held to 1e-5 of the block's largest element
+            for key, param in (("user", ref.user_emb), ("item", ref.item_emb)):
+                want = shapes[f"{tag}_pre_grad_{key}"].astype(np.float64)
+                g = param.grad.numpy()[shapes[f"{tag}_pre_rows_{key}"].astype(np.int64)].astype(np.float64)
+                assert np.abs(g - want).max() <= 1e-5 * np.abs(want).max(), (tag, key)
     got = np.asarray(got)
     np.testing.assert_allclose(got[:, 0], shapes[f"{tag}_loss_bpr"], rtol=1e-5)
     np.testing.assert_allclose(got[:, 1], shapes[f"{tag}_loss_reg"] / (info["batch"] if info["model"] in ("MF", "LightGCN") else 1.0),
@@ -147,10 +165,23 @@ def check_oracle_run(tag, shapes, info, ref, rows=True):
     np.testing.assert_allclose(fi[ri], shapes[f"{tag}_final_item"], rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("tag", ["Y_XSimGCL", "Y_LightGCN"])
+@pytest.mark.parametrize("tag", ["Y_XSimGCL", "Y_LightGCN", "Y_SimGCL"])
 def test_oracle_matches_reference_at_yelp_shape(yelp_data, shapes, smeta, tag):
     info = smeta[tag]
     check_oracle_run(tag, shapes, info, oracle_for(info, yelp_data))
+
+
+@pytest.mark.parametrize("tag", ["E_XSimGCL50", "E_XSimGCL96", "E_SGL96", "E_LightGCN20", "E_MF50"])
+def test_oracle_matches_reference_at_odd_embedding_sizes(tiny_data, shapes, smeta, tag):
+    """embedding.size = 50 / 96 / 20 (goldens section E): the oracle at the real width -- what the zero-padded engine is
+    compared with on the GPU."""
+    info = smeta[tag]
+    torch.manual_seed(info["init_seed"])
+    ref = oracle_for_tables(info, tiny_data, shapes[f"{tag}_init_user"], shapes[f"{tag}_init_item"])
+    if info["model"] == "SGL":
+        random.seed(info["sampler_seed"])
+        ref.resample_views()
+    check_oracle_run(tag, shapes, info, ref, rows=False)
 
 
 def test_oracle_matches_reference_mf_on_douban_book(tmp_path, shapes, smeta):

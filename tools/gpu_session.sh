@@ -79,6 +79,10 @@ benchdriver)
   # what the driver runs: default flags
   timeout 1200 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; echo "benchdriver exit $?"
   tail -3 $OUT/bench_default.err; tail -1 $OUT/bench_default.log | cut -c1-600;;
+benchbig)
+  # BASELINE.json configs[3] at N = 1: the full line with roofline + traffic (profiles/spmm_dense_traffic_1m-500k_d128.json)
+  timeout 1200 python bench.py --shape 1m-500k --emb 128 --steps 40 --warmup 5 > $OUT/bench_1m500k.log 2> $OUT/bench_1m500k.err; echo "benchbig exit $?"
+  tail -3 $OUT/bench_1m500k.err; tail -1 $OUT/bench_1m500k.log | cut -c1-2500;;
 benchquick)
   timeout 600 python bench.py --steps 600 --warmup 30 --no-cpu-baseline --no-eval --no-dropin > $OUT/benchquick.log 2> $OUT/benchquick.err; echo "benchquick exit $?"
   tail -3 $OUT/benchquick.err; tail -1 $OUT/benchquick.log | cut -c1-1500;;
