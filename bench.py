@@ -364,6 +364,12 @@ def stream_bandwidth(dev):
     return out
 
 
+def ops_filtered(ue, uid_dev, ie, g, k, gr):
+    from selfrec_amd import ops
+    return ops.score_mask_topk_filtered(ue, uid_dev, ie, g.r_indptr, g.r_indices, k, sample_items=gr.FILTER_SAMPLE_ITEMS,
+                                        cap=gr.FILTER_CAP, chunk_rows=gr.FILTER_CHUNK_ROWS)
+
+
 def eval_throughput(trainer, data, k=20):
     from selfrec_amd.base.graph_recommender import GraphRecommender
     users = list(data.test_set)
@@ -385,6 +391,15 @@ def eval_throughput(trainer, data, k=20):
     t_e2e = time.time() - t0
     assert len(report) == 5
     flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
+    # how hard the filter has to work on THESE embeddings: survivors per user of the bound from the first 4096 items
+    # (training items included), rows whose list overflowed the 1024 slots (re-ranked by the exact slab pipeline)
+    from selfrec_amd.base import graph_recommender as _gr
+    ue_p, ie_p = rec._device_embeddings()
+    g = data.device_graph(ie_p.device)
+    uid_dev = torch.as_tensor(np.asarray(uid, dtype=np.int32), device=ie_p.device)
+    _, _, counts, _ = ops_filtered(ue_p, uid_dev, ie_p, g, k, _gr)
+    survivors = {"mean": round(float(counts.float().mean()), 1), "max": int(counts.max()),
+                 "rows_over_cap": int((counts > _gr.FILTER_CAP).sum()), "cap": _gr.FILTER_CAP}
     # the scoring GEMM alone (srh_gemm_nt_f32: the same MFMA kernel without the filter epilogue, one 4096-user chunk
     # into a slab): its rate against the fp32 MFMA peak is the kernel-quality figure; `achieved` below is the whole
     # ranking pipeline (bound pass + filter GEMM + candidate ranking + D2H of ids and scores) against the same peak
@@ -403,6 +418,7 @@ def eval_throughput(trainer, data, k=20):
     return {"users": len(uid), "k": k, "device_users_per_s": round(len(uid) / t_kernel, 1),
             "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
             "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
+            "filter_survivors_per_user": survivors,
             "roofline": {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
                          "achieved": round(flops / t_kernel / 1e12, 2),
                          "frac": round(flops / t_kernel / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
