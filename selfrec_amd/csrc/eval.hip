@@ -297,10 +297,13 @@ constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two sta
 // tiles from L2 with one tile of prefetch, ran at 217 us per 4096 x 38048 chunk for 24 us of MFMA work).
 // Operand layout of v_mfma_f32_32x32x16_bf16: lane l gives A[i = l & 31][k = 8 (l >> 5) .. +7], B[k ..][j = l & 31]; k is a
 // free summation index: MFMA step s takes dimensions [16 s + 8 h, + 8) from lane half h.
-template <int D>
+// SLAB: instead of filtering, write the split-bf16 scores of the item range into a (m x n) slab -- the bound stage (the
+// K-th score over a leading slice of the catalogue), which then costs a quarter of the f32 GEMM it replaces; the bound
+// derived from approximate scores is lowered by one more delta_u (see srh_score_mask_topk_filtered).
+template <int D, bool SLAB = false>
 __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
                                                        const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
-                                                       Filter16Args f) {
+                                                       Filter16Args f, float* __restrict__ C = nullptr) {
   constexpr int KS = D / 16;
   constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile
   constexpr int ST = 32768 / TILE_BYTES;             // tiles per stage: 4 (d = 64), 2 (d = 128)
@@ -332,7 +335,9 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
-        thr[ub][t] = (row < m) ? f.thr[(size_t)row * f.thr_stride] - kFilterMargin * f.u_norm[row] * item_norm : INFINITY;
+        // (the bound itself came from split-bf16 scores: one delta to make it a bound, one for the score compared with it)
+        thr[ub][t] = (!SLAB && row < m) ? f.thr[(size_t)row * f.thr_stride] - 2.0f * kFilterMargin * f.u_norm[row] * item_norm
+                                        : INFINITY;
       }
     }
   }
@@ -385,6 +390,14 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
           }
+          if (SLAB) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
+              if (row < m && col < n) C[(size_t)row * n + col] = acc[t];
+            }
+            continue;
+          }
 #pragma unroll
           for (int t = 0; t < 16; ++t) {
             const bool pass = (col < n) && (acc[t] >= thr[ub][t]);          // (rows >= m carry +inf)
@@ -422,7 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ cand_id,
                                                            const float* __restrict__ cand_sc, const float* __restrict__ u_norm,
                                                            const unsigned int* __restrict__ max_item_norm,
-                                                           int cap, int k, const int32_t* __restrict__ r_indptr,
+                                                           int cap, int k, int bitmap_words,
+                                                           const int32_t* __restrict__ r_indptr,
                                                            const int32_t* __restrict__ r_indices,
                                                            int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
   constexpr int DH = D / 2;
@@ -446,18 +460,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // (compaction by wave ballot: one LDS atomic per wave and round -- 370 same-address LDS atomics per row, one per
   // candidate, were a third of this kernel's time)
   const int lane = threadIdx.x & 63;
+  // membership in the user's training row: a bitmap over the catalogue in LDS (bitmap_words > 0: catalogues up to 131 k
+  // items) filled from the row with one coalesced pass -- a binary search per candidate is a chain of 6-7 dependent L2
+  // round trips, ~10 us of this kernel's 40 per workgroup -- or the binary search for larger catalogues
+  unsigned int* s_bits = reinterpret_cast<unsigned int*>(s_sel + cap);
+  if (bitmap_words > 0) {
+    for (int w = threadIdx.x; w < bitmap_words; w += 256) s_bits[w] = 0u;
+    __syncthreads();
+    for (int p = rs + threadIdx.x; p < re; p += 256) {
+      const int item = r_indices[p];
+      atomicOr(&s_bits[item >> 5], 1u << (item & 31));
+    }
+    __syncthreads();
+  }
   for (int t0 = 0; t0 < c; t0 += 256) {
     const int t = t0 + threadIdx.x;
     bool keep = t < c;
     int id = 0;
     if (keep) {
       id = cand_id[(size_t)row * cap + t];
-      int lo = rs, hi = re;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (r_indices[mid] < id) lo = mid + 1; else hi = mid;
+      if (bitmap_words > 0) {
+        keep = !((s_bits[id >> 5] >> (id & 31)) & 1u);
+      } else {
+        int lo = rs, hi = re;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (r_indices[mid] < id) lo = mid + 1; else hi = mid;
+        }
+        keep = !(lo < re && r_indices[lo] == id);
       }
-      keep = !(lo < re && r_indices[lo] == id);
     }
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
     int base = 0;
@@ -794,6 +825,8 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute((const void*)filter16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
       (void)hipFuncSetAttribute((const void*)filter16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
       return true;
     }();
     (void)attr_set;
@@ -803,10 +836,32 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     const float* emb = d_user_ids ? d_user_emb : d_user_emb + lo * d;
     const int32_t* ids = d_user_ids ? d_user_ids + lo : nullptr;
     int32_t* cnt = d_out_counts + lo;
-    // 1. exact top-K over a leading slice of the catalogue: its K-th score is a lower bound of the
-    //    row's overall K-th score (a subset's K-th best cannot beat the whole set's)
-    srh_status_t rc = gemm_dispatch(emb, ids, d_item_emb, slab, m, sample_items, d, st);
-    if (rc) return rc;
+    // 1. top-K over a leading slice of the catalogue: its K-th score is a lower bound of the
+    //    row's overall K-th score (a subset's K-th best cannot beat the whole set's).  Exact f32 scores, or (split path)
+    //    split-bf16 scores s~: the K-th largest exact score is >= the K-th largest s~ - delta_u, which the filter accounts for
+    srh_status_t rc = SRH_OK;
+    if (split) {
+      const int lpr = d / 4, g = 64 / lpr;
+      const int sb = (int)(((m + g - 1) / g + 3) / 4);
+      const int s_tiles = (int)((sample_items + 31) / 32);
+      const int gy = (int)((m + 255) / 256);
+      const int gx = std::max(1, std::min(s_tiles, (512 + gy - 1) / gy));
+      const int tpw = (s_tiles + gx - 1) / gx;
+      dim3 grid((unsigned)((s_tiles + tpw - 1) / tpw), (unsigned)gy);
+      Filter16Args none{};
+      none.max_item_norm = max_norm;
+      if (d == 64) {
+        split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<64, true><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+      } else {
+        split_rows_kernel<32, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
+        filter16_kernel<128, true><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+      }
+      SRH_LAUNCH_CHECK();
+    } else {
+      rc = gemm_dispatch(emb, ids, d_item_emb, slab, m, sample_items, d, st);
+      if (rc) return rc;
+    }
     if (d_r_indptr) {
       mask_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(ids, (int)m, d_r_indptr, d_r_indices, slab, (int)sample_items, (int)lo);
       SRH_LAUNCH_CHECK();
@@ -817,9 +872,7 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int32_t) * m, st);
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
     if (split) {
-      // 2'. the filter on split-bf16 operands against the bound lowered by its error margin (ids only) ...
-      const int lpr = d / 4, g = 64 / lpr;
-      const int sb = (int)(((m + g - 1) / g + 3) / 4);
+      // 2'. the filter on split-bf16 operands against the bound lowered by its error margins ...
       // 256 query rows per workgroup; the item tiles are dealt over enough workgroups to give every CU two
       const int n_tiles = (int)((n_items + 31) / 32);
       const int gy = (int)((m + 255) / 256);
@@ -827,23 +880,21 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int tiles_per_wg = (n_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
       Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cand_sc, cap};
-      if (d == 64) {
-        split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<64><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
-      } else {
-        split_rows_kernel<32, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<128><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
-      }
+      if (d == 64) filter16_kernel<64><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
+      else filter16_kernel<128><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       SRH_LAUNCH_CHECK();
       // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
+      // (training-row membership by an LDS bitmap over the catalogue while it fits: <= 16 KB, i.e. 131 k items)
+      const int bitmap_words = (d_r_indptr && n_items <= 131072) ? (int)((n_items + 31) / 32) : 0;
+      const size_t rs_lds = (size_t)cap * 12 + (size_t)bitmap_words * 4;
       if (d == 64)
-        rescore_topk_kernel<64><<<(int)m, 256, (size_t)cap * 12, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                                       max_norm, cap, k, d_r_indptr, d_r_indices,
-                                                                       d_out_ids + lo * k, d_out_scores + lo * k);
+        rescore_topk_kernel<64><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
+                                                             max_norm, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                             d_out_ids + lo * k, d_out_scores + lo * k);
       else
-        rescore_topk_kernel<128><<<(int)m, 256, (size_t)cap * 12, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                                        max_norm, cap, k, d_r_indptr, d_r_indices,
-                                                                        d_out_ids + lo * k, d_out_scores + lo * k);
+        rescore_topk_kernel<128><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
+                                                              max_norm, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                              d_out_ids + lo * k, d_out_scores + lo * k);
       SRH_LAUNCH_CHECK();
       continue;
     }

@@ -36,6 +36,12 @@ class RankedLists(Mapping):
         return list(zip(self.item_names[self.ids[r]].tolist(), self.scores[r].tolist()))
 
 
+def _left_to_right_sum(x):
+    """0 + x[0] + x[1] + ... in that order, each add rounded to float64 (what `sum(list)` and `+=` loops do)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return float(np.add.accumulate(x)[-1]) if x.size else 0
+
+
 def _fast_report(res, N):
     """ranking_evaluation on a RankedLists carrying hit flags.  Every figure is accumulated in the
     order and precision of the python loops below (left-to-right float adds over users in test-set
@@ -61,11 +67,10 @@ def _fast_report(res, N):
         report.append('Top ' + str(n) + '\n')
         report.append('Hit Ratio:' + str(round(total_hits / relevant, 5)) + '\n')
         report.append('Precision:' + str(round(total_hits / (n_users * n), 5)) + '\n')
-        report.append('Recall:' + str(round(sum((hits / sizes).tolist()) / n_users, 5)) + '\n')
-        total = 0
-        for x in (dcg / ideal).tolist():                      # `sum_NDCG += DCG / IDCG`, user by user
-            total += x
-        report.append('NDCG:' + str(round(total / n_users, 5)) + '\n')
+        # `sum(...)` / `sum_NDCG += DCG / IDCG`, user by user: np.add.accumulate adds strictly left to right in float64 --
+        # the additions of the python loop, bit for bit, without the loop (1.5 of this function's 2 ms at 31.5 k users)
+        report.append('Recall:' + str(round(_left_to_right_sum(hits / sizes) / n_users, 5)) + '\n')
+        report.append('NDCG:' + str(round(_left_to_right_sum(dcg / ideal) / n_users, 5)) + '\n')
     return report
 
 
