@@ -403,9 +403,10 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
  *      >= t_u -- a few hundred (item, score) pairs per user, appended to a list of `cap` slots;
  *   3. training items of u are dropped from its list (binary search in the mask CSR) and the rest is
  *      put in exact (score desc, id asc) order.
- *   d = 64 / 128 (round 3): pass 2 only has to DECIDE, so it runs on split-bf16 operands (3 bf16 MFMAs per 16
- *   dimensions, 5.3x the f32 MFMA's rate) against t_u lowered by a rigorous error margin (4e-5 |u| max|i|) and keeps ids
- *   only; pass 3 re-scores the survivors with the exact-f32 instruction sequence of pass 1 before ranking them.
+ *   d = 64 / 128 (round 3): passes 1 and 2 only have to DECIDE, so they run on split-bf16 operands (3 bf16 MFMAs per
+ *   16 dimensions, 5.3x the f32 MFMA's rate): |s~ - s| <= delta_u = 4e-5 |u| max|i|, the bound from pass 1's approximate
+ *   scores is t~_u - delta_u, pass 2 keeps (id, s~) with s~ >= t~_u - 2 delta_u, and pass 3 re-scores exactly -- by the scalar
+ *   fma chain that is bit-identical to the f32 MFMA's accumulation -- the survivors within 2 delta_u of the K-th s~.
  * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
  * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
  * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with
