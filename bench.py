@@ -500,7 +500,8 @@ def main():
         dist.all_reduce(t)
         if rank == 0:
             print(json.dumps({"launch_check": True, "backend": backend, "world": world, "rank_sum": float(t.item()),
-                              "parallelism": describe_layout(args.emb, world)}), flush=True)
+                              "parallelism": describe_layout(args.emb, world, os.environ.get("SRH_SHARD_LAYOUT") or
+                                                             ("dp" if args.shape != "1m-500k" else None))}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -520,13 +521,17 @@ def main():
     kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
               layer_cl=1, batch_size=args.batch, use_graph=not args.no_graph)
     if sharded:
-        from selfrec_amd.dist import ShardedTrainer
-        trainer = ShardedTrainer(data, args.emb, **kw)
+        from selfrec_amd.dist import GATHER_BOUND_NNZ, ShardedTrainer
+        # N > 1 on a graph this small: data parallel (every rank its own batches, one all-reduce of the dense gradient per
+        # step: weak scaling, global batch N x B) unless SRH_SHARD_LAYOUT asks for a strong-scaling layout of ONE batch;
+        # gather-bound graphs take pick_layout's choice (2-D grid / column blocks)
+        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if 2 * data.interaction_mat.nnz < GATHER_BOUND_NNZ else None)
+        trainer = ShardedTrainer(data, args.emb, layout=layout, **kw)
     else:
         from selfrec_amd.engine import FusedTrainer
         trainer = FusedTrainer(data, args.emb, **kw)
     from selfrec_amd.engine import EpochPrefetcher
-    trainer.sampler.seed(args.seed)
+    trainer.seed_sampler(args.seed)                 # (data parallel: seed + rank -- every rank its own batches)
     pre = EpochPrefetcher(trainer)
     pre.start()
 
@@ -567,13 +572,15 @@ def main():
         elapsed = float(t.item())
     losses = trainer.read_losses()
 
-    # Sharded or not, the global batch is fixed at B pairs per step for every N (strong scaling).
+    # rows / cols / 2-D: the global batch is fixed at B pairs per step for every N (strong scaling).  Data parallel: every
+    # rank trains on its own B pairs per step (weak scaling): N x B pairs per step.
+    dp = bool(getattr(trainer, "dp", False))
     if sharded:
         from selfrec_amd.dist import describe_layout
-        layout = (describe_layout(args.emb, world, str(trainer.layout) if world > 1 else
+        layout = (describe_layout(args.emb, world, str(trainer.layout) if (world > 1 or trainer.dp) else
                                   ("cols" if trainer.cols else "rows"), 2 * trainer.graph.n_edges)
                   + f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU")
-    pairs = args.steps * args.batch
+    pairs = args.steps * args.batch * (world if dp else 1)
     value = pairs / elapsed
     g = trainer.graph
     out = {
@@ -581,7 +588,7 @@ def main():
         "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None,
+        "scaling": "weak" if dp else "strong", "vs_baseline": None,
         "dtype": "f32" + (" (InfoNCE's two n x n x d products on 16-bit MFMA operands with f32 accumulation: the logits on "
                           "split f16 hi+lo = 2^-22, the accuracy of an f32 dot product; P.V on split bf16 = 2^-18 per "
                           "product, gradients 1e-6 rel; all-f32-MFMA path timed in ms_per_step_nce_f32)"
@@ -592,7 +599,7 @@ def main():
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; epochs are sampled by a host thread one epoch ahead and "
                                f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
                                f"(see steady_state for a region that always spans >= 1)",
-                   "global_batch": args.batch, "parallelism": layout if sharded else "single",
+                   "global_batch": args.batch * (world if dp else 1), "parallelism": layout if sharded else "single",
                    "launch": "hipGraph replay" if trainer.use_graph else "eager",
                    # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration
                    # (engine._calibrate_xcd_shares; null: equal dealing)
@@ -617,7 +624,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ss = float(t.item())
     out["steady_state"] = {"steps": ss_steps, "seconds": round(ss, 4), "ms_per_step": round(ss / ss_steps * 1e3, 4),
-                           "pairs_per_s": round(ss_steps * args.batch / ss, 1),
+                           "pairs_per_s": round(ss_steps * args.batch * (world if dp else 1) / ss, 1),
                            "epoch_boundaries_inside": state["uploads"] - uploads0}
     if not sharded and args.model in ("XSimGCL", "SimGCL", "SGL"):
         # the same step with InfoNCE's products on the exact-f32 MFMA path (re-captured graph)
@@ -644,7 +651,7 @@ def main():
             dom = "dense_value_free" if "dense_value_free" in t_spmm else "dense"
             t_spmm["dominant"] = t_spmm[dom]
             ach = alg / t_spmm[dom] / 1e9
-            if not sharded:
+            if not sharded or dp:              # (data parallel: every rank runs the single-GPU launch)
                 traffic, traffic_note = pmc_traffic(args)
             elif getattr(trainer, "cols", False) and trainer.w != args.emb:
                 traffic, traffic_note = pmc_traffic_cols(args, trainer.w)
@@ -655,7 +662,7 @@ def main():
                                           f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
                                           f"{args.emb} columns, perturb epilogue)") if getattr(trainer, "cols", False) else
                                          (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
-                                          f"{'the rows of one rank of the' if sharded else 'the whole'} graph, "
+                                          f"{'the rows of one rank of the' if sharded and not dp else 'the whole'} graph, "
                                           "perturb epilogue; split rows finished in-kernel"
                                           + ("; value-free form: pattern of A over a table pre-scaled by D^-1/2, row scale in "
                                              "the epilogue" if "dense_value_free" in t_spmm else "") + ")"),

@@ -40,6 +40,16 @@ its CSR rows:
 
 Both: the sampler is replicated (same seed, same MT19937 stream => identical batches on every rank) and the
 step keeps its device-side cursor.
+
+**"2d:GCxGR"** -- both at once on a Gc x Gr grid (engine.py), for gather-bound graphs.
+
+**"dp" -- data parallel (round 3).**  The layouts above divide ONE batch's work (strong scaling).  At the Yelp2018 shape a
+step is six latency-bound launches plus an O(batch) loss section, and no table split makes those shorter.  What the
+interconnect can pay for is more batches per step: every rank keeps the whole graph and tables (26 MB + 5 x 17.8 MB at
+this shape), runs the single-GPU step -- hipGraph, value-free products, calibrated plan, all of it -- on ITS OWN batch,
+and the ranks meet once per step in an all-reduce of the dense gradient before Adam takes the mean: synchronous
+data-parallel SGD with a global batch of G x B pairs, the semantics torch's DistributedDataParallel gives the reference's
+model file.  bench.py takes it for N > 1 on graphs below GATHER_BOUND_NNZ and says `"scaling": "weak"`.
 """
 from __future__ import annotations
 
@@ -60,13 +70,13 @@ def pick_layout(emb_size: int, world: int, layout: str | None = None, nnz: int |
     gather-bound graphs (``nnz`` stored non-zeros of the (N x N) adjacency) once d / world < 32.
     ``layout`` / ``SRH_SHARD_LAYOUT`` = rows | cols | 2d | 2d:GCxGR | auto overrides."""
     layout = (layout or os.environ.get("SRH_SHARD_LAYOUT") or "auto").lower()
-    if layout in ("rows", "cols"):
+    if layout in ("rows", "cols", "dp"):
         return layout
     if layout.startswith("2d"):
         gc, gr = parse_grid(layout, world, emb_size)
         return f"2d:{gc}x{gr}"
     if layout != "auto":
-        raise ValueError(f"shard layout {layout!r}: rows, cols, 2d[:GCxGR] or auto")
+        raise ValueError(f"shard layout {layout!r}: rows, cols, 2d[:GCxGR], dp or auto")
     # (a single rank has nothing to split: "auto" keeps it on the row layout's code path, "cols" can still be asked for)
     cols_ok = world > 1 and emb_size % world == 0 and emb_size // world in SLICE_WIDTHS
     if cols_ok and nnz is not None and nnz >= GATHER_BOUND_NNZ and emb_size // world < 32 and world % 2 == 0:
@@ -79,6 +89,9 @@ def pick_layout(emb_size: int, world: int, layout: str | None = None, nnz: int |
 def describe_layout(emb_size: int, world: int, layout: str | None = None, nnz: int | None = None) -> str:
     """One line for bench.py's ``config.parallelism``: the layout this world size takes and what it exchanges."""
     lay = pick_layout(emb_size, world, layout, nnz)
+    if lay == "dp":
+        return (f"data parallel x{world}: whole graph + tables on every rank, each rank its own batches, one all-reduce of "
+                f"the dense gradient (N x d floats) per step, Adam on the mean gradient")
     if lay == "cols":
         return (f"column-sharded tables x{world} (w = {emb_size // max(world, 1)} columns per rank, graph replicated, "
                 f"one all-gather of the batch rows per step)")

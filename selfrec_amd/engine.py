@@ -90,6 +90,9 @@ class TorchComm:
         # (flat views: rank r's contribution is the r-th equal piece of `out`, whatever the shapes)
         _dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
+    def all_reduce_sum(self, t):
+        _dist.all_reduce(t, op=_dist.ReduceOp.SUM, group=self.group)
+
     def assert_replicated(self, what, values, device):
         """Every rank must hold the same `values` (a short list of floats: checksums of state the step code
         assumes replicated -- initial tables, the epoch's sampled indices).  Raises on the ranks that differ
@@ -255,8 +258,19 @@ class FusedTrainer:
         grid = None
         if isinstance(shard, str) and shard.startswith("2d"):
             grid, shard = shard, "2d"
-        if shard not in (False, True, None, "rows", "cols", "2d"):
-            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows', 'cols' or '2d[:GCxGR]')")
+        #
+        # shard="dp": data parallel -- every rank holds the whole graph and the whole tables (the single-GPU step with
+        # every one of its optimisations: hipGraph, value-free products, fetch rider, calibrated plan) and trains on ITS
+        # OWN batches (the sampler is seeded per rank); the ranks meet once per step, in an all-reduce of the dense
+        # gradient gE0 (N x d floats) between the backward chain and Adam, which then takes the MEAN gradient -- the
+        # semantics of synchronous data-parallel SGD with a global batch of G x B pairs (what torch's
+        # DistributedDataParallel would make of the reference's model file; InfoNCE's negatives stay inside a rank's
+        # batch).  Weak scaling: for graphs this small the step is six latency-bound launches that no table split makes
+        # shorter, while more batches per step is what the interconnect can pay for (17.8 MB per step at the Yelp2018
+        # shape).  At one rank it is the single-GPU step bit for bit.
+        if shard not in (False, True, None, "rows", "cols", "2d", "dp"):
+            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows', 'cols', '2d[:GCxGR]' or 'dp')")
+        self.dp = shard == "dp"
         self.G, self.rank = 1, 0
         self.sharded = shard in (True, "rows", "2d")    # rows of the graph / tables dealt over Gr ranks
         self.cols = shard in ("cols", "2d")              # columns of the tables split over Gc ranks
@@ -274,10 +288,12 @@ class FusedTrainer:
             self.Gr, self.rr = int(self.comm_rows.world), int(self.comm_rows.rank)
             self.G, self.rank = self.Gc * self.Gr, self.cr * self.Gr + self.rr
             self.layout = f"2d:{self.Gc}x{self.Gr}"
-        elif self.sharded or self.cols:
+        elif self.sharded or self.cols or self.dp:
             self.comm = comm if comm is not None else TorchComm()
             self.G, self.rank = int(self.comm.world), int(self.comm.rank)
-            if self.cols:
+            if self.dp:
+                pass                                     # (whole tables, whole graph: nothing is dealt)
+            elif self.cols:
                 self.Gc, self.cr = self.G, self.rank
             else:
                 self.Gr, self.rr, self.comm_rows = self.G, self.rank, self.comm
@@ -403,8 +419,8 @@ class FusedTrainer:
         # SRH_SHARDED_GRAPH=0 launches eagerly.  The row-sharded step has a collective after every product: it
         # launches eagerly unless SRH_SHARDED_GRAPH=1 asks for RCCL inside the capture.
         env = os.environ.get("SRH_SHARDED_GRAPH")
-        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols) or env == "1"
-                                              or (self.cols and not self.sharded and env != "0"))
+        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols and not self.dp) or env == "1"
+                                              or ((self.cols or self.dp) and not self.sharded and env != "0"))
         self._graph = None
         self._noise_call = 0
         # counter RNG layout: (optimiser step) * rng_stride + (perturbed-layer call of the step) * P + row; SimGCL makes
@@ -553,6 +569,11 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------
     # sampling
     # ------------------------------------------------------------------------------------
+    def seed_sampler(self, seed: int):
+        """Seed the batch sampler.  Replicated layouts (rows / cols / 2-D) need the SAME stream on every rank; data
+        parallel needs a DIFFERENT one per rank (seed + rank): every rank trains on its own batches."""
+        self.sampler.seed(int(seed) + (self.rank if self.dp else 0))
+
     def seed_sampler_from_python(self):
         """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it)."""
         self.sampler.set_state_from_python()
@@ -608,7 +629,8 @@ class FusedTrainer:
                 self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
         for k, t in self._epoch_dev.items():
             t.copy_(torch.from_numpy(host[k]), non_blocking=True)
-        if self.G > 1:            # replicated sampler: same seed => same batches; one tiny collective per epoch says so
+        if self.G > 1 and not self.dp:   # replicated sampler: same seed => same batches; one tiny collective per epoch says so
+            # (data parallel: every rank samples ITS OWN batches by design)
             w3 = np.arange(1, 4, dtype=np.int64)
             self._assert_replicated("the sampled epoch (u, i, j streams)",
                                     [int(host[k].astype(np.int64).sum()) for k in ("u", "i", "j")] +
@@ -813,6 +835,12 @@ class FusedTrainer:
             self._exchange()
         self._step_back()
 
+    def _dp_allreduce(self):
+        """Data parallel: the step's one collective -- the dense gradient summed over the ranks, then the mean."""
+        self.comm.all_reduce_sum(self.gE0)
+        if self.G > 1:
+            ops.axpby(1.0 / self.G, self.gE0, 0.0, self.gE0)
+
     def _sgl_shared_first(self):
         return self.model == "SGL" and self.L >= 2 and self.w == 64
 
@@ -864,6 +892,13 @@ class FusedTrainer:
 
     def _step_back(self):
         """losses on the batch rows, backward through the encoder, optimiser, row-wise resets."""
+        self._step_grad()
+        if self.dp:
+            self._dp_allreduce()
+        self._step_opt()
+
+    def _step_grad(self):
+        """losses on the batch rows and the backward chain: leaves d loss / d E0 in gE0."""
         m, st = self.model, self.stage
         adj = self.adj
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
@@ -933,6 +968,11 @@ class FusedTrainer:
             self._backward_chain(adj, self.gF, include_ego=True)
             for vi, v in enumerate(self.views):
                 self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True)
+
+    def _step_opt(self):
+        """Adam on the (owned rows of the) table, row-wise resets of the batch-sparse gradient buffers, cursor advance."""
+        m, st = self.model, self.stage
+        rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         if self.fused_reset and self.sparse_reset:
             # Adam's pass over the table also clears this batch's rows (the marked ones) of the batch-sparse gradient
             # buffers and advances the cursor: the separate zero_rows launch (4.5 us) is gone.  Adam reads its step from
@@ -942,8 +982,12 @@ class FusedTrainer:
                 clear += [v["gF"] for v in self.views]
             ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.now[1:2], lr=self.lr, clear=clear,
                           row_mark=self.mark, advance_cursor=self.cursor)
-            return
+            if self.dp and self.gF is self.gE0:
+                self.gE0.zero_()        # MF: gE0 IS the accumulation buffer, and after the all-reduce it holds the OTHER
+            return                      # ranks' batch rows too, which this rank's marks do not name
         ops.adam_step(self._loc(self.E0), self._loc(self.gE0), self.m, self.v, step_dev=self.now[1:2], lr=self.lr)
+        if self.dp and self.gF is self.gE0:
+            self.gE0.zero_()
         self._allgather(self.E0)                     # every rank's next forward pass reads the whole table
         if self.sparse_reset:
             # the gradient buffers hold non-zeros only on this batch's rows: clear just those
@@ -979,7 +1023,7 @@ class FusedTrainer:
             try:
                 self._capture()
             except RuntimeError as e:
-                if not (self.sharded or self.cols):
+                if not (self.sharded or self.cols or self.dp):
                     raise
                 # (a capture next to a live process group is the one thing that could not be exercised beyond one
                 # rank here: fall back to eager launches rather than lose the run -- the state is the snapshot's)
@@ -993,6 +1037,12 @@ class FusedTrainer:
             front = self._graph[0].replay if graphed else self._step_front
             back = self._graph[1].replay if graphed else self._step_back
             return (front, self._exchange, back, done)
+        if self.dp:
+            def grad():
+                self._step_front()
+                self._step_grad()
+            return (self._graph[0].replay if graphed else grad, self._dp_allreduce,
+                    self._graph[1].replay if graphed else self._step_opt, done)
         return (self._graph.replay if graphed else self._step_kernels, done)
 
     def reset_graph(self):
@@ -1009,18 +1059,27 @@ class FusedTrainer:
         snapshot = (self.E0.clone(), self.m.clone(), self.v.clone(), self.cursor.clone())
         with torch.cuda.stream(side):
             self._step_front()
-            self._step_back()
+            if self.dp:                       # (the warm-up skips the all-reduce, like the column layout its all-gather)
+                self._step_grad()
+                self._step_opt()
+            else:
+                self._step_back()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        if self.cols:
+        if self.cols or self.dp:
             # two graphs with the collective between them: RCCL stays outside the captured region
             self._graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
             pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(self._graph[0], pool=pool, capture_error_mode="thread_local"):
                 self._step_front()
+                if self.dp:
+                    self._step_grad()
             with torch.cuda.graph(self._graph[1], pool=pool, capture_error_mode="thread_local"):
-                self._step_back()
+                if self.dp:
+                    self._step_opt()
+                else:
+                    self._step_back()
         else:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):

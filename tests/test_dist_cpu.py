@@ -273,7 +273,7 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0
-    assert rec["parallelism"].startswith("column-sharded tables x2")
+    assert rec["parallelism"].startswith("data parallel x2")
     assert "torch.distributed.run" in p.stderr
 
 
@@ -321,3 +321,64 @@ def test_any_embedding_size_is_stored_padded_and_trains_like_the_oracle(monkeypa
     fu, fi = tr.embeddings()
     wu, wi = ref.embeddings()
     np.testing.assert_allclose(fi.numpy(), wi, rtol=1e-4, atol=2e-6)
+
+
+def _dp_worker(rank, world, port, model, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from selfrec_amd import engine, synth
+    from selfrec_amd.data import device_graph
+    from selfrec_amd.data.ui_graph import Interaction
+    from selfrec_amd.dist import ShardedTrainer
+    from tests import cpu_ops
+    engine.ops = device_graph.ops = cpu_ops
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    torch.manual_seed(0)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
+    gen = torch.Generator().manual_seed(100 + rank)           # every rank draws its OWN perturbation noise
+    tr = ShardedTrainer(data, 64, model=model, n_layers=2, batch_size=500, layer_cl=1, tau=0.2, eps=0.2, cl_rate=0.2,
+                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu", layout="dp")
+    assert tr.dp and not tr.cols and not tr.sharded and tr.G == world and tr.E0.shape == (U + I, 64)
+    tr.seed_sampler(40)                                        # seed + rank: every rank its own batches
+    tr.begin_epoch()
+    losses = []
+    for _ in range(3):
+        tr.step()
+        losses.append(tr.read_losses())
+    eu, ei, ej = tr.epoch_node_ids()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), E0=tr.E0.numpy(), u=eu, i=ei, j=ej, losses=np.asarray(losses),
+             train_u=data.train_u, train_i=data.train_i, ue=ue.numpy(), ie=ie.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,world", [("XSimGCL", 2), ("LightGCN", 4), ("MF", 2)])
+def test_data_parallel_equals_the_mean_gradient_oracle(tmp_path, model, world):
+    """shard="dp": every rank its own batches, one all-reduce of the dense gradient per step, Adam on the MEAN -- against the
+    single-process oracle that evaluates each rank's loss on that rank's batch (with that rank's noise), averages the
+    gradients and takes one Adam step; every rank ends with the same table."""
+    mp.spawn(_dp_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    for k in range(1, world):
+        assert np.array_equal(r[k]["E0"], r[0]["E0"])                          # replicas stay replicas
+        assert not np.array_equal(r[k]["u"][:500], r[0]["u"][:500])            # ... on different batches
+    gens = [torch.Generator().manual_seed(100 + k) for k in range(world)]
+    cur = [0]
+    ref = O.OracleTrainer(model, r[0]["train_u"], r[0]["train_i"], 300, 500, 64, n_layers=2, batch_size=500, layer_cl=1,
+                          tau=0.2, eps=0.2, cl_rate=0.2, user_emb=r[0]["ue"], item_emb=r[0]["ie"],
+                          noise_fn=lambda s: torch.rand(s, generator=gens[cur[0]]))
+    for b in range(3):
+        ref.opt.zero_grad()
+        for k in range(world):
+            cur[0] = k
+            sl = slice(b * 500, (b + 1) * 500)
+            rec, regl, cl = ref.losses(r[k]["u"][sl].tolist(), r[k]["i"][sl].tolist(), r[k]["j"][sl].tolist())
+            ((rec + regl + cl) / world).backward()
+            np.testing.assert_allclose(r[k]["losses"][b], [float(rec), float(regl), float(cl)], rtol=2e-5, atol=1e-9)
+        ref.opt.step()
+    want = torch.cat([ref.user_emb, ref.item_emb]).detach().numpy()
+    np.testing.assert_allclose(r[0]["E0"], want, rtol=1e-4, atol=2e-6)

@@ -467,3 +467,54 @@ def test_virtual_ranks_2d_match_reference_run(golden_models, golden_meta, tiny_d
     for c in range(gc):
         for r in range(1, gr):
             assert torch.equal(res[c * gr + r][0], res[c * gr][0])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_dp_layout_through_rccl_single_rank(golden_models, golden_meta, tiny_data, use_graph):
+    """shard="dp" (data parallel) with its all-reduce of the dense gradient going through RCCL ("nccl"), world size 1: the
+    single-GPU step with one collective between the backward chain and Adam -- eager, and as the two captured graphs around
+    the all-reduce -- reproduces the reference's own 3-step run (injected noise keeps the step eager either way) and, with
+    in-kernel noise, the unsharded trainer."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        gm, meta = golden_models, golden_meta
+        name = "XSimGCL"
+        kw = make_kw(name, gm, meta)
+        gen = torch.Generator().manual_seed(kw.pop("noise_seed"))
+        tr = ShardedTrainer(tiny_data, meta[name]["emb"], layout="dp", noise_fn=lambda shape: torch.rand(shape, generator=gen), **kw)
+        assert tr.dp and tr.G == 1 and tr.w == tr.d and tr.vfree == FusedTrainer(tiny_data, meta[name]["emb"], **make_kw(name, gm, meta, noise=False)).vfree
+        random.seed(meta[name]["sampler_seed"])
+        tr.seed_sampler_from_python()
+        bpr = []
+        for _ in range(tr.begin_epoch()):
+            tr.step()
+            bpr.append(tr.read_losses()[0])
+        np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+        pu, pi = tr.parameters_full()
+        assert rel_err(pu.cpu().numpy(), gm[f"{name}_param_user"]) < 1e-4
+        assert rel_err(pi.cpu().numpy(), gm[f"{name}_param_item"]) < 1e-4
+        # in-kernel noise, graph capture on / off: the same steps as the unsharded trainer
+        kw = make_kw(name, gm, meta, noise=False)
+        single = FusedTrainer(tiny_data, meta[name]["emb"], noise_fn=None, use_graph=use_graph, **kw)
+        dp = ShardedTrainer(tiny_data, meta[name]["emb"], layout="dp", noise_fn=None, use_graph=use_graph, **kw)
+        assert dp.use_graph == use_graph
+        for t in (single, dp):
+            t.seed_sampler(5)
+        for _ in range(2):
+            nb = single.begin_epoch()
+            assert dp.begin_epoch() == nb
+            for _ in range(nb):
+                single.step(); dp.step()
+        torch.cuda.synchronize()
+        assert dp.step_count == single.step_count == 2 * nb
+        assert rel_err(dp.E0.cpu().numpy(), single.E0.cpu().numpy()) < 1e-4
+        np.testing.assert_allclose(dp.read_losses(), single.read_losses(), rtol=1e-4)
+    finally:
+        if created:
+            dist.destroy_process_group()

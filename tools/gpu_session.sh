@@ -135,7 +135,7 @@ big)
 cols)
   COLS_PROBE_KERNELS_ONLY=${COLS_PROBE_KERNELS_ONLY:-0} timeout 900 python tools/cols_probe.py > $OUT/cols_probe.log 2>&1; echo "cols exit $?"; grep -v amdgpu.ids $OUT/cols_probe.log | tail -30;;
 sharded1)
-  for lay in rows cols; do
+  for lay in ${SHARDED1_LAYOUTS:-rows cols dp}; do
     SRH_FORCE_SHARDED=1 SRH_SHARD_LAYOUT=$lay timeout 600 python bench.py --steps 300 --warmup 20 --no-cpu-baseline > $OUT/bench_sharded1_$lay.log 2> $OUT/bench_sharded1_$lay.err; echo "sharded1 $lay exit $?"
     tail -2 $OUT/bench_sharded1_$lay.err; tail -1 $OUT/bench_sharded1_$lay.log | cut -c1-500
   done;;
