@@ -967,6 +967,10 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     return SRH_OK;
   }
   // ---- SRH_NCE_F32: both products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds), one finish per pass ----
+  if constexpr (D > 128) {
+    srh::set_error("infonce_fwd_bwd: the all-f32 MFMA path serves d = 64 / 128");
+    return SRH_ERR_UNSUPPORTED;
+  } else {
   if (bpr) {
     bpr_phase2<LPR><<<n_bpr, 256, 0, st>>>(bp);
     SRH_LAUNCH_CHECK();
@@ -981,6 +985,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
+  }
 }
 
 template <int LPR>
@@ -1088,7 +1093,9 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
                                   float loss_scale, double* d_loss, void* d_ws, void* stream, const BprArgs* bpr) {
   SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
   SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);
-  SRH_REQUIRE(d == 64 || d == 128, "infonce_fwd_bwd: d=%d unsupported (need 64 or 128)", d);
+  SRH_REQUIRE(d == 64 || d == 128 || d == 256, "infonce_fwd_bwd: d=%d unsupported (need 64, 128 or 256)", d);
+  SRH_REQUIRE(d != 256 || g_nce_precision.load(std::memory_order_relaxed) != SRH_NCE_F32,
+              "infonce_fwd_bwd: the all-f32 MFMA path serves d = 64 / 128 (d = 256: the split path only)");
   for (int k = 0; k < n_problems; ++k) {
     const srh_infonce_problem_t& p = problems[k];
     SRH_REQUIRE(p.d_v1 && p.d_v2 && p.d_g1 && p.d_g2, "infonce_fwd_bwd: null tensor in problem %d", k);
@@ -1100,7 +1107,8 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
   }
   hipStream_t st = srh::as_stream(stream);
   if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
-  return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
+  if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
+  return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
 }
 
 srh_status_t srh_infonce_set_precision(int32_t mode) {

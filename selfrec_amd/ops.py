@@ -338,7 +338,7 @@ def spmm(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor | None = None, epilo
 # ---- any table width through the boundary (reference base/recommender.py:16: `embedding.size` is any integer) ----
 SPMM_WIDTHS = (8, 16, 32, 64, 128, 256)      # row widths srh_spmm_f32 serves (csrc/spmm.hip)
 ROW_WIDTHS = (32, 64, 128, 256)              # LPR kernels: BPR / L2 / scoring GEMM (csrc/common.h: dim_supported)
-NCE_WIDTHS = (64, 128)                       # srh_infonce_fwd_bwd
+NCE_WIDTHS = (64, 128, 256)                  # srh_infonce_fwd_bwd (256: the split path only)
 
 
 def padded_width(d: int, widths) -> int | None:

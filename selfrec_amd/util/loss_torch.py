@@ -7,11 +7,11 @@ What runs where:
     HIP kernels; a missing library or device raises (``ops.SelfrecHipError``), nothing is substituted.  Any
     ``embedding.size`` (base/recommender.py:16): rows are zero-padded to the next width the kernels serve -- zero
     columns change no inner product, norm or F.normalize result and receive exactly zero gradient -- BPR up to
-    256 columns, InfoNCE up to 128, the regulariser any size.
+    256 columns, InfoNCE up to 256 (above 128: the split path only), the regulariser any size.
   * CPU tensors, other dtypes, other ranks: the reference's own torch expression (the arithmetic of loss_torch.py:6-50
     restated below), so code that calls these functions off the device -- unit tests of a model file, a CPU dry run --
     behaves as it does with the reference.  This is not a fallback for the HIP path: device fp32 input never reaches it.
-  * InfoNCE on HIP rows wider than 128 columns, BPR wider than 256: the same torch expression on the device (rocBLAS +
+  * InfoNCE or BPR on HIP rows wider than 256 columns: the same torch expression on the device (rocBLAS +
     ATen), announced once with a RuntimeWarning -- no kernel of this package serves those widths yet.
 """
 import warnings

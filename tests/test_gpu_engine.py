@@ -248,7 +248,8 @@ def test_sharded_step_in_a_hipgraph_equals_the_single_gpu_step(golden_models, go
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,d", [("XSimGCL", 128), ("SGL", 128), ("LightGCN", 32), ("LightGCN", 256), ("MF", 128)])
+@pytest.mark.parametrize("name,d", [("XSimGCL", 128), ("SGL", 128), ("LightGCN", 32), ("LightGCN", 256), ("MF", 128),
+                                    ("XSimGCL", 256), ("SimGCL", 200)])
 def test_other_embedding_sizes_match_oracle(name, d):
     """d = 128 is BASELINE.json config 4's size (two rows per wave, D=128 InfoNCE tiles); d = 32 / 256 use the
     8- and 64-lane row shapes.  Three steps against the CPU oracle on the same batches and injected noise."""

@@ -410,7 +410,8 @@ def test_loss_functions_match_reference_outputs(golden_ops, n):
         assert rel_err(gn, g[f"ops_{n}_g_nce"]) < 1e-5
 
 
-@pytest.mark.parametrize("n,d,tau", [(2048, 64, 0.2), (1500, 64, 0.15), (700, 128, 0.2), (17, 64, 0.5)])
+@pytest.mark.parametrize("n,d,tau", [(2048, 64, 0.2), (1500, 64, 0.15), (700, 128, 0.2), (17, 64, 0.5), (900, 256, 0.2),
+                                     (300, 256, 0.05)])
 def test_infonce_gathered_matches_oracle(n, d, tau):
     rng = np.random.default_rng(n)
     rows = 5000
@@ -467,7 +468,7 @@ def test_bpr_l2_fused_matches_oracle_with_duplicates():
             assert rel_err(gri.cpu().numpy(), eb.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("d,B", [(64, 2048), (128, 600)])
+@pytest.mark.parametrize("d,B", [(64, 2048), (128, 600), (256, 500)])
 def test_bpr_infonce_one_call_matches_oracle(d, B):
     """srh_bpr_infonce_fwd_bwd = XSimGCL.py:30-35: rec + reg + cl_rate * (user InfoNCE + item InfoNCE), with
     the gradients of the final and the contrast-layer tables, against torch autograd on the oracle losses."""
