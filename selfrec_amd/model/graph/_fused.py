@@ -33,7 +33,7 @@ class FusedGraphModel(GraphRecommender):
     def __init__(self, conf, training_set, test_set, **kwargs):
         super().__init__(conf, training_set, test_set, **kwargs)
         get = getattr(self.config, 'get', lambda k, d=None: d)
-        # (any embedding.size up to 128 for the contrastive models, 256 for MF / LightGCN: the engine stores the tables
+        # (any embedding.size up to 256: the engine stores the tables
         # zero-padded to the next width its kernels serve -- engine.FusedTrainer.d_valid; wider rows raise there)
         # the in-kernel perturbation noise follows torch's seed (torch.manual_seed / `seed` in the conf), like the
         # reference's torch.rand_like does

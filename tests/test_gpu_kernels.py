@@ -418,7 +418,10 @@ def test_infonce_gathered_matches_oracle(n, d, tau):
     t1 = (rng.standard_normal((rows, d)) * 0.4).astype(np.float32)
     t2 = (t1 + rng.standard_normal((rows, d)) * 0.2).astype(np.float32)
     idx = np.sort(rng.choice(rows, size=n, replace=False)).astype(np.int32)
-    a = torch.tensor(t1, requires_grad=True); b = torch.tensor(t2, requires_grad=True)
+    # the reference's expression evaluated in float64: at tau = 0.05 on these correlated views the loss is ~3e-6 -- the
+    # difference of two numbers near 20 -- and the reference's own f32 arithmetic is off by 1 % there (lse - s_ii with
+    # 2e-6 of rounding on each); the kernel forms log1p(l' / e_ii) and is held to the exact value
+    a = torch.tensor(t1, dtype=torch.float64, requires_grad=True); b = torch.tensor(t2, dtype=torch.float64, requires_grad=True)
     loss = 0.3 * O.info_nce(a[idx.astype(np.int64)], b[idx.astype(np.int64)], tau)
     loss.backward()
     d1, d2 = torch.from_numpy(t1).to(DEV), torch.from_numpy(t2).to(DEV)
