@@ -287,7 +287,7 @@ __device__ __forceinline__ void glds16_b(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
-constexpr int kF16StageCap = 384;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
+constexpr int kF16StageCap = 256;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
 constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two stages + the four waves' survivor lists
 
 // One workgroup: 256 query rows (four waves x 64 rows = two 32-row MFMA blocks, operands resident in registers) against a
