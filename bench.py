@@ -376,7 +376,7 @@ def eval_throughput(trainer, data, k=20):
     if not users:
         return None
     rec = GraphRecommender.__new__(GraphRecommender)
-    rec.data, rec.max_N = data, k
+    rec.data, rec.max_N, rec.topN = data, k, [k]
     rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())
     uid = np.asarray([data.user[u] for u in users], dtype=np.int32)      # (test() caches this array: _test_users)
     rec.rank_on_device(uid)                                               # warm-up at the measured shape (workspace, module load)

@@ -432,6 +432,16 @@ srh_status_t srh_topk_rows(const float* d_scores, int64_t rows, int64_t n, int32
 srh_status_t srh_topk_hit_flags(const int32_t* d_ids, int64_t n_query, int32_t k,
                                 const int32_t* d_user_ids, const int32_t* d_t_indptr,
                                 const int32_t* d_t_indices, uint8_t* d_flags, void* stream);
+/* (f-3) Per-user figures of util/evaluation.py:7-16,66-78 from the hit flags, for up to 8 cut-offs N <= k at once:
+ *   d_hits[c * n_query + q] = number of hits among the first cuts[c] ranked items of row q                (Metric.hits)
+ *   d_ndcg[c * n_query + q] = DCG / IDCG of row q at cuts[c], accumulated exactly as Metric.NDCG does it: float64,
+ *                             positions best first, gain table d_gains[pos] = 1 / log2(pos + 2) and ideal prefix sums
+ *                             d_ideal[c * (k + 1) + min(|truth_q|, cuts[c])] as the HOST computed them (python's
+ *                             math.log: passed in, not recomputed, so the quotients are the reference's bit for bit).
+ * d_sizes[q] = |truth_q| (> 0).  cuts: host array.  The cross-user sums stay on the host (31.5 k adds). */
+srh_status_t srh_metric_rows(const uint8_t* d_flags, const int32_t* d_sizes, int64_t n_query, int32_t k,
+                             const int32_t* cuts, int32_t n_cuts, const double* d_gains, const double* d_ideal,
+                             int32_t* d_hits, double* d_ndcg, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Small device utilities used by the fused engine.

@@ -99,9 +99,10 @@ class GraphRecommender(Recommender):
             ids[redo], sc[redo] = ids_r, sc_r
         return ids, sc
 
-    def rank_on_device(self, user_ids, k=None, with_hits=False):
+    def rank_on_device(self, user_ids, k=None, with_hits=False, metric_cuts=None):
         """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids; with_hits adds the uint8
-        flags 'this ranked item is in the user's test set' (srh_topk_hit_flags)."""
+        flags 'this ranked item is in the user's test set' (srh_topk_hit_flags); metric_cuts (a list of cut-offs N <= k)
+        adds the per-user hits and DCG / IDCG at every cut-off, computed on the device from the flags (srh_metric_rows)."""
         k = self.max_N if k is None else k
         ue, ie = self._device_embeddings()
         g = self.data.device_graph(ie.device)
@@ -110,6 +111,11 @@ class GraphRecommender(Recommender):
         if with_hits:
             t_indptr, t_indices, _ = self._test_csr(ie.device)
             flags = ops.topk_hit_flags(ids_dev, uid, t_indptr, t_indices)
+            if metric_cuts:
+                sizes = (t_indptr[1:] - t_indptr[:-1])[uid.long()].contiguous()
+                hits, ndcg = ops.metric_rows(flags, sizes, metric_cuts)
+                return (ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy(),
+                        {int(n): (hits[c].cpu().numpy(), ndcg[c].cpu().numpy()) for c, n in enumerate(metric_cuts)})
             return ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy()
         return ids_dev.cpu().numpy(), sc_dev.cpu().numpy()
 
@@ -130,11 +136,16 @@ class GraphRecommender(Recommender):
         # catalogue, takes the reference's per-user loop below -- slow, but every config the reference runs, runs)
         on_device = self.max_N <= min(DEVICE_TOPK_MAX, self.data.item_num)
         if on_device and self._device_embeddings() is not None and users:
-            ids, scores, flags = self.rank_on_device(uid, with_hits=True)
+            # the cut-offs ranking_evaluation will be asked for (item.ranking.topN): their per-user hits and DCG / IDCG come
+            # back with the ranking (at most 8 of them, each <= K)
+            cuts = sorted({int(n) for n in getattr(self, 'topN', []) if 1 <= int(n) <= self.max_N})[:8]
+            got = self.rank_on_device(uid, with_hits=True, metric_cuts=cuts or None)
+            ids, scores, flags = got[:3]
             sizes = np.diff(self._test_csr(self.item_emb.device)[2])[uid]
             # reads like the reference's {user: [(item, score), ...]}; rows are built on access and
             # ranking_evaluation works on the arrays (same strings)
-            return RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=self.data.test_set)
+            return RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=self.data.test_set,
+                               per_user=got[3] if len(got) > 3 else None)
         rec_list = {}
         for user in users:                                   # models with a custom predict()
             candidates = self.predict(user)

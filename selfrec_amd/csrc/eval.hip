@@ -718,9 +718,50 @@ __global__ __launch_bounds__(256) void hit_flags_kernel(const int32_t* __restric
   }
   flags[t] = (lo < t_indptr[u + 1] && t_indices[lo] == item) ? 1 : 0;
 }
+// (f-3) per-user hits and DCG / IDCG at up to 8 cut-offs: one thread per user, float64 adds in position order (the adds
+// of Metric.NDCG's generator sum; a non-hit adds nothing there and +0.0 here)
+struct MetricCuts { int32_t n; int32_t cut[8]; };
+__global__ __launch_bounds__(256) void metric_rows_kernel(const uint8_t* __restrict__ flags, const int32_t* __restrict__ sizes,
+                                                          int64_t n_query, int k, MetricCuts cuts,
+                                                          const double* __restrict__ gains, const double* __restrict__ ideal,
+                                                          int32_t* __restrict__ hits, double* __restrict__ ndcg) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_query) return;
+  const uint8_t* f = flags + q * k;
+  const int size = sizes[q];
+  for (int c = 0; c < cuts.n; ++c) {
+    const int n = min(cuts.cut[c], k);
+    int h = 0;
+    double dcg = 0.0;
+    for (int pos = 0; pos < n; ++pos) {
+      const int hit = f[pos] != 0;
+      h += hit;
+      dcg = dcg + (hit ? gains[pos] : 0.0);
+    }
+    hits[(size_t)c * n_query + q] = h;
+    ndcg[(size_t)c * n_query + q] = dcg / ideal[(size_t)c * (k + 1) + min(size, cuts.cut[c])];
+  }
+}
 }  // namespace
 
 extern "C" {
+
+srh_status_t srh_metric_rows(const uint8_t* d_flags, const int32_t* d_sizes, int64_t n_query, int32_t k,
+                             const int32_t* cuts, int32_t n_cuts, const double* d_gains, const double* d_ideal,
+                             int32_t* d_hits, double* d_ndcg, void* stream) {
+  SRH_REQUIRE(d_flags && d_sizes && cuts && d_gains && d_ideal && d_hits && d_ndcg, "metric_rows: null argument");
+  SRH_REQUIRE(n_query > 0 && k >= 1 && n_cuts >= 1 && n_cuts <= 8, "metric_rows: bad shape (1..8 cut-offs)");
+  MetricCuts mc{};
+  mc.n = n_cuts;
+  for (int c = 0; c < n_cuts; ++c) {
+    SRH_REQUIRE(cuts[c] >= 1 && cuts[c] <= k, "metric_rows: cut-off %d outside [1, k = %d]", cuts[c], k);
+    mc.cut[c] = cuts[c];
+  }
+  metric_rows_kernel<<<(unsigned)((n_query + 255) / 256), 256, 0, srh::as_stream(stream)>>>(d_flags, d_sizes, n_query, k, mc,
+                                                                                              d_gains, d_ideal, d_hits, d_ndcg);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
 
 srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int64_t m, int64_t n, int32_t d,
                              void* stream) {

@@ -21,7 +21,7 @@ def gpu_available() -> bool:
     return torch.cuda.is_available()
 
 __all__ = ["Sampler", "DeviceCSR", "column_class_order", "spmm", "spmm_any", "pad_cols", "padded_width", "spmm3", "spmm_probe", "spmm_set_xcd_shares", "spmm_plan_run_tasks", "adj_sym_normalize", "bpr_l2_fwd_bwd", "bpr_fwd", "bpr_bwd",
-           "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags",
+           "sumsq", "set_infonce_precision", "get_infonce_precision", "infonce_fwd_bwd", "infonce_multi", "bpr_infonce", "infonce_ws", "adam_step", "score_mask_topk", "score_mask_topk_filtered", "gemm_nt", "topk_rows", "topk_hit_flags", "metric_rows",
            "axpby", "batch_fetch", "zero_rows", "cursor_advance", "batch_lists", "batch_pack", "batch_unpack", "batch_scatter",
            "SelfrecHipError"]
 
@@ -647,6 +647,33 @@ def topk_hit_flags(ids, user_ids, t_indptr, t_indices):
                                          _p(t_indices, torch.int32), _p(flags, torch.uint8), _stream()),
           "srh_topk_hit_flags")
     return flags
+
+
+def metric_rows(flags, sizes, cuts):
+    """Per-user hits (int32) and DCG / IDCG (float64) at every cut-off of `cuts` (<= 8, each <= K) from the (users, K) hit
+    flags and the users' test-set sizes (int32 device tensor): srh_metric_rows.  The gain table and the ideal prefix
+    sums are computed HERE with python's math.log exactly as util/evaluation.py:66-78 computes them and handed to the
+    kernel, so every quotient is the reference's bit for bit.  Returns (hits, ndcg) of shape (len(cuts), users)."""
+    import math
+    n, k = int(flags.shape[0]), int(flags.shape[1])
+    cuts = [int(c) for c in cuts]
+    gains = [1.0 / math.log(pos + 2, 2) for pos in range(k)]
+    ideal = np.zeros((len(cuts), k + 1), dtype=np.float64)
+    for c, cut in enumerate(cuts):
+        acc = 0.0
+        for m in range(1, cut + 1):
+            acc = acc + 1.0 / math.log(m - 1 + 2, 2)        # sum(... for pos in range(m)): left to right
+            ideal[c, m] = acc
+    dev = flags.device
+    d_gains = torch.tensor(gains, dtype=torch.float64, device=dev)
+    d_ideal = torch.from_numpy(ideal).to(dev)
+    hits = torch.empty((len(cuts), n), dtype=torch.int32, device=dev)
+    ndcg = torch.empty((len(cuts), n), dtype=torch.float64, device=dev)
+    arr = (C.c_int32 * len(cuts))(*cuts)
+    check(_lib.load().srh_metric_rows(_p(flags, torch.uint8), _p(sizes, torch.int32), n, k, arr, len(cuts),
+                                      _p(d_gains, torch.float64), _p(d_ideal, torch.float64), _p(hits, torch.int32),
+                                      _p(ndcg, torch.float64), _stream()), "srh_metric_rows")
+    return hits, ndcg
 
 
 def axpby(a, x, b, y):

@@ -17,11 +17,13 @@ class RankedLists(Mapping):
     ``evaluate()`` and any user code keep working, while ``ranking_evaluation`` takes the arrays.
     """
 
-    def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None):
+    def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None, per_user=None):
         self.users = users if isinstance(users, list) else list(users)
         self._row = None                       # user -> row, built on first lookup
         self.item_names, self.ids, self.scores = item_names, ids, scores
         self.hit_flags, self.truth_sizes, self.origin = hit_flags, truth_sizes, origin
+        # {N: (hits per user int32, DCG / IDCG per user float64)} when the ranking computed them (srh_metric_rows)
+        self.per_user = per_user or {}
 
     def __len__(self):
         return len(self.users)
@@ -46,12 +48,24 @@ def _fast_report(res, N):
     """ranking_evaluation on a RankedLists carrying hit flags.  Every figure is accumulated in the
     order and precision of the python loops below (left-to-right float adds over users in test-set
     order, positions best-first), so the strings are identical, not just close."""
-    flags = res.hit_flags.astype(np.float64)                 # (users, K) 0/1
+    need_flags = any(int(n) not in res.per_user for n in N)
+    flags = res.hit_flags.astype(np.float64) if need_flags else res.hit_flags      # (users, K) 0/1
     sizes = res.truth_sizes.astype(np.int64)
     n_users = flags.shape[0]
     relevant = int(sizes.sum())
     report = []
     for n in N:
+        if int(n) in res.per_user:
+            # per-user figures from the device (same float64 adds in the same order, gains and ideal sums as computed
+            # below by the host); only the two cross-user sums are left
+            hits_i, ndcg_u = res.per_user[int(n)]
+            total_hits = int(hits_i.sum())
+            report.append('Top ' + str(n) + '\n')
+            report.append('Hit Ratio:' + str(round(total_hits / relevant, 5)) + '\n')
+            report.append('Precision:' + str(round(total_hits / (n_users * n), 5)) + '\n')
+            report.append('Recall:' + str(round(_left_to_right_sum(hits_i.astype(np.float64) / sizes) / n_users, 5)) + '\n')
+            report.append('NDCG:' + str(round(_left_to_right_sum(ndcg_u) / n_users, 5)) + '\n')
+            continue
         n_eff = min(n, flags.shape[1])
         hit_n = flags[:, :n_eff]
         hits = hit_n.sum(axis=1)                               # small integers: exact in any order

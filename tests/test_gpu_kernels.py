@@ -625,3 +625,24 @@ def test_full_rank_eval_matches_reference(golden_models, tiny_data, name):
         gaps = np.abs(np.diff(want_sc, axis=1))
         near = np.zeros_like(bad); near[:, :-1] |= gaps < 1e-6; near[:, 1:] |= gaps < 1e-6
         assert not (bad & ~near).any()
+
+
+def test_metric_rows_equals_the_host_loops():
+    """srh_metric_rows: per-user hits and DCG / IDCG at several cut-offs from the hit flags -- bit-identical to the python
+    loops of util/evaluation.py:7-16,66-78 (float64 adds in position order, python's own gain / ideal tables)."""
+    import math
+    rng = np.random.default_rng(5)
+    U, K = 3000, 20
+    flags = (rng.random((U, K)) < 0.07).astype(np.uint8)
+    flags[3] = 1; flags[4] = 0
+    sizes = rng.integers(1, 40, U).astype(np.int32)
+    cuts = [5, 10, 20]
+    hits, ndcg = ops.metric_rows(torch.from_numpy(flags).to(DEV), torch.from_numpy(sizes).to(DEV), cuts)
+    for c, n in enumerate(cuts):
+        want_h, want_n = np.zeros(U, dtype=np.int64), np.zeros(U)
+        for u in range(U):
+            gain = sum(1.0 / math.log(pos + 2, 2) for pos in range(n) if flags[u, pos])
+            ideal = sum(1.0 / math.log(pos + 2, 2) for pos in range(min(int(sizes[u]), n)))
+            want_h[u], want_n[u] = int(flags[u, :n].sum()), gain / ideal
+        assert np.array_equal(hits[c].cpu().numpy(), want_h)
+        assert np.array_equal(ndcg[c].cpu().numpy(), want_n)          # bit for bit
