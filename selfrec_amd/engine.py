@@ -445,10 +445,12 @@ class FusedTrainer:
             return None
         if self.L < 1 or self.d != 64:                  # (the entry points serve d = 128 / 256 too; measured at d = 64 only so far)
             return None
-        # (cached on the plan object itself, per probed launch flavour: table width, value-free or not, perturbed or not --
-        # not by d alone)
+        # Cached on the PLAN OBJECT (so: per plan identity) and table width.  One calibration per plan and width, by the
+        # first trainer that asks: re-calibrating for another launch flavour would rewrite a task list that an earlier
+        # trainer's captured graph still launches (ADVICE r02 asked for the key to include the plan -- it is the plan's
+        # own attribute -- or the flavour; the flavours of one plan share its list by construction).
         done = self.adj.__dict__.setdefault("_xcd_calibrated", {})
-        key = (self.d, bool(self.vfree), self.model == "XSimGCL")
+        key = self.d
         if key in done:
             return done[key]
         nb = (ops.spmm_plan_run_tasks(self.adj, self.d) + 3) // 4
