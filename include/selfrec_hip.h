@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 21
+#define SRH_ABI_VERSION 22
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -90,6 +90,15 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
 srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out);
 /* random.getrandbits(32) -- lets tests pin how much of the stream was consumed. */
 srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out);
+
+/* `torch.rand(n)` of the CPU generator (ATen: mt19937, one 32-bit word per float32, value = (word & 0xFFFFFF) * 2^-24),
+ * replayed on the host from the generator's own words: what model/graph/BUIR.py:118-121 draws per forward pass for its
+ * sparse dropout -- `torch.floor(keep_prob + torch.rand(nnz)).type(torch.bool)` -- at 5 M entries per step on the Yelp2018
+ * shape, where ATen's serial kernel takes 15 ns per draw.  h_mt624 / *pos are the generator's 624 state words and the
+ * index of the next unread word (624: regenerate first), in and out.  h_out (nullable) receives the n uniforms; h_keep
+ * (nullable) receives floorf(keep_addend + u) != 0 as bytes, the fp32 arithmetic of the torch expression. */
+srh_status_t srh_mt19937_uniform_f32(uint32_t* h_mt624, int32_t* pos, int64_t n, float* h_out,
+                                     float keep_addend, uint8_t* h_keep);
 
 /* ------------------------------------------------------------------------------------
  * (a-2) Graph normalisation -- replaces data/graph.py:10-24 normalize_graph_mat and

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -99,6 +99,7 @@ SIGNATURES = {
     "srh_sampler_epoch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
     "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
+    "srh_mt19937_uniform_f32": (_i32, [_vp, C.POINTER(C.c_int32), _i64, _vp, C.c_float, _vp]),
     "srh_adj_sym_normalize": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp]),
     "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32, _i64, _vp]),
     "srh_spmm_plan_set_xcd_shares": (_i32, [_vp, _i32, _vp]),

@@ -90,7 +90,9 @@ class SparseAdjHandle:
         MixGCF.py:84-94 build as a new torch COO tensor.  The result multiplies on the HIP SpMM, backward included
         (its transpose is the same structure with mirrored values)."""
         idx, perm = self._coo()
-        keep = torch.as_tensor(keep).to(device=self.device, dtype=torch.float32)
+        # the mask crosses the link as it is (one byte per entry for a bool mask) and becomes fp32 on the device: a
+        # host-side bool -> float conversion of 2.5 M entries costs up to 30 ms per call on the GPU box's host
+        keep = torch.as_tensor(keep).to(device=self.device).to(dtype=torch.float32)
         if keep.numel() != self.csr.nnz:
             raise ops.SelfrecHipError(f"dropout: mask has {keep.numel()} entries, the matrix {self.csr.nnz}")
         vals = torch.zeros_like(self.csr.vals)

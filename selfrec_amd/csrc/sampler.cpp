@@ -56,13 +56,17 @@ struct MT19937 {
     static const uint32_t mag01[2] = {0x0U, 0x9908b0dfU};
     int kk;
     uint32_t y;
+    // Word kk reads words kk, kk + 1 (not yet rewritten) and kk + M resp. kk + M - N (rewritten >= N - M = 227 words
+    // earlier): any vector width below 227 keeps the scalar order's values, which the compiler cannot see by itself.
+#pragma clang loop vectorize(assume_safety)
     for (kk = 0; kk < N - M; ++kk) {
       y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
-      mt[kk] = mt[kk + M] ^ (y >> 1) ^ mag01[y & 1U];
+      mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
     }
-    for (; kk < N - 1; ++kk) {
+#pragma clang loop vectorize(assume_safety)
+    for (kk = N - M; kk < N - 1; ++kk) {
       y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
-      mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ mag01[y & 1U];
+      mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
     }
     y = (mt[N - 1] & 0x80000000U) | (mt[0] & 0x7fffffffU);
     mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ mag01[y & 1U];
@@ -367,6 +371,45 @@ srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out) {
   if (st) return st;
   SRH_REQUIRE(out, "sampler_next_u32: null output");
   *out = s->rng.next_u32();
+  return SRH_OK;
+}
+
+srh_status_t srh_mt19937_uniform_f32(uint32_t* h_mt624, int32_t* pos, int64_t n, float* h_out,
+                                     float keep_addend, uint8_t* h_keep) {
+  SRH_REQUIRE(h_mt624 && pos, "mt19937_uniform_f32: null state");
+  SRH_REQUIRE(*pos >= 0 && *pos <= MT19937::N, "mt19937_uniform_f32: position outside [0, 624]");
+  SRH_REQUIRE(n >= 0, "mt19937_uniform_f32: negative count");
+  MT19937 g;
+  std::memcpy(g.mt, h_mt624, sizeof(g.mt));
+  g.pos = *pos;
+  int64_t done = 0;
+  while (done < n) {
+    if (g.pos >= MT19937::N) g.refill();
+    const int take = (int)std::min<int64_t>(MT19937::N - g.pos, n - done);
+    const uint32_t* w = g.mt + g.pos;
+    float u[MT19937::N];
+    for (int k = 0; k < take; ++k) {            // (no branches, no carried dependence: vectorised by the host compiler)
+      uint32_t y = w[k];
+      y ^= (y >> 11);
+      y ^= (y << 7) & 0x9d2c5680U;
+      y ^= (y << 15) & 0xefc60000U;
+      y ^= (y >> 18);
+      u[k] = (float)(y & 0xFFFFFFU) * 0x1p-24f;
+    }
+    if (h_out) std::memcpy(h_out + done, u, (size_t)take * sizeof(float));
+    if (h_keep) {
+      // floorf(x) != 0  <=>  not (0 <= x < 1), NaN and -0.0 included -- a compare the compiler vectorises
+      uint8_t* kp = h_keep + done;
+      for (int k = 0; k < take; ++k) {
+        const float x = keep_addend + u[k];
+        kp[k] = (uint8_t)!(x >= 0.0f && x < 1.0f);
+      }
+    }
+    g.pos += take;
+    done += take;
+  }
+  std::memcpy(h_mt624, g.mt, sizeof(g.mt));
+  *pos = g.pos;
   return SRH_OK;
 }
 

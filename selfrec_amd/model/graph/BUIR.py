@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...util import torch_rng
 from ._oplevel import OpLevelRecommender, PropagationEncoder
 
 
@@ -21,8 +22,9 @@ class LGCN_Encoder(PropagationEncoder):
         if self.drop_flag:
             # keep an entry where floor(1 - rate + U[0,1)) == 1, rescale by 1 / (1 - rate); the uniforms are drawn on
             # the host in the entries' (row, column) order, as the reference draws them (BUIR.py:118-121,130-131)
+            # (torch_rng: those draws of torch's CPU generator replayed by the library's host code, 10x ATen's kernel)
             rate = np.random.random() * self.drop_ratio
-            keep = torch.floor(1 - rate + torch.rand(self.sparse_norm_adj._nnz())).type(torch.bool)
+            keep = torch_rng.keep_mask(self.sparse_norm_adj._nnz(), 1 - rate)
             adj = self.sparse_norm_adj.dropout(keep, 1.0 / (1 - rate))
         users, items = super().forward(adj)
         return users[inputs['user']], items[inputs['item']]

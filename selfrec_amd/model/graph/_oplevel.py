@@ -64,7 +64,9 @@ class OpLevelRecommender(GraphRecommender):
         optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=self.lRate)
         for epoch in range(self.maxEpoch):
             model.train()
-            for n, (user_idx, pos_idx, neg_idx) in enumerate(next_batch_pairwise(self.data, self.batch_size, self.n_negs)):
+            for n, batch in enumerate(next_batch_pairwise(self.data, self.batch_size, self.n_negs, as_arrays=True)):
+                # one H2D copy per index stream and step; every table[idx] below then indexes with a device tensor
+                user_idx, pos_idx, neg_idx = (torch.from_numpy(a).cuda() for a in batch)
                 loss = self.batch_loss(user_idx, pos_idx, neg_idx)
                 optimizer.zero_grad()
                 loss.backward()

@@ -54,7 +54,10 @@ def _sampler_for(data):
     return smp
 
 
-def next_batch_pairwise(data, batch_size, n_negs=1):
+def next_batch_pairwise(data, batch_size, n_negs=1, as_arrays=False):
+    """``as_arrays`` (not in the reference's signature): yield the three index streams as int64 numpy arrays instead of
+    python lists -- same values, same order, same RNG state; the package's own train() loops take them so that a batch
+    of 2048 x 64 MixGCF candidates is not boxed into 131 k python ints and unboxed again by every ``table[idx]``."""
     smp = _sampler_for(data)
     smp.set_state_from_python()
     before = smp.order()
@@ -72,4 +75,7 @@ def next_batch_pairwise(data, batch_size, n_negs=1):
         u, i, j = smp.next_batch(ptr, batch_size, n_negs)
         smp.push_state_to_python()
         ptr += len(u)
-        yield u.tolist(), i.tolist(), j.tolist()
+        if as_arrays:
+            yield u.astype(np.int64), i.astype(np.int64), j.astype(np.int64)
+        else:
+            yield u.tolist(), i.tolist(), j.tolist()

@@ -56,8 +56,8 @@ def test_two_steps_match_the_reference_model_file(shapes, smeta, fresh_tiny_data
     real_batches = sampler_mod.next_batch_pairwise
     seen = []
 
-    def batches(data, bs, n_negs=1):
-        for k, b in enumerate(real_batches(data, bs, n_negs)):
+    def batches(data, bs, n_negs=1, **kw):
+        for k, b in enumerate(real_batches(data, bs, n_negs, **kw)):
             if k == m["n_steps"]:
                 return
             seen.append(b)

@@ -67,6 +67,18 @@ determinism)
   timeout 600 python tools/determinism_probe.py > $OUT/determinism.txt 2>&1; echo "determinism exit $?"; grep -v amdgpu.ids $OUT/determinism.txt | tail -12;;
 nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
+oplevel)
+  # per-statement step time of the op-level models + whole 2-epoch runs through main
+  : > $OUT/oplevel.txt
+  for m in ${OPLEVEL_MODELS:-BUIR MixGCF DirectAU SelfCF}; do timeout 200 python tools/oplevel_probe.py $m 30 2>&1 | grep -v amdgpu.ids >> $OUT/oplevel.txt; done
+  PROBE_ATEN_RAND=1 timeout 200 python tools/oplevel_probe.py BUIR 15 2>&1 | grep -v amdgpu.ids >> $OUT/oplevel.txt
+  mkdir -p /tmp/conf_op
+  for m in ${OPLEVEL_MODELS:-BUIR MixGCF DirectAU SelfCF}; do
+    sed "s/^max.epoch:.*/max.epoch: 2/" conf/$m.yaml > /tmp/conf_op/$m.yaml
+    timeout 400 python -m selfrec_amd.main $m --conf /tmp/conf_op/$m.yaml --synthetic yelp2018 > $OUT/main_$m.log 2>&1
+    echo "$m: 2 epochs through selfrec_amd.main, exit $?, $(grep 'Running time' $OUT/main_$m.log)" >> $OUT/oplevel.txt
+  done
+  cat $OUT/oplevel.txt;;
 refmodelsfuse)
   timeout 1500 python tools/run_reference_models.py --ref _refstage --fuse --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels_fuse.log 2>&1; echo "refmodelsfuse exit $?"
   grep -E "^#|parity|epoch\(s\)|byte-for-byte|Error|error" $OUT/refmodels_fuse.log | tail -20;;
