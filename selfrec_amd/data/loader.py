@@ -13,18 +13,39 @@ class TripleFile(MutableSequence):
 
     ``Interaction`` recognises it and builds its id arrays with the native loader
     (``srh_dataset_load``) without ever creating the python triples; any other consumer that
-    indexes, iterates or mutates it gets the ordinary list, materialised on first touch."""
+    indexes, iterates or mutates it gets the ordinary list, materialised on first touch.
+
+    While nobody has touched it, ``len()`` is answered from the native loader's line count and the sampler's in-place
+    shuffles (reference util/sampler.py:7) are kept as ONE pending permutation of the file's rows, applied when the
+    list is first materialised: a run that never reads ``data.training_data`` never builds 1.2 M python lists, and
+    one that does finds them in the order the reference's ``shuffle`` would have left."""
 
     def __init__(self, path):
         self.path = path
         self._rows = None
+        self._known_len = None        # set by Interaction._init_native (lines of the file)
+        self._order = None            # pending permutation: position p holds file row _order[p]
 
     def _list(self):
         if self._rows is None:
-            self._rows = FileIO.load_data_set(self.path, 'graph')
+            rows = FileIO.load_data_set(self.path, 'graph')
+            if self._order is not None:
+                rows = list(map(rows.__getitem__, self._order.tolist()))
+                self._order = None
+            self._rows = rows
         return self._rows
 
+    def unread(self):
+        return self._rows is None
+
+    def permute_unread(self, take):
+        """new[p] = old[take[p]] on a list nobody has materialised yet"""
+        assert self._rows is None
+        self._order = take.copy() if self._order is None else self._order[take]
+
     def __len__(self):
+        if self._rows is None and self._known_len is not None:
+            return self._known_len
         return len(self._list())
 
     def __getitem__(self, k):

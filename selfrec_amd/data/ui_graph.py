@@ -119,6 +119,10 @@ class Interaction(Data, Graph):
             sizes = (C.c_int64 * 5)()
             _lib.check(lib.srh_dataset_sizes(h, sizes))
             n_users, n_items, n_train, n_test, self._n_test_lines = (int(x) for x in sizes)
+            # len(training_data) / len(test_data) (training_size(), test_size(), sampler.py:8) without building the lists
+            self.training_data._known_len = n_train
+            if isinstance(self.test_data, TripleFile):
+                self.test_data._known_len = self._n_test_lines
             self.train_u = np.empty(n_train, dtype=np.int32)
             self.train_i = np.empty(n_train, dtype=np.int32)
             test_u, test_i = np.empty(n_test, dtype=np.int32), np.empty(n_test, dtype=np.int32)
@@ -152,6 +156,9 @@ class Interaction(Data, Graph):
 
     def _edge_ids_in_list_order(self):
         """ids of the CURRENT training_data order (the sampler shuffles that list in place)."""
+        td = self.training_data
+        if isinstance(td, TripleFile) and td.unread():        # file order, or the pending permutation of it
+            return (self.train_u, self.train_i) if td._order is None else (self.train_u[td._order], self.train_i[td._order])
         u = np.fromiter((self.user[r[0]] for r in self.training_data), dtype=np.int32, count=len(self.training_data))
         i = np.fromiter((self.item[r[1]] for r in self.training_data), dtype=np.int32, count=len(self.training_data))
         return u, i

@@ -20,6 +20,11 @@ def _record_ids(td):
     return np.fromiter(map(id, seq), dtype=np.int64, count=len(seq))
 
 
+def _unread(td):
+    """data/loader.TripleFile that no one has indexed yet: its order exists only as a pending permutation"""
+    return getattr(td, "unread", None) is not None and td.unread()
+
+
 def _list_matches(data, smp, edge_u, edge_i, expected_ids=None):
     """Does ``data.training_data`` still have the order the C++ sampler believes it has?  Two checks:
     a FULL fingerprint -- the identities of the record objects in list order against the order this module left them in
@@ -27,7 +32,7 @@ def _list_matches(data, smp, edge_u, edge_i, expected_ids=None):
     VALUES of 64 probed records (first, last, evenly spaced: fields edited in place without replacing the record).
     A mismatch rebuilds the sampler from the list, i.e. from what the reference's generator would read."""
     td, n = data.training_data, smp.n_edges
-    if n == 0:
+    if n == 0 or _unread(td):                                 # (a lazy list nobody has materialised cannot have been edited)
         return True
     if expected_ids is not None and not np.array_equal(_record_ids(td), expected_ids):
         return False
@@ -50,7 +55,7 @@ def _sampler_for(data):
     edge_u, edge_i = np.asarray(edge_u, dtype=np.int32), np.asarray(edge_i, dtype=np.int32)
     smp = ops.Sampler(edge_u, edge_i, len(data.user), len(data.item))
     data._srh_sampler = (smp, data.training_data, len(data.training_data), edge_u, edge_i)
-    data._srh_record_ids = _record_ids(data.training_data)
+    data._srh_record_ids = None if _unread(data.training_data) else _record_ids(data.training_data)
     return smp
 
 
@@ -63,11 +68,23 @@ def next_batch_pairwise(data, batch_size, n_negs=1, as_arrays=False):
     before = smp.order()
     smp.shuffle()
     after = smp.order()
-    # replay the in-place shuffle on the caller-visible list (sampler.py:7)
-    rank = {int(e): p for p, e in enumerate(before)}
+    # replay the in-place shuffle on the caller-visible list (sampler.py:7): position p of the new order holds the record
+    # that sat where edge after[p] was -- one numpy inverse permutation and one C-speed pass over the list (a dict of
+    # positions and a python loop cost 1.5 s per epoch at 1.24 M records: more than an epoch of SelfCF steps)
     td = data.training_data
-    td[:] = [td[rank[int(e)]] for e in after]
-    data._srh_record_ids = _record_ids(td)             # the order this call leaves the list in (checked by the next one)
+    where = np.empty(len(before), dtype=np.int64)
+    where[before] = np.arange(len(before), dtype=np.int64)
+    take = where[after]
+    if _unread(td):
+        td.permute_unread(take)                            # nobody has read the list: the shuffle stays a permutation
+        data._srh_record_ids = None
+    else:
+        seq = td._list() if hasattr(td, "_list") else td
+        old_ids = data._srh_record_ids if data._srh_record_ids is not None else _record_ids(td)
+        seq[:] = list(map(seq.__getitem__, take.tolist()))
+        # the order this call leaves the list in (checked by the next one): the identities in the old order were just
+        # verified / recorded by _sampler_for, so the new fingerprint is that array permuted -- no second pass over them
+        data._srh_record_ids = old_ids[take]
     smp.push_state_to_python()
     ptr, size = 0, smp.n_edges
     while ptr < size:

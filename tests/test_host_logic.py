@@ -377,3 +377,42 @@ def test_torch_cpu_generator_replay_is_bit_exact():
     t0 = time.perf_counter(); torch_rng.keep_mask(2_470_000, 0.95); fast = time.perf_counter() - t0
     t0 = time.perf_counter(); torch.floor(0.95 + torch.rand(2_470_000)).type(torch.bool); slow = time.perf_counter() - t0
     print(f"keep mask of 2.47 M entries: replay {1e3 * fast:.1f} ms, ATen {1e3 * slow:.1f} ms")
+
+
+def test_lazy_training_file_keeps_the_shuffles_as_a_pending_permutation(tmp_path):
+    """data/loader.TripleFile + util/sampler: on a dataset opened lazily the in-place shuffles of sampler.py:7 are carried
+    as one permutation until somebody reads ``data.training_data``; batches, the list a reader then finds, and every later
+    epoch equal the plain-list run's (which the goldens pin against the reference's generator)."""
+    tu, ti, su, si, U, I = synth.make_dataset("small")
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    synth.write_text(str(tr), tu, ti)
+    synth.write_text(str(te), su, si)
+    plain = Interaction({}, FileIO.load_data_set(str(tr), "graph"), FileIO.load_data_set(str(te), "graph"))
+    lazy = Interaction({}, FileIO.open_data_set(str(tr), "graph"), FileIO.open_data_set(str(te), "graph"))
+    assert lazy.training_size() == plain.training_size() and lazy.test_size() == plain.test_size()
+    assert lazy.training_data.unread() and lazy.test_data.unread()          # len() came from the loader's line counts
+    runs = {}
+    for name, data in (("plain", plain), ("lazy", lazy)):
+        random.seed(31)
+        out = []
+        for epoch in range(4):
+            out.append([b for b in next_batch_pairwise(data, 300, n_negs=2 if epoch == 1 else 1)])
+            if name == "lazy" and epoch < 2:
+                assert data.training_data.unread()                           # two epochs without a python triple
+            if epoch == 1:
+                snapshot = [list(r) for r in data.training_data]             # a reader: materialises the lazy list
+                assert not getattr(data.training_data, "unread", lambda: False)()
+                out.append(snapshot)
+            if epoch == 0:
+                smp = data._srh_sampler[0]
+        assert data._srh_sampler[0] is smp                                   # (no rebuild after the materialisation)
+        out.append([list(r) for r in data.training_data])
+        out.append(random.getstate())
+        runs[name] = out
+    assert runs["plain"] == runs["lazy"]
+    # array form: same values
+    random.seed(31)
+    a = [tuple(x.tolist() for x in b) for b in next_batch_pairwise(plain, 300, as_arrays=True)]
+    random.seed(31)
+    l = [b for b in next_batch_pairwise(lazy, 300)]
+    assert a == l
