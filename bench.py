@@ -487,8 +487,13 @@ def main():
     if world != args.gpus:
         args.gpus = world
     sharded = world > 1 or bool(os.environ.get("SRH_FORCE_SHARDED"))     # (knob: exercise the N>1 path on one GPU)
-    backend = os.environ.get("SRH_DIST_BACKEND", "nccl")                  # ("gloo": the CPU test of the launch path)
-    if sharded and backend != "nccl":
+    # SRH_DIST_BACKEND: "nccl" (RCCL, the default); "gloo": the CPU test of the launch path (stops after one collective);
+    # "gloo:device": the WHOLE benchmark with gloo moving device tensors and the ranks dealt over the visible GPUs modulo
+    # their count -- N ranks on the one GPU of a test box (RCCL refuses two ranks per device); its numbers mean nothing,
+    # the point is that every line of the N > 1 path has run with N > 1 (tools/gpu_session.sh stage benchworld2)
+    backend = os.environ.get("SRH_DIST_BACKEND", "nccl")
+    shared_device = backend == "gloo:device"
+    if sharded and backend not in ("nccl", "gloo:device"):
         # launch-path check without GPUs (tests/test_dist_cpu.py): rendezvous, one collective, the layout this world
         # size would take -- then stop; everything after this point needs the HIP library and a device
         import torch.distributed as dist
@@ -507,12 +512,17 @@ def main():
         return
     from selfrec_amd import _lib
     _lib.require_gpu()
+    if shared_device:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if shared_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist = None
 
@@ -579,7 +589,9 @@ def main():
         from selfrec_amd.dist import describe_layout
         layout = (describe_layout(args.emb, world, str(trainer.layout) if (world > 1 or trainer.dp) else
                                   ("cols" if trainer.cols else "rows"), 2 * trainer.graph.n_edges)
-                  + f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU")
+                  + (f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU" if not shared_device
+                     else f"; TEST MODE gloo:device -- {dist.get_world_size()} ranks sharing {torch.cuda.device_count()} GPU(s): "
+                          "the figures of this line are not measurements"))
     pairs = args.steps * args.batch * (world if dp else 1)
     value = pairs / elapsed
     g = trainer.graph
@@ -709,7 +721,10 @@ def main():
     if dist is not None:
         dist.barrier()
         if not args.no_eval:
-            ev = eval_throughput_sharded(trainer, data, dist, rank, world)      # every rank takes part
+            try:
+                ev = eval_throughput_sharded(trainer, data, dist, rank, world)      # every rank takes part
+            except Exception as e:                # (never lose the training line to the evaluation leg)
+                ev = {"error": f"{type(e).__name__}: {e}"}
             if rank == 0:
                 out["eval"] = ev
         dist.barrier()

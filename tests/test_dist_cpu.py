@@ -20,7 +20,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, model, layout, out_path, d=64):
+def _gloo_moves_device_tensors(out_dir, rank):
+    """tests/test_gpu_multiproc.py: ranks of ONE GPU talk over gloo with device tensors (RCCL refuses two ranks on a
+    device).  A torch build whose gloo cannot do that leaves a flag and the test skips."""
+    try:
+        t = torch.full((4,), float(rank + 1), device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        return True
+    except Exception as e:                                   # noqa: BLE001
+        with open(os.path.join(out_dir, "no_device_gloo"), "w") as f:
+            f.write(repr(e))
+        return False
+
+
+def _worker(rank, world, port, model, layout, out_path, d=64, device="cpu"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -31,15 +45,19 @@ def _worker(rank, world, port, model, layout, out_path, d=64):
     from selfrec_amd.data import device_graph
     from selfrec_amd.data.ui_graph import Interaction
     from selfrec_amd.dist import ShardedTrainer
-    from tests import cpu_ops
-    engine.ops = device_graph.ops = cpu_ops   # the product's step code over CPU stand-ins of the kernels
+    if device == "cpu":
+        from tests import cpu_ops
+        engine.ops = device_graph.ops = cpu_ops   # the product's step code over CPU stand-ins of the kernels
+    elif not _gloo_moves_device_tensors(os.path.dirname(out_path), rank):
+        dist.destroy_process_group()
+        return
     tu, ti, su, si, U, I = synth.make_dataset("tiny")
     data = Interaction({}, synth.as_triples(tu, ti), [])
     torch.manual_seed(0)
     ue = torch.nn.init.xavier_uniform_(torch.empty(U, d)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, d))
     gen = torch.Generator().manual_seed(7)
     tr = ShardedTrainer(data, d, model=model, n_layers=3, batch_size=1000, layer_cl=2, tau=0.2, eps=0.2, cl_rate=0.2,
-                        drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu",
+                        drop_rate=0.1, user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device=device,
                         layout=layout)
     assert tr.G == world
     if layout == "rows":
@@ -59,8 +77,8 @@ def _worker(rank, world, port, model, layout, out_path, d=64):
     for _ in range(3):
         tr.step()
         losses.append(tr.read_losses())
-    pu, pi = tr.parameters_full()
-    fu, fi = tr.embeddings()
+    pu, pi = (t.cpu() for t in tr.parameters_full())
+    fu, fi = (t.cpu() for t in tr.embeddings())
     if rank == 0:
         eu, ei, ej = tr.epoch_node_ids()      # staged as table rows: back to node ids for the oracle
         np.savez(out_path, pu=pu.numpy(), pi=pi.numpy(), fu=fu.numpy(), fi=fi.numpy(), losses=np.asarray(losses),
@@ -84,6 +102,12 @@ def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
     layout, _, dd = layout.partition("@")               # (d = 128 over 2 ranks: 64-column slices)
     d = int(dd or 64)
     mp.spawn(_worker, args=(world, _free_port(), model, layout, out, d), nprocs=world, join=True)
+    check_against_oracle(out, model, d)
+
+
+def check_against_oracle(out, model, d, atol=2e-6):
+    """(atol: the device kernels sum in another order than the oracle, and three Adam steps of lr 1e-3 amplify that where
+    a gradient is nearly zero -- tests/test_gpu_multiproc.py passes 2e-5, the bound of the single-process GPU engine tests)"""
     r = np.load(out)
     gen = torch.Generator().manual_seed(7)
     ref = O.OracleTrainer(model, r["train_u"], r["train_i"], 300, 500, d, n_layers=3, batch_size=1000, layer_cl=2,
@@ -98,11 +122,11 @@ def test_sharded_equals_single_process_oracle(tmp_path, model, world, layout):
         lo, hi = b * 1000, (b + 1) * 1000
         want.append(ref.step(r["u"][lo:hi].tolist(), r["i"][lo:hi].tolist(), r["j"][lo:hi].tolist()))
     np.testing.assert_allclose(r["losses"], np.asarray(want), rtol=2e-5, atol=1e-9)
-    np.testing.assert_allclose(r["pu"], ref.user_emb.detach().numpy(), rtol=1e-4, atol=2e-6)
-    np.testing.assert_allclose(r["pi"], ref.item_emb.detach().numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["pu"], ref.user_emb.detach().numpy(), rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(r["pi"], ref.item_emb.detach().numpy(), rtol=1e-4, atol=atol)
     fu, fi = ref.embeddings()
-    np.testing.assert_allclose(r["fu"], fu, rtol=1e-4, atol=2e-6)
-    np.testing.assert_allclose(r["fi"], fi, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["fu"], fu, rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(r["fi"], fi, rtol=1e-4, atol=atol)
 
 
 def _twohop_worker(rank, world, port, gc, gr, flag_dir):
@@ -323,7 +347,7 @@ def test_any_embedding_size_is_stored_padded_and_trains_like_the_oracle(monkeypa
     np.testing.assert_allclose(fi.numpy(), wi, rtol=1e-4, atol=2e-6)
 
 
-def _dp_worker(rank, world, port, model, out_dir):
+def _dp_worker(rank, world, port, model, out_dir, device="cpu"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -333,15 +357,19 @@ def _dp_worker(rank, world, port, model, out_dir):
     from selfrec_amd.data import device_graph
     from selfrec_amd.data.ui_graph import Interaction
     from selfrec_amd.dist import ShardedTrainer
-    from tests import cpu_ops
-    engine.ops = device_graph.ops = cpu_ops
+    if device == "cpu":
+        from tests import cpu_ops
+        engine.ops = device_graph.ops = cpu_ops
+    elif not _gloo_moves_device_tensors(out_dir, rank):
+        dist.destroy_process_group()
+        return
     tu, ti, su, si, U, I = synth.make_dataset("tiny")
     data = Interaction({}, synth.as_triples(tu, ti), [])
     torch.manual_seed(0)
     ue = torch.nn.init.xavier_uniform_(torch.empty(U, 64)); ie = torch.nn.init.xavier_uniform_(torch.empty(I, 64))
     gen = torch.Generator().manual_seed(100 + rank)           # every rank draws its OWN perturbation noise
     tr = ShardedTrainer(data, 64, model=model, n_layers=2, batch_size=500, layer_cl=1, tau=0.2, eps=0.2, cl_rate=0.2,
-                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device="cpu", layout="dp")
+                        user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device=device, layout="dp")
     assert tr.dp and not tr.cols and not tr.sharded and tr.G == world and tr.E0.shape == (U + I, 64)
     tr.seed_sampler(40)                                        # seed + rank: every rank its own batches
     tr.begin_epoch()
@@ -350,7 +378,7 @@ def _dp_worker(rank, world, port, model, out_dir):
         tr.step()
         losses.append(tr.read_losses())
     eu, ei, ej = tr.epoch_node_ids()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), E0=tr.E0.numpy(), u=eu, i=ei, j=ej, losses=np.asarray(losses),
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), E0=tr.E0.cpu().numpy(), u=eu, i=ei, j=ej, losses=np.asarray(losses),
              train_u=data.train_u, train_i=data.train_i, ue=ue.numpy(), ie=ie.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -362,7 +390,11 @@ def test_data_parallel_equals_the_mean_gradient_oracle(tmp_path, model, world):
     single-process oracle that evaluates each rank's loss on that rank's batch (with that rank's noise), averages the
     gradients and takes one Adam step; every rank ends with the same table."""
     mp.spawn(_dp_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
-    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    check_dp_against_oracle(tmp_path, model, world)
+
+
+def check_dp_against_oracle(tmp_path, model, world):
+    r = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
     for k in range(1, world):
         assert np.array_equal(r[k]["E0"], r[0]["E0"])                          # replicas stay replicas
         assert not np.array_equal(r[k]["u"][:500], r[0]["u"][:500])            # ... on different batches

@@ -87,6 +87,12 @@ precision)
 bench)
   timeout 1200 python bench.py --steps ${BENCH_STEPS:-1300} --warmup 50 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"
   tail -3 $OUT/bench.err; tail -1 $OUT/bench.log | cut -c1-3000;;
+benchworld2)
+  # every line of bench.py's N > 1 path with N > 1 real ranks -- on ONE GPU, over gloo (figures meaningless)
+  for lay in ${W2_LAYOUTS:-dp cols}; do
+    SRH_DIST_BACKEND=gloo:device SRH_SHARD_LAYOUT=$lay timeout 600 python bench.py --gpus ${W2_RANKS:-2} --steps 300 --warmup 20 > $OUT/bench_world2_$lay.log 2> $OUT/bench_world2_$lay.err
+    echo "benchworld2 $lay exit $?"; grep -v "Gloo\|socket.cpp\|amdgpu.ids" $OUT/bench_world2_$lay.err | tail -5; tail -1 $OUT/bench_world2_$lay.log | cut -c1-1500
+  done;;
 benchdriver)
   # what the driver runs: default flags
   timeout 1200 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; echo "benchdriver exit $?"
