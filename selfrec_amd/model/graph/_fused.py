@@ -9,7 +9,6 @@ import random
 
 import torch
 
-from ..._lib import SelfrecHipError
 from ...base.graph_recommender import GraphRecommender
 from ...engine import EpochPrefetcher, FusedTrainer
 

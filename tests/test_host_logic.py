@@ -307,7 +307,6 @@ def test_reordered_training_list_rebuilds_the_sampler(golden_ops):
     64 probed positions -- must be noticed (full identity fingerprint of the records), and the next epoch must read
     the list as the reference's generator would."""
     from tests.conftest import _tiny_interaction
-    from selfrec_amd.util import sampler as S
     data = _tiny_interaction(golden_ops)
     random.seed(5)
     first = [b for b in next_batch_pairwise(data, 512)]

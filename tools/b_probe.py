@@ -26,7 +26,6 @@ data = Interaction.from_id_arrays({}, T.first_appearance_ids(tu), T.first_appear
 ue, ie = seeded_init(info)
 kept = {}
 for precision in ("bf16x3", "with-values"):
-    from selfrec_amd import ops
     tr = T.trainer_for(info, data, ue, ie)
     if precision == "with-values":
         tr.vfree = False          # same arithmetic, different rounding order: pattern products + row scaling -> values

@@ -5,7 +5,6 @@ attributes the loss section's time kernel by kernel."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -14,7 +14,6 @@ import argparse
 import collections
 import json
 import os
-import re
 import sqlite3
 import sys
 
