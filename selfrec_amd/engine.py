@@ -1056,6 +1056,24 @@ class FusedTrainer:
         self._graph = None
 
     def _capture(self):
+        """Capture the step as hipGraph(s).  No destructor with a HIP call in it may run while a stream of this thread is
+        capturing: an older trainer's device plans (hipFree), CUDAGraphs, streams, collected by python's cyclic GC in that
+        window, left a graph whose first replayed step was wrong (half of the world-2 data-parallel runs of
+        tests/test_gpu_multiproc.py; never with the collection below -- tools/dp_graph_probe.py, DESIGN.md 6.4;
+        torch >= 2.9 no longer collects on entering torch.cuda.graph).  So: collect first, keep the collector off inside."""
+        import gc
+        guard = not os.environ.get("SRH_NO_CAPTURE_GC")          # (diagnostic knob: reproduces the failure)
+        was_enabled = gc.isenabled()
+        if guard:
+            gc.collect()
+            gc.disable()
+        try:
+            self._capture_guarded()
+        finally:
+            if guard and was_enabled:
+                gc.enable()
+
+    def _capture_guarded(self):
         # warm up once eagerly on a side stream (allocator + lazy module loads), then capture.  (Column-
         # sharded: the warm-up skips the all-gather -- its numbers are thrown away with the snapshot -- so
         # capturing is a purely local act.)

@@ -59,19 +59,22 @@ def _graph_worker(rank, world, port, layout, out_dir):
                             use_graph=graphed, device="cuda", layout=layout)
         tr.seed_sampler(40)
         tr.begin_epoch()
+        per_step = []
         for _ in range(5):                         # (the first graphed step captures, the others replay)
             tr.step()
+            per_step.append(tr.E0.detach().clone())
         torch.cuda.synchronize()
         if layout in ("dp", "cols"):               # the collective sits BETWEEN the two graphs: the capture must succeed
             assert tr.use_graph == graphed and (tr._graph is not None) == graphed
         # (2-D / rows keep collectives inside the step: a capture that the backend refuses falls back to eager launches --
         #  engine.step_phases -- and the run must still be right)
         pu, pi = tr.parameters_full()
-        res[graphed] = (torch.cat([pu, pi]).cpu().numpy(), np.asarray(tr.read_losses()))
+        res[graphed] = (torch.cat([pu, pi]).cpu().numpy(), np.asarray(tr.read_losses()), [t.cpu().numpy() for t in per_step])
     # captured steps == eager steps up to the loss section's float atomics (their order differs from run to run:
     # profiles/r03_c_determinism.txt), amplified by five Adam steps
     diff = np.abs(res[False][0] - res[True][0])
-    assert diff.max() < 2e-5 and np.median(diff) < 1e-7, (float(diff.max()), float(np.median(diff)))
+    by_step = [float(np.abs(a - b).max()) for a, b in zip(res[False][2], res[True][2])]
+    assert diff.max() < 2e-5 and np.median(diff) < 1e-7, (rank, float(diff.max()), float(np.median(diff)), by_step)
     np.testing.assert_allclose(res[False][1], res[True][1], rtol=2e-5)
     np.save(os.path.join(out_dir, f"params{rank}.npy"), res[True][0])
     dist.barrier()
