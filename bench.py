@@ -458,6 +458,12 @@ def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
             "note": f"test users dealt over {world} ranks, item table replicated, ranked ids all-gathered; slowest rank's time"}
 
 
+def default_layout_is_dp(nnz):
+    """bench.py --gpus N > 1 on this graph: data parallel unless SRH_SHARD_LAYOUT says otherwise or the graph is gather-bound"""
+    from selfrec_amd.dist import GATHER_BOUND_NNZ
+    return (os.environ.get("SRH_SHARD_LAYOUT") or "dp") == "dp" and nnz < GATHER_BOUND_NNZ
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` (no launcher, the way the driver's single-GPU command line is spelled): start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` -- one rank per GPU over
@@ -531,11 +537,11 @@ def main():
     kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
               layer_cl=1, batch_size=args.batch, use_graph=not args.no_graph)
     if sharded:
-        from selfrec_amd.dist import GATHER_BOUND_NNZ, ShardedTrainer
+        from selfrec_amd.dist import ShardedTrainer
         # N > 1 on a graph this small: data parallel (every rank its own batches, one all-reduce of the dense gradient per
         # step: weak scaling, global batch N x B) unless SRH_SHARD_LAYOUT asks for a strong-scaling layout of ONE batch;
         # gather-bound graphs take pick_layout's choice (2-D grid / column blocks)
-        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if 2 * data.interaction_mat.nnz < GATHER_BOUND_NNZ else None)
+        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if default_layout_is_dp(2 * data.interaction_mat.nnz) else None)
         trainer = ShardedTrainer(data, args.emb, layout=layout, **kw)
     else:
         from selfrec_amd.engine import FusedTrainer
@@ -600,7 +606,10 @@ def main():
         "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak" if dp else "strong", "vs_baseline": None,
+        # the mode of the layout `--gpus N` takes for this graph (N = 1 reports the mode its N > 1 companions will run in,
+        # so that one SCALE series carries one label): data parallel = weak, the table / graph splits = strong
+        "scaling": "weak" if (dp or (not sharded and default_layout_is_dp(2 * trainer.graph.n_edges))) else "strong",
+        "vs_baseline": None,
         "dtype": "f32" + (" (InfoNCE's two n x n x d products on 16-bit MFMA operands with f32 accumulation: the logits on "
                           "split f16 hi+lo = 2^-22, the accuracy of an f32 dot product; P.V on split bf16 = 2^-18 per "
                           "product, gradients 1e-6 rel; all-f32-MFMA path timed in ms_per_step_nce_f32)"
