@@ -26,7 +26,10 @@ MASKED_SCORE = -10e8
 # users per scoring call: chunk * n_items * 4 B stays well inside the 256 MiB Infinity Cache
 SCORE_SLAB_BYTES = 96 << 20
 # filtered ranking: items scored exactly to bound each user's K-th score, survivor slots per user, users per chunk
-FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 4096
+# (tools/eval_sweep.py on trained embeddings, 31.5 k users: chunks of 4096 / 8192 / 16384 / 32768 users rank at 15.8 / 17.9 /
+#  19.0 / 19.0 M users/s -- a chunk's six launches fill the chip better and there are fewer of them; its workspace is
+#  chunk x (sample + 2 cap) x 4 B = 400 MB at 16384.  A 2048- or 8192-item sample, or 512 slots, move it by < 3 %.)
+FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 16384
 DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered): k <= 128
 
 

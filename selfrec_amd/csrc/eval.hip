@@ -287,6 +287,9 @@ __device__ __forceinline__ void glds16_b(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
+#ifndef SRH_F16_EXP
+#define SRH_F16_EXP 0
+#endif
 constexpr int kF16StageCap = 256;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
 constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two stages + the four waves' survivor lists
 
@@ -346,6 +349,10 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
   short* stage_row = s_row + wv * kF16StageCap;
   int staged = 0;                // wave-uniform
   auto flush = [&]() {
+#if SRH_F16_EXP == 1                          // (timing experiment: what the survivors' global atomics + stores cost)
+    staged = 0;
+    return;
+#endif
     for (int e = lane; e < staged; e += 64) {
       const int row = m0 + stage_row[e];
       const int slot = atomicAdd(f.cnt + row, 1);
@@ -398,19 +405,40 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
             }
             continue;
           }
+#if SRH_F16_EXP == 2                          // (timing experiment: MFMAs + operand traffic + barriers alone)
+          {
+            float mx = acc[0];
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const bool pass = (col < n) && (acc[t] >= thr[ub][t]);          // (rows >= m carry +inf)
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
-            if (bal == 0) continue;                                          // wave-uniform
-            if (pass) {
+            for (int t = 1; t < 16; ++t) mx = fmaxf(mx, acc[t]);
+            if (mx == 12345.678f) f.cand_sc[0] = mx;
+            continue;
+          }
+#endif
+          // The common case -- nothing passes -- is straight-line code: every lane packs its 16 comparisons into a bit
+          // mask (two VALU operations per output, no branch), ONE ballot per 32 x 32 block decides.  (The first version
+          // tested a ballot per accumulator register: 32 taken branches per tile, each around an inlined flush loop --
+          // 65 cycles per ballot, 117-129 us per chunk against 52 us for the same kernel without an epilogue.)
+          unsigned pm = 0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) pm |= (acc[t] >= thr[ub][t] ? 1u : 0u) << t;           // (rows >= m carry +inf)
+          if (col >= n) pm = 0;
+          unsigned long long bal = __builtin_amdgcn_ballot_w64(pm != 0);
+          while (bal != 0) {                                                 // wave-uniform; one pass per survivor of the
+            const bool act = pm != 0;                                        // lane that has the most (almost always 1)
+            const int t = act ? __builtin_ctz(pm) : 0;
+            pm &= pm - 1u;
+            float sc = acc[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) sc = (t == k) ? acc[k] : sc;       // (registers cannot be indexed by t)
+            if (act) {
               const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
               stage_row[at] = (short)(32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h);
               stage_col[at] = col;
-              stage_sc[at] = acc[t];
+              stage_sc[at] = sc;
             }
             staged += __builtin_popcountll(bal);
             if (staged > kF16StageCap - 64) flush();                        // (rare: a tie-heavy block)
+            bal = __builtin_amdgcn_ballot_w64(pm != 0);
           }
         }
       }

@@ -63,6 +63,17 @@ nceab)
     find $OUT/nceab_$N -name "*.db" -delete
   done
   cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
+evalab)
+  # eval kernels per alt library (ALT_SRC=eval tools/spmm_lab/build_alt.sh <name> "<flags>"): per-kernel times of eval_probe
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so; : > $OUT/evalab.txt
+  for N in product ${EVAL_LIBS:-}; do
+    [ $N = product ] || cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so
+    rm -rf $OUT/evalab_$N; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/evalab_$N -o trace -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalab_$N.log 2>&1); echo "evalab $N exit $?"
+    echo "== $N" >> $OUT/evalab.txt; stats $OUT/evalab_$N | grep -E "filter16|rescore|topk_kernel|split_rows" >> $OUT/evalab.txt; grep -v amdgpu.ids $OUT/evalab_$N.log | tail -1 >> $OUT/evalab.txt
+    find $OUT/evalab_$N -name "*.db" -delete
+    cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so
+  done
+  cat $OUT/evalab.txt;;
 determinism)
   timeout 600 python tools/determinism_probe.py > $OUT/determinism.txt 2>&1; echo "determinism exit $?"; grep -v amdgpu.ids $OUT/determinism.txt | tail -12;;
 nceprec)
@@ -125,8 +136,8 @@ prof)
   stats $OUT/prof > $OUT/prof_kernel_stats.txt && head -20 $OUT/prof_kernel_stats.txt; tail -1 $OUT/prof.log | cut -c1-300
   find $OUT/prof -name "*.db" -size +40M -delete;;
 profeval)
-  rm -rf $OUT/profeval; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profeval -o trace -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dropin > $OLDPWD/$OUT/profeval.log 2>&1); echo "profeval exit $?"
-  stats $OUT/profeval | grep -E "kernel  |gemm_nt|topk|mask_kernel|cand_|hit_flags" > $OUT/profeval_kernel_stats.txt; cat $OUT/profeval_kernel_stats.txt
+  rm -rf $OUT/profeval; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profeval -o trace -- python $OLDPWD/bench.py --steps ${PROFEVAL_STEPS:-5} --warmup 2 --no-cpu-baseline --no-dropin > $OLDPWD/$OUT/profeval.log 2>&1); echo "profeval exit $?"
+  stats $OUT/profeval | grep -E "kernel  |gemm_nt|filter16|rescore|topk|mask_kernel|split_rows|metric_rows|cand_|hit_flags" > $OUT/profeval_kernel_stats.txt; cat $OUT/profeval_kernel_stats.txt
   find $OUT/profeval -name "*.db" -size +40M -delete;;
 pmc)
   # HBM-side traffic + L2 hit rate + issue counters of the dense SpMM launch (separate passes, counters only)
