@@ -591,6 +591,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 //   rank  : each candidate counts the candidates that precede it; rank < K writes slot rank.
 //   If the candidate list overflows (many ties), fall back to K rounds of block arg-max.
 // ---------------------------------------------------------------------------------------
+// The bound stage needs ONE number per row: a lower bound of the K-th largest score of the (masked) sample slab.  One wave per
+// row: every lane keeps the maxima of four interleaved groups of the row (256 disjoint groups in all), then K rounds of
+// "wave maximum, remove it once": the K-th largest of 256 maxima of disjoint groups is attained by K distinct elements, so it
+// is a lower bound of the row's K-th largest element (equal to it unless two of the row's top K share a group).  One pass over
+// the slab at the fabric's rate instead of topk_kernel's two passes + candidate ranking (152 -> 64 us per 16384 x 4096 slab).
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int iv = __float_as_int(v);
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  v = dpp_max<0x121>(v); v = dpp_max<0x122>(v); v = dpp_max<0x124>(v); v = dpp_max<0x128>(v);     // row_ror 1, 2, 4, 8
+  const int iv = __float_as_int(v);
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
+}
+
+__global__ __launch_bounds__(256) void bound_rows_kernel(const float* __restrict__ scores, int rows, int n, int k,
+                                                         float* __restrict__ out, int out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = scores + (size_t)row * n;
+  const int n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float g0 = -INFINITY, g1 = -INFINITY, g2 = -INFINITY, g3 = -INFINITY;
+  auto m4 = [](float4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); };
+  int i = lane;
+  for (; i + 192 < n4; i += 256) {
+    const float4 a = x4[i], b = x4[i + 64], c = x4[i + 128], d = x4[i + 192];
+    g0 = fmaxf(g0, m4(a)); g1 = fmaxf(g1, m4(b)); g2 = fmaxf(g2, m4(c)); g3 = fmaxf(g3, m4(d));
+  }
+  for (; i < n4; i += 64) g0 = fmaxf(g0, m4(x4[i]));                  // (groups stay disjoint whatever their sizes)
+  for (int j = 4 * n4 + lane; j < n; j += 64) g1 = fmaxf(g1, x[j]);
+  float kth = -INFINITY;
+  for (int r = 0; r < k; ++r) {                                       // k <= 128 < 256 groups
+    const float mine = fmaxf(fmaxf(g0, g1), fmaxf(g2, g3));
+    kth = wave_max_f(mine);
+    const unsigned long long has = __builtin_amdgcn_ballot_w64(mine == kth);
+    if (has == 0) break;                                              // (NaN scores: no lane equals the maximum)
+    if (lane == (int)__builtin_ctzll(has)) {
+      if (g0 == kth) g0 = -INFINITY; else if (g1 == kth) g1 = -INFINITY; else if (g2 == kth) g2 = -INFINITY; else g3 = -INFINITY;
+    }
+  }
+  if (lane == 0) out[(size_t)row * out_stride] = kth;
+}
+
 constexpr int kTopkThreads = 256;
 constexpr int kTopkCap = 2048;
 
@@ -935,8 +982,14 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       mask_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(ids, (int)m, d_r_indptr, d_r_indices, slab, (int)sample_items, (int)lo);
       SRH_LAUNCH_CHECK();
     }
-    rc = srh_topk_rows(slab, m, sample_items, k, s_ids, s_sc, stream);
-    if (rc) return rc;
+    if (split) {
+      // (the split path needs the bound only, not the sample's ranked list: one pass, one wave per row)
+      bound_rows_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(slab, (int)m, (int)sample_items, k, s_sc + (k - 1), k);
+      SRH_LAUNCH_CHECK();
+    } else {
+      rc = srh_topk_rows(slab, m, sample_items, k, s_ids, s_sc, stream);
+      if (rc) return rc;
+    }
     // 2. all scores again, never stored: only those reaching the bound and not masked are kept
     hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int32_t) * m, st);
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
