@@ -292,8 +292,13 @@ __device__ __forceinline__ void glds16_b(const void* gsrc, void* ldst) {
 #endif
 constexpr int kF16StageCap = 256;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
 constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two stages + the four waves' survivor lists
+#ifndef SRH_F16_UB
+#define SRH_F16_UB 1                // 32-row MFMA blocks per wave: 1 (8 waves per 256-row workgroup) or 2 (4 waves; the first version)
+#endif
 
-// One workgroup: 256 query rows (four waves x 64 rows = two 32-row MFMA blocks, operands resident in registers) against a
+// One workgroup: 256 query rows (UB = 1: eight waves x one 32-row MFMA block, 110 VGPRs, four waves per SIMD with two workgroups
+// per CU -- 400 -> 303 us per 16384-row chunk against UB = 2, the first version: four waves x two blocks, 189 VGPRs, two waves per
+// SIMD, where one wave's operand reads / epilogue and the other's MFMAs overlapped little; operands resident in registers) against a
 // contiguous range of 32-item tiles, which it copies into LDS a stage of ST tiles at a time (double-buffered: the copy
 // of stage k + 1 runs under the MFMAs of stage k) -- one L2 read of the item images per 256 query rows instead of one
 // per 64, and no wave ever waits for a global round trip per tile (the first version, every wave streaming its own B
@@ -303,8 +308,8 @@ constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two sta
 // SLAB: instead of filtering, write the split-bf16 scores of the item range into a (m x n) slab -- the bound stage (the
 // K-th score over a leading slice of the catalogue), which then costs a quarter of the f32 GEMM it replaces; the bound
 // derived from approximate scores is lowered by one more delta_u (see srh_score_mask_topk_filtered).
-template <int D, bool SLAB = false>
-__global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
+template <int D, bool SLAB = false, int UB = 2>
+__global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
                                                        const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
                                                        Filter16Args f, float* __restrict__ C = nullptr) {
   constexpr int KS = D / 16;
@@ -312,23 +317,24 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
   constexpr int ST = 32768 / TILE_BYTES;             // tiles per stage: 4 (d = 64), 2 (d = 128)
   extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
   constexpr int STAGE_BYTES = ST * TILE_BYTES;       // 32 KB
+  constexpr int WAVES = 8 / UB, CAP = kF16StageCap * UB / 2;       // (same LDS either way: 8 shorter lists or 4 longer ones)
   int* s_col = reinterpret_cast<int*>(f16_smem + 2 * ST * TILE_BYTES);
-  float* s_sc = reinterpret_cast<float*>(s_col + 4 * kF16StageCap);
-  short* s_row = reinterpret_cast<short*>(s_sc + 4 * kF16StageCap);
+  float* s_sc = reinterpret_cast<float*>(s_col + WAVES * CAP);
+  short* s_row = reinterpret_cast<short*>(s_sc + WAVES * CAP);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 256 + wv * 64;
+  const int m0 = blockIdx.y * 256 + wv * 32 * UB;
   const int n_tiles = (n + 31) / 32;
   const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
   if (t_begin >= t_end) return;
   const bool live = m0 < m;                          // (a wave beyond the chunk's rows still copies and synchronises)
   auto ld8 = [](const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); };
-  bf16x8 ah[2][KS], al[2][KS];
-  float thr[2][16];              // lowered bounds of the rows this lane holds results for
+  bf16x8 ah[UB][KS], al[UB][KS];
+  float thr[UB][16];             // lowered bounds of the rows this lane holds results for
   {
     const float item_norm = __uint_as_float(*f.max_item_norm);
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
+    for (int ub = 0; ub < UB; ++ub) {
       const int ar = min(m0 + 32 * ub + r32, m - 1);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -344,9 +350,9 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
       }
     }
   }
-  int* stage_col = s_col + wv * kF16StageCap;
-  float* stage_sc = s_sc + wv * kF16StageCap;
-  short* stage_row = s_row + wv * kF16StageCap;
+  int* stage_col = s_col + wv * CAP;
+  float* stage_sc = s_sc + wv * CAP;
+  short* stage_row = s_row + wv * CAP;
   int staged = 0;                // wave-uniform
   auto flush = [&]() {
 #if SRH_F16_EXP == 1                          // (timing experiment: what the survivors' global atomics + stores cost)
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
   auto copy_stage = [&](int t0, unsigned char* dst) {           // tiles [t0, min(t0 + ST, t_end)) -> dst
     const int frags = min(ST, t_end - t0) * 2 * KS;
     const unsigned char* src = img + (size_t)t0 * TILE_BYTES;
-    for (int k = wv; k < frags; k += 4) glds16_b(src + (size_t)k * 1024 + lane * 16, dst + k * 1024);
+    for (int k = wv; k < frags; k += WAVES) glds16_b(src + (size_t)k * 1024 + lane * 16, dst + k * 1024);
   };
   copy_stage(t_begin, f16_smem);
   int cur = 0;
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
         }
         const int col = (t0 + tt) * 32 + r32;
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
+        for (int ub = 0; ub < UB; ++ub) {
           floatx16 acc;
 #pragma unroll
           for (int t = 0; t < 16; ++t) acc[t] = 0.f;
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void filter16_kernel(const uint16_t* __restric
               stage_sc[at] = sc;
             }
             staged += __builtin_popcountll(bal);
-            if (staged > kF16StageCap - 64) flush();                        // (rare: a tie-heavy block)
+            if (staged > CAP - 64) flush();                                 // (rare: a tie-heavy block)
             bal = __builtin_amdgcn_ballot_w64(pm != 0);
           }
         }
@@ -939,10 +945,10 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
     SRH_LAUNCH_CHECK();
     static const bool attr_set = [] {
-      (void)hipFuncSetAttribute((const void*)filter16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
-      (void)hipFuncSetAttribute((const void*)filter16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
-      (void)hipFuncSetAttribute((const void*)filter16_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
-      (void)hipFuncSetAttribute((const void*)filter16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<64, false, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<128, false, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<64, true, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
+      (void)hipFuncSetAttribute((const void*)filter16_kernel<128, true, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
       return true;
     }();
     (void)attr_set;
@@ -968,10 +974,10 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       none.max_item_norm = max_norm;
       if (d == 64) {
         split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<64, true><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+        filter16_kernel<64, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
       } else {
         split_rows_kernel<32, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<128, true><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+        filter16_kernel<128, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
       }
       SRH_LAUNCH_CHECK();
     } else {
@@ -1002,8 +1008,8 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int tiles_per_wg = (n_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
       Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cand_sc, cap};
-      if (d == 64) filter16_kernel<64><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
-      else filter16_kernel<128><<<grid, 256, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
+      if (d == 64) filter16_kernel<64, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
+      else filter16_kernel<128, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       SRH_LAUNCH_CHECK();
       // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
       // (training-row membership by an LDS bitmap over the catalogue while it fits: <= 16 KB, i.e. 131 k items)
