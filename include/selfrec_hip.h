@@ -419,7 +419,11 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
  * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
  * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
  * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with
- * srh_score_mask_topk.  d_ws: srh_score_mask_topk_filtered_ws_bytes(chunk_rows, ...) bytes. */
+ * srh_score_mask_topk.  d_ws: srh_score_mask_topk_filtered_ws_bytes(chunk_rows, ...) bytes.
+ * Shape constants measured on the Yelp2018 shape (profiles/r03_m_*): chunk_rows 16384 (larger chunks fill the chip: 4096 ->
+ * 16384 users per chunk is +20 %), sample_items 4096 (within 7 % of the best for trained tables, 1.5x better than 2048 for
+ * untrained ones), cap 1024.  In the split path, pass 1 derives t~_u as the K-th largest of 256 disjoint group maxima of
+ * the masked sample scores (a lower bound of their K-th largest: K distinct items attain it). */
 int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
                                               int64_t n_items, int32_t d);
 srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t* d_user_ids, int64_t n_query,
