@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = a list of stages; everything lands in gpurun_out/.
-# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsnew lab labprobe labplans labbalance labgap labbits gatherlds bench benchquick refmodels prof pmc big cols
+# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsall testsf4 testsnew bench benchquick benchdriver benchbig benchworld2 prof profeval evalprobe evalab evalpmc lossprobe nceab nceprec pmc big cols oplevel refmodels refmodelsfuse determinism precision lab*
 # (budget note from round 2: a call is charged for getting the box as well as for the run -- 20 s when a warm box is at hand,
 #  3-5 min when not, whatever the command: batch stages into one call, and keep the last minutes for a final check)
 set -u
