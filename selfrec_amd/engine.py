@@ -292,7 +292,10 @@ class FusedTrainer:
             self.comm = comm if comm is not None else TorchComm()
             self.G, self.rank = int(self.comm.world), int(self.comm.rank)
             if self.dp:
-                pass                                     # (whole tables, whole graph: nothing is dealt)
+                # whole tables, whole graph: nothing is dealt.  Every rank perturbs with ITS OWN noise (what independent
+                # generators give DistributedDataParallel replicas of the reference's model): the counter RNG's seed
+                # is offset by the rank; rank 0 keeps the seed, so a one-rank job is the single-GPU run
+                self.rng_seed = (self.rng_seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
             elif self.cols:
                 self.Gc, self.cr = self.G, self.rank
             else:

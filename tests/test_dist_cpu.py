@@ -371,6 +371,7 @@ def _dp_worker(rank, world, port, model, out_dir, device="cpu"):
     tr = ShardedTrainer(data, 64, model=model, n_layers=2, batch_size=500, layer_cl=1, tau=0.2, eps=0.2, cl_rate=0.2,
                         user_emb=ue, item_emb=ie, noise_fn=lambda s: torch.rand(s, generator=gen), device=device, layout="dp")
     assert tr.dp and not tr.cols and not tr.sharded and tr.G == world and tr.E0.shape == (U + I, 64)
+    assert (tr.rng_seed == 0x5E1F0EC) == (rank == 0)           # in-kernel noise: every rank its own stream, rank 0 the single-GPU one
     tr.seed_sampler(40)                                        # seed + rank: every rank its own batches
     tr.begin_epoch()
     losses = []
