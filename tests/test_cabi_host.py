@@ -202,3 +202,26 @@ def test_exchange_entry_points_validate_their_arguments_before_any_launch():
                             C.cast((C.c_int32 * 16)(), C.c_void_p), 8, C.byref(ep), None) == -1
     assert b"column slice" in lib.srh_last_error_string()
     lib.srh_spmm_plan_destroy(plan)
+
+
+def test_integration_md_structs_match_the_binding():
+    """INTEGRATION.md spells the ctypes structures a maintainer would paste into the reference tree: they must be the
+    layouts of selfrec_amd/_lib.py (which the GPU tests exercise against include/selfrec_hip.h) -- a field dropped from the
+    document (round 3 found `g2_exclusive` missing) makes an array of problems read garbage."""
+    import ctypes as C
+    import re
+    from selfrec_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    found = {}
+    for b in blocks:
+        for m in re.finditer(r"^class (\w+)\(C\.Structure\):.*?\n((?:    .*\n|\n)+)", b, flags=re.M):
+            ns = {"C": C}
+            exec(m.group(0), ns)                                  # (class statements only: ctypes field lists)
+            found[m.group(1)] = ns[m.group(1)]
+    pairs = {"BprProblem": _lib.BprProblem, "InfonceProblem": _lib.InfonceProblem, "BatchLists": _lib.BatchLists}
+    assert set(pairs) <= set(found), sorted(found)
+    for name, ref in pairs.items():
+        doc = found[name]
+        assert C.sizeof(doc) == C.sizeof(ref), name
+        assert [(n, getattr(doc, n).offset) for n, _ in doc._fields_] == [(n, getattr(ref, n).offset) for n, _ in ref._fields_], name
