@@ -225,3 +225,12 @@ def test_integration_md_structs_match_the_binding():
         doc = found[name]
         assert C.sizeof(doc) == C.sizeof(ref), name
         assert [(n, getattr(doc, n).offset) for n, _ in doc._fields_] == [(n, getattr(ref, n).offset) for n, _ in ref._fields_], name
+
+
+def test_integration_md_names_only_declared_entry_points():
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "selfrec_hip.h")).read()
+    declared = set(re.findall(r"\b(srh_\w+)\s*\(", header))
+    named = set(re.findall(r"\b_lib\.(srh_\w+)\(", text)) | set(re.findall(r"`(srh_\w+)`", text))
+    named = {n for n in named if not n.endswith("_") and not n.endswith("_t")}     # (`srh_sampler_*` prefixes, type names)
+    assert named and named <= declared, sorted(named - declared)
