@@ -396,6 +396,18 @@ def eval_throughput(trainer, data, k=20):
         times.append(time.perf_counter() - t0)
     t_e2e = sorted(times)[len(times) // 2]
     assert len(report) == 5
+    # "up to and including the python rec_list" -- the same call with the reference's return value fully
+    # built: {user: [(item name, score), ...]} for every test user, every tuple a python object (630 k of them here);
+    # test() itself returns a lazy Mapping over the arrays (rows are built on access) and the figure above times that
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = rec.test()
+        rec_list = out.materialise() if hasattr(out, "materialise") else dict(out)
+        report_m = ranking_evaluation(data.test_set, out, [k])
+        times.append(time.perf_counter() - t0)
+    t_mat = sorted(times)[len(times) // 2]
+    assert len(rec_list) == len(out) and len(rec_list[users[0]]) == k and report_m == report
     flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
     # how hard the filter has to work on THESE embeddings: survivors per user of the bound from the first 4096 items
     # (training items included), rows whose list overflowed the 1024 slots (re-ranked by the exact slab pipeline)
@@ -423,6 +435,10 @@ def eval_throughput(trainer, data, k=20):
     del slab
     return {"users": len(uid), "k": k, "timing": "median of 5 calls", "device_users_per_s": round(len(uid) / t_kernel, 1),
             "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
+            "end_to_end_what": "test() + ranking_evaluation(); test() returns a lazy Mapping over the (users x K) arrays",
+            "end_to_end_materialised_users_per_s": round(len(out) / t_mat, 1),
+            "end_to_end_materialised_what": "the same plus the reference's rec_list built in full: a dict of every user's "
+                                            "list of (item name, score) tuples (SURVEY 8d's definition of eval time)",
             "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
             "filter_survivors_per_user": survivors,
             "roofline": {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
@@ -470,22 +486,246 @@ def default_layout_is_dp(nnz):
     return (os.environ.get("SRH_SHARD_LAYOUT") or "dp") == "dp" and nnz < GATHER_BOUND_NNZ
 
 
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of a self-launched job: never a fixed number -- two jobs on one
+    node, or a stale listener of a crashed one, would collide on it)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_gpus():
+    """HIP devices this process can open (0 without a GPU: never an error)."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def refuse_gpu_count(n, backend):
+    """`--gpus N` with N above the visible devices: say so and leave with exit code 2 instead of letting N ranks fight over
+    fewer GPUs (RCCL refuses two ranks per device with an error that names neither N nor the device count).  The CPU
+    launch check ("gloo") and the shared-device test mode ("gloo:device") do not need N devices."""
+    have = visible_gpus()
+    if backend in ("gloo", "gloo:device") or n <= have:
+        return
+    msg = (f"bench.py --gpus {n}: only {have} HIP device(s) visible on this node (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
+           f"= {os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES') or 'unset'}); run with "
+           f"--gpus <= {have}")
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"error": msg, "n_gpus": n, "visible_gpus": have}), flush=True)
+    raise SystemExit(2)
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` (no launcher, the way the driver's single-GPU command line is spelled): start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` -- one rank per GPU over
     RCCL -- and hand its exit code back.  Rank 0 of the child job prints the JSON line on the inherited stdout."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    refuse_gpu_count(n, os.environ.get("SRH_DIST_BACKEND", "nccl"))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool's hosts (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] --gpus {n} without a launcher: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """First-contact safety of the N > 1 run (no line of it has met more than one real GPU): a daemon thread that ends the
+    PROCESS -- message on stderr, an error JSON line on rank 0, exit code 3 -- when the main thread has not reported progress
+    for `seconds`.  A collective that never returns cannot be recovered from inside the process that is stuck in it; what can
+    be done is to stop within a bounded time, say where, and leave the GPU free (a job that hangs until the driver's own
+    limit is a strike against the box).  `beat(phase)` after every phase that contains a collective."""
+
+    def __init__(self, seconds, rank=0, enabled=True):
+        import threading
+        self.seconds, self.rank = float(seconds), rank
+        self.phase, self.last = "start", time.monotonic()
+        self._stop = threading.Event()
+        self.thread = None
+        if enabled and self.seconds > 0:
+            self.thread = threading.Thread(target=self._watch, daemon=True)
+            self.thread.start()
+
+    def beat(self, phase):
+        self.phase, self.last = phase, time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        while not self._stop.wait(min(1.0, self.seconds / 4)):
+            idle = time.monotonic() - self.last
+            if idle > self.seconds:
+                msg = (f"watchdog: rank {self.rank} made no progress for {idle:.0f} s in phase '{self.phase}' "
+                       f"(limit SRH_BENCH_WATCHDOG_S = {self.seconds:.0f} s) -- a collective or a captured graph around one "
+                       f"did not return; rerun with SRH_SHARDED_GRAPH=0 (eager launches) or SRH_SHARD_LAYOUT=rows|cols to "
+                       f"narrow it down")
+                print(f"[bench] {msg}", file=sys.stderr, flush=True)
+                if self.rank == 0:
+                    print(json.dumps({"error": msg, "phase": self.phase}), flush=True)
+                os._exit(3)
+
+
+class Runner:
+    """A trainer driven the way a training run drives it: the host samples epoch e + 1 on a worker thread while the device
+    works on epoch e; an epoch boundary = hand-over of the sampled arrays + a 25 MB index upload."""
+
+    def __init__(self, trainer, seed, dist=None, watchdog=None):
+        from selfrec_amd.engine import EpochPrefetcher
+        self.trainer, self.dist, self.watchdog = trainer, dist, watchdog
+        trainer.seed_sampler(seed)                 # (data parallel: seed + rank -- every rank its own batches)
+        self.pre = EpochPrefetcher(trainer)
+        self.pre.start()
+        self.left, self.uploads = 0, 0
+
+    def run(self, n_steps):
+        done = 0
+        while done < n_steps:
+            if self.left == 0:
+                self.uploads += 1
+                self.trainer.upload_epoch(self.pre.take())
+                self.pre.start()                       # host samples the next epoch while this one runs
+                self.left = self.trainer.epoch_batches
+            take = min(self.left, n_steps - done)
+            for _ in range(take):
+                self.trainer.step()
+            self.left -= take
+            done += take
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(self, n_steps, phase):
+        """(seconds, epoch boundaries inside) of exactly n_steps steps between two fences; the MAX over the ranks."""
+        self.fence()
+        up0 = self.uploads
+        t0 = time.perf_counter()
+        self.run(n_steps)
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if self.watchdog is not None:
+            self.watchdog.beat(phase)
+        return dt, self.uploads - up0
+
+
+def first_steps_guarded(make_trainer, runner_of, watchdog, what):
+    """The first steps of a multi-rank trainer (capture of the two graphs around the collective, the first replays): if
+    they RAISE -- an RCCL timeout, a capture error next to a live communicator, the engine's replay-vs-eager check -- fall
+    back to eager launches ONCE; a second failure ends the run with exit code 4 and the message.  (A hang that raises
+    nothing is the watchdog's.)  Returns (trainer, runner, note)."""
+    note = None
+    for attempt in (0, 1):
+        trainer = make_trainer(eager=attempt == 1)
+        runner = runner_of(trainer)
+        try:
+            runner.run(2)
+            runner.fence()
+            if watchdog is not None:
+                watchdog.beat(f"{what}: first steps")
+            return trainer, runner, note
+        except (RuntimeError, ValueError) as e:
+            note = f"{what}: {type(e).__name__} in the first steps ({str(e)[:300]})"
+            print(f"[bench] {note}; " + ("falling back to eager launches once" if attempt == 0 else "giving up"),
+                  file=sys.stderr, flush=True)
+            if attempt == 1:
+                if int(os.environ.get("RANK", "0")) == 0:
+                    print(json.dumps({"error": note}), flush=True)
+                os._exit(4)
+    raise AssertionError("unreachable")
+
+
+def spmm_roofline(args, trainer, sharded, dp, step_s, g):
+    """The roofline block of one trainer: its dominant propagation launch against HBM on algorithmic bytes,
+    the counters' traffic where a PMC pass of this kernel source is committed, and the bare gather stream on the live
+    graph's column array (ops.gather_floor_probe) -- the floor of the vector-memory path for the launch's row fetches."""
+    from selfrec_amd import ops
+    t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
+    if not t_spmm:
+        return None
+    alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
+    # the dominant launch: the value-free dense product when the engine uses it (2L - 3 of the 2L launches of a
+    # step), else the dense product with values.  Algorithmic bytes stay SURVEY 8(d)'s CSR figure either way.
+    dom = "dense_value_free" if "dense_value_free" in t_spmm else "dense"
+    t_spmm["dominant"] = t_spmm[dom]
+    ach = alg / t_spmm[dom] / 1e9
+    cols = bool(getattr(trainer, "cols", False))
+    if not sharded or dp:              # (data parallel: every rank runs the single-GPU launch)
+        traffic, traffic_note = pmc_traffic(args)
+    elif cols and trainer.w != args.emb:
+        traffic, traffic_note = pmc_traffic_cols(args, trainer.w)
+    else:
+        traffic, traffic_note = None, "PMC passes exist for the unsharded and the column-sharded launches only"
+    floor = None
+    if trainer.w in (64, 128, 256):
+        try:
+            floor_us = ops.gather_floor_probe(trainer.adj.indices, trainer.E0)
+            floor = {"gather_floor_us": round(floor_us, 2),
+                     "gather_floor_what": (f"srh_gather_floor_probe: the {trainer.adj.nnz} row fetches of one launch "
+                                           f"({trainer.adj.nnz * trainer.w * 4 / 1e6:.0f} MB through the vector-memory path) "
+                                           "over the live graph's CSR column array, 8 in flight per row-group, no values / "
+                                           "epilogue / output; HIP events, 30 passes"),
+                     "gather_floor_TBps": round(trainer.adj.nnz * trainer.w * 4 / (floor_us * 1e-6) / 1e12, 2),
+                     "launch_over_gather_floor": round(t_spmm[dom] * 1e6 / floor_us, 3),
+                     "frac_of_attainable": round(floor_us / (t_spmm[dom] * 1e6), 4)}
+        except Exception as e:          # (a footnote never costs the line)
+            floor = {"gather_floor_us": None, "gather_floor_error": f"{type(e).__name__}: {e}"}
+    step_bytes = step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch)
+    return {"bound": "hbm",
+            "kernel": (f"{slice_kernel_name(trainer.w)} "
+                       f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
+                       f"{args.emb} columns, perturb epilogue)") if cols else
+                      (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
+                       f"{'the rows of one rank of the' if sharded and not dp else 'the whole'} graph, "
+                       "perturb epilogue; split rows finished in-kernel"
+                       + ("; value-free form: pattern of A over a table pre-scaled by D^-1/2, row scale in "
+                          "the epilogue" if "dense_value_free" in t_spmm else "") + ")"),
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            **(floor or {}),
+            "measured_stream_GBps": stream_bandwidth(trainer.dev),
+            "traffic_source": traffic_note,
+            "traffic_GBps": round(traffic / t_spmm["dominant"] / 1e9, 1) if traffic else None,
+            "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dominant"] * 1e6, 2),
+            # ADVICE r02: the value-free launch streams no value array -- the same launch priced by the
+            # bytes ITS formulation has to move (indices + indptr + D^-1/2 + x + y), next to SURVEY
+            # 8(d)'s figure for the problem (CSR with values) that `achieved` / `frac` use
+            **({"value_free_byte_model": {
+                "bytes_per_launch": alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4,
+                "achieved": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9, 1),
+                "frac": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9 / HBM_PEAK_GBS, 4)}}
+               if dom == "dense_value_free" else {}),
+            "with_values": ({"launch_us": round(t_spmm["dense"] * 1e6, 2),
+                             "achieved": round(alg / t_spmm["dense"] / 1e9, 1),
+                             "frac": round(alg / t_spmm["dense"] / 1e9 / HBM_PEAK_GBS, 4)}
+                            if "dense" in t_spmm else None),
+            "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
+            "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
+                    "launch_us_by_flavour.step_mix (profiles/)",
+            "step_alg_bytes": step_bytes, "step_GBps": round(step_bytes / step_s / 1e9, 1)}
+
+
+def steady_state(runner, step_s, pairs_per_step):
+    """>= 2 epochs (>= 1 epoch boundary: sampler hand-over + 25 MB index upload inside the region) and >= 0.6 s of
+    device time, whatever --steps the driver passed.  SURVEY.md 8(d): sampling and the index upload are INSIDE the metric."""
+    tr = runner.trainer
+    n = max(2 * tr.epoch_batches, int(0.6 / step_s))
+    if n * step_s > 30.0:          # (the 1 M x 500 k shape: an epoch is 19,657 steps of 25 ms -- bounded instead)
+        n = max(20, int(5.0 / step_s))
+    dt, bounds = runner.timed(n, "steady state")
+    return {"steps": n, "seconds": round(dt, 4), "ms_per_step": round(dt / n * 1e3, 4),
+            "pairs_per_s": round(n * pairs_per_step / dt, 1), "epoch_boundaries_inside": bounds}
 
 
 def main():
@@ -505,107 +745,105 @@ def main():
     # the point is that every line of the N > 1 path has run with N > 1 (tools/gpu_session.sh stage benchworld2)
     backend = os.environ.get("SRH_DIST_BACKEND", "nccl")
     shared_device = backend == "gloo:device"
+    wd_seconds = float(os.environ.get("SRH_BENCH_WATCHDOG_S", "240"))
+    import datetime
+    coll_timeout = datetime.timedelta(seconds=max(30.0, wd_seconds))
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                # (one process standing in for a job: SRH_FORCE_SHARDED)
+            os.environ["MASTER_PORT"] = str(free_port())
     if sharded and backend not in ("nccl", "gloo:device"):
         # launch-path check without GPUs (tests/test_dist_cpu.py): rendezvous, one collective, the layout this world
         # size would take -- then stop; everything after this point needs the HIP library and a device
         import torch.distributed as dist
         from selfrec_amd.dist import describe_layout
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=coll_timeout)
+        wd = Watchdog(wd_seconds, rank)
+        if os.environ.get("SRH_BENCH_TEST_STALL"):          # (tests/test_dist_cpu.py: the watchdog's exit path)
+            time.sleep(float(os.environ["SRH_BENCH_TEST_STALL"]))
         t = torch.tensor([rank + 1.0])
         dist.all_reduce(t)
+        wd.beat("launch check")
         if rank == 0:
+            strong = os.environ.get("SRH_STRONG_LAYOUT") or None
             print(json.dumps({"launch_check": True, "backend": backend, "world": world, "rank_sum": float(t.item()),
+                              "master_port": int(os.environ["MASTER_PORT"]),
                               "parallelism": describe_layout(args.emb, world, os.environ.get("SRH_SHARD_LAYOUT") or
-                                                             ("dp" if args.shape != "1m-500k" else None))}), flush=True)
+                                                             ("dp" if args.shape != "1m-500k" else None)),
+                              "strong_parallelism": describe_layout(args.emb, world, strong)}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
+        wd.stop()
         return
+    refuse_gpu_count(world, backend)
     from selfrec_amd import _lib
     _lib.require_gpu()
     if shared_device:
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    watchdog = None
     if sharded:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         if shared_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=coll_timeout)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=coll_timeout)
+        watchdog = Watchdog(wd_seconds, rank, enabled=world > 1)
     else:
         dist = None
 
     data, raw = build_data(args.shape, args.seed)
-    torch.manual_seed(args.seed)
+    if watchdog is not None:
+        watchdog.beat("data built")
+    nnz_adj = 2 * data.interaction_mat.nnz
     kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
-              layer_cl=1, batch_size=args.batch, use_graph=not args.no_graph)
+              layer_cl=1, batch_size=args.batch)
+
+    def make(layout):
+        """a trainer of this layout on the SAME initial tables (torch.manual_seed before every construction)"""
+        def build(eager=False):
+            torch.manual_seed(args.seed)
+            use_graph = not args.no_graph and not eager
+            if layout is False:
+                from selfrec_amd.engine import FusedTrainer
+                return FusedTrainer(data, args.emb, use_graph=use_graph, **kw)
+            from selfrec_amd.dist import ShardedTrainer
+            return ShardedTrainer(data, args.emb, layout=layout, use_graph=use_graph, **kw)
+        return build
+
+    notes = []
     if sharded:
-        from selfrec_amd.dist import ShardedTrainer
-        # N > 1 on a graph this small: data parallel (every rank its own batches, one all-reduce of the dense gradient per
-        # step: weak scaling, global batch N x B) unless SRH_SHARD_LAYOUT asks for a strong-scaling layout of ONE batch;
-        # gather-bound graphs take pick_layout's choice (2-D grid / column blocks)
-        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if default_layout_is_dp(2 * data.interaction_mat.nnz) else None)
-        trainer = ShardedTrainer(data, args.emb, layout=layout, **kw)
+        # N > 1 on a graph this small: the headline is data parallel (every rank its own batches, one all-reduce of the
+        # dense gradient per step: weak scaling, global batch N x B) unless SRH_SHARD_LAYOUT asks for a strong-scaling
+        # layout of ONE batch; gather-bound graphs take pick_layout's choice (2-D grid / column blocks).  The line ALSO
+        # carries a `strong` record: a layout that divides one batch of B pairs over the ranks (north_star's partition).
+        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if default_layout_is_dp(nnz_adj) else None)
+        trainer, runner, note = first_steps_guarded(make(layout), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
+                                                    f"layout {layout or 'auto'}")
+        if note:
+            notes.append(note)
     else:
-        from selfrec_amd.engine import FusedTrainer
-        trainer = FusedTrainer(data, args.emb, **kw)
-    from selfrec_amd.engine import EpochPrefetcher
-    trainer.seed_sampler(args.seed)                 # (data parallel: seed + rank -- every rank its own batches)
-    pre = EpochPrefetcher(trainer)
-    pre.start()
+        trainer = make(False)()
+        runner = Runner(trainer, args.seed, None, None)
 
-    state = {"left": 0}
-
-    def run(n_steps):
-        done = 0
-        while done < n_steps:
-            if state["left"] == 0:
-                state["uploads"] = state.get("uploads", 0) + 1
-                trainer.upload_epoch(pre.take())
-                pre.start()                       # host samples the next epoch while this one runs
-                state["left"] = trainer.epoch_batches
-            take = min(state["left"], n_steps - done)
-            for _ in range(take):
-                trainer.step()
-            state["left"] -= take
-            done += take
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    state["uploads"] = 0
-    run(args.warmup)
-    fence()
-    uploads0 = state["uploads"]
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    epochs_in_region = state["uploads"] - uploads0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    runner.run(args.warmup)
+    elapsed, epochs_in_region = runner.timed(args.steps, "timed region")
     losses = trainer.read_losses()
 
     # rows / cols / 2-D: the global batch is fixed at B pairs per step for every N (strong scaling).  Data parallel: every
     # rank trains on its own B pairs per step (weak scaling): N x B pairs per step.
     dp = bool(getattr(trainer, "dp", False))
-    if sharded:
+
+    def parallelism_of(tr):
         from selfrec_amd.dist import describe_layout
-        layout = (describe_layout(args.emb, world, str(trainer.layout) if (world > 1 or trainer.dp) else
-                                  ("cols" if trainer.cols else "rows"), 2 * trainer.graph.n_edges)
-                  + (f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU" if not shared_device
-                     else f"; TEST MODE gloo:device -- {dist.get_world_size()} ranks sharing {torch.cuda.device_count()} GPU(s): "
-                          "the figures of this line are not measurements"))
-    pairs = args.steps * args.batch * (world if dp else 1)
-    value = pairs / elapsed
+        return (describe_layout(args.emb, world, str(tr.layout) if (world > 1 or tr.dp) else
+                                ("cols" if tr.cols else "rows"), 2 * tr.graph.n_edges)
+                + (f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU" if not shared_device
+                   else f"; TEST MODE gloo:device -- {dist.get_world_size()} ranks sharing {torch.cuda.device_count()} GPU(s): "
+                        "the figures of this line are not measurements"))
+    pairs_per_step = args.batch * (world if dp else 1)
+    value = args.steps * pairs_per_step / elapsed
     g = trainer.graph
     out = {
         "metric": f"train pairs/sec ({args.model}, {'Yelp2018' if args.shape == 'yelp2018' else args.shape}-shape)",
@@ -625,8 +863,9 @@ def main():
                                f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
                                f"d={args.emb}, B={args.batch}, Adam lr=1e-3; epochs are sampled by a host thread one epoch ahead and "
                                f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
-                               f"(see steady_state for a region that always spans >= 1)",
-                   "global_batch": args.batch * (world if dp else 1), "parallelism": layout if sharded else "single",
+                               f"(value_steady_state is the same quantity over a region that always spans >= 1)",
+                   "global_batch": pairs_per_step, "parallelism": parallelism_of(trainer) if sharded else "single",
+                   "rccl_ranks": (dist.get_world_size() if sharded and not shared_device else None),
                    "launch": "hipGraph replay" if trainer.use_graph else "eager",
                    # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration
                    # (engine._calibrate_xcd_shares; null: equal dealing)
@@ -634,107 +873,100 @@ def main():
                                   else [int(v) for v in trainer.xcd_shares])},
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
-    # ---- steady state: >= 2 epochs (>= 1 epoch boundary: sampler hand-over + 25 MB index upload inside the region)
-    # and >= 0.6 s of device time, whatever --steps the driver passed
+    if notes:
+        out["notes"] = notes
     step_s = max(elapsed / args.steps, 1e-6)
-    ss_steps = max(2 * trainer.epoch_batches, int(0.6 / step_s))
-    if ss_steps * step_s > 30.0:          # (the 1 M x 500 k shape: an epoch is 19,657 steps of 25 ms -- bounded instead)
-        ss_steps = max(20, int(5.0 / step_s))
-    uploads0 = state["uploads"]
-    fence()
-    t0 = time.perf_counter()
-    run(ss_steps)
-    fence()
-    ss = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([ss], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ss = float(t.item())
-    out["steady_state"] = {"steps": ss_steps, "seconds": round(ss, 4), "ms_per_step": round(ss / ss_steps * 1e3, 4),
-                           "pairs_per_s": round(ss_steps * args.batch * (world if dp else 1) / ss, 1),
-                           "epoch_boundaries_inside": state["uploads"] - uploads0}
+    out["steady_state"] = steady_state(runner, step_s, pairs_per_step)
+    # SURVEY.md 8(d) puts sampling and the index upload inside the metric: `value` times exactly --steps steps (the driver's
+    # contract; a short region holds no epoch boundary), value_steady_state is the same quantity with >= 1 boundary inside
+    out["value_steady_state"] = out["steady_state"]["pairs_per_s"]
+    out["ms_per_step_steady_state"] = out["steady_state"]["ms_per_step"]
     if not sharded and args.model in ("XSimGCL", "SimGCL", "SGL"):
         # the same step with InfoNCE's products on the exact-f32 MFMA path (re-captured graph)
-        from selfrec_amd import ops as _ops
-        _ops.set_infonce_precision("f32")
-        trainer.reset_graph()
-        run(20); fence()
-        t0 = time.perf_counter(); run(300); fence()
+        trainer.set_nce_precision("f32")
+        runner.run(20); runner.fence()
+        t0 = time.perf_counter(); runner.run(300); runner.fence()
         out["ms_per_step_nce_f32"] = round((time.perf_counter() - t0) / 300 * 1e3, 4)
-        _ops.set_infonce_precision("split")
-        trainer.reset_graph()
-        run(5); fence()
+        trainer.set_nce_precision("split")
+        runner.run(5); runner.fence()
     if rank == 0:
         try:
-            t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
+            roof = spmm_roofline(args, trainer, sharded, dp, step_s, g)
         except RuntimeError as e:             # (never lose a multi-GPU line to its footnotes)
             if not sharded:
                 raise
-            t_spmm, out["roofline"] = None, {"error": str(e)}
-        if t_spmm:
-            alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
-            # the dominant launch: the value-free dense product when the engine uses it (2L - 3 of the 2L launches of a
-            # step), else the dense product with values.  Algorithmic bytes stay SURVEY 8(d)'s CSR figure either way.
-            dom = "dense_value_free" if "dense_value_free" in t_spmm else "dense"
-            t_spmm["dominant"] = t_spmm[dom]
-            ach = alg / t_spmm[dom] / 1e9
-            if not sharded or dp:              # (data parallel: every rank runs the single-GPU launch)
-                traffic, traffic_note = pmc_traffic(args)
-            elif getattr(trainer, "cols", False) and trainer.w != args.emb:
-                traffic, traffic_note = pmc_traffic_cols(args, trainer.w)
-            else:
-                traffic, traffic_note = None, "PMC passes exist for the unsharded and the column-sharded launches only"
-            out["roofline"] = {"bound": "hbm",
-                               "kernel": (f"{slice_kernel_name(trainer.w)} "
-                                          f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
-                                          f"{args.emb} columns, perturb epilogue)") if getattr(trainer, "cols", False) else
-                                         (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
-                                          f"{'the rows of one rank of the' if sharded and not dp else 'the whole'} graph, "
-                                          "perturb epilogue; split rows finished in-kernel"
-                                          + ("; value-free form: pattern of A over a table pre-scaled by D^-1/2, row scale in "
-                                             "the epilogue" if "dense_value_free" in t_spmm else "") + ")"),
-                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "measured_stream_GBps": stream_bandwidth(trainer.dev),
-                               "traffic_source": traffic_note,
-                               "traffic_GBps": round(traffic / t_spmm["dominant"] / 1e9, 1) if traffic else None,
-                               "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dominant"] * 1e6, 2),
-                               # the value-free launch streams no value array -- the same launch priced by the
-                               # bytes ITS formulation has to move (indices + indptr + D^-1/2 + x + y), next to SURVEY
-                               # 8(d)'s figure for the problem (CSR with values) that `achieved` / `frac` use
-                               **({"value_free_byte_model": {
-                                   "bytes_per_launch": alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4,
-                                   "achieved": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9, 1),
-                                   "frac": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9 / HBM_PEAK_GBS, 4)}}
-                                  if dom == "dense_value_free" else {}),
-                               "with_values": ({"launch_us": round(t_spmm["dense"] * 1e6, 2),
-                                                "achieved": round(alg / t_spmm["dense"] / 1e9, 1),
-                                                "frac": round(alg / t_spmm["dense"] / 1e9 / HBM_PEAK_GBS, 4)}
-                                               if "dense" in t_spmm else None),
-                               "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
-                               "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
-                                       "launch_us_by_flavour.step_mix (profiles/)",
-                               "step_alg_bytes": step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch),
-                               "step_GBps": round(step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch)
-                                                  / (elapsed / args.steps) / 1e9, 1)}
-        if not args.no_eval and not sharded and len(raw[0]) <= 5_000_000:
+            roof = {"error": str(e)}
+        if roof:
+            out["roofline"] = roof
+    if watchdog is not None:
+        watchdog.beat("roofline")
+
+    # ---- N > 1: the strong-scaling record -- ONE batch of B pairs divided over the ranks (north_star / SURVEY 8e: tables
+    # and graph sharded, the global batch fixed), next to the data-parallel headline.  Column blocks where d / N is a
+    # width the kernels serve (one all-gather of the batch rows per step), else row blocks (an all-gather per product).
+    if sharded and dp and os.environ.get("SRH_STRONG_RECORD", "1") != "0":
+        dist.barrier()
+        strong_layout = os.environ.get("SRH_STRONG_LAYOUT") or None        # None: pick_layout's cols / rows / 2-D choice
+        try:
+            from selfrec_amd.dist import pick_layout
+            chosen = pick_layout(args.emb, world, strong_layout, nnz_adj)
+            s_tr, s_run, s_note = first_steps_guarded(make(chosen), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
+                                                      f"strong layout {chosen}")
+            s_run.run(args.warmup)
+            s_dt, s_bounds = s_run.timed(args.steps, "strong timed region")
+            s_step = max(s_dt / args.steps, 1e-6)
+            rec = {"layout": chosen, "scaling": "strong", "global_batch": args.batch,
+                   "value": round(args.steps * args.batch / s_dt, 1), "unit": "pairs/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(s_step * 1e3, 4),
+                   "epoch_boundaries_inside": s_bounds, "parallelism": parallelism_of(s_tr),
+                   "rccl_ranks": dist.get_world_size() if not shared_device else None,
+                   "launch": "hipGraph replay" if s_tr.use_graph else "eager",
+                   "steady_state": steady_state(s_run, s_step, args.batch)}
+            if s_note:
+                rec["note"] = s_note
+            if rank == 0:
+                try:
+                    rec["roofline"] = spmm_roofline(args, s_tr, True, False, s_step, s_tr.graph)
+                except RuntimeError as e:
+                    rec["roofline"] = {"error": str(e)}
+            out["strong"] = rec
+            del s_tr, s_run
+        except Exception as e:                    # (never lose the headline to its companion record)
+            out["strong"] = {"error": f"{type(e).__name__}: {e}"}
+        if watchdog is not None:
+            watchdog.beat("strong record")
+        dist.barrier()
+
+    if rank == 0:
+        small = len(raw[0]) <= 5_000_000
+        if not args.no_eval and not sharded and small:
             out["eval"] = eval_throughput(trainer, data)
-        if not sharded and not args.no_dropin and args.model == "XSimGCL" and len(raw[0]) <= 5_000_000:
+        if not sharded and not args.no_dropin and args.model == "XSimGCL" and small:
             out["dropin"] = dropin_throughput(args, raw)
             out["dropin_pairs_per_s"] = out["dropin"]["pairs_per_s"]
             out["dropin_fused"] = dropin_fused_throughput(args, raw)
             out["dropin_fused_pairs_per_s"] = out["dropin_fused"]["pairs_per_s"]
-        if not sharded and not args.no_cpu_baseline and len(raw[0]) > 5_000_000:
+        # the CPU baseline rides on rank 0 at every N (the other ranks wait at the barrier below: ~15 s)
+        if not args.no_cpu_baseline and not small:
             out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "kind": "port", "cores": torch.get_num_threads(),
                                    "sample": "not run at this shape: the reference's step needs ~25 GB of python objects and "
                                              "~10 min per step here (tests/golden/make_golden_shapes.py section B ran it once: "
                                              "216 s for one step on 8 threads = 9.5 pairs/s)"}
-        elif not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, raw, args.cpu_seconds)
+        elif not args.no_cpu_baseline:
+            if watchdog is not None:
+                watchdog.beat("cpu baseline (rank 0 alone)")
+            out["cpu_baseline"] = cpu_baseline(args, raw, min(args.cpu_seconds, max(5.0, wd_seconds / 4)) if sharded
+                                               else args.cpu_seconds)
+            if "strong" in out and "error" not in out["strong"]:
+                out["strong"]["cpu_baseline"] = out["cpu_baseline"]
             if out.get("eval"):
                 out["eval"]["cpu_baseline"] = eval_cpu_baseline(trainer, data)
+    if watchdog is not None:
+        watchdog.beat("cpu baseline")
     if dist is not None:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.beat("after baseline barrier")
         if not args.no_eval:
             try:
                 ev = eval_throughput_sharded(trainer, data, dist, rank, world)      # every rank takes part
@@ -744,6 +976,8 @@ def main():
                 out["eval"] = ev
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.stop()
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)        # RCCL's banner goes through C stdio: keep the JSON line last

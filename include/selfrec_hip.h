@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 22
+#define SRH_ABI_VERSION 23
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -323,21 +323,25 @@ typedef struct srh_infonce_problem {
                            contrast-layer gradient table of XSimGCL: user-side and item-side problems name disjoint rows):
                            plain read-add-store instead of 4 device-scope atomics per lane */
 } srh_infonce_problem_t;
+/* precision: SRH_NCE_SPLIT16 / SRH_NCE_F32 for THIS call, or SRH_NCE_DEFAULT (the process default below). */
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems,
                                        int32_t d, float tau, float loss_scale, double* d_loss,
-                                       void* d_ws, void* stream);
+                                       void* d_ws, int32_t precision, void* stream);
 
 /* Arithmetic of InfoNCE's two n x n x d products (util/loss_torch.py:46-47's matmul and its backward).  The
  * reference computes them in fp32.  Default (SRH_NCE_SPLIT16): operands carried as short sums of 16-bit pieces on the
  * 16-bit MFMA pipe with f32 accumulation -- the similarity product on scaled f16 hi + lo (x to 2^-22: logits as accurate
  * as an f32 dot product, the loss to f32 rounding), the P.V product on bf16 hi + mid (2^-18 per product; gradients within
  * 1e-6 relative of the f64 expression; the library can be built with SRH_NCE_PV_TERMS=6 for 2^-27).  SRH_NCE_F32
- * evaluates every multiply-add on the f32 MFMA at ~2.5x the time of the two passes.  Process-wide; the environment
- * variable SRH_NCE_F32 (set to anything) selects F32 as the initial mode.  (SRH_NCE_SPLIT_BF16: the mode's name in
+ * evaluates every multiply-add on the f32 MFMA at ~2.5x the time of the two passes.  The mode is an ARGUMENT of
+ * srh_infonce_fwd_bwd_multi / srh_bpr_infonce_fwd_bwd (a trainer carries its own: two models in one process do not share
+ * it); srh_infonce_set_precision sets the process DEFAULT that SRH_NCE_DEFAULT and srh_infonce_fwd_bwd resolve to, and the
+ * environment variable SRH_NCE_F32 (set to anything) selects F32 as its initial value.  (SRH_NCE_SPLIT_BF16: the mode's name in
  * ABI <= 20, when both products ran on bf16 hi + lo and the logits were good to 2e-5 only.) */
 #define SRH_NCE_SPLIT16 0
 #define SRH_NCE_SPLIT_BF16 SRH_NCE_SPLIT16
 #define SRH_NCE_F32 1
+#define SRH_NCE_DEFAULT (-1)
 srh_status_t srh_infonce_set_precision(int32_t mode);
 int32_t srh_infonce_get_precision(void);
 
@@ -368,7 +372,7 @@ typedef struct srh_bpr_problem {
 } srh_bpr_problem_t;
 srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* bpr, const srh_infonce_problem_t* problems,
                                      int32_t n_problems, int32_t d, float tau, float cl_scale,
-                                     double* d_cl_loss, void* d_nce_ws, void* stream);
+                                     double* d_cl_loss, void* d_nce_ws, int32_t precision, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-9) Dense Adam -- replaces torch.optim.Adam(...).step() at XSimGCL.py:25,37
@@ -508,6 +512,14 @@ srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t*
 srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals,
                                 const float* d_x, float* d_y, int32_t d, const srh_spmm_epilogue_t* epi,
                                 uint64_t* d_stamps, void* stream);
+/* The bare gather stream of a propagation launch, for the roofline block of bench.py (the step's dominant
+ * kernel is priced against HBM on ALGORITHMIC bytes; this probe says what the chip's vector-memory path needs for the row
+ * fetches alone).  Walks d_indices[0 .. n_idx) -- the live graph's CSR column array, as data/ui_graph.py:47-56 orders it --
+ * and fetches row d_indices[k] of the (n_x_rows, d) fp32 table d_x for every k, 8 fetches in flight per row-group, summing
+ * into registers: no values, no epilogue, no output (d_sink: 16 bytes, never written for finite tables).  `blocks`
+ * workgroups of 256 threads.  d = 64 / 128 / 256.  Replaces nothing in the reference: measurement only. */
+srh_status_t srh_gather_floor_probe(const int32_t* d_indices, int64_t n_idx, const float* d_x, int64_t n_x_rows, int32_t d,
+                                    int32_t blocks, float* d_sink, void* stream);
 /* Zero the listed rows of up to SRH_MAX_ZERO_LISTS (rows, d) tables in one launch: rows
  * d_idx[k][0 .. count_k) + row_offset[k] of d_tables[k], count_k = *d_counts[k] (or n_max[k] when
  * d_counts[k] is NULL).  The sparse counterpart of a memset for gradient buffers that only

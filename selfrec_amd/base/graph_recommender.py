@@ -31,6 +31,7 @@ SCORE_SLAB_BYTES = 96 << 20
 #  chunk x (sample + 2 cap) x 4 B = 400 MB at 16384.  A 2048- or 8192-item sample, or 512 slots, move it by < 3 %.)
 FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 16384
 DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered): k <= 128
+FILTER_WS_KEEP_BYTES = 1 << 30  # the filtered ranking's workspace is cached on the model up to this size
 
 
 class GraphRecommender(Recommender):
@@ -93,14 +94,36 @@ class GraphRecommender(Recommender):
         (tie-heavy scores) are re-ranked by the exact path.  Same ids and scores either way."""
         if ie.shape[0] < 4 * FILTER_SAMPLE_ITEMS:
             return self._rank_exact(ue, uid, ie, g, k)
-        ids, sc, counts, self._filter_ws = ops.score_mask_topk_filtered(
+        chunk = self._filter_chunk_rows(ie.device)
+        ws = getattr(self, '_filter_ws', None)
+        if ws is not None and getattr(self, '_filter_ws_chunk', chunk) != chunk:
+            ws = self._filter_ws = None
+        ids, sc, counts, ws = ops.score_mask_topk_filtered(
             ue, uid, ie, g.r_indptr, g.r_indices, k, sample_items=FILTER_SAMPLE_ITEMS, cap=FILTER_CAP,
-            chunk_rows=FILTER_CHUNK_ROWS, ws=getattr(self, '_filter_ws', None))
+            chunk_rows=chunk, ws=ws)
+        # the workspace stays with the model between evaluations only while it is small next to the device's memory: a large
+        # one (big catalogues, big chunks) would sit beside the training state for the whole run (ADVICE r03)
+        keep = ws is not None and ws.numel() * ws.element_size() <= FILTER_WS_KEEP_BYTES
+        self._filter_ws, self._filter_ws_chunk = (ws if keep else None), chunk
         redo = torch.nonzero(counts > FILTER_CAP).flatten()
         if redo.numel():
             ids_r, sc_r = self._rank_exact(ue, uid[redo].contiguous(), ie, g, k)
             ids[redo], sc[redo] = ids_r, sc_r
         return ids, sc
+
+    @staticmethod
+    def _filter_chunk_rows(device):
+        """Users per chunk of the filtered ranking: FILTER_CHUNK_ROWS, halved while the chunk's workspace -- chunk x (sample +
+        2 cap) x 4 B plus the split images -- would take more than 1/16 of the memory that is FREE on the device right
+        now (never below 2048: the launches stop filling the chip)."""
+        chunk = FILTER_CHUNK_ROWS
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+        except Exception:                                    # noqa: BLE001  (no such query: keep the measured default)
+            return chunk
+        while chunk > 2048 and chunk * (FILTER_SAMPLE_ITEMS + 2 * FILTER_CAP) * 4 > free // 16:
+            chunk //= 2
+        return chunk
 
     def rank_on_device(self, user_ids, k=None, with_hits=False, metric_cuts=None):
         """ids, scores (numpy, shape (len(user_ids), k)) for integer user ids; with_hits adds the uint8

@@ -239,7 +239,7 @@ constexpr int kNcePvTerms = SRH_NCE_PV_TERMS;
 // Arithmetic of the two n x n x d products (srh_infonce_set_precision): split 16-bit operands on the 16-bit MFMA pipe
 // (default: the similarity product on scaled f16 hi + lo -- logits to 2^-22, the accuracy of an f32 dot product -- the
 // P.V product on bf16 hi + mid [+ lo]) or exact f32 multiply-adds on the f32 MFMA (~2.5x the time of the two passes).
-// Process-wide, read at launch time.
+// The mode is an argument of the multi-problem entry points; this is the process DEFAULT (SRH_NCE_DEFAULT resolves to it).
 std::atomic<int> g_nce_precision{getenv("SRH_NCE_F32") ? SRH_NCE_F32 : SRH_NCE_SPLIT_BF16};
 
 struct NceWs {
@@ -596,7 +596,11 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
       atomic_add_row<LPR>(w.g2 + (size_t)dst * LPR * 4, dv2, sub, scr);
     }
   }
-  return (valid && sub == 0) ? (double)log1pf(l / eii) : 0.0;
+  // log(L) - (s_ii / tau - 1 / tau).  log1p(l / e_ii) is the cancellation-free form of it, but e_ii underflows once
+  // (1 - cos_ii) / tau > ~87 (below the tau >= 0.03 this entry accepts today: 2 / 0.03 = 67; kept for when that bound moves): there log(l) - (s_ii - 1 / tau) is exact to
+  // rounding (e_ii no longer reaches l's last bit) and stays finite, like the reference's log_softmax
+  const float li = (eii > 0.f && eii >= 1e-30f * l) ? log1pf(l / eii) : (logf(l) - (sii - a.inv_tau));
+  return (valid && sub == 0) ? (double)li : 0.0;
 }
 
 // LDS-staged form of nce_tile_bf16 (the default).  The register version is latency-bound: a workgroup's
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(256) void nce_finish_bpr2(NceBatch batch, NceFinish
 
 template <int D>
 srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float tau, float loss_scale, double* loss,
-                            void* ws, hipStream_t st, const BprArgs* bpr = nullptr) {
+                            void* ws, hipStream_t st, int precision, const BprArgs* bpr = nullptr) {
   constexpr int LPR = D / 4, G = 64 / LPR;
   NceBatch batch{};
   batch.count = count;
@@ -948,7 +952,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   SRH_LAUNCH_CHECK();
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
-  if (g_nce_precision.load(std::memory_order_relaxed) == SRH_NCE_SPLIT_BF16) {
+  if (precision == SRH_NCE_SPLIT16) {
     constexpr int kLds = nce_lds_bytes<D, kNcePvTerms>();
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, 1, 8, kNcePvTerms>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
@@ -1090,11 +1094,15 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
 }
 
 static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d, float tau,
-                                  float loss_scale, double* d_loss, void* d_ws, void* stream, const BprArgs* bpr) {
+                                  float loss_scale, double* d_loss, void* d_ws, int32_t precision, void* stream,
+                                  const BprArgs* bpr) {
+  SRH_REQUIRE(precision == SRH_NCE_DEFAULT || precision == SRH_NCE_SPLIT16 || precision == SRH_NCE_F32,
+              "infonce_fwd_bwd: unknown precision %d", precision);
+  if (precision == SRH_NCE_DEFAULT) precision = g_nce_precision.load(std::memory_order_relaxed);
   SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
   SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);
   SRH_REQUIRE(d == 64 || d == 128 || d == 256, "infonce_fwd_bwd: d=%d unsupported (need 64, 128 or 256)", d);
-  SRH_REQUIRE(d != 256 || g_nce_precision.load(std::memory_order_relaxed) != SRH_NCE_F32,
+  SRH_REQUIRE(d != 256 || precision != SRH_NCE_F32,
               "infonce_fwd_bwd: the all-f32 MFMA path serves d = 64 / 128 (d = 256: the split path only)");
   for (int k = 0; k < n_problems; ++k) {
     const srh_infonce_problem_t& p = problems[k];
@@ -1106,9 +1114,9 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
     return SRH_ERR_UNSUPPORTED;
   }
   hipStream_t st = srh::as_stream(stream);
-  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
-  if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
-  return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, bpr);
+  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
+  if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
+  return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
 }
 
 srh_status_t srh_infonce_set_precision(int32_t mode) {
@@ -1119,13 +1127,14 @@ srh_status_t srh_infonce_set_precision(int32_t mode) {
 int32_t srh_infonce_get_precision(void) { return g_nce_precision.load(std::memory_order_relaxed); }
 
 srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d,
-                                       float tau, float loss_scale, double* d_loss, void* d_ws, void* stream) {
-  return infonce_entry(problems, n_problems, d, tau, loss_scale, d_loss, d_ws, stream, nullptr);
+                                       float tau, float loss_scale, double* d_loss, void* d_ws, int32_t precision,
+                                       void* stream) {
+  return infonce_entry(problems, n_problems, d, tau, loss_scale, d_loss, d_ws, precision, stream, nullptr);
 }
 
 srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* b, const srh_infonce_problem_t* problems,
                                      int32_t n_problems, int32_t d, float tau, float cl_scale, double* d_cl_loss,
-                                     void* d_nce_ws, void* stream) {
+                                     void* d_nce_ws, int32_t precision, void* stream) {
   SRH_REQUIRE(b, "bpr_infonce_fwd_bwd: null bpr problem");
   SRH_REQUIRE(b->d_user && b->d_item && b->d_reg_user && b->d_reg_item && b->d_u_idx && b->d_i_idx && b->d_j_idx,
               "bpr_infonce_fwd_bwd: null input");
@@ -1136,14 +1145,14 @@ srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* b, const srh_infon
             (int)b->B, b->reg_coef, b->loss_scale, b->reg_include_neg, b->d_g_user, b->d_g_item, b->d_greg_user,
             b->d_greg_item, b->d_losses, reinterpret_cast<double*>(b->d_ws),
             reinterpret_cast<float*>(reinterpret_cast<char*>(b->d_ws) + bpr_part_bytes(b->B)), 0};
-  return infonce_entry(problems, n_problems, d, tau, cl_scale, d_cl_loss, d_nce_ws, stream, &a);
+  return infonce_entry(problems, n_problems, d, tau, cl_scale, d_cl_loss, d_nce_ws, precision, stream, &a);
 }
 
 srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,
                                  const int32_t* d_n, int32_t d, float tau, float loss_scale, double* d_loss,
                                  float* d_g1, float* d_g2, void* d_ws, void* stream) {
   srh_infonce_problem_t p{d_v1, d_v2, d_idx, n, d_n, d_g1, d_g2};
-  return srh_infonce_fwd_bwd_multi(&p, 1, d, tau, loss_scale, d_loss, d_ws, stream);
+  return srh_infonce_fwd_bwd_multi(&p, 1, d, tau, loss_scale, d_loss, d_ws, SRH_NCE_DEFAULT, stream);
 }
 
 }  // extern "C"

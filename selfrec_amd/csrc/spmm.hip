@@ -1211,6 +1211,43 @@ __global__ __launch_bounds__(256) void spmm_slice_kernel(const Task* __restrict_
   row_epilogue<LPR>(acc, row, sub, live, Y, ep);
 }
 
+// ---------------------------------------------------------------------------------------------
+// srh_gather_floor_probe: the bare gather stream of a product -- nothing else.  Every wave walks a strided share of an index
+// array 8 * G entries at a time (the next iteration's indices in flight under the current gathers), fetches the 4 * LPR-float
+// x row of each entry with 8 loads in flight per row-group and adds it into a register; no values, no row structure, no
+// epilogue, no y.  Run over the LIVE graph's CSR column array it times what the vector-memory path of this chip needs for the
+// row fetches one propagation launch makes: the floor bench.py prints as roofline.gather_floor_us next to the launch's own
+// time (the figure used to live in tools/microbench/gather_zipf.hip on a synthetic Zipf stream).
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_floor_kernel(const float4* __restrict__ X, const int32_t* __restrict__ idx,
+                                                           long n_idx, float4* __restrict__ sink) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const long wave = (blockIdx.x * 256L + threadIdx.x) >> 6, n_waves = gridDim.x * 4L;
+  float4 acc = f4_zero();
+  long base = wave * 8 * G;
+  int nxt[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) nxt[t] = (base + 8 * G <= n_idx) ? idx[base + t * G + g] : 0;
+  for (; base + 8 * G <= n_idx; base += n_waves * 8 * G) {
+    int cur[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+    const long nb = base + n_waves * 8 * G;
+    if (nb + 8 * G <= n_idx) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) nxt[t] = idx[nb + t * G + g];
+    }
+    float4 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = ld_x<LPR>(X, cur[t], sub);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = f4_add(acc, x[t]);
+  }
+  if (acc.x == 123.456f) sink[0] = acc;       // (never true on finite tables: keeps the loads alive)
+}
+
 }  // namespace
 
 struct srh_spmm_plan {
@@ -1536,6 +1573,22 @@ srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_in
   SRH_REQUIRE(d_stamps, "spmm_f32_probe: null stamp buffer");
   SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_f32_probe: d=%d unsupported (64, 128 or 256)", d);
   return spmm_launch(plan, d_indices, d_vals, d_x, d_y, d, epi, nullptr, reinterpret_cast<unsigned long long*>(d_stamps), stream);
+}
+
+srh_status_t srh_gather_floor_probe(const int32_t* d_indices, int64_t n_idx, const float* d_x, int64_t n_x_rows, int32_t d,
+                                    int32_t blocks, float* d_sink, void* stream) {
+  SRH_REQUIRE(d_indices && d_x && d_sink && n_idx > 0 && n_x_rows > 0, "gather_floor_probe: null / empty argument");
+  SRH_REQUIRE(d == 64 || d == 128 || d == 256, "gather_floor_probe: d=%d unsupported (64, 128 or 256)", d);
+  SRH_REQUIRE(n_x_rows * (int64_t)d * 4 < (int64_t(1) << 32), "gather_floor_probe: x must be smaller than 4 GiB");
+  SRH_REQUIRE(blocks > 0 && blocks <= (1 << 20), "gather_floor_probe: bad grid");
+  hipStream_t st = srh::as_stream(stream);
+  const float4* X = reinterpret_cast<const float4*>(d_x);
+  float4* sink = reinterpret_cast<float4*>(d_sink);
+  if (d == 64) gather_floor_kernel<16><<<blocks, 256, 0, st>>>(X, d_indices, (long)n_idx, sink);
+  else if (d == 128) gather_floor_kernel<32><<<blocks, 256, 0, st>>>(X, d_indices, (long)n_idx, sink);
+  else gather_floor_kernel<64><<<blocks, 256, 0, st>>>(X, d_indices, (long)n_idx, sink);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
 }
 
 int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d) {

@@ -206,7 +206,8 @@ def shard_adjacency(norm_adj_csr, rank, world):
 class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
-                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False, comm=None):
+                 noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False, comm=None,
+                 nce_precision=None):
         if model not in MODELS:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
         ops.require_gpu()
@@ -228,6 +229,11 @@ class FusedTrainer:
         self.layer_cl, self.drop_rate, self.aug_type = int(layer_cl), float(drop_rate), int(aug_type)
         self.B = int(batch_size)
         self.noise_fn = noise_fn                  # (N, d) -> tensor; None = in-kernel counter RNG
+        # arithmetic of InfoNCE's two n x n x d products, carried by THIS trainer and passed with every loss call ('split' |
+        # 'f32'; None = the process default of srh_infonce_set_precision / SRH_NCE_F32, resolved at launch / capture time)
+        if nce_precision is not None and nce_precision not in ops.NCE_PRECISIONS:
+            raise SelfrecHipError(f"FusedTrainer: nce_precision {nce_precision!r}: one of {sorted(ops.NCE_PRECISIONS)} or None")
+        self.nce_precision = nce_precision
         self.rng_seed = int(rng_seed)
         if model != "MF" and self.L < 1:
             raise SelfrecHipError("n_layers must be >= 1")
@@ -583,7 +589,14 @@ class FusedTrainer:
         self.sampler.seed(int(seed) + (self.rank if self.dp else 0))
 
     def seed_sampler_from_python(self):
-        """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it)."""
+        """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it).  Data parallel over more than
+        one rank has no reference stream to be exact to -- every rank needs ITS OWN batches -- so there one 63-bit draw of
+        the (replicated) global stream seeds the sampler, offset by the rank (adopting the state itself would
+        hand every rank the same batches)."""
+        if self.dp and self.G > 1:
+            import random
+            self.sampler.seed((random.getrandbits(63) + self.rank) & ((1 << 63) - 1))
+            return
         self.sampler.set_state_from_python()
 
     def sample_epoch_host(self):
@@ -940,7 +953,8 @@ class FusedTrainer:
                    g_user=GT(self.gF), g_item=GT(self.gF), greg_user=GT(greg_t), greg_item=GT(greg_t),
                    losses=self.losses[0:2])
         bpr_in = (T(F), T(F), T(reg_t), T(reg_t), ix["u"], ix["i"], ix["j"])
-        nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws)
+        nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws,
+                   precision=self.nce_precision)
         # ---- recommendation + contrastive loss (a-5..a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
@@ -1055,8 +1069,17 @@ class FusedTrainer:
 
     def reset_graph(self):
         """Forget the captured hipGraph (it is re-captured on the next step): needed after anything that changes which
-        kernels a step launches, e.g. ops.set_infonce_precision."""
+        kernels a step launches."""
         self._graph = None
+
+    def set_nce_precision(self, mode):
+        """'split' | 'f32' | None (the process default) for this trainer's InfoNCE products from the next step on; a captured
+        step is re-captured (it keeps the kernels it was captured with)."""
+        if mode is not None and mode not in ops.NCE_PRECISIONS:
+            raise SelfrecHipError(f"nce_precision {mode!r}: one of {sorted(ops.NCE_PRECISIONS)} or None")
+        if mode != self.nce_precision:
+            self.nce_precision = mode
+            self.reset_graph()
 
     def _capture(self):
         """Capture the step as hipGraph(s).  No destructor with a HIP call in it may run while a stream of this thread is
@@ -1111,6 +1134,42 @@ class FusedTrainer:
             with torch.cuda.graph(self._graph):
                 self._step_kernels()
         self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
+        if (self.cols or self.dp) and self.G > 1 and isinstance(self.comm, TorchComm) \
+                and os.environ.get("SRH_CAPTURE_CHECK", "1") != "0":
+            self._check_replay_against_eager(snapshot)
+
+    def _check_replay_against_eager(self, snapshot):
+        """Two graphs around a live collective have never met more than one real GPU (the one failure seen so far,
+        a collector-run destructor inside the capture window, left a graph whose FIRST replayed step was wrong): before the
+        graphs are trusted, one step is run eagerly and once more as a replay from the same state -- collective included,
+        same batch, same noise counters -- and the parameters must agree on every rank (the verdict is all-reduced, so the
+        ranks fall back together).  A mismatch raises; step_phases() then launches eagerly and says so."""
+        def restore():
+            self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
+        results = []
+        for replay in (False, True):
+            if self.cols:
+                phases = ((self._graph[0].replay, self._exchange, self._graph[1].replay) if replay
+                          else (self._step_front, self._exchange, self._step_back))
+            else:
+                def grad():
+                    self._step_front()
+                    self._step_grad()
+                phases = ((self._graph[0].replay, self._dp_allreduce, self._graph[1].replay) if replay
+                          else (grad, self._dp_allreduce, self._step_opt))
+            for ph in phases:
+                ph()
+            torch.cuda.synchronize()
+            results.append(self.E0.clone())
+            restore()
+        moved = (results[0] - snapshot[0]).abs().max().item()
+        diff = (results[0] - results[1]).abs().max().item()
+        ok = torch.tensor([1.0 if (diff <= 0.1 * self.lr and moved > 0.0) else 0.0], device=self.dev)
+        _dist.all_reduce(ok, op=_dist.ReduceOp.MIN, group=self.comm.group)
+        if ok.item() < 1.0:
+            self._graph = None
+            raise RuntimeError(f"captured step differs from the eager step on some rank (this rank {self.rank}: max |E0 eager - "
+                               f"E0 replay| = {diff:.3e}, one step moves E0 by {moved:.3e}, lr = {self.lr:g})")
 
     def read_losses(self):
         """(bpr, reg, cl) of the last step -- a device-to-host sync, call sparingly."""

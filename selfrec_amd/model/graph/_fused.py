@@ -38,23 +38,18 @@ class FusedGraphModel(GraphRecommender):
         # reference's torch.rand_like does
         seed = get('seed', None)
         rng_seed = (int(seed) if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
+        # "f32" | "split": the arithmetic of InfoNCE's two products belongs to THIS model's trainer and travels with every
+        # loss call (no process-wide state: a model neither inherits nor leaves behind another model's setting)
+        self.nce_precision = str(get('engine.nce_precision', 'split'))
         self.trainer = FusedTrainer(self.data, self.emb_size, model=self.engine_model, lr=self.lRate,
                                     reg=self.reg, batch_size=self.batch_size, rng_seed=rng_seed,
-                                    use_graph=_as_bool(get('engine.hipgraph', True)), **self.engine_kwargs())
+                                    use_graph=_as_bool(get('engine.hipgraph', True)), nce_precision=self.nce_precision,
+                                    **self.engine_kwargs())
         self.exact_sampling = _as_bool(get('sampler.python_state', True))
-        # "f32" | "split".  The library's setting is process-wide, so every model states its own -- the default
-        # included (a model must not inherit the arithmetic an earlier model in the process asked for) --
-        # and train() re-asserts it before the step is captured
-        self.nce_precision = str(get('engine.nce_precision', 'split'))
-        from ... import ops
-        ops.set_infonce_precision(self.nce_precision)
 
     def train(self):
         tr = self.trainer
-        from ... import ops
-        if ops.NCE_PRECISIONS[ops.get_infonce_precision()] != ops.NCE_PRECISIONS[self.nce_precision]:
-            ops.set_infonce_precision(self.nce_precision)
-            tr.reset_graph()                   # (a captured step keeps the kernels it was captured with)
+        tr.set_nce_precision(self.nce_precision)
         if self.exact_sampling:           # consume the global `random` stream like the reference
             tr.seed_sampler_from_python()
         else:

@@ -415,6 +415,28 @@ def spmm_probe(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor, epilogue: Spm
     return finish, begin, end, xcd
 
 
+def gather_floor_probe(indices: torch.Tensor, x: torch.Tensor, blocks: int = 4096, iters: int = 30) -> float:
+    """us per pass of the bare gather stream over `indices` into the (rows, d) table `x` (srh_gather_floor_probe: the row
+    fetches of one propagation launch and nothing else), HIP events on the launch stream.  Measurement only."""
+    d = int(x.shape[1])
+    sink = torch.zeros(4, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+
+    def once():
+        check(lib.srh_gather_floor_probe(_p(indices, torch.int32, "indices"), int(indices.numel()), _p(x, torch.float32, "x"),
+                                         int(x.shape[0]), d, int(blocks), sink.data_ptr(), _stream()), "srh_gather_floor_probe")
+    for _ in range(5):
+        once()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        once()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
 def adj_sym_normalize(indptr, indices, edge_id, keep, n_rows: int, weight=None, out=None, deg_ws=None,
                       inv_sqrt_table=None, row_offset: int = 0, phase: int = 0):
     dev = indices.device
@@ -481,12 +503,23 @@ def sumsq(x, out):
 
 # SRH_NCE_SPLIT16, SRH_NCE_F32 (include/selfrec_hip.h); "bf16x3" is the round-1/2 name of the split mode, kept as an alias
 NCE_PRECISIONS = {"split": 0, "f32": 1, "bf16x3": 0}
+NCE_DEFAULT = -1               # SRH_NCE_DEFAULT: the process default (srh_infonce_set_precision / SRH_NCE_F32)
+
+
+def _nce_mode(precision):
+    """None -> the process default; 'split' | 'f32' -> that arithmetic for this call only."""
+    if precision is None:
+        return NCE_DEFAULT
+    if precision not in NCE_PRECISIONS:
+        raise SelfrecHipError(f"InfoNCE precision {precision!r}: one of {sorted(NCE_PRECISIONS)}")
+    return NCE_PRECISIONS[precision]
 
 
 def set_infonce_precision(mode: str):
     """'split' (default: operands as short sums of 16-bit pieces on the 16-bit MFMA pipe -- logits on scaled f16 hi + lo,
     accurate to 2^-22 like an f32 dot product; P.V on bf16 pieces) or 'f32' (every multiply-add on the f32 MFMA).
-    Process-wide; a step already captured in a hipGraph keeps the kernels it was captured with."""
+    The process DEFAULT: what calls that name no precision run on (the loss mirrors of the op-level tier); a trainer
+    carries its own mode and passes it with every call (engine.FusedTrainer.nce_precision)."""
     if mode not in NCE_PRECISIONS:
         raise SelfrecHipError(f"InfoNCE precision {mode!r}: one of {sorted(NCE_PRECISIONS)}")
     check(_lib.load().srh_infonce_set_precision(NCE_PRECISIONS[mode]), "srh_infonce_set_precision")
@@ -512,7 +545,7 @@ def infonce_fwd_bwd(v1, v2, idx, n, *, n_dev=None, tau, loss_scale, loss, g1, g2
                                           _p(ws), _stream()), "srh_infonce_fwd_bwd")
 
 
-def infonce_multi(problems, *, d, tau, loss_scale, loss, ws):
+def infonce_multi(problems, *, d, tau, loss_scale, loss, ws, precision=None):
     """problems: [(v1, v2, idx, n_max, n_dev, g1, g2[, g2_exclusive]), ...] evaluated by one set of launches."""
     lib = _lib.load()
     arr = (_lib.InfonceProblem * len(problems))()
@@ -526,12 +559,13 @@ def infonce_multi(problems, *, d, tau, loss_scale, loss, ws):
     if ws.numel() * ws.element_size() < need:
         raise SelfrecHipError(f"infonce workspace too small: {ws.numel() * ws.element_size()} < {need}")
     check(lib.srh_infonce_fwd_bwd_multi(arr, len(problems), int(d), float(tau), float(loss_scale),
-                                        _p(loss, torch.float64), _p(ws), _stream()), "srh_infonce_fwd_bwd_multi")
+                                        _p(loss, torch.float64), _p(ws), _nce_mode(precision), _stream()),
+          "srh_infonce_fwd_bwd_multi")
 
 
 def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
                 reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws,
-                problems, tau, cl_scale, cl_loss, nce_ws):
+                problems, tau, cl_scale, cl_loss, nce_ws, precision=None):
     """bpr_l2_fwd_bwd + infonce_multi with their O(batch) kernels sharing launches (srh_bpr_infonce_fwd_bwd)."""
     lib = _lib.load()
     d = int(user.shape[1])
@@ -555,7 +589,8 @@ def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n
     if nce_ws.numel() * nce_ws.element_size() < need:
         raise SelfrecHipError(f"infonce workspace too small: {nce_ws.numel() * nce_ws.element_size()} < {need}")
     check(lib.srh_bpr_infonce_fwd_bwd(C.byref(b), arr, len(problems), d, float(tau), float(cl_scale),
-                                      _p(cl_loss, torch.float64), _p(nce_ws), _stream()), "srh_bpr_infonce_fwd_bwd")
+                                      _p(cl_loss, torch.float64), _p(nce_ws), _nce_mode(precision), _stream()),
+          "srh_bpr_infonce_fwd_bwd")
 
 
 # ----------------------------------------------------------------------------------------

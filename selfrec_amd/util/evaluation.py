@@ -37,6 +37,13 @@ class RankedLists(Mapping):
         r = self._row[user]
         return list(zip(self.item_names[self.ids[r]].tolist(), self.scores[r].tolist()))
 
+    def materialise(self):
+        """The reference's return value as a plain dict -- {user: [(item name, score), ...]} for every user, every tuple
+        built (graph_recommender.py:52-53) -- in two bulk conversions instead of one row at a time."""
+        names = self.item_names[self.ids].tolist()          # (users x K) python strings
+        scores = self.scores.tolist()                       # (users x K) python floats
+        return {u: list(zip(n, s)) for u, n, s in zip(self.users, names, scores)}
+
 
 def _left_to_right_sum(x):
     """0 + x[0] + x[1] + ... in that order, each add rounded to float64 (what `sum(list)` and `+=` loops do)."""

@@ -209,13 +209,16 @@ def _infonce(problems, tau, scale, loss):
             g2 += b.grad
 
 
-def infonce_multi(problems, *, d, tau, loss_scale, loss, ws=None):
+NCE_PRECISIONS = {"split": 0, "f32": 1, "bf16x3": 0}
+
+
+def infonce_multi(problems, *, d, tau, loss_scale, loss, ws=None, precision=None):
     _infonce(problems, tau, loss_scale, loss)
 
 
 def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
                 reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws=None, problems,
-                tau, cl_scale, cl_loss, nce_ws=None):
+                tau, cl_scale, cl_loss, nce_ws=None, precision=None):
     bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, batch=batch, n_rows_dev=n_rows_dev,
                    reg_coef=reg_coef, reg_include_neg=reg_include_neg, loss_scale=loss_scale, g_user=g_user,
                    g_item=g_item, greg_user=greg_user, greg_item=greg_item, losses=losses)

@@ -234,13 +234,3 @@ def test_integration_md_names_only_declared_entry_points():
     named = set(re.findall(r"\b_lib\.(srh_\w+)\(", text)) | set(re.findall(r"`(srh_\w+)`", text))
     named = {n for n in named if not n.endswith("_") and not n.endswith("_t")}     # (`srh_sampler_*` prefixes, type names)
     assert named and named <= declared, sorted(named - declared)
-
-
-def test_design_md_quotes_the_current_abi():
-    from selfrec_amd import _lib
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    header = open(os.path.join(root, "include", "selfrec_hip.h")).read()
-    declared = set(re.findall(r"^(?:srh_status_t|int32_t|int64_t|void|const char\*)\s+(srh_\w+)\s*\(", header, flags=re.M))
-    m = re.search(r"(\d+) symbols \(ABI v(\d+)", open(os.path.join(root, "DESIGN.md")).read())
-    assert m, "DESIGN.md section 1 states the symbol count and the ABI version"
-    assert (int(m.group(1)), int(m.group(2))) == (len(declared), _lib.ABI_VERSION)

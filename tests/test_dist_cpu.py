@@ -298,7 +298,89 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
     rec = json.loads(line)
     assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0
     assert rec["parallelism"].startswith("data parallel x2")
+    # the companion record of the same line: ONE batch divided over the ranks (d / 2 = 32 columns per rank)
+    assert rec["strong_parallelism"].startswith("column-sharded tables x2")
     assert "torch.distributed.run" in p.stderr
+    # the rendezvous port is picked free per launch, never a fixed number
+    assert rec["master_port"] != 29511 and f"--master-port {rec['master_port']}" in p.stderr
+
+
+def _bench(args, **env_extra):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SRH_DIST_BACKEND")}
+    env.update(OMP_NUM_THREADS="1", **env_extra)
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bench_refuses_more_ranks_than_visible_devices():
+    """`--gpus N` above the visible HIP devices (none in this container): a clear message and exit code 2 BEFORE any rank is
+    started, not N ranks fighting over fewer GPUs."""
+    import json
+    p = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 2, (p.returncode, p.stderr[-1500:])
+    assert "--gpus 4" in p.stderr and "HIP device(s) visible" in p.stderr
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["visible_gpus"] < 4 and "error" in rec
+    assert "torch.distributed.run" not in p.stderr
+
+
+def test_bench_watchdog_ends_a_stalled_job():
+    """A rank that makes no progress for SRH_BENCH_WATCHDOG_S seconds (here: a stall injected before the first collective)
+    ends the job with exit code 3 and a message that names the phase -- it never hangs until the driver's limit."""
+    import time
+    t0 = time.time()
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], SRH_DIST_BACKEND="gloo", SRH_BENCH_WATCHDOG_S="3",
+               SRH_BENCH_TEST_STALL="600")
+    assert p.returncode != 0
+    assert "watchdog: rank" in p.stderr and "made no progress" in p.stderr and "phase 'start'" in p.stderr
+    assert time.time() - t0 < 120
+
+
+def test_bench_runner_counts_epoch_boundaries_and_takes_the_max_over_ranks():
+    """bench.Runner / first_steps_guarded on a stub trainer: exactly n steps per timed region, epoch boundaries counted,
+    and a trainer whose first steps raise is rebuilt ONCE with eager launches."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    class Stub:
+        epoch_batches = 5
+
+        def __init__(self, fail=False):
+            self.steps, self.uploads, self.fail = 0, 0, fail
+
+        def seed_sampler(self, seed):
+            self.seed = seed
+
+        def sample_epoch_host(self):
+            return {"e": 1}
+
+        def upload_epoch(self, host):
+            self.uploads += 1
+
+        def step(self):
+            if self.fail:
+                raise RuntimeError("captured replay differs from the eager step")
+            self.steps += 1
+
+    class NoFence(bench.Runner):
+        def fence(self):
+            pass
+
+    r = NoFence(Stub(), 7)
+    r.run(3)
+    dt, bounds = r.timed(9, "x")
+    assert r.trainer.steps == 12 and r.trainer.uploads == 3 and bounds == 2 and dt >= 0
+    built = []
+
+    def make(eager=False):
+        built.append(eager)
+        return Stub(fail=not eager)
+    tr, runner, note = bench.first_steps_guarded(make, lambda t: NoFence(t, 7), None, "layout dp")
+    assert built == [False, True] and tr.steps == 2 and "RuntimeError" in note
 
 
 @pytest.mark.parametrize("model,d", [("XSimGCL", 50), ("SGL", 96), ("LightGCN", 20), ("SimGCL", 100)])

@@ -237,18 +237,36 @@ def test_yelp_shape_two_steps_match_reference_run(yelp_data, shapes, smeta, tag)
     want_ids, want_sc = shapes[f"{tag}_eval_ids"], shapes[f"{tag}_eval_scores"]
     assert (ids.cpu().numpy() == want_ids).mean() > 0.995          # (exact ties / 1-ulp neighbours may swap)
     np.testing.assert_allclose(sc.cpu().numpy(), want_sc, rtol=1e-4, atol=1e-7)
+    # ... and through the path production (and bench.py) ranks with: GraphRecommender.rank_on_device -- the FILTERED pipeline
+    # with the shipped constants (bound from a 4096-item sample, split-bf16 filter pass, 1024 candidate slots, 16384-user
+    # chunks, exact re-score) on these TRAINED embeddings (VERDICT r03 #4a): same ids, same scores as the reference's loop
+    from selfrec_amd.base import graph_recommender as gr
+    rec = gr.GraphRecommender.__new__(gr.GraphRecommender)
+    rec.data, rec.max_N, rec.topN = yelp_data, 20, [20]
+    rec.user_emb, rec.item_emb = fu.contiguous(), fi.contiguous()
+    assert fi.shape[0] >= 4 * gr.FILTER_SAMPLE_ITEMS                # (this catalogue takes the filtered pipeline)
+    ids_f, sc_f = rec.rank_on_device(shapes[f"{tag}_eval_users"].astype(np.int32))
+    assert getattr(rec, "_filter_ws", None) is not None            # (... and it did)
+    assert (ids_f == want_ids).mean() > 0.995
+    np.testing.assert_allclose(sc_f, want_sc, rtol=1e-4, atol=1e-7)
+    # the two pipelines agree with each other bit for bit (ids and scores)
+    assert np.array_equal(ids_f, ids.cpu().numpy()) and np.array_equal(sc_f, sc.cpu().numpy())
+    # all test users at once, as test() asks: the golden users' rows are the same rows
+    every = np.arange(yelp_data.user_num, dtype=np.int32)
+    ids_all, sc_all = rec.rank_on_device(every)
+    pick = shapes[f"{tag}_eval_users"].astype(np.int64)
+    assert np.array_equal(ids_all[pick], ids_f) and np.array_equal(sc_all[pick], sc_f)
 
 
 def test_yelp_shape_xsimgcl_exact_f32_infonce(yelp_data, shapes, smeta):
-    """The same run with InfoNCE's products on the exact-f32 MFMA path (srh_infonce_set_precision): the contrastive
-    loss then agrees with the reference to 2e-6 instead of the split-bf16 path's 2e-5."""
+    """The same run with InfoNCE's products on the exact-f32 MFMA path (the trainer's own nce_precision: no process-wide
+    state): the contrastive loss agrees with the reference to 2e-6, as the default split path does."""
     info = smeta["Y_XSimGCL"]
     ue, ie = seeded_init(info)
-    ops.set_infonce_precision("f32")
-    try:
-        run_and_check("Y_XSimGCL", shapes, info, trainer_for(info, yelp_data, ue, ie), nce_rtol=2e-6)
-    finally:
-        ops.set_infonce_precision("split")
+    tr = trainer_for(info, yelp_data, ue, ie)
+    tr.set_nce_precision("f32")
+    assert ops.get_infonce_precision() == "split"          # (the process default is untouched)
+    run_and_check("Y_XSimGCL", shapes, info, tr, nce_rtol=2e-6)
 
 
 @pytest.mark.parametrize("tag", ["F_SGL", "F_SGL3"])

@@ -32,9 +32,9 @@ for tag, shape in (("Y_XSimGCL", "yelp2018"), ("F_SGL", "ifashion")):
     data = Interaction({}, synth.as_triples(tu, ti), [])
     info = meta[tag]
     for mode in ops.NCE_PRECISIONS:
-        ops.set_infonce_precision(mode)
         ue, ie = seeded_init(info)
         tr = trainer_for(info, data, ue, ie)
+        tr.set_nce_precision(mode)
         random.seed(info["sampler_seed"])
         tr.seed_sampler_from_python()
         tr.begin_epoch()
@@ -51,4 +51,3 @@ for tag, shape in (("Y_XSimGCL", "yelp2018"), ("F_SGL", "ifashion")):
               f"{rel(tr.item_emb[ri].cpu().numpy(), shapes[f'{tag}_param_item'])}; final user "
               f"{rel(fu[ru].cpu().numpy(), shapes[f'{tag}_final_user'])} item {rel(fi[ri].cpu().numpy(), shapes[f'{tag}_final_item'])}")
         del tr
-ops.set_infonce_precision("split")
