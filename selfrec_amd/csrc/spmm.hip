@@ -551,15 +551,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int c_raw = 0;
   float v_raw = 0.f;
   auto chunk_late = [&](int nr, int jn, int end) {
+    // The prefetch loads are issued INSIDE inline asm: the multiply-adds of the PF form wait with vmcnt(8 .. 1),
+    // which is only right while these loads sit between the gathers and the multiply-adds -- a plain C++ load of a
+    // `const __restrict__` array may legally be moved past an asm block by the compiler, and vmcnt(8) would then stop
+    // waiting for the oldest gather.  asm volatile statements keep their order; the pair is first read after an explicit
+    // vmcnt(0) below (the compiler inserts no waits for loads it did not issue).
     auto issue = [&]() {
       const int jj = max(min(jn, end - 1), 0);
-      c_raw = indices[jj];
-      v_raw = vals ? vals[jj] : 1.0f;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(c_raw) : "v"(indices + jj) : "memory");
+      if (vals) asm volatile("global_load_dword %0, %1, off" : "=v"(v_raw) : "v"(vals + jj) : "memory");
+      else v_raw = 1.0f;
     };
     gather8_tail<false>(min(nr, 8), cs, v, sub16, X, xx, acc);
     if (nr > 8) {
       gather8_tail<true, true>(min(nr, 16) - 8, cs, v, sub16, X, xx, acc, issue);
-      asm volatile("" : "+v"(c_raw), "+v"(v_raw));      // first use of the prefetched pair: after the last multiply-add
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_raw), "+v"(v_raw) :: "memory");      // first use of the prefetched pair
       v = jn < end ? v_raw : 0.f;
       cs = (v == 0.f) ? 0x80000000u : (unsigned)c_raw * (unsigned)(LPR * 16);
     }

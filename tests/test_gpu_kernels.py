@@ -158,6 +158,13 @@ def test_spmm_xcd_shares_and_probe(d):
     ref, ref_pat = ops.spmm(csr, tx), ops.spmm(csr, tx, pattern=True)
     ref_cols = ops.spmm(csr, tx, epilogue=ep_cols())
     ref_rows = torch.zeros((n, d), device=DEV); ops.spmm(csr, tx, out=ref_rows, epilogue=ep_rows())
+    # the row-masked launch (d = 64: its own instantiation, the next chunk's indices issued AFTER the gathers from inline
+    # asm) adds the same entries in the same order as the unmasked kernel: identical bits on the marked rows, with a value
+    # stream and as a pattern launch; unmarked rows are not touched
+    live = mark == 7
+    assert torch.equal(ref_rows[live], ref[live]) and not ref_rows[~live].any()
+    pat_rows = torch.zeros((n, d), device=DEV); ops.spmm(csr, tx, out=pat_rows, epilogue=ep_rows(), pattern=True)
+    assert torch.equal(pat_rows[live], ref_pat[live]) and not pat_rows[~live].any()
     n_canon = ops.spmm_plan_run_tasks(csr, d)
     nb = (n_canon + 3) // 4
     canon = np.array([len(range(k, nb, 8)) for k in range(8)])

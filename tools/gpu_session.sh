@@ -175,6 +175,16 @@ sharded1)
   done;;
 modelmatrix)
   timeout 1200 python tools/model_matrix.py > $OUT/model_matrix.log 2>&1; echo "modelmatrix exit $?"; grep -v amdgpu.ids $OUT/model_matrix.log | tail -12;;
+timeline)
+  timeout 600 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1; echo "timeline exit $?"; grep -v amdgpu.ids $OUT/step_timeline.txt | cut -c1-700;;
+cpuref)
+  # the reference's own XSimGCL.train() step beside the oracle's on this host's cores (needs _refstage/)
+  (cd /tmp && timeout 900 python $OLDPWD/tools/cpu_reference_vs_port.py --ref $OLDPWD/_refstage --steps ${CPUREF_STEPS:-12} > $OLDPWD/$OUT/cpu_reference_vs_port.txt 2>&1); echo "cpuref exit $?"
+  grep -v "amdgpu.ids\|UserWarning\|FloatTensor" $OUT/cpu_reference_vs_port.txt | tail -6;;
+startup)
+  timeout 600 python tools/startup_probe.py > $OUT/startup_yelp.txt 2>&1; echo "startup exit $?"; grep -v amdgpu.ids $OUT/startup_yelp.txt | tail -14;;
+startupbig)
+  timeout 1500 python tools/startup_probe.py --shape 1m-500k --emb 128 > $OUT/startup_1m500k.txt 2>&1; echo "startupbig exit $?"; grep -v amdgpu.ids $OUT/startup_1m500k.txt | tail -14;;
 *) echo "unknown stage $s";;
 esac
 echo "-- $s: $(( $(date +%s) - t0 )) s"
