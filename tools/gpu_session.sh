@@ -175,6 +175,10 @@ sharded1)
   done;;
 modelmatrix)
   timeout 1200 python tools/model_matrix.py > $OUT/model_matrix.log 2>&1; echo "modelmatrix exit $?"; grep -v amdgpu.ids $OUT/model_matrix.log | tail -12;;
+benchdriver20)
+  # the driver's literal command line
+  timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver20.log 2> $OUT/bench_driver20.err; echo "benchdriver20 exit $?"
+  tail -3 $OUT/bench_driver20.err; tail -1 $OUT/bench_driver20.log | cut -c1-900;;
 timeline)
   timeout 600 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1; echo "timeline exit $?"; grep -v amdgpu.ids $OUT/step_timeline.txt | cut -c1-700;;
 cpuref)
