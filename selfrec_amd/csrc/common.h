@@ -89,6 +89,19 @@ __device__ __forceinline__ void batch_fetch_body(const srh_batch_fetch_args_t& f
 }
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// 16-byte store of a streamed output.  WT = write-through (`sc1`): the bytes go to the fabric as they are produced and the
+// line is not left dirty in this XCD's L2 -- a kernel that ends with tens of MB of dirty lines pays their write-back at
+// its boundary (MI355X_MICROARCH.md price list, row "boundary": + B / 6 TB/s), and nothing on this XCD reads them again.
+template <bool WT>
+__device__ __forceinline__ void st_f4(float4* p, float4 v) {
+  if constexpr (WT) {
+    typedef float fx4_t __attribute__((ext_vector_type(4)));
+    const fx4_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  } else {
+    *p = v;
+  }
+}
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

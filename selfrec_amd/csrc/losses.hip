@@ -233,6 +233,11 @@ constexpr float kNceInvKqScale2 = 1.0f / (kNceKqScale * kNceKqScale);   // the s
 #endif
 static_assert(SRH_NCE_SPLITS == 8 || SRH_NCE_SPLITS == 16, "SRH_NCE_SPLITS: 8 or 16");
 static_assert(SRH_NCE_PV_TERMS == 3 || SRH_NCE_PV_TERMS == 6, "SRH_NCE_PV_TERMS: 3 or 6");
+//   SRH_NCE_WT        1: the tile passes' partial outputs (16.8 MB per step at n = 2048) leave with write-through stores
+#ifndef SRH_NCE_WT
+#define SRH_NCE_WT 0
+#endif
+constexpr bool kNceWT = SRH_NCE_WT != 0;
 constexpr int kNceUsedSplits = SRH_NCE_SPLITS;   // key-range splits per query tile (NceBatch::splits; the finish kernels unroll over it)
 constexpr int kNcePvTerms = SRH_NCE_PV_TERMS;
 
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
 #pragma unroll
         for (int u = 0; u < NT / 4; ++u) {
           const float4 v = make_float4(O[t][4 * u + 0][r], O[t][4 * u + 1][r], O[t][4 * u + 2][r], O[t][4 * u + 3][r]);
-          reinterpret_cast<float4*>(rowp)[u] = v;
+          st_f4<kNceWT>(reinterpret_cast<float4*>(rowp) + u, v);
         }
       }
       if (!PASS2) {

@@ -5,8 +5,14 @@
 //   algorithmic bytes = 7 * n_elem * 4  (read p, g, m, v; write p, m, v).
 #include "common.h"
 
+// Build-time experiment switch (tools/spmm_lab/build_alt.sh): SRH_ADAM_WT 1 = p, m, v leave with write-through stores
+#ifndef SRH_ADAM_WT
+#define SRH_ADAM_WT 0
+#endif
+
 namespace {
 using namespace srh;
+constexpr bool kAdamWT = SRH_ADAM_WT != 0;
 
 // Optional fused reset (the engine's step): tables in `clr` get the rows whose activity mark equals this step's stamp
 // zeroed in the same pass -- the batch-sparse gradient buffers (gF, gCL, ...) hold non-zeros only there -- and
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     pp.c -= step_size * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
     SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
 #undef SRH_ADAM_LANE
-    m[i] = mm; v[i] = vv; p[i] = pp;
+    st_f4<kAdamWT>(m + i, mm); st_f4<kAdamWT>(v + i, vv); st_f4<kAdamWT>(p + i, pp);
     if (clr.n > 0 && clr.mark[i >> clr.lpr_shift] == (int32_t)t) {
       for (int k = 0; k < clr.n; ++k) clr.table[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }

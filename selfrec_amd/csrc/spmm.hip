@@ -29,9 +29,25 @@
 
 #include "common.h"
 
+// Build-time experiment switches (tools/spmm_lab/build_alt.sh builds the other settings for a file-level A/B of bench.py;
+// no run-time knob ships):
+//   SRH_Y_WT      1: the epilogue's output rows (y, the layer mean, FANOUT copies) leave with write-through stores
+//   SRH_RM_DEPTH  8 | 16: gathers in flight per row-group in the ROW-MASKED launch (its few live waves run on a chain of
+//                 dependent gather batches: 16 halves the chain of a 512-entry segment at 4 waves per SIMD)
+#ifndef SRH_Y_WT
+#define SRH_Y_WT 0
+#endif
+#ifndef SRH_RM_DEPTH
+#define SRH_RM_DEPTH 8
+#endif
+#ifndef SRH_RM_WAVES
+#define SRH_RM_WAVES 4        // waves per SIMD the 16-deep row-masked instantiation is compiled for (4: 128 VGPRs, 3: 168)
+#endif
+
 namespace {
 
 using namespace srh;
+constexpr bool kYWT = SRH_Y_WT != 0;
 
 struct Seg {
   int32_t row, start, end, slot;  // slot < 0: final result of `row`; else partial[slot]
@@ -210,10 +226,10 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
     if (!ep.main_clean) y = perturb_row<LPR>(raw, row, sub, at, ep.noise, ep.off_lo, ep.off_hi, ep);
     for (int k = 0; k < ep.n_extra; ++k) {
       const float4 yk = perturb_row<LPR>(raw, row, sub, at, ep.extra_noise[k], ep.extra_off_lo[k], ep.extra_off_hi[k], ep);
-      if (store) reinterpret_cast<float4*>(ep.extra_out[k])[at] = out_scaled ? f4_scale(yk, r) : yk;
+      if (store) st_f4<kYWT>(reinterpret_cast<float4*>(ep.extra_out[k]) + at, out_scaled ? f4_scale(yk, r) : yk);
     }
   }
-  if (store) Y[at] = out_scaled ? f4_scale(y, r) : y;
+  if (store) st_f4<kYWT>(Y + at, out_scaled ? f4_scale(y, r) : y);
   if (ep.flags & SRH_EPI_MEAN) {
     const float rinv = (ep.prev_unscale && r > 0.f) ? 1.0f / r : 0.f;
     float4 m = y;
@@ -231,7 +247,7 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
     }
     if (store) {
       float4 o = f4_scale(m, ep.mean_rcp);
-      reinterpret_cast<float4*>(ep.mean_out)[at] = o;
+      st_f4<kYWT>(reinterpret_cast<float4*>(ep.mean_out) + at, o);
     }
   }
 }
@@ -362,6 +378,52 @@ __device__ __forceinline__ void gather8_tail(int nr, unsigned cs, float v, unsig
   }
 }
 
+// SRH_RM_DEPTH = 16 (row-masked launches): all sixteen entries of the DPP row in flight before the first multiply-add.
+// The row-masked launch runs a few thousand live waves on an almost empty chip; each is a chain of dependent gather batches
+// (sixteen for a 512-entry segment) and the launch ends when the longest chain does -- twice the loads per batch halves the
+// chain.  Costs 32 more VGPRs (4 waves per SIMD: irrelevant for this launch).  Same entries in the same order: the sums
+// are the 8-deep form's bit for bit.  `issue_next` issues the next chunk's raw (col [, val]) after the gathers (LATEPF).
+#define SRH_DPP_OR_TO(T, DST) \
+  asm volatile("v_or_b32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(DST[T & 7]) : "v"(cs), "v"(sub16))
+#define SRH_DPP_MOV_TO(T, DST) \
+  asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(DST[T & 7]) : "v"(v))
+template <class F>
+__device__ __forceinline__ void gather16_late(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xa)[8],
+                                              floatx4_t (&xb)[8], Acc2& acc, F issue_next) {
+  // (offsets and values of the two halves live one after the other, not side by side: the kernel has to fit 128 VGPRs)
+  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
+  {
+    unsigned ofa[8];
+    SRH_DPP_OR_TO(0, ofa); SRH_DPP_OR_TO(1, ofa); SRH_DPP_OR_TO(2, ofa); SRH_DPP_OR_TO(3, ofa);
+    SRH_DPP_OR_TO(4, ofa); SRH_DPP_OR_TO(5, ofa); SRH_DPP_OR_TO(6, ofa); SRH_DPP_OR_TO(7, ofa);
+    pred_load8_tail(8, xa[0], xa[1], xa[2], xa[3], xa[4], xa[5], xa[6], xa[7], ofa, X);
+  }
+  {
+    unsigned ofb[8];
+    SRH_DPP_OR_TO(8, ofb); SRH_DPP_OR_TO(9, ofb); SRH_DPP_OR_TO(10, ofb); SRH_DPP_OR_TO(11, ofb);
+    SRH_DPP_OR_TO(12, ofb); SRH_DPP_OR_TO(13, ofb); SRH_DPP_OR_TO(14, ofb); SRH_DPP_OR_TO(15, ofb);
+    pred_load8_tail(8, xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7], ofb, X);
+  }
+  issue_next();                         // YOUNGER than the sixteen gathers (one or two loads: the waits below assume >= 1)
+  asm volatile("s_nop 4" ::: "memory");
+  {
+    float va[8];
+    SRH_DPP_MOV_TO(0, va); SRH_DPP_MOV_TO(1, va); SRH_DPP_MOV_TO(2, va); SRH_DPP_MOV_TO(3, va);
+    SRH_DPP_MOV_TO(4, va); SRH_DPP_MOV_TO(5, va); SRH_DPP_MOV_TO(6, va); SRH_DPP_MOV_TO(7, va);
+    const floatx2_t p0 = {va[0], va[1]}, p1 = {va[2], va[3]}, p2 = {va[4], va[5]}, p3 = {va[6], va[7]};
+    SRH_FMA(16, 0, p0, xa[0]); SRH_FMA(15, 1, p0, xa[1]); SRH_FMA(14, 0, p1, xa[2]); SRH_FMA(13, 1, p1, xa[3]);
+    SRH_FMA(12, 0, p2, xa[4]); SRH_FMA(11, 1, p2, xa[5]); SRH_FMA(10, 0, p3, xa[6]); SRH_FMA(9, 1, p3, xa[7]);
+  }
+  {
+    float vb[8];
+    SRH_DPP_MOV_TO(8, vb); SRH_DPP_MOV_TO(9, vb); SRH_DPP_MOV_TO(10, vb); SRH_DPP_MOV_TO(11, vb);
+    SRH_DPP_MOV_TO(12, vb); SRH_DPP_MOV_TO(13, vb); SRH_DPP_MOV_TO(14, vb); SRH_DPP_MOV_TO(15, vb);
+    const floatx2_t q0 = {vb[0], vb[1]}, q1 = {vb[2], vb[3]}, q2 = {vb[4], vb[5]}, q3 = {vb[6], vb[7]};
+    SRH_FMA(8, 0, q0, xb[0]); SRH_FMA(7, 1, q0, xb[1]); SRH_FMA(6, 0, q1, xb[2]); SRH_FMA(5, 1, q1, xb[3]);
+    SRH_FMA(4, 0, q2, xb[4]); SRH_FMA(3, 1, q2, xb[5]); SRH_FMA(2, 0, q3, xb[6]); SRH_FMA(1, 1, q3, xb[7]);
+  }
+}
+
 // The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
 // entries are dead): the compiler's version branches over a gather whose whole wave is dead, where the asm form
 // still issues the exec = 0 load -- measured 34.2 against 38.1 us at the Yelp2018 shape (profiles/r02_a_spmm_lab.txt).
@@ -450,7 +512,7 @@ struct alignas(64) Task64 {
 // us with it (their waves overlap enough for the early prefetch to be free), the ROW-MASKED launch -- a few thousand live
 // cooperative waves on a chain of dependent gather batches -- gains 1.5-1.8 us: instantiated for that flavour only.
 template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LATEPF && SRH_RM_DEPTH == 16) ? SRH_RM_WAVES : 8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,
@@ -491,6 +553,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   floatx4_t xx[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) xx[t] = zero;
+  constexpr bool DEEP = LATEPF && SRH_RM_DEPTH == 16;     // (row-masked launches: sixteen gathers in flight per row-group)
+  floatx4_t xy[DEEP ? 8 : 1];
+#pragma unroll
+  for (int t = 0; t < (DEEP ? 8 : 1); ++t) xy[t] = zero;
 
   const Task64* tp = tasks + wave;       // uniform address: s_load
   const int kind = tp->kind, count = tp->count, slot = tp->slot;
@@ -562,6 +628,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (vals) asm volatile("global_load_dword %0, %1, off" : "=v"(v_raw) : "v"(vals + jj) : "memory");
       else v_raw = 1.0f;
     };
+    if constexpr (DEEP) {
+      if (nr >= 16) {                     // a whole chunk: all sixteen rounds in flight at once
+        gather16_late(cs, v, sub16, X, xx, xy, acc, issue);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_raw), "+v"(v_raw) :: "memory");
+        v = jn < end ? v_raw : 0.f;
+        cs = (v == 0.f) ? 0x80000000u : (unsigned)c_raw * (unsigned)(LPR * 16);
+        return;
+      }
+    }
     gather8_tail<false>(min(nr, 8), cs, v, sub16, X, xx, acc);
     if (nr > 8) {
       gather8_tail<true, true>(min(nr, 16) - 8, cs, v, sub16, X, xx, acc, issue);

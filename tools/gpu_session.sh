@@ -179,6 +179,17 @@ benchdriver20)
   # the driver's literal command line
   timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver20.log 2> $OUT/bench_driver20.err; echo "benchdriver20 exit $?"
   tail -3 $OUT/bench_driver20.err; tail -1 $OUT/bench_driver20.log | cut -c1-900;;
+ablibs)
+  bash tools/spmm_lab/ab_libs.sh ${AB_LIBS:-} 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_libs.txt | cut -c1-420;;
+abtest)
+  # kernel + engine parity tests under an alt library (AB_TEST_LIBS), the product's restored afterwards
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig_t.so
+  for N in ${AB_TEST_LIBS:-}; do
+    cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so
+    timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider -x -k "${AB_TEST_K:-spmm or yelp or engine or infonce or adam or bpr or step}" > $OUT/abtest_$N.log 2>&1
+    echo "abtest $N exit $?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/abtest_$N.log | tail -5
+  done
+  cp /tmp/orig_t.so selfrec_amd/lib/libselfrec_hip.so;;
 timeline)
   timeout 600 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1; echo "timeline exit $?"; grep -v amdgpu.ids $OUT/step_timeline.txt | cut -c1-700;;
 cpuref)

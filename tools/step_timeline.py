@@ -59,3 +59,28 @@ for k in range(5):
     dt = time.perf_counter() - t0
     print(f"E. 20 bare graph.replay() + synchronize: {dt / 20 * 1e3:.4f} ms/step")
     tr.step_count += 20
+
+# F. no sampler thread alive, GPU idle for 0.3 s first: a slow first region here is the GPU's own ramp (clocks), not the host
+if r.pre._thread is not None:
+    r.pre._thread.join()
+for idle in (0.3, 0.0, 1.0):
+    r.fence()
+    time.sleep(idle)
+    out = []
+    for k in range(4):
+        dt, _ = r.timed(20, "f")
+        out.append(f"{dt / 20 * 1e3:.4f}")
+    print(f"F. after {idle:.1f} s idle, sampler thread finished: fenced regions of 20 steps, ms/step:", " ".join(out))
+# G. a sampler thread working on the host next to the launches (what the first 46 ms after an epoch boundary look like)
+import threading  # noqa: E402
+for rep in range(2):
+    r.fence()
+    th = threading.Thread(target=tr.sample_epoch_host, daemon=True)
+    th.start()
+    out = []
+    for k in range(4):
+        dt, _ = r.timed(20, "g")
+        out.append(f"{dt / 20 * 1e3:.4f}")
+    alive = th.is_alive()
+    th.join()
+    print(f"G. with a sampler thread running (still alive after the 4 regions: {alive}): ms/step:", " ".join(out))
