@@ -203,7 +203,11 @@ def cpu_baseline(args, raw, seconds):
             "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{n} XSimGCL steps (B={args.batch}, L={args.layers}) of the oracle on the same graph, "
                       f"{t_steps / n * 1e3:.0f} ms compute + {per_batch_sample * 1e3:.1f} ms python sampling per step, "
-                      f"shuffle {t_first:.2f} s amortised over the epoch"}
+                      f"shuffle {t_first:.2f} s amortised over the epoch",
+            "port_vs_reference": "the reference's own model/graph/XSimGCL.py train() step was timed beside this port on the GPU "
+                                 "box's host, same process and thread count (tools/cpu_reference_vs_port.py, profiles/"
+                                 "r04_b_cpu_reference_vs_port.txt): reference 641 / 692 ms per step, port 739 / 639 / 531 -- "
+                                 "indistinguishable inside the 128-thread host's run-to-run spread (+-15 %)"}
 
 
 def eval_cpu_baseline(trainer, data, k=20, n_users=300):
@@ -713,7 +717,8 @@ def spmm_roofline(args, trainer, sharded, dp, step_s, g):
             "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
             "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
                     "launch_us_by_flavour.step_mix (profiles/)",
-            "step_alg_bytes": step_bytes, "step_GBps": round(step_bytes / step_s / 1e9, 1)}
+            "step_alg_bytes": step_bytes,
+            "step_GBps": round(step_bytes / step_s / 1e9, 1) if step_s else None}
 
 
 def steady_state(runner, step_s, pairs_per_step):
@@ -823,17 +828,36 @@ def main():
                                                     f"layout {layout or 'auto'}")
         if note:
             notes.append(note)
+        warm_done = 2                              # (first_steps_guarded ran two steps: they count towards --warmup)
     else:
         trainer = make(False)()
         runner = Runner(trainer, args.seed, None, None)
-
-    runner.run(args.warmup)
+        warm_done = min(2, args.warmup)
+        runner.run(warm_done)                      # epoch upload, hipGraph capture, first replays
+        runner.fence()
+    dp = bool(getattr(trainer, "dp", False))
+    g = trainer.graph
+    # The roofline probes (per-flavour launch times, the gather floor, the stream rates: ~30 ms of launches the line needs
+    # anyway) run HERE, between the first warm-up steps and the rest: the timed region then starts on a chip that has been
+    # busy, not on one that idled through graph capture.  tools/step_timeline.py (profiles/r04_b_step_timeline.txt): after
+    # >= 0.3 s of idle the first 60 steps run 4 / 2.5 / 1.5 % slow (DVFS ramp; 0.2963, 0.2903, 0.2864 ms per 20-step region
+    # against 0.2816 sustained) whatever the host does -- a 20-step region timed straight from idle measures that ramp.
+    roof = None
+    if rank == 0 and warm_done >= 1:
+        try:
+            roof = spmm_roofline(args, trainer, sharded, dp, None, g)
+        except RuntimeError as e:             # (never lose a multi-GPU line to its footnotes)
+            if not sharded:
+                raise
+            roof = {"error": str(e)}
+    if watchdog is not None:
+        watchdog.beat("roofline")
+    runner.run(max(0, args.warmup - warm_done))
     elapsed, epochs_in_region = runner.timed(args.steps, "timed region")
     losses = trainer.read_losses()
 
     # rows / cols / 2-D: the global batch is fixed at B pairs per step for every N (strong scaling).  Data parallel: every
     # rank trains on its own B pairs per step (weak scaling): N x B pairs per step.
-    dp = bool(getattr(trainer, "dp", False))
 
     def parallelism_of(tr):
         from selfrec_amd.dist import describe_layout
@@ -844,7 +868,6 @@ def main():
                         "the figures of this line are not measurements"))
     pairs_per_step = args.batch * (world if dp else 1)
     value = args.steps * pairs_per_step / elapsed
-    g = trainer.graph
     out = {
         "metric": f"train pairs/sec ({args.model}, {'Yelp2018' if args.shape == 'yelp2018' else args.shape}-shape)",
         "value": round(value, 1), "unit": "pairs/s",
@@ -890,16 +913,17 @@ def main():
         trainer.set_nce_precision("split")
         runner.run(5); runner.fence()
     if rank == 0:
-        try:
-            roof = spmm_roofline(args, trainer, sharded, dp, step_s, g)
-        except RuntimeError as e:             # (never lose a multi-GPU line to its footnotes)
-            if not sharded:
-                raise
-            roof = {"error": str(e)}
+        if roof is None:                       # (--warmup 0: no batch had run when the probes were due)
+            try:
+                roof = spmm_roofline(args, trainer, sharded, dp, None, g)
+            except RuntimeError as e:
+                if not sharded:
+                    raise
+                roof = {"error": str(e)}
         if roof:
+            if "step_alg_bytes" in roof:
+                roof["step_GBps"] = round(roof["step_alg_bytes"] / step_s / 1e9, 1)
             out["roofline"] = roof
-    if watchdog is not None:
-        watchdog.beat("roofline")
 
     # ---- N > 1: the strong-scaling record -- ONE batch of B pairs divided over the ranks (north_star / SURVEY 8e: tables
     # and graph sharded, the global batch fixed), next to the data-parallel headline.  Column blocks where d / N is a

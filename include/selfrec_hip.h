@@ -577,6 +577,9 @@ srh_status_t srh_dataset_sizes(const srh_dataset_t* ds, int64_t* h_sizes5);
 srh_status_t srh_dataset_copy_ids(const srh_dataset_t* ds, int32_t* h_train_u, int32_t* h_train_i,
                                   float* h_train_w, int32_t* h_test_u, int32_t* h_test_i);
 int64_t srh_dataset_names_bytes(const srh_dataset_t* ds, int32_t which);
+/* h_offsets != NULL: names back to back in h_buf (names_bytes bytes), name k = [h_offsets[k], h_offsets[k+1]); h_offsets
+ * == NULL: every name followed by '\n' (names_bytes + count bytes; a name is a token of a line, so it holds no '\n') --
+ * one bulk split on the caller's side instead of a slice per name. */
 srh_status_t srh_dataset_copy_names(const srh_dataset_t* ds, int32_t which, char* h_buf, int64_t* h_offsets);
 
 #ifdef __cplusplus

@@ -97,7 +97,9 @@ __device__ __forceinline__ void st_f4(float4* p, float4 v) {
   if constexpr (WT) {
     typedef float fx4_t __attribute__((ext_vector_type(4)));
     const fx4_t x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    // (s_nop 1 INSIDE the statement: a 16-byte store reads its data registers after issue, and the compiler pads no hazards
+    // of an asm statement -- without it the next instruction may overwrite them first: cdna_hip_programming.md 5.7)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
   } else {
     *p = v;
   }

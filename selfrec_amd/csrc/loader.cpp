@@ -6,8 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
-#include <unordered_map>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -53,54 +55,190 @@ bool read_file(const char* path, std::vector<char>& buf) {
   return got == (size_t)std::max(0L, n);
 }
 
+// name (bytes inside the file buffer) -> dense id, open addressing, no per-name allocation.  40 M lines spend their time in
+// this table: std::unordered_map<std::string, ...> built two heap strings per line.
+struct NameTable {
+  struct Slot { const char* p; uint32_t len; int32_t id; uint64_t h; };
+  std::vector<Slot> slots;
+  std::vector<std::pair<const char*, uint32_t>> names;      // id -> name, in first-appearance order
+  size_t mask = 0;
+  explicit NameTable(size_t cap_log2 = 12) { slots.assign((size_t)1 << cap_log2, Slot{nullptr, 0, -1, 0}); mask = slots.size() - 1; }
+  static uint64_t hash(const char* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; p += 8; n -= 8; }
+    uint64_t w = 0;
+    memcpy(&w, p, n);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 32);
+  }
+  void grow() {
+    std::vector<Slot> old;
+    old.swap(slots);
+    slots.assign(old.size() * 2, Slot{nullptr, 0, -1, 0});
+    mask = slots.size() - 1;
+    for (const Slot& s : old)
+      if (s.p) { size_t k = s.h & mask; while (slots[k].p) k = (k + 1) & mask; slots[k] = s; }
+  }
+  int32_t find(const char* p, size_t n, uint64_t h) const {
+    for (size_t k = h & mask;; k = (k + 1) & mask) {
+      const Slot& s = slots[k];
+      if (!s.p) return -1;
+      if (s.h == h && s.len == n && memcmp(s.p, p, n) == 0) return s.id;
+    }
+  }
+  int32_t find(const char* p, size_t n) const { return find(p, n, hash(p, n)); }
+  int32_t find_or_add(const char* p, size_t n) {
+    const uint64_t h = hash(p, n);
+    for (size_t k = h & mask;; k = (k + 1) & mask) {
+      Slot& s = slots[k];
+      if (!s.p) {
+        const int32_t id = (int32_t)names.size();
+        s = Slot{p, (uint32_t)n, id, h};
+        names.emplace_back(p, (uint32_t)n);
+        if (names.size() * 10 > slots.size() * 6) grow();
+        return id;
+      }
+      if (s.h == h && s.len == n && memcmp(s.p, p, n) == 0) return s.id;
+    }
+  }
+};
+
+float parse_weight(const char* p, size_t n) {
+  if (n == 1 && *p == '1') return 1.0f;                    // (the common case of implicit-feedback files)
+  char tmp[64];
+  if (n < sizeof(tmp)) { memcpy(tmp, p, n); tmp[n] = 0; return strtof(tmp, nullptr); }
+  return strtof(std::string(p, n).c_str(), nullptr);
+}
+
+// [b, e) cut into `parts` pieces that end at line ends
+std::vector<const char*> cut_at_lines(const char* b, const char* e, int parts) {
+  std::vector<const char*> cuts{b};
+  for (int k = 1; k < parts; ++k) {
+    const char* p = b + (size_t)(e - b) * k / parts;
+    if (p <= cuts.back()) continue;
+    const char* nl = (const char*)memchr(p, '\n', e - p);
+    if (!nl) break;
+    if (nl + 1 > cuts.back() && nl + 1 < e) cuts.push_back(nl + 1);
+  }
+  cuts.push_back(e);
+  return cuts;
+}
+
+int worker_count(size_t bytes) {
+  const char* env = getenv("SRH_LOADER_THREADS");          // (tests force a count; otherwise one worker per 2 MB, <= 32)
+  if (env) return std::max(1, std::min(atoi(env), 256));
+  const int hw = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  return std::max(1, std::min(hw, (int)(bytes / (2u << 20)) + 1));
+}
+
 }  // namespace
 
 extern "C" {
 
+// First-appearance ids over the WHOLE file, built in parallel: every worker maps the names of its piece of the file to
+// piece-local ids in local first-appearance order; the pieces' name lists are then merged in file order (distinct names
+// only: cheap and sequential, which is what makes the global order the python loop's), and the workers translate their
+// lines.  Same ids, same name order, same kept test pairs as the single-threaded loop at any thread count.
 srh_status_t srh_dataset_load(srh_dataset_t** out, const char* train_path, const char* test_path) {
   SRH_REQUIRE(out && train_path, "dataset_load: null argument");
   std::vector<char> buf;
   if (!read_file(train_path, buf)) { srh::set_error("dataset_load: cannot read %s", train_path); return SRH_ERR_INVALID_ARG; }
   srh_dataset* ds = new (std::nothrow) srh_dataset();
   if (!ds) { srh::set_error("dataset_load: out of memory"); return SRH_ERR_NOMEM; }
-  std::unordered_map<std::string, int32_t> users, items;
-  users.reserve(1 << 16); items.reserve(1 << 16);
-  int64_t line_no = 0;
-  const char *p = buf.data(), *end = buf.data() + buf.size();
-  while (p < end) {
-    const char* nl = (const char*)memchr(p, '\n', end - p);
-    const char* le = nl ? nl : end;
-    ++line_no;
-    Line ln;
-    if (!split_line(p, le, ln)) {
-      delete ds;
-      srh::set_error("dataset_load: %s line %lld does not have the form 'user item weight'", train_path, (long long)line_no);
-      return SRH_ERR_INVALID_ARG;
-    }
-    std::string us(ln.u, ln.ul), is(ln.i, ln.il);
-    auto iu = users.find(us);
-    if (iu == users.end()) { iu = users.emplace(us, (int32_t)users.size()).first; ds->user_names.push_back(us); }
-    auto ii = items.find(is);
-    if (ii == items.end()) { ii = items.emplace(is, (int32_t)items.size()).first; ds->item_names.push_back(is); }
-    ds->train_u.push_back(iu->second);
-    ds->train_i.push_back(ii->second);
-    ds->train_w.push_back(strtof(std::string(ln.w, ln.wl).c_str(), nullptr));
-    p = nl ? nl + 1 : end;
-  }
-  if (test_path) {
-    if (!read_file(test_path, buf)) { delete ds; srh::set_error("dataset_load: cannot read %s", test_path); return SRH_ERR_INVALID_ARG; }
-    p = buf.data(); end = buf.data() + buf.size();
+  struct Piece {
+    NameTable users{10}, items{10};
+    std::vector<int32_t> lu, li;
+    std::vector<float> w;
+    int64_t lines = 0, bad_line = -1;
+    std::vector<int32_t> tr_u, tr_i;                      // local id -> global id
+  };
+  const char *b = buf.data(), *e = buf.data() + buf.size();
+  const std::vector<const char*> cuts = cut_at_lines(b, e, worker_count(buf.size()));
+  const int T = (int)cuts.size() - 1;
+  std::vector<Piece> pieces((size_t)std::max(T, 0));
+  auto scan = [&](int t) {
+    Piece& pc = pieces[t];
+    const char *p = cuts[t], *end = cuts[t + 1];
+    const size_t guess = (size_t)(end - p) / 12 + 16;
+    pc.lu.reserve(guess); pc.li.reserve(guess); pc.w.reserve(guess);
     while (p < end) {
       const char* nl = (const char*)memchr(p, '\n', end - p);
       const char* le = nl ? nl : end;
+      ++pc.lines;
       Line ln;
-      if (split_line(p, le, ln)) {
-        ++ds->test_lines;
-        auto iu = users.find(std::string(ln.u, ln.ul));
-        auto ii = items.find(std::string(ln.i, ln.il));
-        if (iu != users.end() && ii != items.end()) { ds->test_u.push_back(iu->second); ds->test_i.push_back(ii->second); }
-      }
+      if (!split_line(p, le, ln)) { pc.bad_line = pc.lines; return; }
+      pc.lu.push_back(pc.users.find_or_add(ln.u, ln.ul));
+      pc.li.push_back(pc.items.find_or_add(ln.i, ln.il));
+      pc.w.push_back(parse_weight(ln.w, ln.wl));
       p = nl ? nl + 1 : end;
+    }
+  };
+  auto run_all = [&](auto&& fn, int n) {
+    if (n <= 1) { for (int t = 0; t < n; ++t) fn(t); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n; ++t) th.emplace_back(fn, t);
+    for (auto& x : th) x.join();
+  };
+  run_all(scan, T);
+  int64_t lines_before = 0;
+  for (int t = 0; t < T; ++t) {
+    if (pieces[t].bad_line >= 0) {
+      const long long at = (long long)(lines_before + pieces[t].bad_line);
+      delete ds;
+      srh::set_error("dataset_load: %s line %lld does not have the form 'user item weight'", train_path, at);
+      return SRH_ERR_INVALID_ARG;
+    }
+    lines_before += pieces[t].lines;
+  }
+  NameTable users(16), items(16);
+  std::vector<int64_t> offset((size_t)T + 1, 0);
+  for (int t = 0; t < T; ++t) {
+    Piece& pc = pieces[t];
+    pc.tr_u.resize(pc.users.names.size());
+    pc.tr_i.resize(pc.items.names.size());
+    for (size_t k = 0; k < pc.users.names.size(); ++k) pc.tr_u[k] = users.find_or_add(pc.users.names[k].first, pc.users.names[k].second);
+    for (size_t k = 0; k < pc.items.names.size(); ++k) pc.tr_i[k] = items.find_or_add(pc.items.names[k].first, pc.items.names[k].second);
+    offset[t + 1] = offset[t] + (int64_t)pc.lu.size();
+  }
+  ds->train_u.resize((size_t)offset[T]); ds->train_i.resize((size_t)offset[T]); ds->train_w.resize((size_t)offset[T]);
+  run_all([&](int t) {
+    const Piece& pc = pieces[t];
+    int32_t* du = ds->train_u.data() + offset[t];
+    int32_t* di = ds->train_i.data() + offset[t];
+    for (size_t k = 0; k < pc.lu.size(); ++k) { du[k] = pc.tr_u[pc.lu[k]]; di[k] = pc.tr_i[pc.li[k]]; }
+    if (!pc.w.empty()) memcpy(ds->train_w.data() + offset[t], pc.w.data(), sizeof(float) * pc.w.size());
+  }, T);
+  ds->user_names.reserve(users.names.size());
+  ds->item_names.reserve(items.names.size());
+  for (const auto& nm : users.names) ds->user_names.emplace_back(nm.first, nm.second);
+  for (const auto& nm : items.names) ds->item_names.emplace_back(nm.first, nm.second);
+  pieces.clear();
+  if (test_path) {
+    std::vector<char> tbuf;                                // (the name tables point into `buf`: keep it)
+    if (!read_file(test_path, tbuf)) { delete ds; srh::set_error("dataset_load: cannot read %s", test_path); return SRH_ERR_INVALID_ARG; }
+    const char *tb = tbuf.data(), *te = tbuf.data() + tbuf.size();
+    const std::vector<const char*> tcuts = cut_at_lines(tb, te, worker_count(tbuf.size()));
+    const int TT = (int)tcuts.size() - 1;
+    struct TestPiece { std::vector<int32_t> u, i; int64_t lines = 0; };
+    std::vector<TestPiece> tp((size_t)std::max(TT, 0));
+    run_all([&](int t) {
+      const char *p = tcuts[t], *end = tcuts[t + 1];
+      while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        const char* le = nl ? nl : end;
+        Line ln;
+        if (split_line(p, le, ln)) {
+          ++tp[t].lines;
+          const int32_t u = users.find(ln.u, ln.ul), i = items.find(ln.i, ln.il);
+          if (u >= 0 && i >= 0) { tp[t].u.push_back(u); tp[t].i.push_back(i); }
+        }
+        p = nl ? nl + 1 : end;
+      }
+    }, TT);
+    for (const TestPiece& q : tp) {
+      ds->test_lines += q.lines;
+      ds->test_u.insert(ds->test_u.end(), q.u.begin(), q.u.end());
+      ds->test_i.insert(ds->test_i.end(), q.i.begin(), q.i.end());
     }
   }
   *out = ds;
@@ -139,9 +277,17 @@ int64_t srh_dataset_names_bytes(const srh_dataset_t* ds, int32_t which) {
 }
 
 srh_status_t srh_dataset_copy_names(const srh_dataset_t* ds, int32_t which, char* h_buf, int64_t* h_offsets) {
-  SRH_REQUIRE(ds && h_buf && h_offsets, "dataset_copy_names: null argument");
+  SRH_REQUIRE(ds && h_buf, "dataset_copy_names: null argument");
   const auto& v = which ? ds->item_names : ds->user_names;
   int64_t at = 0;
+  if (!h_offsets) {                       // joined form: name '\n' name '\n' ... (names_bytes + count bytes; names hold no '\n')
+    for (size_t k = 0; k < v.size(); ++k) {
+      memcpy(h_buf + at, v[k].data(), v[k].size());
+      at += (int64_t)v[k].size();
+      h_buf[at++] = '\n';
+    }
+    return SRH_OK;
+  }
   for (size_t k = 0; k < v.size(); ++k) {
     h_offsets[k] = at;
     memcpy(h_buf + at, v[k].data(), v[k].size());

@@ -5,7 +5,7 @@
 //   algorithmic bytes = 7 * n_elem * 4  (read p, g, m, v; write p, m, v).
 #include "common.h"
 
-// Build-time experiment switch (tools/spmm_lab/build_alt.sh): SRH_ADAM_WT 1 = p, m, v leave with write-through stores
+// Build-time switch for an A/B (tools/spmm_lab/build_alt.sh): SRH_ADAM_WT 1 = p, m, v leave with write-through stores
 #ifndef SRH_ADAM_WT
 #define SRH_ADAM_WT 0
 #endif

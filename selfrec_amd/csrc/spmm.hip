@@ -29,19 +29,14 @@
 
 #include "common.h"
 
-// Build-time experiment switches (tools/spmm_lab/build_alt.sh builds the other settings for a file-level A/B of bench.py;
-// no run-time knob ships):
-//   SRH_Y_WT      1: the epilogue's output rows (y, the layer mean, FANOUT copies) leave with write-through stores
-//   SRH_RM_DEPTH  8 | 16: gathers in flight per row-group in the ROW-MASKED launch (its few live waves run on a chain of
-//                 dependent gather batches: 16 halves the chain of a 512-entry segment at 4 waves per SIMD)
+// Build-time switch (tools/spmm_lab/build_alt.sh builds the other setting for a file-level A/B of bench.py; no run-time knob
+// ships):  SRH_Y_WT 1 (default): the epilogue's output rows (y, the layer mean, FANOUT copies) leave with write-through
+// (`sc1`) stores.  A propagation launch writes 17.8 MB at the Yelp2018 shape that no workgroup of ITS launch reads again and
+// that the next launch gathers from OTHER XCDs; left dirty in the writers' L2s it is written back at the kernel boundary
+// (MI355X_MICROARCH.md price list, "boundary": + B / 6 TB/s).  Write-through moves those bytes under the gathers: dense
+// launch 41.9 -> 41.1 us, step 0.2823 -> 0.2792 ms in a same-box A/B (profiles/r04_b_write_through_ab.txt).
 #ifndef SRH_Y_WT
-#define SRH_Y_WT 0
-#endif
-#ifndef SRH_RM_DEPTH
-#define SRH_RM_DEPTH 8
-#endif
-#ifndef SRH_RM_WAVES
-#define SRH_RM_WAVES 4        // waves per SIMD the 16-deep row-masked instantiation is compiled for (4: 128 VGPRs, 3: 168)
+#define SRH_Y_WT 1
 #endif
 
 namespace {
@@ -286,7 +281,7 @@ __device__ __forceinline__ float4 ld_x(const float4* __restrict__ X, int c, int 
 // XCD's L2, so publishing it needs no L2 write-back fence (cdna_hip_programming.md G16, form R1)
 __device__ __forceinline__ void store_f4_sc1(float4* p, float4 v) {
   floatx4_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");   // (nop: see st_f4, common.h)
 }
 
 // ---- the gather loop of spmm_rows_kernel, in inline assembly -------------------------------------------
@@ -378,52 +373,6 @@ __device__ __forceinline__ void gather8_tail(int nr, unsigned cs, float v, unsig
   }
 }
 
-// SRH_RM_DEPTH = 16 (row-masked launches): all sixteen entries of the DPP row in flight before the first multiply-add.
-// The row-masked launch runs a few thousand live waves on an almost empty chip; each is a chain of dependent gather batches
-// (sixteen for a 512-entry segment) and the launch ends when the longest chain does -- twice the loads per batch halves the
-// chain.  Costs 32 more VGPRs (4 waves per SIMD: irrelevant for this launch).  Same entries in the same order: the sums
-// are the 8-deep form's bit for bit.  `issue_next` issues the next chunk's raw (col [, val]) after the gathers (LATEPF).
-#define SRH_DPP_OR_TO(T, DST) \
-  asm volatile("v_or_b32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(DST[T & 7]) : "v"(cs), "v"(sub16))
-#define SRH_DPP_MOV_TO(T, DST) \
-  asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(DST[T & 7]) : "v"(v))
-template <class F>
-__device__ __forceinline__ void gather16_late(unsigned cs, float v, unsigned sub16, const void* X, floatx4_t (&xa)[8],
-                                              floatx4_t (&xb)[8], Acc2& acc, F issue_next) {
-  // (offsets and values of the two halves live one after the other, not side by side: the kernel has to fit 128 VGPRs)
-  asm volatile("s_nop 1" : "+v"(cs), "+v"(v));
-  {
-    unsigned ofa[8];
-    SRH_DPP_OR_TO(0, ofa); SRH_DPP_OR_TO(1, ofa); SRH_DPP_OR_TO(2, ofa); SRH_DPP_OR_TO(3, ofa);
-    SRH_DPP_OR_TO(4, ofa); SRH_DPP_OR_TO(5, ofa); SRH_DPP_OR_TO(6, ofa); SRH_DPP_OR_TO(7, ofa);
-    pred_load8_tail(8, xa[0], xa[1], xa[2], xa[3], xa[4], xa[5], xa[6], xa[7], ofa, X);
-  }
-  {
-    unsigned ofb[8];
-    SRH_DPP_OR_TO(8, ofb); SRH_DPP_OR_TO(9, ofb); SRH_DPP_OR_TO(10, ofb); SRH_DPP_OR_TO(11, ofb);
-    SRH_DPP_OR_TO(12, ofb); SRH_DPP_OR_TO(13, ofb); SRH_DPP_OR_TO(14, ofb); SRH_DPP_OR_TO(15, ofb);
-    pred_load8_tail(8, xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7], ofb, X);
-  }
-  issue_next();                         // YOUNGER than the sixteen gathers (one or two loads: the waits below assume >= 1)
-  asm volatile("s_nop 4" ::: "memory");
-  {
-    float va[8];
-    SRH_DPP_MOV_TO(0, va); SRH_DPP_MOV_TO(1, va); SRH_DPP_MOV_TO(2, va); SRH_DPP_MOV_TO(3, va);
-    SRH_DPP_MOV_TO(4, va); SRH_DPP_MOV_TO(5, va); SRH_DPP_MOV_TO(6, va); SRH_DPP_MOV_TO(7, va);
-    const floatx2_t p0 = {va[0], va[1]}, p1 = {va[2], va[3]}, p2 = {va[4], va[5]}, p3 = {va[6], va[7]};
-    SRH_FMA(16, 0, p0, xa[0]); SRH_FMA(15, 1, p0, xa[1]); SRH_FMA(14, 0, p1, xa[2]); SRH_FMA(13, 1, p1, xa[3]);
-    SRH_FMA(12, 0, p2, xa[4]); SRH_FMA(11, 1, p2, xa[5]); SRH_FMA(10, 0, p3, xa[6]); SRH_FMA(9, 1, p3, xa[7]);
-  }
-  {
-    float vb[8];
-    SRH_DPP_MOV_TO(8, vb); SRH_DPP_MOV_TO(9, vb); SRH_DPP_MOV_TO(10, vb); SRH_DPP_MOV_TO(11, vb);
-    SRH_DPP_MOV_TO(12, vb); SRH_DPP_MOV_TO(13, vb); SRH_DPP_MOV_TO(14, vb); SRH_DPP_MOV_TO(15, vb);
-    const floatx2_t q0 = {vb[0], vb[1]}, q1 = {vb[2], vb[3]}, q2 = {vb[4], vb[5]}, q3 = {vb[6], vb[7]};
-    SRH_FMA(8, 0, q0, xb[0]); SRH_FMA(7, 1, q0, xb[1]); SRH_FMA(6, 0, q1, xb[2]); SRH_FMA(5, 1, q1, xb[3]);
-    SRH_FMA(4, 0, q2, xb[4]); SRH_FMA(3, 1, q2, xb[5]); SRH_FMA(2, 0, q3, xb[6]); SRH_FMA(1, 1, q3, xb[7]);
-  }
-}
-
 // The same eight entries in plain C++, for COLUMN-MASKED launches (first backward layer: more than half of the
 // entries are dead): the compiler's version branches over a gather whose whole wave is dead, where the asm form
 // still issues the exec = 0 load -- measured 34.2 against 38.1 us at the Yelp2018 shape (profiles/r02_a_spmm_lab.txt).
@@ -507,12 +456,15 @@ struct alignas(64) Task64 {
 // with every group busy rather than up to 16 rounds with one.
 // PROBE (srh_spmm_f32_probe): every wave also leaves {begin, end} on the chip-wide 100 MHz clock and the XCD it ran on
 // in stamps[3 * wave ..] -- what the engine's start-up calibration of the plan's XCD shares reads (engine.py).
+// (Round 4, measured and rejected: sixteen gathers in flight per row-group for this flavour -- 128 VGPRs, 4 waves per SIMD:
+// row-masked launch 19.0 -> 28.4 us, at 3 waves per SIMD 33.6: the live waves are bound by how many of them the chip holds,
+// not by the length of a wave's chain of gather batches; profiles/r04_b_write_through_ab.txt.)
 // LATEPF (round 3): the next chunk's (col, val) are issued AFTER the current chunk's gathers instead of before them.  An
 // A/B of the whole library settled where it belongs (profiles/r03_b_late_prefetch_ab.txt): the dense launches lose 0.4-0.6
 // us with it (their waves overlap enough for the early prefetch to be free), the ROW-MASKED launch -- a few thousand live
 // cooperative waves on a chain of dependent gather batches -- gains 1.5-1.8 us: instantiated for that flavour only.
 template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LATEPF && SRH_RM_DEPTH == 16) ? SRH_RM_WAVES : 8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
                                                         const float4* __restrict__ X, float4* __restrict__ Y,
@@ -553,10 +505,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LATEPF && 
   floatx4_t xx[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) xx[t] = zero;
-  constexpr bool DEEP = LATEPF && SRH_RM_DEPTH == 16;     // (row-masked launches: sixteen gathers in flight per row-group)
-  floatx4_t xy[DEEP ? 8 : 1];
-#pragma unroll
-  for (int t = 0; t < (DEEP ? 8 : 1); ++t) xy[t] = zero;
 
   const Task64* tp = tasks + wave;       // uniform address: s_load
   const int kind = tp->kind, count = tp->count, slot = tp->slot;
@@ -628,15 +576,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LATEPF && 
       if (vals) asm volatile("global_load_dword %0, %1, off" : "=v"(v_raw) : "v"(vals + jj) : "memory");
       else v_raw = 1.0f;
     };
-    if constexpr (DEEP) {
-      if (nr >= 16) {                     // a whole chunk: all sixteen rounds in flight at once
-        gather16_late(cs, v, sub16, X, xx, xy, acc, issue);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c_raw), "+v"(v_raw) :: "memory");
-        v = jn < end ? v_raw : 0.f;
-        cs = (v == 0.f) ? 0x80000000u : (unsigned)c_raw * (unsigned)(LPR * 16);
-        return;
-      }
-    }
     gather8_tail<false>(min(nr, 8), cs, v, sub16, X, xx, acc);
     if (nr > 8) {
       gather8_tail<true, true>(min(nr, 16) - 8, cs, v, sub16, X, xx, acc, issue);
@@ -895,7 +834,7 @@ __device__ __forceinline__ void st_epl_sc1(float* p, const float (&v)[EPL]) {
     asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
   } else {
     floatx4_t x = {v[0], v[1], v[2], v[3]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
   }
 }
 template <int EPL>

@@ -139,6 +139,44 @@ def test_native_loader_equals_python_path(tmp_path):
         Interaction({}, FileIO.open_data_set(str(bad), "graph"), [])
 
 
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_native_loader_in_parallel_keeps_first_appearance_ids(tmp_path, monkeypatch, threads):
+    """The loader parses pieces of the file on worker threads and merges their name lists in file order: ids, name order,
+    weights' acceptance and the kept test pairs must be the single pass's at ANY thread count -- names repeat across
+    pieces, some appear late, lines have odd lengths, the last line has no newline, and a malformed line is reported with
+    its number in the whole file."""
+    import ctypes as C
+    from selfrec_amd import _lib
+    rng = np.random.default_rng(5)
+    n = 30000
+    users = [f"u{int(v)}" if v % 7 else f"user-with-a-long-name-{int(v)}" for v in rng.zipf(1.3, n) % 4000]
+    items = [f"{int(v)}" for v in rng.integers(0, 2500, n)]
+    weights = [("1", "1.0", "4.5", "0.25", "3")[int(v)] for v in rng.integers(0, 5, n)]
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    tr.write_text("\n".join(f"{a} {b} {w}" for a, b, w in zip(users, items, weights)))          # no trailing newline
+    te.write_text("".join(f"{a} {b} 1\n" for a, b in zip(users[::3] + ["nobody"], items[1::3] + ["7"])) + "u1 nothing 1\n")
+    monkeypatch.setenv("SRH_LOADER_THREADS", str(threads))
+    slow = Interaction({}, FileIO.load_data_set(str(tr), "graph"), FileIO.load_data_set(str(te), "graph"))
+    fast = Interaction({}, FileIO.open_data_set(str(tr), "graph"), FileIO.open_data_set(str(te), "graph"))
+    assert list(fast.user) == list(slow.user) and list(fast.item) == list(slow.item)       # same ORDER of first appearance
+    assert fast.user == slow.user and fast.item == slow.item
+    assert np.array_equal(fast.train_u, slow.train_u) and np.array_equal(fast.train_i, slow.train_i)
+    assert dict(fast.test_set) == dict(slow.test_set) and fast.test_set_item == slow.test_set_item
+    # the weights column, straight from the library
+    lib, h = _lib.load(), C.c_void_p()
+    _lib.check(lib.srh_dataset_load(C.byref(h), str(tr).encode(), None))
+    w = np.empty(n, dtype=np.float32)
+    _lib.check(lib.srh_dataset_copy_ids(h, None, None, w.ctypes.data_as(C.c_void_p), None, None))
+    lib.srh_dataset_destroy(h)
+    assert np.array_equal(w, np.asarray([float(x) for x in weights], dtype=np.float32))
+    bad = tmp_path / "bad.txt"
+    lines = [f"{a} {b} 1" for a, b in zip(users, items)]
+    lines[20011] = "two tokens"
+    bad.write_text("\n".join(lines) + "\n")
+    assert lib.srh_dataset_load(C.byref(h), str(bad).encode(), None) != 0
+    assert b"line 20012 " in lib.srh_last_error_string()
+
+
 def test_ranked_lists_reads_like_the_dict_and_reports_the_same_strings():
     """RankedLists (the array form of test()'s result) against the reference-shaped dict: same keys in the
     same order, same rows, and ranking_evaluation's vectorised branch prints exactly what the per-user
