@@ -655,9 +655,10 @@ def spmm_roofline(args, trainer, sharded, dp, step_s, g):
     the counters' traffic where a PMC pass of this kernel source is committed, and the bare gather stream on the live
     graph's column array (ops.gather_floor_probe) -- the floor of the vector-memory path for the launch's row fetches."""
     from selfrec_amd import ops
-    t_spmm = time_spmm_kernel(trainer) if trainer.L >= 1 else None
-    if not t_spmm:
+    if trainer.L < 1:
         return None
+    stream = stream_bandwidth(trainer.dev)      # (first: it allocates and frees 2 GiB -- the chip idles through the frees)
+    t_spmm = time_spmm_kernel(trainer)
     alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
     # the dominant launch: the value-free dense product when the engine uses it (2L - 3 of the 2L launches of a
     # step), else the dense product with values.  Algorithmic bytes stay SURVEY 8(d)'s CSR figure either way.
@@ -698,7 +699,7 @@ def spmm_roofline(args, trainer, sharded, dp, step_s, g):
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             **(floor or {}),
-            "measured_stream_GBps": stream_bandwidth(trainer.dev),
+            "measured_stream_GBps": stream,
             "traffic_source": traffic_note,
             "traffic_GBps": round(traffic / t_spmm["dominant"] / 1e9, 1) if traffic else None,
             "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dominant"] * 1e6, 2),

@@ -233,9 +233,10 @@ constexpr float kNceInvKqScale2 = 1.0f / (kNceKqScale * kNceKqScale);   // the s
 #endif
 static_assert(SRH_NCE_SPLITS == 8 || SRH_NCE_SPLITS == 16, "SRH_NCE_SPLITS: 8 or 16");
 static_assert(SRH_NCE_PV_TERMS == 3 || SRH_NCE_PV_TERMS == 6, "SRH_NCE_PV_TERMS: 3 or 6");
-//   SRH_NCE_WT        1: the tile passes' partial outputs (16.8 MB per step at n = 2048) leave with write-through stores
+//   SRH_NCE_WT        1 (default): the tile passes' partial outputs (16.8 MB per step at n = 2048) leave with write-through
+//                     stores: read next by the finish kernel on other XCDs, never again by their writers (-1.2 us per step)
 #ifndef SRH_NCE_WT
-#define SRH_NCE_WT 0
+#define SRH_NCE_WT 1
 #endif
 constexpr bool kNceWT = SRH_NCE_WT != 0;
 constexpr int kNceUsedSplits = SRH_NCE_SPLITS;   // key-range splits per query tile (NceBatch::splits; the finish kernels unroll over it)

@@ -5,9 +5,12 @@
 //   algorithmic bytes = 7 * n_elem * 4  (read p, g, m, v; write p, m, v).
 #include "common.h"
 
-// Build-time switch for an A/B (tools/spmm_lab/build_alt.sh): SRH_ADAM_WT 1 = p, m, v leave with write-through stores
+// Build-time switch for an A/B (tools/spmm_lab/build_alt.sh): SRH_ADAM_WT 1 (default) = p, m, v leave with write-through
+// (`sc1`) stores -- 53 MB per step that the next launch's gathers read from other XCDs, not left dirty for the kernel
+// boundary to write back.  Together with the InfoNCE partials (losses.hip: SRH_NCE_WT): 0.2813 -> 0.2776 ms per step in a
+// same-box A/B, each alone -1.2 us (profiles/r04_c_write_through_ab.txt).
 #ifndef SRH_ADAM_WT
-#define SRH_ADAM_WT 0
+#define SRH_ADAM_WT 1
 #endif
 
 namespace {

@@ -40,11 +40,11 @@ import numpy as np
 import torch
 import torch.distributed as _dist
 
-from . import ops
+from . import layouts, ops
 from ._lib import SelfrecHipError
+from .layouts import SLICE_WIDTHS, parse_grid  # noqa: F401  (public: dist.py and the tests import them from here)
 
 MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
-SLICE_WIDTHS = (8, 16, 32, 64, 128)   # column slices the SpMM kernels serve (csrc/spmm.hip: pair, slice<4/8>, rows<16/32>)
 
 
 class TorchComm:
@@ -166,27 +166,6 @@ class TwoHopRows:
             out[r * n:(r + 1) * n].copy_(inp)
 
 
-def parse_grid(spec, world, emb_size):
-    """"2d" or "2d:GCxGR" -> (column blocks, row parts) with GC * GR = world.  Unspecified: two row parts (the exchange a
-    rank waits for per layer is (Gr - 1) / Gr of an (N, w) slice -- DESIGN.md 6.2 -- so rows are split as little as
-    the column widths allow), more only while d / GC would fall below the narrowest slice the kernels serve."""
-    world, d = int(world), int(emb_size)
-    if ":" in str(spec):
-        try:
-            gc, gr = (int(v) for v in str(spec).split(":", 1)[1].lower().split("x"))
-        except ValueError:
-            raise SelfrecHipError(f"shard layout {spec!r}: expected 2d:GCxGR, e.g. 2d:4x2") from None
-        if gc * gr != world:
-            raise SelfrecHipError(f"shard layout {spec!r}: {gc} x {gr} != world size {world}")
-        return gc, gr
-    gr = 2 if world % 2 == 0 else 1
-    while world % gr or d % (world // gr) or (world // gr > 1 and d // (world // gr) not in SLICE_WIDTHS):
-        gr += 1
-        if gr > world:
-            raise SelfrecHipError(f"no 2-D grid for {world} ranks at d = {d}")
-    return world // gr, gr
-
-
 def shard_adjacency(norm_adj_csr, rank, world):
     """CSR rows of the nodes owned by `rank` (nodes rank, rank + world, ...), columns rewritten to the
     all-gather layout (owner * n_pad + local row).  Returns (indptr, indices, data, n_pad)."""
@@ -243,95 +222,21 @@ class FusedTrainer:
         self.dev = dev
         self.U, self.I = data.user_num, data.item_num
         self.N = self.U + self.I
-        # ---- table layout.  Every (.., d) table has P rows; node p lives at row pos[p].  One GPU:
-        # pos = identity.  G ranks (shard=True): nodes are dealt round-robin, node p is owned by rank
-        # p % G as its local row p // G, and the tables are kept in all-gather order
-        # (row = owner * n_pad + local row), so `all_gather_into_tensor` of the owners' slices IS the
-        # table.  Each rank owns the rows self.loc of the parameters, the Adam state and every
-        # layer output; batch-level work (losses, their gradients) is O(batch) and replicated.
-        #
-        # shard="cols": the tables are split by COLUMNS instead -- rank r keeps columns [r*w, (r+1)*w),
-        # w = d / G, of every table, the graph is replicated, pos = identity.  A sparse product is
-        # independent per column, so the 2L + 1 products of a step need NO exchange; the losses read
-        # whole rows, but only the O(batch) rows the staged lists name: those are all-gathered once per
-        # step into compact (5B, d) tables (csrc/exchange.hip) on which the unchanged loss kernels run.
-        #
-        # shard="2d" (or "2d:GCxGR"): both at once on G = Gc * Gr ranks -- rank q keeps column block q // Gr of every
-        # table and computes row part q % Gr of every product: the column layout's one batch-row exchange over the Gc
-        # ranks of its row part, the row layout's per-layer all-gather over the Gr ranks of its column block, on
-        # (N / Gr, d / Gc) slices.  For graphs whose products are bound by the GATHERS (1 M x 500 k: a rank's launch
-        # costs one line fetch per non-zero whatever its width), where more column blocks stop paying.
-        grid = None
-        if isinstance(shard, str) and shard.startswith("2d"):
-            grid, shard = shard, "2d"
-        #
-        # shard="dp": data parallel -- every rank holds the whole graph and the whole tables (the single-GPU step with
-        # every one of its optimisations: hipGraph, value-free products, fetch rider, calibrated plan) and trains on ITS
-        # OWN batches (the sampler is seeded per rank); the ranks meet once per step, in an all-reduce of the dense
-        # gradient gE0 (N x d floats) between the backward chain and Adam, which then takes the MEAN gradient -- the
-        # semantics of synchronous data-parallel SGD with a global batch of G x B pairs (what torch's
-        # DistributedDataParallel would make of the reference's model file; InfoNCE's negatives stay inside a rank's
-        # batch).  Weak scaling: for graphs this small the step is six latency-bound launches that no table split makes
-        # shorter, while more batches per step is what the interconnect can pay for (17.8 MB per step at the Yelp2018
-        # shape).  At one rank it is the single-GPU step bit for bit.
-        if shard not in (False, True, None, "rows", "cols", "2d", "dp"):
-            raise SelfrecHipError(f"FusedTrainer: unknown shard layout {shard!r} (False, 'rows', 'cols', '2d[:GCxGR]' or 'dp')")
-        self.dp = shard == "dp"
-        self.G, self.rank = 1, 0
-        self.sharded = shard in (True, "rows", "2d")    # rows of the graph / tables dealt over Gr ranks
-        self.cols = shard in ("cols", "2d")              # columns of the tables split over Gc ranks
-        self.layout = {True: "rows", None: False}.get(shard, shard)
-        self.comm = self.comm_rows = None                # comm: the batch-row exchange (cols); comm_rows: table rows
-        self.Gc = self.Gr = 1
-        self.cr = self.rr = 0                            # this rank's column block / row part
-        if shard == "2d":
-            if comm is None:
-                world = _dist.get_world_size() if _dist.is_initialized() else 1
-                gc, gr = parse_grid(grid, world, int(emb_size))
-                comm = TorchComm.grid(gc, gr)
-            self.comm, self.comm_rows = comm
-            self.Gc, self.cr = int(self.comm.world), int(self.comm.rank)
-            self.Gr, self.rr = int(self.comm_rows.world), int(self.comm_rows.rank)
-            self.G, self.rank = self.Gc * self.Gr, self.cr * self.Gr + self.rr
-            self.layout = f"2d:{self.Gc}x{self.Gr}"
-        elif self.sharded or self.cols or self.dp:
-            self.comm = comm if comm is not None else TorchComm()
-            self.G, self.rank = int(self.comm.world), int(self.comm.rank)
-            if self.dp:
-                # whole tables, whole graph: nothing is dealt.  Every rank perturbs with ITS OWN noise (what independent
-                # generators give DistributedDataParallel replicas of the reference's model): the counter RNG's seed
-                # is offset by the rank; rank 0 keeps the seed, so a one-rank job is the single-GPU run
-                self.rng_seed = (self.rng_seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
-            elif self.cols:
-                self.Gc, self.cr = self.G, self.rank
-            else:
-                self.Gr, self.rr, self.comm_rows = self.G, self.rank, self.comm
+        # ---- placement (layouts.py): who owns which rows and columns of the tables, what the ranks exchange per step.
+        # `shard`: False (one GPU) | "rows" | "cols" | "2d[:GCxGR]" | "dp"; every layout is the SAME step code below,
+        # run against the placement's three components -- self.rows, self.colx, self.sync.
+        self.place = layouts.make_placement(shard, comm, int(emb_size), TorchComm, TorchComm.grid)
+        self.rows, self.colx, self.sync = self.place.rows, self.place.colx, self.place.sync
+        self.layout = self.place.name
+        self.G, self.rank = self.place.G, self.place.rank
+        self.rng_seed = self.sync.rng_seed(self.rng_seed)
         N, d, B = self.N, self.d, self.B
-        self.w = d                                       # width of this rank's tables
-        if self.cols and self.d_valid != d and self.Gc > 1:
-            raise SelfrecHipError(f"embedding.size = {self.d_valid} is stored padded to {d} columns: column-sharded layouts need "
-                                  f"one of {ops.ROW_WIDTHS} (use SRH_SHARD_LAYOUT=rows)")
-        if self.cols:
-            # (a single rank keeps whole rows: the layout then only adds the batch-row exchange -- a way to run
-            # this code path, collective included, on one GPU)
-            if d % self.Gc or ((d // self.Gc) not in SLICE_WIDTHS and self.Gc > 1):
-                raise SelfrecHipError(f"column-sharded layout: d / column blocks = {d}/{self.Gc} must be one of {SLICE_WIDTHS}")
-            self.w = d // self.Gc
-        self.col0 = self.cr * self.w if self.cols else 0
-        G = self.Gr                                      # ranks the ROWS are dealt over
-        self.n_pad = (N + G - 1) // G
-        self.P = G * self.n_pad
-        nodes = np.arange(N, dtype=np.int64)
-        self._pos = ((nodes % G) * self.n_pad + nodes // G).astype(np.int32)
-        self._pos_dev = torch.from_numpy(self._pos.astype(np.int64)).to(dev)
-        self.loc = slice(self.rr * self.n_pad, (self.rr + 1) * self.n_pad) if self.sharded else slice(0, self.P)
-        if not self.sharded:
-            self.graph = data.device_graph(dev, column_classes=not self.cols)
-            self.adj = self.graph.adj
-        else:
-            from .data import device_graph as _dg
-            self.graph = _dg.ShardedDeviceGraph(data.interaction_mat, self.rr, G, dev, self._allgather)
-            self.adj = self.graph.adj
+        self.colx.bind(d, self.d_valid)
+        self.rows.bind(N, self.U, dev)
+        self.w, self.col0 = self.colx.w, self.colx.col0     # width / first column of this rank's tables
+        self.n_pad, self.P = self.rows.n_pad, self.rows.P   # rows this rank owns / rows of a whole table
+        self.graph = self.rows.build_graph(data, dev, column_classes=not self.colx.split)
+        self.adj = self.graph.adj
         g = self.graph
         P = self.P
 
@@ -350,7 +255,7 @@ class FusedTrainer:
             raise SelfrecHipError(f"initial tables have {ue.shape[1]} / {ie.shape[1]} columns, embedding.size is {self.d_valid}")
         whole = torch.zeros((N, d), dtype=torch.float32)
         whole[:, :self.d_valid] = torch.cat([ue, ie])
-        self.E0[self._pos_dev] = whole[:, self.col0:self.col0 + w].contiguous().to(dev)
+        self.E0[self.rows.pos_dev] = whole[:, self.col0:self.col0 + w].contiguous().to(dev)
         # the step code assumes the tables (and, per epoch, the sampled batches) are replicated: check, don't trust
         self._assert_replicated("initial embedding tables",
                                 [ue.double().sum().item(), ie.double().sum().item(), ue.double().abs().sum().item(),
@@ -383,7 +288,8 @@ class FusedTrainer:
         # (running batch_fetch beside the first L - 1 products and zero_rows beside Adam on a side stream was measured:
         # 0.3435 against 0.3167 ms per step -- fork / join edges inside the captured graph cost more than the two
         # launches; round 1 saw the same with BPR beside InfoNCE.  The reset is folded into Adam instead.)
-        self.fused_reset = dev.type == "cuda" and not self.sharded and not self.cols
+        single = dev.type == "cuda" and self.place.single_gpu_step     # whole rows and columns here (single, dp)
+        self.fused_reset = single
         # Value-free products: on a unit-weight graph A_hat_ij = d_i^-1/2 d_j^-1/2, so a layer that reads
         # a table stored PRE-SCALED by D^-1/2 needs no value stream -- the kernel sums x rows over the pattern and the
         # epilogue multiplies the row by d_i^-1/2 (-10 % per launch at the Yelp2018 shape).  Layer outputs Y_1 .. Y_(L-1)
@@ -391,7 +297,7 @@ class FusedTrainer:
         # the last layer's mean un-scales them on the batch rows, InfoNCE is invariant to a positive row scale (its
         # gradient w.r.t. Z re-enters the chain times d_i^-1/2), BPR / L2 read the true mean F.  The first product of a
         # chain reads true values (E0, gF) and keeps the value array.
-        self.vfree = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
+        self.vfree = (single and self.L >= 2 and self.d >= 64
                       and model in ("LightGCN", "XSimGCL", "SimGCL") and self.graph.weight is None)
         self.dinv = self.graph.dinv if self.vfree else None
         # The column-masked launch (first backward product: 3/4 of its entries are dead, its waves run on a latency chain)
@@ -400,12 +306,11 @@ class FusedTrainer:
         # 23.1 instead of 27.4 us at the Yelp2018 shape (profiles/r02_i_spmm_plans_by_flavour.txt; the dense launches lose
         # 10 us without the classes, the row-masked one is indifferent).
         self.adj_cm = None
-        if dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 1 and self.d >= 64:
+        if single and self.L >= 1 and self.d >= 64:
             self.adj_cm = self.adj.replanned(split_len=256)
         # batch_fetch as a rider of the step's first product (see _step_front): models whose step starts with a plain
         # srh_spmm_f32 launch of a layer that is not the last
-        self.ride_fetch = (dev.type == "cuda" and not self.sharded and not self.cols and self.L >= 2 and self.d >= 64
-                           and model in ("LightGCN", "XSimGCL", "SimGCL"))
+        self.ride_fetch = single and self.L >= 2 and self.d >= 64 and model in ("LightGCN", "XSimGCL", "SimGCL")
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -427,16 +332,13 @@ class FusedTrainer:
         # outside the captured region (one GPU, stand-in communicator, 8 ranks: 197 us captured, 211 us eager);
         # SRH_SHARDED_GRAPH=0 launches eagerly.  The row-sharded step has a collective after every product: it
         # launches eagerly unless SRH_SHARDED_GRAPH=1 asks for RCCL inside the capture.
-        env = os.environ.get("SRH_SHARDED_GRAPH")
-        self.use_graph = bool(use_graph) and ((not self.sharded and not self.cols and not self.dp) or env == "1"
-                                              or ((self.cols or self.dp) and not self.sharded and env != "0"))
+        self.use_graph = bool(use_graph) and self.place.graph_by_default(os.environ.get("SRH_SHARDED_GRAPH"))
         self._graph = None
         self._noise_call = 0
         # counter RNG layout: (optimiser step) * rng_stride + (perturbed-layer call of the step) * P + row; SimGCL makes
         # 2L calls per step, XSimGCL L -- the stride leaves room for all of them at any depth
         self._rng_calls = max(16, 2 * self.L)
-        if self.cols:
-            self._init_exchange()
+        self.colx.init_exchange(self)                  # (column blocks: the compact batch-row tables; else nothing)
         self.xcd_shares = self._calibrate_xcd_shares()
 
     # ------------------------------------------------------------------------------------
@@ -450,7 +352,8 @@ class FusedTrainer:
         together: 45.1 -> 42.7 us per dense launch in the lab (profiles/r02_j_xcd_balance_closed_loop.txt).  Same tasks, same
         sums -- placement only.  Once per (plan, table width), before anything captures a launch of the plan;
         SRH_XCD_CALIBRATE=0 keeps the equal dealing.  Returns the shares, or None."""
-        if os.environ.get("SRH_XCD_CALIBRATE", "1") == "0" or self.dev.type != "cuda" or self.sharded or self.cols:
+        self.xcd_calibration = None                    # the record of what was decided (also logged); None: equal dealing
+        if not layouts.calibration_enabled() or self.dev.type != "cuda" or not self.place.single_gpu_step:
             return None
         if self.L < 1 or self.d != 64:                  # (the entry points serve d = 128 / 256 too; measured at d = 64 only so far)
             return None
@@ -461,6 +364,7 @@ class FusedTrainer:
         done = self.adj.__dict__.setdefault("_xcd_calibrated", {})
         key = self.d
         if key in done:
+            self.xcd_calibration = self.adj.__dict__.get("_xcd_calibration_record", {}).get(key)
             return done[key]
         nb = (ops.spmm_plan_run_tasks(self.adj, self.d) + 3) // 4
         if nb < 4096:                                   # nothing to balance on a small graph
@@ -472,6 +376,7 @@ class FusedTrainer:
         ep = ops.make_epilogue(**kw) if kw else None
         canon = np.array([len(range(k, nb, 8)) for k in range(8)], dtype=np.int64)
         shares, best = canon.copy(), (float("inf"), canon.copy())
+        spread = []                                     # us between the first and the last XCD to finish, per round
 
         def finish_times():
             runs = [ops.spmm_probe(self.adj, self.E0, self.Ha, epilogue=ep, pattern=bool(self.vfree))[0] for _ in range(3)]
@@ -479,6 +384,7 @@ class FusedTrainer:
         finish_times()                                  # warm-up (module load, caches)
         for rnd in range(rounds):
             fin = finish_times()
+            spread.append(float(fin.max() - fin.min()))
             if fin.max() < best[0]:
                 best = (float(fin.max()), shares.copy())
             if fin.max() - fin.min() < 0.4 or rnd == rounds - 1:
@@ -494,91 +400,77 @@ class FusedTrainer:
         if not np.array_equal(best[1], shares):
             ops.spmm_set_xcd_shares(self.adj, self.d, None if np.array_equal(best[1], canon) else best[1])
         done[key] = best[1]
+        # what was decided, on the record (logging: logger "selfrec_amd", level INFO) and on the trainer
+        self.xcd_calibration = {"shares": [int(v) for v in best[1]], "canonical": [int(v) for v in canon],
+                                "xcd_finish_spread_us_by_round": [round(v, 2) for v in spread], "last_finish_us": round(best[0], 2)}
+        self.adj.__dict__.setdefault("_xcd_calibration_record", {})[key] = self.xcd_calibration
+        import logging
+        logging.getLogger("selfrec_amd").info(
+            "XCD shares of the dense SpMM plan calibrated at start-up (d = %d, %d workgroups): %s (equal dealing: %s); XCDs "
+            "finished %.2f us apart before, %.2f after; SRH_XCD_CALIBRATE=0 keeps the equal dealing", self.d, nb,
+            self.xcd_calibration["shares"], self.xcd_calibration["canonical"], spread[0] if spread else 0.0,
+            spread[-1] if spread else 0.0)
         return best[1]
 
     # ------------------------------------------------------------------------------------
-    # column-sharded layout: the batch-row exchange (csrc/exchange.hip)
+    # the placement's answers under the names the rest of the package (and the tests) read
     # ------------------------------------------------------------------------------------
-    def _init_exchange(self):
-        m, B, d, dev = self.model, self.B, self.d, self.dev
-        a, b = (self.views + [None, None])[:2]
-        if m == "MF":
-            tables, grads = [self.E0], [self.gF]
-        elif m == "LightGCN":
-            tables, grads = [self.F, self.E0], [self.gF, self.gReg]
-        elif m == "XSimGCL":
-            cl = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
-            tables, grads = [self.F, cl], [self.gF, self.gCL]
-        elif m == "SimGCL":
-            tables, grads = [self.F, a["F"], b["F"]], [self.gF]       # (the views' gradients join gF: one chain)
-        else:
-            tables, grads = [self.F, a["F"], b["F"]], [self.gF, a["gF"], b["gF"]]
-        rows = 5 * B
+    @property
+    def ops(self):
+        """the kernel module the step runs on (this module's `ops`: the CPU tests swap it for stand-ins)"""
+        return ops
 
-        def compact():
-            return torch.zeros((rows, d), dtype=torch.float32, device=dev)
-        self._x_tables = tables
-        self._x_compact = {id(t): compact() for t in tables}
-        self._x_cgrad = {id(g): compact() for g in grads}
-        self._x_pairs = [(self._x_cgrad[id(g)], g) for g in grads]
-        self._x_send = torch.zeros((len(tables), rows, self.w), dtype=torch.float32, device=dev)
-        self._x_recv = torch.zeros((self.Gc, len(tables), rows, self.w), dtype=torch.float32, device=dev)
-        slots = torch.arange(rows, dtype=torch.int32, device=dev)
-        self._x_idx = {k: slots[s * B:(s + 1) * B] for s, k in enumerate(("u", "i", "j", "uniq_u", "uniq_i"))}
-        self._x_cat = torch.zeros(2 * B, dtype=torch.int32, device=dev) if m == "SGL" else None
-        self._x_lists = ops.batch_lists(self.stage, self.meta, B)
-
-    def _pack(self):
-        ops.batch_pack(self._x_lists, self._x_tables, self._x_send, cat_idx=self._x_cat)
+    sharded = property(lambda self: self.rows.dealt)            # rows of the graph / tables dealt over Gr ranks
+    cols = property(lambda self: self.colx.split)               # columns of the tables split over Gc ranks
+    dp = property(lambda self: self.sync.active)                # data parallel: gradient all-reduce before Adam
+    Gc = property(lambda self: self.colx.blocks)
+    cr = property(lambda self: self.colx.block)
+    Gr = property(lambda self: self.rows.parts)
+    rr = property(lambda self: self.rows.part)
+    loc = property(lambda self: self.rows.own)
+    _pos = property(lambda self: self.rows.pos)
+    _pos_dev = property(lambda self: self.rows.pos_dev)
+    comm = property(lambda self: self.sync.comm if self.sync.active else self.colx.comm if self.colx.split else self.rows.comm)
+    comm_rows = property(lambda self: self.rows.comm)
 
     def _exchange(self):
-        """The step's one collective: every rank's slices of the batch rows."""
-        self.comm.all_gather(self._x_recv, self._x_send)
+        """the step's one collective of the column layouts (tests drive virtual ranks through it)"""
+        self.colx.exchange()
 
-    def _unpack(self):
-        ops.batch_unpack(self._x_lists, self._x_recv, self.Gc, self.w, [self._x_compact[id(t)] for t in self._x_tables],
-                         [c for c, _ in self._x_pairs])
+    def _dp_allreduce(self):
+        """the step's one collective of the data-parallel layout"""
+        self.sync.reduce(self)
 
     def _assert_replicated(self, what, values):
-        for comm in {id(c): c for c in (self.comm, self.comm_rows) if c is not None}.values():
+        for comm in self.place.comms():
             check = getattr(comm, "assert_replicated", None)       # (test stand-in communicators may not have it)
             if check is not None and comm.world > 1:
                 check(what, values, self.dev)                      # (2-D: row part + column block span the grid)
-
-    def _full(self, t):
-        """(rows, w) slice on every rank -> the whole (rows, d) table (a collective; plumbing, not per step)."""
-        if not self.cols:
-            return t
-        recv = torch.empty((self.Gc,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.comm.all_gather(recv, t.contiguous())
-        return recv.permute(1, 0, 2).reshape(t.shape[0], self.d).contiguous()
 
     # ------------------------------------------------------------------------------------
     # views of the tables
     # ------------------------------------------------------------------------------------
     @property
     def user_emb(self):
-        t = self._valid(self._full(self.E0))             # (column-sharded: a collective -- every rank must ask)
-        return t[:self.U] if not self.sharded else t[self._pos_dev[:self.U]]
+        t = self._valid(self.colx.full(self.E0))         # (column blocks: a collective -- every rank must ask)
+        return self.rows.rows_of_users(t)
 
     @property
     def item_emb(self):
-        t = self._valid(self._full(self.E0))
-        return t[self.U:] if not self.sharded else t[self._pos_dev[self.U:]]
+        t = self._valid(self.colx.full(self.E0))
+        return self.rows.rows_of_items(t)
 
     def _valid(self, t):
         """The real columns of a whole-row table (tables are stored zero-padded to a width the kernels serve)."""
         return t if self.d_valid == self.d else t[:, :self.d_valid]
 
     def _loc(self, t):
-        """The rows of a table this rank owns (the whole table on one GPU)."""
-        return t if not self.sharded or t is None else t[self.loc]
+        """The rows of a table this rank owns (the whole table unless the rows are dealt)."""
+        return self.rows.mine(t)
 
     def _allgather(self, t):
         """Make a table whose owned rows were just written whole again on every rank."""
-        if self.sharded:
-            mine = t[self.loc]
-            self.comm_rows.all_gather(t, mine if self.dev.type == "cuda" else mine.clone())
+        self.rows.make_whole(t)
 
     # ------------------------------------------------------------------------------------
     # sampling
@@ -586,16 +478,16 @@ class FusedTrainer:
     def seed_sampler(self, seed: int):
         """Seed the batch sampler.  Replicated layouts (rows / cols / 2-D) need the SAME stream on every rank; data
         parallel needs a DIFFERENT one per rank (seed + rank): every rank trains on its own batches."""
-        self.sampler.seed(int(seed) + (self.rank if self.dp else 0))
+        self.sampler.seed(self.sync.sampler_seed(int(seed)))
 
     def seed_sampler_from_python(self):
         """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it).  Data parallel over more than
         one rank has no reference stream to be exact to -- every rank needs ITS OWN batches -- so there one 63-bit draw of
         the (replicated) global stream seeds the sampler, offset by the rank (adopting the state itself would
         hand every rank the same batches)."""
-        if self.dp and self.G > 1:
+        if self.sync.active and self.sync.world > 1:
             import random
-            self.sampler.seed((random.getrandbits(63) + self.rank) & ((1 << 63) - 1))
+            self.sampler.seed(self.sync.sampler_seed(random.getrandbits(63)) & ((1 << 63) - 1))
             return
         self.sampler.set_state_from_python()
 
@@ -623,25 +515,14 @@ class FusedTrainer:
                 masks.append(mk)
             out["masks"] = masks
         ep = self.sampler.epoch(self.B, 1, with_unique=True)
-        # node ids -> table rows (items follow the users; all-gather order when sharded)
-        if not self.sharded:
-            for k in ("i", "j", "uniq_i"):
-                ep[k] += self.U
-        else:
-            pos_u, pos_i = self._pos[:self.U], self._pos[self.U:]
-            for k, table in (("u", pos_u), ("i", pos_i), ("j", pos_i), ("uniq_u", pos_u), ("uniq_i", pos_i)):
-                ep[k] = table[ep[k]]
-        out.update(ep)
+        # node ids -> table rows (items follow the users; all-gather order when the rows are dealt)
+        out.update(self.rows.epoch_to_table_rows(ep))
         return out
 
     def epoch_node_ids(self, host=None):
         """(u, i, j) of an epoch as the reference's user / item ids (the staged arrays hold table rows)."""
         host = self._epoch_host if host is None else host
-        if not self.sharded:
-            return host["u"], host["i"] - self.U, host["j"] - self.U
-        node_of_row = np.full(self.P, -1, dtype=np.int64)
-        node_of_row[self._pos] = np.arange(self.N)
-        return node_of_row[host["u"]], node_of_row[host["i"]] - self.U, node_of_row[host["j"]] - self.U
+        return self.rows.epoch_node_ids(host, self.P)
 
     def upload_epoch(self, host):
         dev = self.dev
@@ -650,7 +531,7 @@ class FusedTrainer:
                 self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
         for k, t in self._epoch_dev.items():
             t.copy_(torch.from_numpy(host[k]), non_blocking=True)
-        if self.G > 1 and not self.dp:   # replicated sampler: same seed => same batches; one tiny collective per epoch says so
+        if self.place.replicated_batches:   # same seed => same batches on every rank; one tiny collective per epoch says so
             # (data parallel: every rank samples ITS OWN batches by design)
             w3 = np.arange(1, 4, dtype=np.int64)
             self._assert_replicated("the sampled epoch (u, i, j streams)",
@@ -674,21 +555,16 @@ class FusedTrainer:
         t = torch.as_tensor(self.noise_fn((self.N, self.d_valid)), dtype=torch.float32)     # torch.rand_like(h): XSimGCL.py:90
         if self.d_valid != self.d:
             t = torch.nn.functional.pad(t, (0, self.d - self.d_valid))
-        t = t.to(self.dev)
-        if not self.sharded:
-            return t.contiguous()          # (column-sharded: whole rows too -- the unit vector spans the row)
-        full = torch.zeros((self.P, self.d), dtype=torch.float32, device=self.dev)
-        full[self._pos_dev] = t
-        return full[self.loc].contiguous()
+        return self.rows.place_noise(t.to(self.dev), self.d)     # (column blocks: whole rows too -- the unit vector spans the row)
 
     def _rng_offset(self, call):
         """Counter offset of perturbed-layer call number `call` of this step (rows of all ranks)."""
-        return (call * self.P + (self.rr * self.n_pad if self.sharded else 0)) & ((1 << 62) - 1)
+        return (call * self.P + self.rows.rng_row_offset()) & ((1 << 62) - 1)
 
     def _slice_kw(self):
         """PERTURB on a column slice: tell the kernel where the slice sits in the whole row; on zero-padded rows: where
         the real columns end."""
-        kw = dict(d_full=self.d, col0=self.col0) if self.cols and self.w != self.d else {}
+        kw = self.colx.slice_kw()
         if self.d_valid != self.d:
             kw["d_valid"] = self.d_valid
         return kw
@@ -850,17 +726,27 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch
     # ------------------------------------------------------------------------------------
-    def _step_kernels(self):
+    # A step = before | collective | after.  The collective is the placement's: the batch-row exchange of column blocks
+    # (then the losses come after it), the gradient all-reduce of data parallel (then the losses come before it), or
+    # nothing.  Layouts with a collective run the three as separate phases (step_phases) and capture the two halves.
+    def _step_before(self):
         self._step_front()
-        if self.cols:
-            self._exchange()
-        self._step_back()
+        if self.sync.active:
+            self._step_grad()
 
-    def _dp_allreduce(self):
-        """Data parallel: the step's one collective -- the dense gradient summed over the ranks, then the mean."""
-        self.comm.all_reduce_sum(self.gE0)
-        if self.G > 1:
-            ops.axpby(1.0 / self.G, self.gE0, 0.0, self.gE0)
+    def _step_collective(self):
+        self.colx.exchange()
+        self.sync.reduce(self)
+
+    def _step_after(self):
+        if not self.sync.active:
+            self._step_grad()
+        self._step_opt()
+
+    def _step_kernels(self):
+        self._step_before()
+        self._step_collective()
+        self._step_after()
 
     def _sgl_shared_first(self):
         return self.model == "SGL" and self.L >= 2 and self.w == 64
@@ -908,14 +794,12 @@ class FusedTrainer:
                                    batch_rows_only=True)
         if self._rider is not None:
             raise SelfrecHipError("internal: the batch fetch found no product to ride on")
-        if self.cols:
-            self._pack()
+        self.colx.pack(self)                      # (column blocks: this rank's slices of the batch rows; else nothing)
 
     def _step_back(self):
-        """losses on the batch rows, backward through the encoder, optimiser, row-wise resets."""
+        """losses on the batch rows, backward through the encoder, (gradient sync,) optimiser, row-wise resets."""
         self._step_grad()
-        if self.dp:
-            self._dp_allreduce()
+        self.sync.reduce(self)
         self._step_opt()
 
     def _step_grad(self):
@@ -924,17 +808,9 @@ class FusedTrainer:
         adj = self.adj
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
         F = self.F
-        if self.cols:
-            # whole rows exist only for the batch: compact (5B, d) tables, slot -> slot index lists
-            self._unpack()
-            T = lambda t: self._x_compact[id(t)]            # noqa: E731
-            GT = lambda g: self._x_cgrad[id(g)]             # noqa: E731
-            ix = self._x_idx
-            cat_idx = self._x_cat
-        else:
-            T = GT = lambda t: t                            # noqa: E731
-            ix = st
-            cat_idx = self.stage_cat
+        # the tables the losses read and the index lists into them: the rank's own (whole rows here), or -- column blocks --
+        # the compact (5B, d) tables the batch-row exchange just filled, with slot -> slot lists
+        T, GT, ix, cat_idx = self.colx.loss_views(self)
         # ---- recommendation loss + regulariser (a-5..a-7)
         if m == "LightGCN":
             # regulariser on the EGO rows (LightGCN.py:25); its gradient joins gE0 in the last product
@@ -974,9 +850,7 @@ class FusedTrainer:
             ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems)
         else:
             ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=self.bpr_ws)
-        if self.cols:
-            # this rank's columns of the batch-row gradients, added to the nodes' rows of the local tables
-            ops.batch_scatter(self._x_lists, self._x_pairs, self.d, self.col0, self.w)
+        self.colx.scatter(self)                   # (column blocks: this rank's columns of the batch-row gradients go home)
         # ---- backward through the encoder (a-4) and optimiser (a-9)
         if m == "MF":
             pass                                     # gF is gE0
@@ -1004,11 +878,11 @@ class FusedTrainer:
                 clear += [v["gF"] for v in self.views]
             ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.now[1:2], lr=self.lr, clear=clear,
                           row_mark=self.mark, advance_cursor=self.cursor)
-            if self.dp and self.gF is self.gE0:
+            if self.sync.active and self.gF is self.gE0:
                 self.gE0.zero_()        # MF: gE0 IS the accumulation buffer, and after the all-reduce it holds the OTHER
             return                      # ranks' batch rows too, which this rank's marks do not name
         ops.adam_step(self._loc(self.E0), self._loc(self.gE0), self.m, self.v, step_dev=self.now[1:2], lr=self.lr)
-        if self.dp and self.gF is self.gE0:
+        if self.sync.active and self.gF is self.gE0:
             self.gE0.zero_()
         self._allgather(self.E0)                     # every rank's next forward pass reads the whole table
         if self.sparse_reset:
@@ -1035,9 +909,9 @@ class FusedTrainer:
             phase()
 
     def step_phases(self):
-        """The step as a sequence of calls.  One GPU / row-sharded: a single call.  Column-sharded: (local
-        kernels, the one all-gather, local kernels) -- so a test can drive several ranks in lock-step on one
-        GPU, and so the collective stays outside the two captured graphs."""
+        """The step as a sequence of calls: (whole step, done), or -- placements with a collective in the step --
+        (before, the collective, after, done), so that a test can drive several ranks in lock-step on one GPU and the
+        collective stays outside the two captured graphs."""
         if not self._epoch_ready:
             raise SelfrecHipError("call begin_epoch() first")
         graphed = self.use_graph and self.noise_fn is None
@@ -1045,7 +919,7 @@ class FusedTrainer:
             try:
                 self._capture()
             except RuntimeError as e:
-                if not (self.sharded or self.cols or self.dp):
+                if self.G == 1 and not self.place.collective_in_step and not self.rows.dealt:
                     raise
                 # (a capture next to a live process group is the one thing that could not be exercised beyond one
                 # rank here: fall back to eager launches rather than lose the run -- the state is the snapshot's)
@@ -1055,16 +929,9 @@ class FusedTrainer:
 
         def done():
             self.step_count += 1
-        if self.cols:
-            front = self._graph[0].replay if graphed else self._step_front
-            back = self._graph[1].replay if graphed else self._step_back
-            return (front, self._exchange, back, done)
-        if self.dp:
-            def grad():
-                self._step_front()
-                self._step_grad()
-            return (self._graph[0].replay if graphed else grad, self._dp_allreduce,
-                    self._graph[1].replay if graphed else self._step_opt, done)
+        if self.place.collective_in_step:
+            return (self._graph[0].replay if graphed else self._step_before, self._step_collective,
+                    self._graph[1].replay if graphed else self._step_after, done)
         return (self._graph.replay if graphed else self._step_kernels, done)
 
     def reset_graph(self):
@@ -1100,72 +967,56 @@ class FusedTrainer:
                 gc.enable()
 
     def _capture_guarded(self):
-        # warm up once eagerly on a side stream (allocator + lazy module loads), then capture.  (Column-
-        # sharded: the warm-up skips the all-gather -- its numbers are thrown away with the snapshot -- so
-        # capturing is a purely local act.)
+        # warm up once eagerly on a side stream (allocator + lazy module loads), then capture.  (The warm-up skips the
+        # placement's collective -- its numbers are thrown away with the snapshot -- so capturing is a purely local act.)
+        two = self.place.collective_in_step
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snapshot = (self.E0.clone(), self.m.clone(), self.v.clone(), self.cursor.clone())
+
+        def restore():
+            self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
         with torch.cuda.stream(side):
-            self._step_front()
-            if self.dp:                       # (the warm-up skips the all-reduce, like the column layout its all-gather)
-                self._step_grad()
-                self._step_opt()
-            else:
-                self._step_back()
+            self._step_before()
+            self._step_after()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        if self.cols or self.dp:
+        restore()
+        if two:
             # two graphs with the collective between them: RCCL stays outside the captured region
             self._graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
             pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(self._graph[0], pool=pool, capture_error_mode="thread_local"):
-                self._step_front()
-                if self.dp:
-                    self._step_grad()
+                self._step_before()
             with torch.cuda.graph(self._graph[1], pool=pool, capture_error_mode="thread_local"):
-                if self.dp:
-                    self._step_opt()
-                else:
-                    self._step_back()
+                self._step_after()
         else:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._step_kernels()
-        self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
-        if (self.cols or self.dp) and self.G > 1 and isinstance(self.comm, TorchComm) \
+        restore()
+        if two and self.G > 1 and all(isinstance(c, (TorchComm, TwoHopRows)) for c in self.place.comms()) \
                 and os.environ.get("SRH_CAPTURE_CHECK", "1") != "0":
-            self._check_replay_against_eager(snapshot)
+            self._check_replay_against_eager(restore, snapshot[0])
 
-    def _check_replay_against_eager(self, snapshot):
+    def _check_replay_against_eager(self, restore, e0_before):
         """Two graphs around a live collective have never met more than one real GPU (the one failure seen so far,
         a collector-run destructor inside the capture window, left a graph whose FIRST replayed step was wrong): before the
         graphs are trusted, one step is run eagerly and once more as a replay from the same state -- collective included,
-        same batch, same noise counters -- and the parameters must agree on every rank (the verdict is all-reduced, so the
-        ranks fall back together).  A mismatch raises; step_phases() then launches eagerly and says so."""
-        def restore():
-            self.E0.copy_(snapshot[0]); self.m.copy_(snapshot[1]); self.v.copy_(snapshot[2]); self.cursor.copy_(snapshot[3])
+        same batch, same noise counters -- and the parameters must agree on every rank (the verdict is all-reduced over
+        the whole job, so the ranks fall back together).  A mismatch raises; step_phases() then launches eagerly and says so."""
         results = []
-        for replay in (False, True):
-            if self.cols:
-                phases = ((self._graph[0].replay, self._exchange, self._graph[1].replay) if replay
-                          else (self._step_front, self._exchange, self._step_back))
-            else:
-                def grad():
-                    self._step_front()
-                    self._step_grad()
-                phases = ((self._graph[0].replay, self._dp_allreduce, self._graph[1].replay) if replay
-                          else (grad, self._dp_allreduce, self._step_opt))
+        for phases in ((self._step_before, self._step_collective, self._step_after),
+                       (self._graph[0].replay, self._step_collective, self._graph[1].replay)):
             for ph in phases:
                 ph()
             torch.cuda.synchronize()
             results.append(self.E0.clone())
             restore()
-        moved = (results[0] - snapshot[0]).abs().max().item()
+        moved = (results[0] - e0_before).abs().max().item()
         diff = (results[0] - results[1]).abs().max().item()
         ok = torch.tensor([1.0 if (diff <= 0.1 * self.lr and moved > 0.0) else 0.0], device=self.dev)
-        _dist.all_reduce(ok, op=_dist.ReduceOp.MIN, group=self.comm.group)
+        _dist.all_reduce(ok, op=_dist.ReduceOp.MIN)
         if ok.item() < 1.0:
             self._graph = None
             raise RuntimeError(f"captured step differs from the eager step on some rank (this rank {self.rank}: max |E0 eager - "
@@ -1186,12 +1037,8 @@ class FusedTrainer:
         out = torch.zeros_like(self.E0)
         Ys = [torch.zeros_like(self.E0) for _ in range(self.L)]
         self._forward_pass(self.adj, Ys, out, perturbed=False, include_ego=self.model in ("LightGCN", "SGL"))
-        if self.cols:
-            out = self._full(out)                 # (a collective: every rank must ask)
-        out = self._valid(out)
-        if not self.sharded:
-            return out[:self.U], out[self.U:]
-        return out[self._pos_dev[:self.U]], out[self._pos_dev[self.U:]]
+        out = self._valid(self.colx.full(out))    # (column blocks: a collective -- every rank must ask)
+        return self.rows.rows_of_users(out), self.rows.rows_of_items(out)
 
 
 class EpochPrefetcher:

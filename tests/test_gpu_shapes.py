@@ -294,12 +294,13 @@ def first_appearance_ids(raw):
     return rank[raw]
 
 
-def test_xcd_share_calibration_changes_placement_not_results(yelp_data):
+@pytest.mark.parametrize("model", ["LightGCN", "XSimGCL"])
+def test_xcd_share_calibration_changes_placement_not_results(yelp_data, model):
     """engine.FusedTrainer calibrates the dense plan's XCD shares at start-up (probe launches -> unequal numbers of
     workgroups per XCD).  At the Yelp2018 shape it does move workgroups, and a trainer on the calibrated list takes the
     same steps as one on the canonical list: same batches, same losses, same embeddings (to the order of the loss
-    section's atomics)."""
-    kw = dict(model="XSimGCL", n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048)
+    section's atomics).  The decision is on the record (trainer.xcd_calibration, logger "selfrec_amd")."""
+    kw = dict(model=model, n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048)
 
     def run(tr):
         tr.sampler.seed(11)
@@ -322,13 +323,16 @@ def test_xcd_share_calibration_changes_placement_not_results(yelp_data):
     np.testing.assert_allclose(la, lb, rtol=2e-6)
     # Two runs of ONE trainer configuration already differ (tools/determinism_probe.py, profiles/r03_c_determinism.txt:
     # the loss section scatters with atomics -- 12 % of the gradient elements differ in their last bits, 5e-8 relative --
-    # and three Adam steps later the embeddings by 2.5e-7).  And once in a few runs such a last-bit difference lands on a
-    # layer-output element within rounding of zero, where XSimGCL.py:90's sign(h) turns it into a 2 eps |unit| jump of
-    # one element and its neighbours (observed: one run at 1.8e-4).  So: all but 1e-5 of the elements within 2e-6, every
-    # element within 2e-3 -- a placement bug (a task dropped or run twice) moves whole rows by O(1).
+    # and three Adam steps later the embeddings by 2.5e-7).  LightGCN: nothing amplifies that -- all but 1e-5 of the
+    # elements within 2e-6, every element within 2e-5; a placement bug (a task dropped or run twice) moves whole rows by
+    # O(1).  XSimGCL: once in a few runs such a last-bit difference lands on a layer-output element within rounding of
+    # zero, where XSimGCL.py:90's sign(h) turns it into a 2 eps |unit| jump that the next two products spread over the
+    # element's two-hop neighbourhood (observed: 1,600 of 2 M elements above 2e-6, the largest 1.8e-4: round 4's
+    # gpurun session c) -- so there the bulk is held to 2e-6 on all but 0.5 % of the elements and every element to 2e-3.
+    frac, worst = (1e-5, 2e-5) if model == "LightGCN" else (5e-3, 2e-3)
     for x, y in zip(ea, eb):
         err = np.abs(x.astype(np.float64) - y) / np.abs(y).max()
-        assert (err > 2e-6).mean() < 1e-5 and err.max() < 2e-3, ((err > 2e-6).mean(), err.max())
+        assert (err > 2e-6).mean() < frac and err.max() < worst, ((err > 2e-6).mean(), err.max())
     ops.spmm_set_xcd_shares(a.adj, 64, shares)                  # leave the module's shared graph as the engine set it
 
 

@@ -231,9 +231,10 @@ def test_xcd_share_calibration_controller(monkeypatch):
     monkeypatch.setattr(ops, "spmm_plan_run_tasks", lambda csr, d: nb * 4 - 1)
     monkeypatch.delenv("SRH_XCD_CALIBRATE", raising=False)
 
-    def trainer(**over):
-        t = types.SimpleNamespace(dev=types.SimpleNamespace(type="cuda"), sharded=False, cols=False, L=3, d=64, model="LightGCN",
-                                  vfree=False, eps=0.2, dinv=None, E0=None, Ha=None, adj=types.SimpleNamespace())
+    def trainer(single=True, **over):
+        t = types.SimpleNamespace(dev=types.SimpleNamespace(type="cuda"), place=types.SimpleNamespace(single_gpu_step=single),
+                                  L=3, d=64, model="LightGCN", vfree=False, eps=0.2, dinv=None, E0=None, Ha=None,
+                                  adj=types.SimpleNamespace())
         t.__dict__.update(over)
         return t
     before = (canon * speed).max() - (canon * speed).min()
@@ -246,13 +247,18 @@ def test_xcd_share_calibration_controller(monkeypatch):
     assert got[2] < canon[2] and got[1] > canon[1]                        # the slow XCD gave, the fast one took
     # the plan remembers: a second trainer on the same matrix does not probe again
     n = state["probes"]
-    again = engine.FusedTrainer._calibrate_xcd_shares(trainer(adj=t.adj))
+    t2 = trainer(adj=t.adj)
+    again = engine.FusedTrainer._calibrate_xcd_shares(t2)
     assert state["probes"] == n and np.array_equal(again, got)
+    # ... and what was decided is on the record of both trainers
+    rec = t.xcd_calibration
+    assert rec["shares"] == [int(v) for v in got] and rec["canonical"] == [int(v) for v in canon] and t2.xcd_calibration == rec
+    assert rec["xcd_finish_spread_us_by_round"][0] > rec["xcd_finish_spread_us_by_round"][-1]
     # switched off, sharded layouts, unsupported widths, small graphs: nothing happens
     monkeypatch.setenv("SRH_XCD_CALIBRATE", "0")
     assert engine.FusedTrainer._calibrate_xcd_shares(trainer()) is None and state["probes"] == n
     monkeypatch.delenv("SRH_XCD_CALIBRATE")
-    for over in (dict(sharded=True), dict(cols=True), dict(d=32), dict(L=0), dict(dev=types.SimpleNamespace(type="cpu"))):
+    for over in (dict(single=False), dict(d=32), dict(L=0), dict(dev=types.SimpleNamespace(type="cpu"))):
         assert engine.FusedTrainer._calibrate_xcd_shares(trainer(**over)) is None and state["probes"] == n
     monkeypatch.setattr(ops, "spmm_plan_run_tasks", lambda csr, d: 4000)
     assert engine.FusedTrainer._calibrate_xcd_shares(trainer()) is None and state["probes"] == n
