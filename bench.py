@@ -242,7 +242,8 @@ def dropin_throughput(args, raw, steps=60, warmup=8):
     session (profiles/r02_a_dropin_reference_models.txt); /root/reference does not exist where bench.py runs."""
     import random
     import torch.nn.functional as F
-    from selfrec_amd import synth
+    from selfrec_amd import dropin, synth
+    dropin.install(fuse=False)         # the mirrors under the reference's module names + the host-side fast paths (util/fastpath.py)
     from selfrec_amd.base.torch_interface import TorchGraphInterface
     from selfrec_amd.data.ui_graph import Interaction
     from selfrec_amd.util.loss_torch import InfoNCE, bpr_loss, l2_reg_loss
@@ -277,7 +278,8 @@ def dropin_throughput(args, raw, steps=60, warmup=8):
             torch.cuda.synchronize(); t0 = time.perf_counter()
         ue, ie, cu, ci = encode(True)
         u, p, n = ue[u_idx], ie[i_idx], ie[j_idx]
-        uu = torch.unique(torch.tensor(u_idx, device="cuda")); ui = torch.unique(torch.tensor(i_idx, device="cuda"))
+        uu = torch.unique(torch.Tensor(u_idx).type(torch.long)).cuda()          # (XSimGCL.py:46-47, as the file spells it)
+        ui = torch.unique(torch.Tensor(i_idx).type(torch.long)).cuda()
         cl = InfoNCE(ue[uu], cu[uu], tau) + InfoNCE(ie[ui], ci[ui], tau)
         loss = bpr_loss(u, p, n) + l2_reg_loss(reg, u, p) + lam * cl
         opt.zero_grad(); loss.backward(); opt.step()
@@ -286,9 +288,11 @@ def dropin_throughput(args, raw, steps=60, warmup=8):
             break
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dropin.uninstall()
     return {"pairs_per_s": round(steps * args.batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "what": "XSimGCL written against SELFRec's API (raw torch.sparse.mm on the handle, torch autograd, torch Adam, "
-                    "python generator sampler pulled synchronously), HIP SpMM / loss / sampler kernels underneath",
+            "what": "XSimGCL written against SELFRec's API (raw torch.sparse.mm on the handle, torch autograd, torch.optim.Adam, "
+                    "python generator sampler pulled synchronously, table[list] gathers, torch.unique(torch.Tensor(list))) under "
+                    "dropin.install(): HIP SpMM / loss / sampler / Adam kernels underneath, ids uploaded once per batch",
             "final_loss": float(loss.item())}
 
 

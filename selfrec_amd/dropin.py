@@ -67,9 +67,17 @@ def maybe_fuse(cls) -> bool:
     return True
 
 
-def install(overwrite: bool = True, fuse: bool | None = None) -> None:
+def install(overwrite: bool = True, fuse: bool | None = None, fast: bool = True) -> None:
+    """``fast`` (default on; ``SRH_DROPIN_FAST=0`` turns it off): the host-side fast paths of the op-level tier --
+    ``table[list]`` row gathers as one ``index_select`` on ids uploaded once per batch, ``torch.unique`` of a batch stream
+    answered by the sampler, ``torch.optim.Adam`` stepping through the fused kernel (util/fastpath.py).  They apply to ANY
+    model file written the reference's way -- an edited copy, a new model -- not only to the five byte-identical ones
+    ``fuse`` recognises."""
     if fuse is not None:
         _state["fuse"] = bool(fuse)
+    if fast and os.environ.get("SRH_DROPIN_FAST", "1") != "0":
+        from .util import fastpath
+        fastpath.install()
     for pkg, mods in MIRRORED.items():
         mirror = importlib.import_module(f"{__package__}.{pkg}")
         if overwrite or pkg not in sys.modules:
@@ -81,6 +89,8 @@ def install(overwrite: bool = True, fuse: bool | None = None) -> None:
 
 
 def uninstall() -> None:
+    from .util import fastpath
+    fastpath.uninstall()
     for pkg, mods in MIRRORED.items():
         for m in mods:
             sys.modules.pop(f"{pkg}.{m}", None)

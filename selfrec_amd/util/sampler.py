@@ -10,6 +10,7 @@ order.
 import numpy as np
 
 from .. import ops
+from . import fastpath
 
 _PROBES = 64
 
@@ -95,4 +96,7 @@ def next_batch_pairwise(data, batch_size, n_negs=1, as_arrays=False):
         if as_arrays:
             yield u.astype(np.int64), i.astype(np.int64), j.astype(np.int64)
         else:
-            yield u.tolist(), i.tolist(), j.tolist()
+            lists = (u.tolist(), i.tolist(), j.tolist())
+            if fastpath.active():             # (dropin.install(): the lists' device copies, uploaded once -- util/fastpath.py)
+                fastpath.register_batch(lists, (u, i, j))
+            yield lists

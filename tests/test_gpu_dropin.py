@@ -64,6 +64,67 @@ def test_client_training_loop_matches_oracle(golden_models, golden_meta, fresh_t
     assert rel_err(fu.cpu().numpy(), gm["LightGCN_final_user"]) < 1e-4
 
 
+def test_fast_paths_take_the_reference_idioms_and_the_same_steps(golden_models, golden_meta, golden_ops):
+    """dropin.install()'s host-side fast paths (util/fastpath.py) on a model written the reference's way -- table[list]
+    gathers, torch.unique(torch.Tensor(list).type(torch.long)).cuda(), torch.optim.Adam: every one of them is TAKEN, and
+    the run takes the steps of the same loop without them (same batches; parameters equal to the order of fp32 sums)."""
+    from selfrec_amd import dropin
+    from selfrec_amd.util import fastpath
+    from tests.conftest import _tiny_interaction
+    gm, m = golden_models, golden_meta["LightGCN"]
+
+    def run(fast):
+        dropin.install(fuse=False, fast=fast)
+        try:
+            assert fastpath.active() == fast
+            data = _tiny_interaction(golden_ops)               # (a fresh list order for each run: same batches)
+            enc = ClientEncoder(data, m["emb"], 3, gm["LightGCN_init_user"], gm["LightGCN_init_item"]).cuda()
+            opt = torch.optim.Adam(enc.parameters(), lr=m["lr"])
+            assert isinstance(opt, fastpath.Adam) == fast
+            random.seed(m["sampler_seed"])
+            seen = []
+            for k, (u_idx, i_idx, j_idx) in enumerate(next_batch_pairwise(data, m["batch"])):
+                assert type(u_idx) is list and type(j_idx) is list           # the reference's protocol: python lists
+                ue, ie = enc()
+                u, p, n = ue[u_idx], ie[i_idx], ie[j_idx]
+                uu = torch.unique(torch.Tensor(u_idx).type(torch.long)).cuda()          # XSimGCL.py:46-47
+                ui = torch.unique(torch.Tensor(i_idx).type(torch.long)).cuda()
+                assert uu.is_cuda and torch.equal(uu.cpu(), torch.unique(torch.tensor(u_idx)))
+                cl = InfoNCE(ue[uu], ue[uu].detach() * 0.9, 0.2) + InfoNCE(ie[ui], ie[ui].detach() * 0.9, 0.2)
+                loss = bpr_loss(u, p, n) + l2_reg_loss(m["reg"], u, p) + 0.2 * cl
+                opt.zero_grad(); loss.backward(); opt.step()
+                seen.append((u_idx[:5], float(loss)))
+                if k == 3:
+                    break
+            return seen, enc.embedding_dict["user_emb"].detach().cpu().numpy(), enc.embedding_dict["item_emb"].detach().cpu().numpy()
+        finally:
+            dropin.uninstall()
+    for k in fastpath.hits:
+        fastpath.hits[k] = 0
+    slow = run(False)
+    assert not any(fastpath.hits.values())
+    fast = run(True)
+    assert fastpath.hits["gather_list"] >= 12 and fastpath.hits["unique"] == 8 and fastpath.hits["gather_index"] >= 8
+    assert fastpath.hits["adam"] == 8                                   # two tables x four steps
+    assert "__getitem__" not in torch.Tensor.__dict__ and torch.optim.Adam is not fastpath.Adam     # uninstall() restored torch
+    assert [a[0] for a in slow[0]] == [a[0] for a in fast[0]]
+    np.testing.assert_allclose([a[1] for a in slow[0]], [a[1] for a in fast[0]], rtol=2e-6)
+    assert rel_err(fast[1], slow[1]) < 2e-6 and rel_err(fast[2], slow[2]) < 2e-6
+    # a list the caller edited after it was yielded is NOT served from the registry
+    dropin.install(fuse=False)
+    try:
+        data = _tiny_interaction(golden_ops)
+        random.seed(3)
+        u_idx, i_idx, j_idx = next(iter(next_batch_pairwise(data, 64)))
+        table = torch.arange(data.user_num * 4, dtype=torch.float32, device="cuda").reshape(data.user_num, 4)
+        want = table[torch.tensor(u_idx, device="cuda")]
+        assert torch.equal(table[u_idx], want)
+        u_idx[0] = (u_idx[0] + 1) % data.user_num
+        assert torch.equal(table[u_idx], table[torch.tensor(u_idx, device="cuda")])
+    finally:
+        dropin.uninstall()
+
+
 def test_handle_rectangular_backward_uses_transpose():
     import scipy.sparse as sp
     rng = np.random.default_rng(0)

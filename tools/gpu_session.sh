@@ -120,6 +120,13 @@ benchab)
     timeout 600 python bench.py --steps 1300 --warmup 30 --no-cpu-baseline --no-eval --no-dropin $flag > $OUT/benchab.log 2> $OUT/benchab.err; echo "benchab [$flag] exit $?"
     python -c "import json,sys; d=json.loads(open('$OUT/benchab.log').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['steady_state']['ms_per_step'], d['value'])"
   done;;
+refedited)
+  # the tier an EDITED / new model file gets: copies of the reference's files with one comment appended (no SHA match),
+  # with and without the host-side fast paths
+  timeout 900 python tools/run_reference_models.py --ref _refstage --edited --models ${REF_MODELS:-XSimGCL,LightGCN} > $OUT/refmodels_edited.log 2>&1; echo "refedited exit $?"
+  grep -E "^#|parity|epoch\(s\)|Error|error" $OUT/refmodels_edited.log | tail -12
+  timeout 900 python tools/run_reference_models.py --ref _refstage --edited --no-fast --models ${REF_MODELS:-XSimGCL,LightGCN} > $OUT/refmodels_edited_nofast.log 2>&1; echo "refedited (no fast paths) exit $?"
+  grep -E "^#|parity|epoch\(s\)|Error|error" $OUT/refmodels_edited_nofast.log | tail -12;;
 refmodels)
   timeout 1500 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL,LightGCN,SimGCL,SGL} > $OUT/refmodels.log 2>&1; echo "refmodels exit $?"
   grep -E "^#|parity|1 epoch|Error|error" $OUT/refmodels.log | tail -20;;

@@ -88,10 +88,24 @@ def main():
                     "building the engine -- plan, XCD calibration, hipGraph capture -- is ~0.1 s of a 0.17 s epoch)")
     ap.add_argument("--profile", type=int, default=0, help="instead of the epoch: torch.profiler over this many steps of "
                     "train() (after 20 unprofiled ones); prints the operator tables by host and by device time")
+    ap.add_argument("--edited", action="store_true", help="run COPIES of the model files with one comment line appended (made "
+                    "in a temporary directory at run time): any edit defeats the SHA-256 gate of --fuse, so this is the tier an "
+                    "edited or new model gets (VERDICT r03 next #5)")
+    ap.add_argument("--no-fast", action="store_true", help="dropin.install(fast=False): without util/fastpath.py's host paths")
     args = ap.parse_args()
     from selfrec_amd import dropin, synth
-    dropin.install(fuse=args.fuse)
+    from selfrec_amd.util import fastpath
+    dropin.install(fuse=args.fuse, fast=not args.no_fast)
     sys.dont_write_bytecode = True
+    if args.edited:
+        import shutil
+        stage = tempfile.mkdtemp(prefix="srh_edited_")
+        shutil.copytree(os.path.join(os.path.abspath(args.ref), "model"), os.path.join(stage, "model"))
+        for name in args.models.split(","):
+            with open(os.path.join(stage, "model", "graph", f"{name}.py"), "a") as f:
+                f.write("\n# one comment line appended by tools/run_reference_models.py --edited\n")
+        args.ref = stage
+        print(f"# --edited: model files copied to {stage} with one comment line appended (SHA-256 no longer the reference's)")
     sys.path.insert(0, os.path.abspath(args.ref))
     golden = np.load(os.path.join(REPO, "tests", "golden", "shapes.npz"))
     with open(os.path.join(REPO, "tests", "golden", "shapes_meta.json")) as f:
@@ -108,7 +122,7 @@ def main():
         assert src.startswith(os.path.abspath(args.ref)), src
         assert mod.next_batch_pairwise.__module__ == "selfrec_amd.util.sampler", mod.next_batch_pairwise.__module__
         fused = name in dropin._state["fused"]
-        assert fused == bool(args.fuse), (name, fused)
+        assert fused == (bool(args.fuse) and not args.edited), (name, fused)
         if fused:
             print(f"{name}: {os.path.relpath(src, os.path.abspath(args.ref))} is byte-for-byte the reference's "
                   f"(SHA-256 {dropin.FUSABLE[name][:16]}...): train() -> engine.FusedTrainer")
@@ -200,6 +214,7 @@ def main():
                       f"sampling{', engine construction + calibration + graph capture' if fused else ''} included); fast_evaluation {t_eval[0]:.2f} s")
             finally:
                 os.chdir(cwd)
+    print(f"# host fast paths (util/fastpath.py) {'off' if args.no_fast else 'on'}: taken {dict(fastpath.hits)}")
 
 
 if __name__ == "__main__":
