@@ -938,7 +938,9 @@ def main():
         strong_layout = os.environ.get("SRH_STRONG_LAYOUT") or None        # None: pick_layout's cols / rows / 2-D choice
         try:
             from selfrec_amd.dist import pick_layout
-            chosen = pick_layout(args.emb, world, strong_layout, nnz_adj)
+            chosen = pick_layout(args.emb, world, strong_layout or "auto", nnz_adj)     # ("auto": never SRH_SHARD_LAYOUT's dp)
+            if chosen == "dp":
+                raise ValueError("SRH_STRONG_LAYOUT=dp is not a strong-scaling layout (rows, cols, 2d[:GCxGR] or auto)")
             s_tr, s_run, s_note = first_steps_guarded(make(chosen), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
                                                       f"strong layout {chosen}")
             s_run.run(args.warmup)

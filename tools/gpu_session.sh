@@ -135,7 +135,7 @@ bprobe)
 splitprobe)
   timeout 600 python tools/split_probe.py > $OUT/split_probe.log 2>&1; echo "splitprobe exit $?"; grep -v amdgpu.ids $OUT/split_probe.log | tail -12;;
 refprof)
-  timeout 900 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL} --profile 40 > $OUT/refprof.log 2>&1; echo "refprof exit $?"
+  timeout 900 python tools/run_reference_models.py --ref _refstage --models ${REF_MODELS:-XSimGCL} --profile 40 ${REFPROF_ARGS:-} > $OUT/refprof.log 2>&1; echo "refprof exit $?"
   grep -v "amdgpu.ids\|^training" $OUT/refprof.log | cut -c1-230 | tail -80;;
 prof)
   # per-kernel times of the captured step (hipGraph replay), the command bench.py times
@@ -155,7 +155,7 @@ pmc)
   done
   # the record bench.py quotes as roofline.traffic, stamped with the blob id of the spmm.hip it was measured on
   python tools/pmc_to_json.py $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE_TCC_HIT_sum_TCC_MISS_sum $OUT/pmc_SQ_WAVES* -name "*.db") \
-    --tail ${PMC_TAIL:-40} --out $OUT/spmm_dense_traffic${PMC_NAME:-}.json --summary "${PMC_SUMMARY:-profiles/r03_pmc_dense_spmm.txt}" \
+    --tail ${PMC_TAIL:-40} --out $OUT/spmm_dense_traffic${PMC_NAME:-}.json --summary "${PMC_SUMMARY:-profiles/r04_e_pmc_dense_spmm.txt}" \
     --what "${PMC_WHAT:-spmm_rows_kernel<16,false>, dominant launch of the step: dense value-free flavour, yelp2018-shape graph, d=64}" > /dev/null && echo "wrote $OUT/spmm_dense_traffic${PMC_NAME:-}.json"
   find $OUT/pmc_* -name "*.db" -size +30M -delete;;
 losspmc)
