@@ -107,6 +107,23 @@ def pmc_traffic(args):
     return rec["traffic_bytes_per_launch"], f"{rec['summary']}: {rec['how']}"
 
 
+def eval_mfma_busy():
+    """MFMA-pipe utilisation of the ranking's filter kernel from the committed counter pass (profiles/eval_mfma_busy.json,
+    written from tools/gpu_session.sh evalpmc; bench.py cannot run under rocprofv3 --pmc itself).  Stamped with the git blob of
+    the csrc/eval.hip it was measured on: a record of another kernel source is refused (None + the reason)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "profiles", "eval_mfma_busy.json")
+    if not os.path.exists(path):
+        return None, "no counter pass committed (profiles/eval_mfma_busy.json)"
+    with open(path) as f:
+        rec = json.load(f)
+    have = git_blob_hash(os.path.join(here, "selfrec_amd", "csrc", "eval.hip"))
+    if rec.get("eval_hip_blob") != have:
+        return None, (f"profiles/eval_mfma_busy.json was measured on csrc/eval.hip blob {str(rec.get('eval_hip_blob'))[:12]}, this tree "
+                      f"has {have[:12]}: stale record refused (re-run tools/gpu_session.sh evalpmc)")
+    return rec["mfma_busy_filter16"], f"{rec['summary']}: {rec['how']}"
+
+
 def pmc_traffic_cols(args, w):
     """Same for one rank's launch on (N, w) tables in the column-sharded layout: profiles/spmm_cols_traffic.json."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "spmm_cols_traffic.json")
@@ -456,7 +473,9 @@ def eval_throughput(trainer, data, k=20):
                                  "(exact-f32 MFMA chain, masks, top-K, ids + scores to the host)",
                          "gemm_alone_tflops": round(gemm_tflops, 2),
                          "gemm_alone_frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                         "mfma_busy": "profiles/r03_*_eval_pmc.txt (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"}}
+                         # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of filter16_kernel (the dominant ranking kernel, 3-term split-bf16
+                         # products): how busy the matrix pipe is, NOT the algorithmic fraction above
+                         "mfma_busy": eval_mfma_busy()[0], "mfma_busy_source": eval_mfma_busy()[1]}}
 
 
 def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):

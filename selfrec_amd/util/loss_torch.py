@@ -55,7 +55,9 @@ class _BprFn(torch.autograd.Function):
     def backward(ctx, gout):
         u, p, n, coef = ctx.saved_tensors
         gu, gp, gn = torch.empty_like(u), torch.empty_like(p), torch.empty_like(n)
-        ops.bpr_bwd(u, p, n, coef, float(gout) / u.shape[0], gu, gp, gn)
+        # the upstream gradient stays ON THE DEVICE (folded into the per-row coefficients): a float(gout) here is a
+        # device-to-host sync in the middle of every backward pass -- the host could no longer run ahead of the device
+        ops.bpr_bwd(u, p, n, coef * (gout.to(torch.float32) / u.shape[0]), 1.0, gu, gp, gn)
         d = ctx.d
         return gu[:, :d], gp[:, :d], gn[:, :d]
 
@@ -95,12 +97,10 @@ class _FrobNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         x, norm = ctx.saved_tensors
-        n = float(norm)
-        if x.numel() % 4:                         # (srh_axpby works on float4s: odd sizes take one ATen multiply)
-            return x * (float(gout) / n if n > 0.0 else 0.0)
-        g = torch.empty_like(x)
-        ops.axpby(float(gout) / n if n > 0.0 else 0.0, x, 0.0, g)
-        return g
+        # gout / ||x|| (0 at ||x|| = 0) as a DEVICE scalar: no float(...) -- every one of those is a device-to-host sync
+        # that stops the host from running ahead (four per step of the reference's XSimGCL.py before round 4)
+        coef = torch.where(norm > 0, gout.to(torch.float32) / norm, torch.zeros_like(norm))
+        return x * coef
 
 
 def l2_reg_loss(reg, *args):
