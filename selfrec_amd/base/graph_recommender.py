@@ -34,6 +34,17 @@ DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered):
 FILTER_WS_KEEP_BYTES = 1 << 30  # the filtered ranking's workspace is cached on the model up to this size
 
 
+def _to_host(*tensors):
+    """Device results -> numpy arrays: every copy into PINNED host memory (torch's caching host allocator: a fresh block per
+    call, so an earlier result is never overwritten), all of them asynchronous, ONE synchronisation -- instead of a
+    synchronous pageable copy per array (ids + scores of 31.5 k users: 5 MB; 0.25 of the ranking's 1.33 ms)."""
+    outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    for o, t in zip(outs, tensors):
+        o.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return tuple(o.numpy() for o in outs)
+
+
 class GraphRecommender(Recommender):
     def __init_subclass__(cls, **kwargs):
         super().__init_subclass__(**kwargs)
@@ -132,7 +143,7 @@ class GraphRecommender(Recommender):
         k = self.max_N if k is None else k
         ue, ie = self._device_embeddings()
         g = self.data.device_graph(ie.device)
-        uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=ie.device)
+        uid = self._device_user_ids(user_ids, ie.device)
         ids_dev, sc_dev = self._rank(ue, uid, ie, g, k)
         if with_hits:
             t_indptr, t_indices, _ = self._test_csr(ie.device)
@@ -140,10 +151,21 @@ class GraphRecommender(Recommender):
             if metric_cuts:
                 sizes = (t_indptr[1:] - t_indptr[:-1])[uid.long()].contiguous()
                 hits, ndcg = ops.metric_rows(flags, sizes, metric_cuts)
-                return (ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy(),
-                        {int(n): (hits[c].cpu().numpy(), ndcg[c].cpu().numpy()) for c, n in enumerate(metric_cuts)})
-            return ids_dev.cpu().numpy(), sc_dev.cpu().numpy(), flags.cpu().numpy()
-        return ids_dev.cpu().numpy(), sc_dev.cpu().numpy()
+                got = _to_host(ids_dev, sc_dev, flags, *[t for c in range(len(metric_cuts)) for t in (hits[c], ndcg[c])])
+                return (got[0], got[1], got[2], {int(n): (got[3 + 2 * c], got[4 + 2 * c]) for c, n in enumerate(metric_cuts)})
+            return _to_host(ids_dev, sc_dev, flags)
+        return _to_host(ids_dev, sc_dev)
+
+    def _device_user_ids(self, user_ids, device):
+        """The int32 ids on the device; test() passes the SAME cached array every epoch, so the upload happens once."""
+        cached = getattr(self, '_uid_dev_cache', None)
+        ends = (len(user_ids), int(user_ids[0]), int(user_ids[-1])) if len(user_ids) else (0, 0, 0)
+        if cached is not None and cached[0] is user_ids and cached[2] == ends and cached[1].device == torch.device(device):
+            return cached[1]
+        uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=device)
+        if isinstance(user_ids, np.ndarray):
+            self._uid_dev_cache = (user_ids, uid, ends)
+        return uid
 
     def _test_users(self):
         """Test users in test-set order with their ids, test-set sizes and the item-name table (built once)."""
