@@ -60,7 +60,8 @@ bool read_file(const char* path, std::vector<char>& buf) {
 struct NameTable {
   struct Slot { const char* p; uint32_t len; int32_t id; uint64_t h; };
   std::vector<Slot> slots;
-  std::vector<std::pair<const char*, uint32_t>> names;      // id -> name, in first-appearance order
+  struct Name { const char* first; uint32_t second; uint64_t h; };
+  std::vector<Name> names;                                   // id -> name (+ its hash), in first-appearance order
   size_t mask = 0;
   explicit NameTable(size_t cap_log2 = 12) { slots.assign((size_t)1 << cap_log2, Slot{nullptr, 0, -1, 0}); mask = slots.size() - 1; }
   static uint64_t hash(const char* p, size_t n) {
@@ -94,7 +95,7 @@ struct NameTable {
       if (!s.p) {
         const int32_t id = (int32_t)names.size();
         s = Slot{p, (uint32_t)n, id, h};
-        names.emplace_back(p, (uint32_t)n);
+        names.push_back(Name{p, (uint32_t)n, h});
         if (names.size() * 10 > slots.size() * 6) grow();
         return id;
       }
@@ -190,16 +191,75 @@ srh_status_t srh_dataset_load(srh_dataset_t** out, const char* train_path, const
     }
     lines_before += pieces[t].lines;
   }
-  NameTable users(16), items(16);
-  std::vector<int64_t> offset((size_t)T + 1, 0);
+  // ---- merge, in parallel by NAME: partition q owns the names whose hash falls to it, walks every piece's list of ITS
+  // names in file order and records, for each, the (piece, local id) of its first appearance.  (Merging the pieces' lists
+  // one after the other into one table is sequential and, with mostly-distinct names in every piece, costs T x names
+  // look-ups: it was 60 % of the loader's time at 8 threads.)
+  const int Q = std::max(T, 1);
+  auto part_of = [Q](uint64_t h) { return (int)((h >> 33) % (uint64_t)Q); };
+  struct Owner { int32_t piece, local; };
+  struct Part { NameTable users{12}, items{12}; std::vector<Owner> own_u, own_i; };
+  std::vector<Part> parts((size_t)Q);
+  std::vector<std::vector<Owner>> owner_u((size_t)T), owner_i((size_t)T);       // per piece, per local id: where it first appeared
+  std::vector<std::vector<uint8_t>> new_u((size_t)T), new_i((size_t)T);
   for (int t = 0; t < T; ++t) {
-    Piece& pc = pieces[t];
-    pc.tr_u.resize(pc.users.names.size());
-    pc.tr_i.resize(pc.items.names.size());
-    for (size_t k = 0; k < pc.users.names.size(); ++k) pc.tr_u[k] = users.find_or_add(pc.users.names[k].first, pc.users.names[k].second);
-    for (size_t k = 0; k < pc.items.names.size(); ++k) pc.tr_i[k] = items.find_or_add(pc.items.names[k].first, pc.items.names[k].second);
-    offset[t + 1] = offset[t] + (int64_t)pc.lu.size();
+    owner_u[t].resize(pieces[t].users.names.size()); new_u[t].assign(pieces[t].users.names.size(), 0);
+    owner_i[t].resize(pieces[t].items.names.size()); new_i[t].assign(pieces[t].items.names.size(), 0);
   }
+  run_all([&](int q) {
+    Part& pt = parts[q];
+    auto walk = [&](bool is_user) {
+      NameTable& tab = is_user ? pt.users : pt.items;
+      std::vector<Owner>& own = is_user ? pt.own_u : pt.own_i;
+      for (int t = 0; t < T; ++t) {
+        const auto& names = is_user ? pieces[t].users.names : pieces[t].items.names;
+        auto& owner = is_user ? owner_u[t] : owner_i[t];
+        auto& fresh = is_user ? new_u[t] : new_i[t];
+        for (size_t k = 0; k < names.size(); ++k) {
+          if (part_of(names[k].h) != q) continue;
+          const int32_t id = tab.find_or_add(names[k].first, names[k].second);
+          if ((size_t)id == own.size()) { own.push_back(Owner{t, (int32_t)k}); fresh[k] = 1; }
+          owner[k] = own[id];
+        }
+      }
+    };
+    walk(true);
+    walk(false);
+  }, Q);
+  // global id of a name = how many names appeared for the first time before it: pieces in file order, local ids in order
+  std::vector<std::vector<int32_t>> rank_u((size_t)T), rank_i((size_t)T);
+  int32_t n_users = 0, n_items = 0;
+  for (int t = 0; t < T; ++t) {
+    rank_u[t].resize(new_u[t].size()); rank_i[t].resize(new_i[t].size());
+    for (size_t k = 0; k < new_u[t].size(); ++k) { rank_u[t][k] = n_users; n_users += new_u[t][k]; }
+    for (size_t k = 0; k < new_i[t].size(); ++k) { rank_i[t][k] = n_items; n_items += new_i[t][k]; }
+  }
+  std::vector<int64_t> offset((size_t)T + 1, 0);
+  for (int t = 0; t < T; ++t) offset[t + 1] = offset[t] + (int64_t)pieces[t].lu.size();
+  ds->user_names.resize((size_t)n_users);
+  ds->item_names.resize((size_t)n_items);
+  run_all([&](int t) {
+    Piece& pc = pieces[t];
+    pc.tr_u.resize(owner_u[t].size());
+    pc.tr_i.resize(owner_i[t].size());
+    for (size_t k = 0; k < owner_u[t].size(); ++k) {
+      pc.tr_u[k] = rank_u[owner_u[t][k].piece][owner_u[t][k].local];
+      if (new_u[t][k]) ds->user_names[(size_t)pc.tr_u[k]].assign(pc.users.names[k].first, pc.users.names[k].second);
+    }
+    for (size_t k = 0; k < owner_i[t].size(); ++k) {
+      pc.tr_i[k] = rank_i[owner_i[t][k].piece][owner_i[t][k].local];
+      if (new_i[t][k]) ds->item_names[(size_t)pc.tr_i[k]].assign(pc.items.names[k].first, pc.items.names[k].second);
+    }
+  }, T);
+  // name -> global id for the test file: through the partition that owns the name
+  auto global_id = [&](bool is_user, const char* p, size_t n) -> int32_t {
+    const uint64_t h = NameTable::hash(p, n);
+    const Part& pt = parts[part_of(h)];
+    const int32_t id = (is_user ? pt.users : pt.items).find(p, n, h);
+    if (id < 0) return -1;
+    const Owner o = (is_user ? pt.own_u : pt.own_i)[(size_t)id];
+    return (is_user ? rank_u : rank_i)[o.piece][o.local];
+  };
   ds->train_u.resize((size_t)offset[T]); ds->train_i.resize((size_t)offset[T]); ds->train_w.resize((size_t)offset[T]);
   run_all([&](int t) {
     const Piece& pc = pieces[t];
@@ -208,11 +268,7 @@ srh_status_t srh_dataset_load(srh_dataset_t** out, const char* train_path, const
     for (size_t k = 0; k < pc.lu.size(); ++k) { du[k] = pc.tr_u[pc.lu[k]]; di[k] = pc.tr_i[pc.li[k]]; }
     if (!pc.w.empty()) memcpy(ds->train_w.data() + offset[t], pc.w.data(), sizeof(float) * pc.w.size());
   }, T);
-  ds->user_names.reserve(users.names.size());
-  ds->item_names.reserve(items.names.size());
-  for (const auto& nm : users.names) ds->user_names.emplace_back(nm.first, nm.second);
-  for (const auto& nm : items.names) ds->item_names.emplace_back(nm.first, nm.second);
-  pieces.clear();
+  // (the partitions' tables point into `buf` and into the pieces' name lists: both stay alive until the test file is done)
   if (test_path) {
     std::vector<char> tbuf;                                // (the name tables point into `buf`: keep it)
     if (!read_file(test_path, tbuf)) { delete ds; srh::set_error("dataset_load: cannot read %s", test_path); return SRH_ERR_INVALID_ARG; }
@@ -229,7 +285,7 @@ srh_status_t srh_dataset_load(srh_dataset_t** out, const char* train_path, const
         Line ln;
         if (split_line(p, le, ln)) {
           ++tp[t].lines;
-          const int32_t u = users.find(ln.u, ln.ul), i = items.find(ln.i, ln.il);
+          const int32_t u = global_id(true, ln.u, ln.ul), i = global_id(false, ln.i, ln.il);
           if (u >= 0 && i >= 0) { tp[t].u.push_back(u); tp[t].i.push_back(i); }
         }
         p = nl ? nl + 1 : end;
