@@ -89,7 +89,7 @@ def test_fast_paths_take_the_reference_idioms_and_the_same_steps(golden_models, 
                 u, p, n = ue[u_idx], ie[i_idx], ie[j_idx]
                 uu = torch.unique(torch.Tensor(u_idx).type(torch.long)).cuda()          # XSimGCL.py:46-47
                 ui = torch.unique(torch.Tensor(i_idx).type(torch.long)).cuda()
-                assert uu.is_cuda and torch.equal(uu.cpu(), torch.unique(torch.tensor(u_idx)))
+                assert uu.is_cuda and np.array_equal(uu.cpu().numpy(), np.unique(u_idx)) and np.array_equal(ui.cpu().numpy(), np.unique(i_idx))
                 cl = InfoNCE(ue[uu], ue[uu].detach() * 0.9, 0.2) + InfoNCE(ie[ui], ie[ui].detach() * 0.9, 0.2)
                 loss = bpr_loss(u, p, n) + l2_reg_loss(m["reg"], u, p) + 0.2 * cl
                 opt.zero_grad(); loss.backward(); opt.step()
