@@ -197,6 +197,8 @@ abtest)
     echo "abtest $N exit $?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/abtest_$N.log | tail -5
   done
   cp /tmp/orig_t.so selfrec_amd/lib/libselfrec_hip.so;;
+evalbreak)
+  timeout 600 python tools/eval_breakdown.py > $OUT/eval_breakdown.txt 2>&1; echo "evalbreak exit $?"; grep -v amdgpu.ids $OUT/eval_breakdown.txt | tail -3;;
 timeline)
   timeout 600 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1; echo "timeline exit $?"; grep -v amdgpu.ids $OUT/step_timeline.txt | cut -c1-700;;
 cpuref)
