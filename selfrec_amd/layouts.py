@@ -20,7 +20,7 @@ A layout is a choice of the three (``make_placement``):
 
 ``Placement`` also answers the questions that depend on the combination (may the step use the single-GPU-only kernels --
 value-free products, the fetch rider, the fused Adam reset, the calibrated plan; how is it captured; which phases does a
-step have).  Communicators are ``engine.TorchComm`` objects or test stand-ins with the same two methods."""
+step have).  Communicators are ``comm.TorchComm`` objects or test stand-ins with the same two methods."""
 from __future__ import annotations
 
 import os

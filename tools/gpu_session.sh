@@ -166,7 +166,7 @@ losspmc)
 evalpmc)
   # MFMA utilisation of the scoring GEMM (double-buffered gemm_nt_kernel<64, 8, filter>) + per-kernel times of the ranking
   rm -rf $OUT/evalpmc $OUT/evalprof
-  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d $OLDPWD/$OUT/evalpmc -o pmc -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalpmc.log 2>&1); echo "evalpmc exit $?"
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc ${EVALPMC_COUNTERS:-SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES} -d $OLDPWD/$OUT/evalpmc -o pmc -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalpmc.log 2>&1); echo "evalpmc exit $?"
   f=$(find $OUT/evalpmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "gemm_nt|filter16|rescore|topk|cand_|mask_kernel|hit_flags|split_rows" | tee $OUT/eval_pmc.txt
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/evalprof -o trace -- python $OLDPWD/tools/eval_probe.py > $OLDPWD/$OUT/evalprof.log 2>&1); echo "evalprof exit $?"
   stats $OUT/evalprof | grep -E "kernel  |gemm_nt|topk|mask_kernel|cand_|hit_flags" | tee $OUT/eval_kernel_stats.txt; grep -v amdgpu.ids $OUT/evalprof.log | tail -1
