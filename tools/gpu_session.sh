@@ -197,6 +197,16 @@ abtest)
     echo "abtest $N exit $?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/abtest_$N.log | tail -5
   done
   cp /tmp/orig_t.so selfrec_amd/lib/libselfrec_hip.so;;
+evalbreakab)
+  # the ranking on TRAINED embeddings under the product's library and under each alt library (EVAL_LIBS)
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig_e.so; : > $OUT/eval_breakdown_ab.txt
+  for N in product ${EVAL_LIBS:-} product; do
+    [ $N = product ] || cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so
+    echo "== $N" >> $OUT/eval_breakdown_ab.txt
+    EVAL_TRAIN_STEPS=1300 timeout 300 python tools/eval_breakdown.py 2>&1 | grep -v amdgpu.ids | tail -1 >> $OUT/eval_breakdown_ab.txt
+    cp /tmp/orig_e.so selfrec_amd/lib/libselfrec_hip.so
+  done
+  cat $OUT/eval_breakdown_ab.txt;;
 evalbreak)
   timeout 600 python tools/eval_breakdown.py > $OUT/eval_breakdown.txt 2>&1; echo "evalbreak exit $?"; grep -v amdgpu.ids $OUT/eval_breakdown.txt | tail -3;;
 timeline)
