@@ -308,9 +308,6 @@ constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two sta
 // SLAB: instead of filtering, write the split-bf16 scores of the item range into a (m x n) slab -- the bound stage (the
 // K-th score over a leading slice of the catalogue), which then costs a quarter of the f32 GEMM it replaces; the bound
 // derived from approximate scores is lowered by one more delta_u (see srh_score_mask_topk_filtered).
-#ifndef SRH_F16_PIPE
-#define SRH_F16_PIPE 0
-#endif
 template <int D, bool SLAB = false, int UB = 2>
 __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
                                                        const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
@@ -387,54 +384,25 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
     if (live) {
       const unsigned char* buf = f16_smem + cur * STAGE_BYTES;
       const int nt = min(ST, t_end - t0);
-#if SRH_F16_PIPE
-      // (SRH_F16_PIPE, round 4 experiment: the hi fragments of tile t + 1 are read from LDS under the MFMAs of tile t, the lo
-      // fragments of tile t at its head, and the products that need only hi operands -- al . bh -- go first, so that no tile
-      // starts with an exposed LDS round trip; 16 more VGPRs: still 4 waves per SIMD at d = 64)
-      bf16x8 bh[KS], bh_next[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) bh[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + s * 1024 + lane * 16));
-#endif
       for (int tt = 0; tt < nt; ++tt) {
-#if SRH_F16_PIPE
-        bf16x8 bl[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-          bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + KS + s) * 1024 + lane * 16));
-        const int tn = min(tt + 1, nt - 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-          bh_next[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tn * 2 * KS + s) * 1024 + lane * 16));
-#else
         bf16x8 bh[KS], bl[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           bh[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + s) * 1024 + lane * 16));
           bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + KS + s) * 1024 + lane * 16));
         }
-#endif
         const int col = (t0 + tt) * 32 + r32;
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
           floatx16 acc;
 #pragma unroll
           for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-#if SRH_F16_PIPE
-#pragma unroll
-          for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
-          }
-#else
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
           }
-#endif
           if (SLAB) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -479,10 +447,6 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
             bal = __builtin_amdgcn_ballot_w64(pm != 0);
           }
         }
-#if SRH_F16_PIPE
-#pragma unroll
-        for (int s = 0; s < KS; ++s) bh[s] = bh_next[s];
-#endif
       }
       if (staged > 0) flush();      // once per stage, right before the wait the pipeline makes anyway
     }

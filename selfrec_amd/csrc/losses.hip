@@ -235,6 +235,11 @@ static_assert(SRH_NCE_SPLITS == 8 || SRH_NCE_SPLITS == 16, "SRH_NCE_SPLITS: 8 or
 static_assert(SRH_NCE_PV_TERMS == 3 || SRH_NCE_PV_TERMS == 6, "SRH_NCE_PV_TERMS: 3 or 6");
 //   SRH_NCE_WT        1 (default): the tile passes' partial outputs (16.8 MB per step at n = 2048) leave with write-through
 //                     stores: read next by the finish kernel on other XCDs, never again by their writers (-1.2 us per step)
+//   SRH_NCE_PIPE      1: the tile passes read the operand fragments of key block j + 1 under the MFMAs of block j (two
+//                     register sets, ping-pong)
+#ifndef SRH_NCE_PIPE
+#define SRH_NCE_PIPE 0
+#endif
 #ifndef SRH_NCE_WT
 #define SRH_NCE_WT 1
 #endif
@@ -707,31 +712,33 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
     __syncthreads();
     if (!wave_live) continue;
 
-    for (int j0 = 0; j0 < cn; j0 += 32) {
-      f16x8 kh[2][KS], kl[2][KS];
+    // one 32-key block: its operand fragments out of the LDS stage ...
+    struct Blk { f16x8 kh[2][KS], kl[2][KS]; bf16x8 vh[NT], vm[NT], vl[PVT == 6 ? NT : 1]; float il[2][4]; };
+    auto load_blk = [&](int j0, Blk& b) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const int off = (((j0 >> 4) + h) * KS + s) * 1024 + lane * 16;
-          kh[h][s] = lds_f16x8(smem + off);
-          kl[h][s] = lds_f16x8(smem + SPAN + off);
+          b.kh[h][s] = lds_f16x8(smem + off);
+          b.kl[h][s] = lds_f16x8(smem + SPAN + off);
         }
-      bf16x8 vh[NT], vm[NT], vl[PVT == 6 ? NT : 1];
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int off = ((j0 >> 5) * NT + u) * 1024 + lane * 16;
-        vh[u] = lds_bf16x8(smem + 2 * SPAN + off);
-        vm[u] = lds_bf16x8(smem + 3 * SPAN + off);
-        if (PVT == 6) vl[u] = lds_bf16x8(smem + 4 * SPAN + off);
+        b.vh[u] = lds_bf16x8(smem + 2 * SPAN + off);
+        b.vm[u] = lds_bf16x8(smem + 3 * SPAN + off);
+        if (PVT == 6) b.vl[u] = lds_bf16x8(smem + 4 * SPAN + off);
       }
-      float il[2][4];
       if (PASS2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) il[h][r] = invl_s[j0 + 16 * h + 4 * g + r];
+          for (int r = 0; r < 4; ++r) b.il[h][r] = invl_s[j0 + 16 * h + 4 * g + r];
       }
+    };
+    // ... and the block's work: logits (three f16 MFMA terms), weights, P.V (three bf16 terms)
+    auto compute_blk = [&](int j0, const Blk& b) {
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         floatx4 a[2];
@@ -741,9 +748,9 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             // smallest terms first into the f32 accumulator
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[h][s], qh[t][s], a[h], 0, 0, 0);
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[h][s], ql[t][s], a[h], 0, 0, 0);
-            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[h][s], qh[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.kl[h][s], qh[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.kh[h][s], ql[t][s], a[h], 0, 0, 0);
+            a[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.kh[h][s], qh[t][s], a[h], 0, 0, 0);
           }
         }
         bf16x8 ph, pm, pl;
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
             // -(1 - p_ii) v_i = -(l' / l) v_i from the off-diagonal sum l' directly, and the loss as log1p(l' / e_ii).
             const bool own = key == qrow;
             if (!PASS2 && own && key < n) w.ediag[qrow] = e;
-            if (PASS2) e *= il[h][r];
+            if (PASS2) e *= b.il[h][r];
             const float wt = (key < n && !own) ? e : 0.f;
             lsum[t] += wt;
             const __bf16 bh = (__bf16)wt;
@@ -775,16 +782,39 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
         for (int u = 0; u < NT; ++u) {
           // the block's partial product summed smallest terms first, then added to the running output in one MFMA chain
           if (PVT == 6) {
-            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], O[t][u], 0, 0, 0);
-            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], O[t][u], 0, 0, 0);
-            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vm[u], O[t][u], 0, 0, 0);
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, b.vh[u], O[t][u], 0, 0, 0);
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, b.vl[u], O[t][u], 0, 0, 0);
+            O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, b.vm[u], O[t][u], 0, 0, 0);
           }
-          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, vh[u], O[t][u], 0, 0, 0);
-          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vm[u], O[t][u], 0, 0, 0);
-          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm, b.vh[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, b.vm[u], O[t][u], 0, 0, 0);
+          O[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, b.vh[u], O[t][u], 0, 0, 0);
         }
       }
+    };
+#if SRH_NCE_PIPE
+    // Two register sets, ping-pong: the fragments of block j + 1 are read from LDS under the MFMAs of block j (a workgroup
+    // holds all 128 KB of its CU's stage, so only two waves share a SIMD and an exposed LDS round trip per block is not
+    // covered by anyone; 64 more VGPRs of the 256 a wave may have here).  Same blocks, same order, same arithmetic.
+    {
+      Blk ba, bb;
+      load_blk(0, ba);
+      int j0 = 0;
+      for (; j0 + 32 < cn; j0 += 64) {
+        load_blk(j0 + 32, bb);
+        compute_blk(j0, ba);
+        if (j0 + 64 < cn) load_blk(j0 + 64, ba);
+        compute_blk(j0 + 32, bb);
+      }
+      if (j0 < cn) compute_blk(j0, ba);               // (an odd number of blocks: the last one is already loaded)
     }
+#else
+    for (int j0 = 0; j0 < cn; j0 += 32) {
+      Blk b;
+      load_blk(j0, b);
+      compute_blk(j0, b);
+    }
+#endif
   }
   if (!wave_live) return;
 
