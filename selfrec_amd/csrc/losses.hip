@@ -235,11 +235,6 @@ static_assert(SRH_NCE_SPLITS == 8 || SRH_NCE_SPLITS == 16, "SRH_NCE_SPLITS: 8 or
 static_assert(SRH_NCE_PV_TERMS == 3 || SRH_NCE_PV_TERMS == 6, "SRH_NCE_PV_TERMS: 3 or 6");
 //   SRH_NCE_WT        1 (default): the tile passes' partial outputs (16.8 MB per step at n = 2048) leave with write-through
 //                     stores: read next by the finish kernel on other XCDs, never again by their writers (-1.2 us per step)
-//   SRH_NCE_PIPE      1: the tile passes read the operand fragments of key block j + 1 under the MFMAs of block j (two
-//                     register sets, ping-pong)
-#ifndef SRH_NCE_PIPE
-#define SRH_NCE_PIPE 0
-#endif
 #ifndef SRH_NCE_WT
 #define SRH_NCE_WT 1
 #endif
@@ -792,29 +787,14 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
         }
       }
     };
-#if SRH_NCE_PIPE
-    // Two register sets, ping-pong: the fragments of block j + 1 are read from LDS under the MFMAs of block j (a workgroup
-    // holds all 128 KB of its CU's stage, so only two waves share a SIMD and an exposed LDS round trip per block is not
-    // covered by anyone; 64 more VGPRs of the 256 a wave may have here).  Same blocks, same order, same arithmetic.
-    {
-      Blk ba, bb;
-      load_blk(0, ba);
-      int j0 = 0;
-      for (; j0 + 32 < cn; j0 += 64) {
-        load_blk(j0 + 32, bb);
-        compute_blk(j0, ba);
-        if (j0 + 64 < cn) load_blk(j0 + 64, ba);
-        compute_blk(j0 + 32, bb);
-      }
-      if (j0 < cn) compute_blk(j0, ba);               // (an odd number of blocks: the last one is already loaded)
-    }
-#else
+    // (Round 4, measured and dropped: two register sets in ping-pong -- the fragments of block j + 1 read under the MFMAs of
+    // block j, 228 VGPRs -- left the step where it was, 0.2788 against 0.2770 / 0.2784 ms for the product before / after in
+    // the same session: the exposed LDS round trip per block is not what these passes wait for.)
     for (int j0 = 0; j0 < cn; j0 += 32) {
       Blk b;
       load_blk(j0, b);
       compute_blk(j0, b);
     }
-#endif
   }
   if (!wave_live) return;
 
