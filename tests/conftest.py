@@ -32,6 +32,20 @@ def golden_meta():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def golden_edges():
+    """reference runs of the configurations make_golden.py's EDGE_CASES lists (d = 256, one / four layers, l* = 0 / L)"""
+    import json
+    import numpy as np
+    with open(os.path.join(GOLDEN, "edges_meta.json")) as f:
+        meta = json.load(f)
+    return np.load(os.path.join(GOLDEN, "edges.npz")), meta
+
+
+EDGE_TAGS = ["XSimGCL_d256", "LightGCN_d256", "XSimGCL_L1_s0", "XSimGCL_L1_s1", "XSimGCL_L4_s0", "XSimGCL_L4_s4",
+             "LightGCN_L1", "LightGCN_L4", "SimGCL_L1", "SimGCL_L4", "SGL_L1", "SGL_L4"]
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

@@ -11,6 +11,7 @@ Shims: numba is not installed and util/algorithm.py:3 imp
 -> ``torch.Tensor.cuda`` / ``nn.Module.cuda`` patched to return self.
 
 Run:  python tests/golden/make_golden.py        (writes next to this file)
+      python tests/golden/make_golden.py edges  (only edges.npz: the configurations EDGE_CASES lists)
 """
 import json
 import os
@@ -61,11 +62,11 @@ def tiny_graph():
     return tu, ti, su, si
 
 
-def make_conf(tmp, model, extra):
+def make_conf(tmp, model, extra, emb=EMB):
     lines = [
         "training.set: ./train.txt", "test.set: ./test.txt",
         "model:", f"  name: {model}", "  type: graph",
-        "item.ranking.topN: [10,20]", f"embedding.size: {EMB}", f"max.epoch: {extra.pop('max_epoch', 1)}",
+        "item.ranking.topN: [10,20]", f"embedding.size: {emb}", f"max.epoch: {extra.pop('max_epoch', 1)}",
         f"batch.size: {BATCH}", "learning.rate: 0.001", "reg.lambda: 0.0001", "output: ./results/",
     ]
     if extra:
@@ -174,17 +175,37 @@ MODELS = {
 }
 
 
-def golden_models(out, meta):
+# Configurations the five runs above do not reach: the 64-lane row shape (d = 256), a single layer (the only product
+# also carries the mean), four layers, and the contrast view taken at the ego table (l* = 0: XSimGCL.py's
+# ``k == self.layer_cl - 1`` never fires) or at the last layer.  tag -> (model, its section, embedding.size)
+EDGE_CASES = {
+    "XSimGCL_d256": ("XSimGCL", {"n_layer": 2, "l_star": 2, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 256),
+    "LightGCN_d256": ("LightGCN", {"n_layer": 2}, 256),
+    "XSimGCL_L1_s0": ("XSimGCL", {"n_layer": 1, "l_star": 0, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 64),
+    "XSimGCL_L1_s1": ("XSimGCL", {"n_layer": 1, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 64),
+    "XSimGCL_L4_s0": ("XSimGCL", {"n_layer": 4, "l_star": 0, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 64),
+    "XSimGCL_L4_s4": ("XSimGCL", {"n_layer": 4, "l_star": 4, "lambda": 0.2, "eps": 0.2, "tau": 0.2}, 64),
+    "LightGCN_L1": ("LightGCN", {"n_layer": 1}, 64),
+    "LightGCN_L4": ("LightGCN", {"n_layer": 4}, 64),
+    "SimGCL_L1": ("SimGCL", {"n_layer": 1, "lambda": 0.5, "eps": 0.1}, 64),
+    "SimGCL_L4": ("SimGCL", {"n_layer": 4, "lambda": 0.5, "eps": 0.1}, 64),
+    "SGL_L1": ("SGL", {"n_layer": 1, "lambda": 0.1, "drop_rate": 0.1, "aug_type": 1, "temp": 0.2}, 64),
+    "SGL_L4": ("SGL", {"n_layer": 4, "lambda": 0.1, "drop_rate": 0.1, "aug_type": 1, "temp": 0.2}, 64),
+}
+
+
+def golden_models(out, meta, cases=None, with_ranking=True):
     import importlib
+    cases = cases or {name: (name, extra, EMB) for name, extra in MODELS.items()}
     tu, ti, su, si = tiny_graph()
     train, test = synth.as_triples(tu, ti), synth.as_triples(su, si)
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)
         try:
-            for name, extra in MODELS.items():
+            for tag, (name, extra, emb) in cases.items():
                 mod = importlib.import_module(f"model.graph.{name}")
-                conf = make_conf(tmp, name, dict(extra))
+                conf = make_conf(tmp, name, dict(extra), emb)
                 rec = {"batches": [], "bpr": [], "reg": [], "nce": []}
 
                 def wrap(fn, key):
@@ -218,35 +239,49 @@ def golden_models(out, meta):
                     assert name == "SGL" and "best_user_emb" in str(e), e
                     with torch.no_grad():
                         model.user_emb, model.item_emb = model.model()
-                rec_list = model.test()
-                measure = ranking_evaluation(model.data.test_set, rec_list, [10, 20])
-                d = model.data
-                users = list(d.test_set.keys())
-                out[f"{name}_init_user"] = init_u
-                out[f"{name}_init_item"] = init_i
-                out[f"{name}_param_user"] = params["user_emb"].detach().numpy().copy()
-                out[f"{name}_param_item"] = params["item_emb"].detach().numpy().copy()
-                out[f"{name}_final_user"] = model.user_emb.detach().numpy().copy()
-                out[f"{name}_final_item"] = model.item_emb.detach().numpy().copy()
+                out[f"{tag}_init_user"] = init_u
+                out[f"{tag}_init_item"] = init_i
+                out[f"{tag}_param_user"] = params["user_emb"].detach().numpy().copy()
+                out[f"{tag}_param_item"] = params["item_emb"].detach().numpy().copy()
                 nb = len(rec["batches"])
-                out[f"{name}_batch_sizes"] = np.asarray([len(b[0]) for b in rec["batches"]], dtype=np.int32)
-                out[f"{name}_batch_u"] = np.concatenate([b[0] for b in rec["batches"]]).astype(np.int32)
-                out[f"{name}_batch_i"] = np.concatenate([b[1] for b in rec["batches"]]).astype(np.int32)
-                out[f"{name}_batch_j"] = np.concatenate([b[2] for b in rec["batches"]]).astype(np.int32)
-                out[f"{name}_loss_bpr"] = np.asarray(rec["bpr"], dtype=np.float64)
-                out[f"{name}_loss_reg"] = np.asarray(rec["reg"], dtype=np.float64)
-                out[f"{name}_loss_nce"] = np.asarray(rec["nce"], dtype=np.float64)
-                out[f"{name}_test_users"] = np.asarray([d.user[u] for u in users], dtype=np.int32)
-                out[f"{name}_rec_ids"] = np.asarray([[d.item[it] for it, _ in rec_list[u]] for u in users], dtype=np.int32)
-                out[f"{name}_rec_scores"] = np.asarray([[s for _, s in rec_list[u]] for u in users], dtype=np.float32)
-                meta[name] = {"conf": extra, "n_batches": nb, "measure": measure,
-                              "emb": EMB, "batch": BATCH, "lr": 0.001, "reg": 0.0001,
-                              "noise_seed": 4242, "init_seed": 31, "sampler_seed": 2718}
-                print(name, "steps", nb, "bpr", rec["bpr"][:3], "nce", rec["nce"][:2], measure[6:])
+                out[f"{tag}_batch_sizes"] = np.asarray([len(b[0]) for b in rec["batches"]], dtype=np.int32)
+                out[f"{tag}_batch_u"] = np.concatenate([b[0] for b in rec["batches"]]).astype(np.int32)
+                out[f"{tag}_batch_i"] = np.concatenate([b[1] for b in rec["batches"]]).astype(np.int32)
+                out[f"{tag}_batch_j"] = np.concatenate([b[2] for b in rec["batches"]]).astype(np.int32)
+                out[f"{tag}_loss_bpr"] = np.asarray(rec["bpr"], dtype=np.float64)
+                out[f"{tag}_loss_reg"] = np.asarray(rec["reg"], dtype=np.float64)
+                out[f"{tag}_loss_nce"] = np.asarray(rec["nce"], dtype=np.float64)
+                meta[tag] = {"model": name, "conf": extra, "n_batches": nb,
+                             "emb": emb, "batch": BATCH, "lr": 0.001, "reg": 0.0001,
+                             "noise_seed": 4242, "init_seed": 31, "sampler_seed": 2718}
+                if with_ranking:
+                    rec_list = model.test()
+                    measure = ranking_evaluation(model.data.test_set, rec_list, [10, 20])
+                    d = model.data
+                    users = list(d.test_set.keys())
+                    out[f"{tag}_final_user"] = model.user_emb.detach().numpy().copy()
+                    out[f"{tag}_final_item"] = model.item_emb.detach().numpy().copy()
+                    out[f"{tag}_test_users"] = np.asarray([d.user[u] for u in users], dtype=np.int32)
+                    out[f"{tag}_rec_ids"] = np.asarray([[d.item[it] for it, _ in rec_list[u]] for u in users], dtype=np.int32)
+                    out[f"{tag}_rec_scores"] = np.asarray([[s for _, s in rec_list[u]] for u in users], dtype=np.float32)
+                    meta[tag]["measure"] = measure
+                print(tag, "steps", nb, "bpr", rec["bpr"][:3], "nce", rec["nce"][:2])
         finally:
             os.chdir(cwd)
     out["test_u_ids_raw"] = su.astype(np.int32)
     out["test_i_ids_raw"] = si.astype(np.int32)
+
+
+def edges_main():
+    """python tests/golden/make_golden.py edges  ->  edges.npz + edges_meta.json (models.npz etc. untouched)"""
+    out, meta = {}, {"graph": GRAPH, "torch": torch.__version__, "numpy": np.__version__}
+    golden_models(out, meta, EDGE_CASES, with_ranking=False)
+    for k in ("test_u_ids_raw", "test_i_ids_raw"):
+        out.pop(k)
+    np.savez_compressed(os.path.join(HERE, "edges.npz"), **out)
+    with open(os.path.join(HERE, "edges_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("written edges.npz", os.path.getsize(os.path.join(HERE, "edges.npz")))
 
 
 def main():
@@ -263,4 +298,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    edges_main() if sys.argv[1:] == ["edges"] else main()

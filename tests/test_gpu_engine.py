@@ -12,6 +12,8 @@ from selfrec_amd import ops, synth
 from selfrec_amd.data.ui_graph import Interaction
 from selfrec_amd.engine import FusedTrainer
 
+from .conftest import EDGE_TAGS
+
 pytestmark = pytest.mark.gpu
 MODELS = ["MF", "LightGCN", "XSimGCL", "SimGCL", "SGL"]
 
@@ -23,12 +25,13 @@ def rel_err(got, want):
 
 def make_trainer(name, gm, meta, data, **over):
     m = meta[name]; c = m["conf"]
+    tag, name = name, m.get("model", name)
     gen = torch.Generator().manual_seed(m["noise_seed"])
     kw = dict(model=name, n_layers=int(c.get("n_layer", 0)), lr=m["lr"], reg=m["reg"],
               cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)),
               tau=float(c.get("tau", c.get("temp", 0.2))), layer_cl=int(c.get("l_star", 1)),
               drop_rate=float(c.get("drop_rate", 0.1)), batch_size=m["batch"],
-              user_emb=gm[f"{name}_init_user"], item_emb=gm[f"{name}_init_item"],
+              user_emb=gm[f"{tag}_init_user"], item_emb=gm[f"{tag}_init_item"],
               noise_fn=lambda shape: torch.rand(shape, generator=gen))
     kw.update(over)
     return FusedTrainer(data, m["emb"], **kw)
@@ -64,6 +67,38 @@ def test_three_steps_match_reference_run(golden_models, golden_meta, tiny_data, 
     fu, fi = tr.embeddings()
     assert rel_err(fu.cpu().numpy(), gm[f"{name}_final_user"]) < 1e-4
     assert rel_err(fi.cpu().numpy(), gm[f"{name}_final_item"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", EDGE_TAGS)
+def test_edge_configurations_match_reference_run(golden_edges, tiny_data, tag):
+    """The reference's own runs at d = 256 (64 lanes per row), with one layer (the only product also carries the mean),
+    with four, and with the contrast view at the ego table (l* = 0) or at the last layer -- tests/golden/make_golden.py
+    edges; the same bounds as the five main runs above."""
+    ge, meta = golden_edges
+    m = meta[tag]
+    tr = make_trainer(tag, ge, meta, tiny_data)
+    random.seed(m["sampler_seed"])
+    tr.seed_sampler_from_python()
+    nb = tr.begin_epoch()
+    assert nb == m["n_batches"]
+    eu, ei, ej = tr.epoch_node_ids()
+    assert np.array_equal(eu, ge[f"{tag}_batch_u"]) and np.array_equal(ei, ge[f"{tag}_batch_i"]) \
+        and np.array_equal(ej, ge[f"{tag}_batch_j"])
+    bpr, cl = [], []
+    for _ in range(nb):
+        tr.step()
+        b, _, c = tr.read_losses()
+        bpr.append(b); cl.append(c)
+    np.testing.assert_allclose(bpr, ge[f"{tag}_loss_bpr"], rtol=1e-5)
+    nce, lam = ge[f"{tag}_loss_nce"], tr.cl_rate
+    if m["model"] in ("XSimGCL", "SimGCL"):
+        np.testing.assert_allclose(cl, nce.reshape(nb, 2).sum(1) * lam, rtol=2e-5)
+    elif m["model"] == "SGL":
+        np.testing.assert_allclose(cl, nce * lam, rtol=2e-5)
+    for side, got in (("user", tr.user_emb), ("item", tr.item_emb)):
+        got, want, init = got.cpu().numpy(), ge[f"{tag}_param_{side}"], ge[f"{tag}_init_{side}"]
+        assert rel_err(got, want) < 1e-4
+        assert np.abs((got - init) - (want - init)).max() < 1e-5       # << one Adam step (lr = 1e-3)
 
 
 @pytest.mark.parametrize("name", ["LightGCN", "XSimGCL"])

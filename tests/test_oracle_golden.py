@@ -7,6 +7,8 @@ import pytest
 import scipy.sparse as sp
 import torch
 
+from .conftest import EDGE_TAGS
+
 from oracle import selfrec_oracle as O
 
 
@@ -93,12 +95,21 @@ def test_find_k_largest_ties(golden_ops):
 MODELS = ["MF", "LightGCN", "XSimGCL", "SimGCL", "SGL"]
 
 
+def edge_cl_reference(ge, m, tag):
+    """the contrastive term per step as the trainer reports it: the reference logs the user and the item InfoNCE
+    separately and unscaled for XSimGCL / SimGCL, their sum for SGL"""
+    nce, lam = ge[f"{tag}_loss_nce"], float(m["conf"].get("lambda", 0.0))
+    if m["model"] in ("XSimGCL", "SimGCL"):
+        return nce.reshape(m["n_batches"], 2).sum(1) * lam
+    return nce * lam if m["model"] == "SGL" else np.zeros(m["n_batches"])
+
+
 def make_oracle_trainer(name, gm, meta, golden_ops):
     m = meta[name]
     c = m["conf"]
     gen = torch.Generator().manual_seed(m["noise_seed"])
     tr = O.OracleTrainer(
-        name, golden_ops["graph_train_u_ids"], golden_ops["graph_train_i_ids"], 200, 300, m["emb"],
+        m.get("model", name), golden_ops["graph_train_u_ids"], golden_ops["graph_train_i_ids"], 200, 300, m["emb"],
         n_layers=int(c.get("n_layer", 0)), lr=m["lr"], reg=m["reg"],
         cl_rate=float(c.get("lambda", 0.0)), eps=float(c.get("eps", 0.0)),
         tau=float(c.get("tau", c.get("temp", 0.2))), layer_cl=int(c.get("l_star", 1)),
@@ -133,6 +144,31 @@ def test_training_steps_match_reference(golden_models, golden_meta, golden_ops, 
     fu, fi = tr.embeddings()
     np.testing.assert_allclose(fu, gm[f"{name}_final_user"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(fi, gm[f"{name}_final_item"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", EDGE_TAGS)
+def test_edge_configurations_match_reference(golden_edges, golden_ops, tag):
+    """d = 256, a single layer, four layers, the contrast view at the ego table (l* = 0) and at the last layer:
+    the reference's own runs of those configurations (tests/golden/make_golden.py edges)."""
+    ge, meta = golden_edges
+    m = meta[tag]
+    tr = make_oracle_trainer(tag, ge, meta, golden_ops)
+    random.seed(m["sampler_seed"])
+    if m["model"] == "SGL":
+        tr.resample_views()
+    sampler = O.PairwiseSampler(golden_ops["graph_train_u_ids"], golden_ops["graph_train_i_ids"], 200, 300)
+    off, bpr, cl = 0, [], []
+    for k, (u, i, j) in enumerate(sampler.epoch(m["batch"])):
+        n = int(ge[f"{tag}_batch_sizes"][k])
+        assert np.array_equal(u, ge[f"{tag}_batch_u"][off:off + n]) and np.array_equal(j, ge[f"{tag}_batch_j"][off:off + n])
+        off += n
+        r, _, c = tr.step(u, i, j)
+        bpr.append(r); cl.append(c)
+    assert len(bpr) == m["n_batches"]
+    np.testing.assert_allclose(bpr, ge[f"{tag}_loss_bpr"], rtol=1e-5)
+    np.testing.assert_allclose(cl, edge_cl_reference(ge, m, tag), rtol=2e-5)
+    np.testing.assert_allclose(tr.user_emb.detach().numpy(), ge[f"{tag}_param_user"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(tr.item_emb.detach().numpy(), ge[f"{tag}_param_item"], rtol=1e-4, atol=1e-7)
 
 
 @pytest.mark.parametrize("name", MODELS)
