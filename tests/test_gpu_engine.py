@@ -275,8 +275,11 @@ def test_sharded_step_in_a_hipgraph_equals_the_single_gpu_step(golden_models, go
             outs.append((torch.cat([tr.user_emb, tr.item_emb]).cpu().numpy(), tr.read_losses()))
         assert np.isfinite(outs[0][0]).all()
         # (the sharded graph is stored without column classes: long rows are summed in a different order, and six
-        # Adam steps amplify that -- see tests/test_gpu_shapes.py's docstring; observed 0.8e-5 .. 1.2e-5)
-        assert rel_err(outs[1][0], outs[0][0]) < 3e-5
+        # Adam steps amplify that where a gradient element is ~1e-8 itself -- see tests/test_gpu_shapes.py's docstring.
+        # Observed: max |diff| 0.8e-6 .. 3.0e-6 on single elements, i.e. 0.3 % of ONE Adam step of lr = 1e-3; so the
+        # bulk is held tight and the outliers to 2 % of a step)
+        diff = np.abs(outs[1][0] - outs[0][0])
+        assert (diff > 1e-6).mean() < 1e-3 and diff.max() < 2e-5
         np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5)
     finally:
         if created:

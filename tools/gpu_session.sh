@@ -16,7 +16,7 @@ case $s in
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -3 $OUT/smoke.log;;
 tests)
-  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > $OUT/tests.log 2>&1; echo "tests exit $?"
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed" $OUT/tests.log | tail -30;;
 testsall)
   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests exit $?"
