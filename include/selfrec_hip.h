@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 23
+#define SRH_ABI_VERSION 24
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -279,15 +279,33 @@ srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item,
                                 float* d_greg_user, float* d_greg_item, double* d_losses,
                                 void* d_ws, void* stream);
 
-/* Plain (non-gathered) forms used by the drop-in autograd functions. */
+/* Plain (non-gathered) forms behind the op-level tier's loss functions (selfrec_amd/util/loss_torch.py: the signatures of
+ * util/loss_torch.py:6-22).  Each call is ONE launch and leaves its scalar on the device as f32, the way the reference's
+ * expression would: the last workgroup to finish (a ticket in d_scalar_ws) turns the double accumulators into the result.
+ * d_scalar_ws: SRH_SCALAR_WS_BYTES bytes, zero before its first use; every call leaves it zero again (calls that share
+ * one must be ordered on a stream).  The upstream gradient d_gout is a DEVICE scalar: no host synchronisation in a
+ * backward pass. */
+#define SRH_SCALAR_WS_BYTES 64
+/* bpr_loss (loss_torch.py:6-10):  *d_loss = mean_b -log(1e-5 + sigmoid(u_b.p_b - u_b.n_b));  d_coef[b] = d loss / d (pos_b - neg_b) */
 srh_status_t srh_bpr_fwd(const float* d_u, const float* d_p, const float* d_n, int64_t B,
-                         int32_t d, double* d_loss_sum /* += sum_b loss_b */, float* d_coef /* B */,
+                         int32_t d, void* d_scalar_ws, float* d_loss, float* d_coef /* B */,
                          void* stream);
 srh_status_t srh_bpr_bwd(const float* d_u, const float* d_p, const float* d_n,
-                         const float* d_coef, int64_t B, int32_t d, float scale /* gout/B */,
+                         const float* d_coef, int64_t B, int32_t d, const float* d_gout,
                          float* d_gu, float* d_gp, float* d_gn, void* stream);
-/* sum of squares of a (rows, d) block:  d_out[0] += sum x^2 (double). */
-srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* stream);
+/* l2_reg_loss(reg, *embs) (loss_torch.py:18-22):  *d_loss = reg * sum_k ||x_k||_F / rows_k, summed left to right in f32;
+ * d_norms[k] = ||x_k||_F (kept for the backward pass).  Backward: d_gx_k = x_k * (((*d_gout * reg) / rows_k) / ||x_k||),
+ * zero where the norm is zero (torch.norm's subgradient).  1..4 blocks of rows per call; `blocks` is a HOST array. */
+typedef struct srh_l2_block {
+  const float* d_x; /* (rows, cols) contiguous f32 */
+  int64_t rows;
+  int64_t cols;
+  float* d_gx;      /* backward only */
+} srh_l2_block_t;
+srh_status_t srh_l2_reg_fwd(const srh_l2_block_t* blocks, int32_t n_blocks, float reg, void* d_scalar_ws,
+                            float* d_norms /* n_blocks */, float* d_loss, void* stream);
+srh_status_t srh_l2_reg_bwd(const srh_l2_block_t* blocks, int32_t n_blocks, float reg, const float* d_norms,
+                            const float* d_gout, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-8) InfoNCE forward + backward -- replaces util/loss_torch.py:35-50 InfoNCE(view1,

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -40,6 +40,14 @@ class InfonceProblem(C.Structure):
     """struct srh_infonce_problem (include/selfrec_hip.h)."""
     _fields_ = [("d_v1", C.c_void_p), ("d_v2", C.c_void_p), ("d_idx", C.c_void_p), ("n", C.c_int64),
                 ("d_n", C.c_void_p), ("d_g1", C.c_void_p), ("d_g2", C.c_void_p), ("g2_exclusive", C.c_int32)]
+
+
+class L2Block(C.Structure):
+    """struct srh_l2_block (include/selfrec_hip.h)."""
+    _fields_ = [("d_x", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("d_gx", C.c_void_p)]
+
+
+SCALAR_WS_BYTES = 64         # SRH_SCALAR_WS_BYTES
 
 
 class BprProblem(C.Structure):
@@ -112,9 +120,10 @@ SIGNATURES = {
     "srh_bpr_ws_bytes": (_i64, [_i64]),
     "srh_bpr_l2_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i32, _f32,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "srh_bpr_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "srh_bpr_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
-    "srh_sumsq": (_i32, [_vp, _i64, _vp, _vp]),
+    "srh_bpr_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "srh_bpr_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "srh_l2_reg_fwd": (_i32, [C.POINTER(L2Block), _i32, _f32, _vp, _vp, _vp, _vp]),
+    "srh_l2_reg_bwd": (_i32, [C.POINTER(L2Block), _i32, _f32, _vp, _vp, _vp]),
     "srh_infonce_ws_bytes": (_i64, [_i64, _i32]),
     "srh_infonce_set_precision": (_i32, [_i32]),
     "srh_infonce_get_precision": (_i32, []),

@@ -168,10 +168,36 @@ __global__ __launch_bounds__(256) void bpr_phase1(BprArgs a) { bpr_phase1_body<L
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_phase2(BprArgs a) { bpr_phase2_body<LPR>(a, blockIdx.x); }
 
+// ---- the op-level tier's losses: every scalar is FINISHED ON THE DEVICE ------------------------------------------------
+// A model file written the reference's way calls bpr_loss / l2_reg_loss once per step and gets a 0-dim tensor back; with
+// torch ops around a partial-sum kernel that is a fill, a division, a conversion (forward) and a comparison, a where, two
+// multiplies (backward) per call -- eight host dispatches for one number.  Here the LAST workgroup of the launch (a
+// ticket in the caller's 64-byte scalar workspace) turns the double accumulators into the f32 result and leaves the
+// workspace zero for the next call: one launch forward, one backward.
+struct ScalarWs {
+  double acc[4];
+  unsigned int ticket;
+  unsigned int pad[7];
+};
+static_assert(sizeof(ScalarWs) == SRH_SCALAR_WS_BYTES, "scalar workspace layout");
+
+// block-wide sum handed to one atomic; returns true in thread 0 of the LAST block to arrive (all blocks' sums are then
+// visible to it through device-scope atomics)
+__device__ __forceinline__ bool block_acc_then_ticket(double part, double* acc, unsigned int* ticket, unsigned int n_blocks) {
+  __shared__ double s_part[4];
+  part = wave_sum_d(part);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x != 0) return false;
+  atomicAdd(acc, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+  __threadfence();
+  return atomicAdd(ticket, 1u) == n_blocks - 1;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_plain_fwd(const float4* __restrict__ U, const float4* __restrict__ P,
-                                                     const float4* __restrict__ Nn, int B, double* loss_sum,
-                                                     float* __restrict__ coef) {
+                                                     const float4* __restrict__ Nn, int B, ScalarWs* ws,
+                                                     float* __restrict__ loss_mean, float* __restrict__ coef) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
@@ -182,35 +208,83 @@ __global__ __launch_bounds__(256) void bpr_plain_fwd(const float4* __restrict__ 
   const float neg = group_sum<LPR>(f4_dot(u, n));
   float loss, c;
   bpr_row(pos, neg, loss, c);
-  if (valid && sub == 0) coef[b] = c;
-  double part = wave_sum_d((valid && sub == 0) ? (double)loss : 0.0);
-  if (lane == 0) atomicAdd(loss_sum, part);
+  if (valid && sub == 0) coef[b] = c / (float)B;          // d mean / d (pos - neg) of row b
+  if (block_acc_then_ticket((valid && sub == 0) ? (double)loss : 0.0, &ws->acc[0], &ws->ticket, gridDim.x)) {
+    *loss_mean = (float)(atomicAdd(&ws->acc[0], 0.0) / (double)B);      // torch.mean(loss): loss_torch.py:10
+    ws->acc[0] = 0.0;
+    ws->ticket = 0u;
+  }
 }
 
 template <int LPR>
 __global__ __launch_bounds__(256) void bpr_plain_bwd(const float4* __restrict__ U, const float4* __restrict__ P,
                                                      const float4* __restrict__ Nn, const float* __restrict__ coef,
-                                                     int B, float scale, float4* __restrict__ GU,
+                                                     int B, const float* __restrict__ gout, float4* __restrict__ GU,
                                                      float4* __restrict__ GP, float4* __restrict__ GN) {
   const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
   if (t >= (size_t)B * LPR) return;
   const int b = (int)(t / LPR);
-  const float c = coef[b] * scale;
+  const float c = coef[b] * gout[0];                    // the upstream gradient is read on the device: no host sync
   const float4 u = U[t], p = P[t], n = Nn[t];
   GU[t] = make_float4(c * (p.x - n.x), c * (p.y - n.y), c * (p.z - n.z), c * (p.w - n.w));
   GP[t] = f4_scale(u, c);
   GN[t] = f4_scale(u, -c);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* out) {
+// l2_reg_loss(reg, *embs) = reg * sum_k ||emb_k||_F / rows_k (loss_torch.py:18-22), all blocks in one launch
+constexpr int kL2Blocks = 4;
+constexpr int kL2MaxWg = 1024;       // workgroups per block of rows
+struct L2Args {
+  const float* x[kL2Blocks];
+  float* gx[kL2Blocks];
+  int64_t n[kL2Blocks];              // elements
+  float rows[kL2Blocks];
+  int first_wg[kL2Blocks + 1];       // block k owns workgroups [first_wg[k], first_wg[k + 1])
+  int count;
+  float reg;
+};
+
+__global__ __launch_bounds__(256) void l2_reg_fwd_kernel(L2Args a, ScalarWs* ws, float* __restrict__ norms, float* __restrict__ loss) {
+  int k = 0;
+  while (k + 1 < a.count && (int)blockIdx.x >= a.first_wg[k + 1]) ++k;
+  const int wg = (int)blockIdx.x - a.first_wg[k], n_wg = a.first_wg[k + 1] - a.first_wg[k];
+  const float* __restrict__ x = a.x[k];
+  const int64_t n = a.n[k], stride = (int64_t)n_wg * 256;
   double acc = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+  for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < n; i += stride) {
     const float v = x[i];
     acc += (double)v * (double)v;
   }
+  __shared__ double s_part[4];
   acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  atomicAdd(&ws->acc[k], (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+  __threadfence();
+  if (atomicAdd(&ws->ticket, 1u) != gridDim.x - 1) return;
+  float emb_loss = 0.f;                                     // the reference's left-to-right float32 sum
+  for (int j = 0; j < a.count; ++j) {
+    const float nrm = (float)sqrt(atomicAdd(&ws->acc[j], 0.0));        // torch.norm(emb, p=2)
+    norms[j] = nrm;
+    emb_loss += nrm / a.rows[j];
+    ws->acc[j] = 0.0;
+  }
+  *loss = emb_loss * a.reg;
+  ws->ticket = 0u;
+}
+
+// d loss / d emb_k = emb_k * (((gout * reg) / rows_k) / ||emb_k||), 0 where the norm is 0 (torch's norm backward)
+__global__ __launch_bounds__(256) void l2_reg_bwd_kernel(L2Args a, const float* __restrict__ norms, const float* __restrict__ gout) {
+  int k = 0;
+  while (k + 1 < a.count && (int)blockIdx.x >= a.first_wg[k + 1]) ++k;
+  const int wg = (int)blockIdx.x - a.first_wg[k], n_wg = a.first_wg[k + 1] - a.first_wg[k];
+  const float nrm = norms[k];
+  const float coef = (nrm > 0.f) ? ((gout[0] * a.reg) / a.rows[k]) / nrm : 0.f;
+  const float* __restrict__ x = a.x[k];
+  float* __restrict__ g = a.gx[k];
+  const int64_t n = a.n[k], stride = (int64_t)n_wg * 256;
+  for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < n; i += stride) g[i] = x[i] * coef;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1052,15 +1126,16 @@ srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item, const 
 }
 
 srh_status_t srh_bpr_fwd(const float* d_u, const float* d_p, const float* d_n, int64_t B, int32_t d,
-                         double* d_loss_sum, float* d_coef, void* stream) {
-  SRH_REQUIRE(d_u && d_p && d_n && d_loss_sum && d_coef, "bpr_fwd: null argument");
+                         void* d_scalar_ws, float* d_loss, float* d_coef, void* stream) {
+  SRH_REQUIRE(d_u && d_p && d_n && d_scalar_ws && d_loss && d_coef, "bpr_fwd: null argument");
   SRH_REQUIRE(B > 0 && B < (int64_t(1) << 30), "bpr_fwd: bad batch size");
   SRH_REQUIRE(srh::dim_supported(d), "bpr_fwd: d=%d unsupported", d);
   hipStream_t st = srh::as_stream(stream);
   const float4 *U = reinterpret_cast<const float4*>(d_u), *P = reinterpret_cast<const float4*>(d_p),
                *N = reinterpret_cast<const float4*>(d_n);
+  ScalarWs* ws = reinterpret_cast<ScalarWs*>(d_scalar_ws);
 #define SRH_BPR_FWD(LPR)                                                                       \
-  bpr_plain_fwd<LPR><<<(int)(((B + 64 / LPR - 1) / (64 / LPR) + 3) / 4), 256, 0, st>>>(U, P, N, (int)B, d_loss_sum, d_coef)
+  bpr_plain_fwd<LPR><<<(int)(((B + 64 / LPR - 1) / (64 / LPR) + 3) / 4), 256, 0, st>>>(U, P, N, (int)B, ws, d_loss, d_coef)
   switch (d) {
     case 32: SRH_BPR_FWD(8); break;
     case 64: SRH_BPR_FWD(16); break;
@@ -1073,8 +1148,8 @@ srh_status_t srh_bpr_fwd(const float* d_u, const float* d_p, const float* d_n, i
 }
 
 srh_status_t srh_bpr_bwd(const float* d_u, const float* d_p, const float* d_n, const float* d_coef,
-                         int64_t B, int32_t d, float scale, float* d_gu, float* d_gp, float* d_gn, void* stream) {
-  SRH_REQUIRE(d_u && d_p && d_n && d_coef && d_gu && d_gp && d_gn, "bpr_bwd: null argument");
+                         int64_t B, int32_t d, const float* d_gout, float* d_gu, float* d_gp, float* d_gn, void* stream) {
+  SRH_REQUIRE(d_u && d_p && d_n && d_coef && d_gout && d_gu && d_gp && d_gn, "bpr_bwd: null argument");
   SRH_REQUIRE(B > 0 && B < (int64_t(1) << 30), "bpr_bwd: bad batch size");
   SRH_REQUIRE(srh::dim_supported(d), "bpr_bwd: d=%d unsupported", d);
   hipStream_t st = srh::as_stream(stream);
@@ -1084,20 +1159,50 @@ srh_status_t srh_bpr_bwd(const float* d_u, const float* d_p, const float* d_n, c
                *N = reinterpret_cast<const float4*>(d_n);
   float4 *GU = reinterpret_cast<float4*>(d_gu), *GP = reinterpret_cast<float4*>(d_gp), *GN = reinterpret_cast<float4*>(d_gn);
   switch (d) {
-    case 32: bpr_plain_bwd<8><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
-    case 64: bpr_plain_bwd<16><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
-    case 128: bpr_plain_bwd<32><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
-    default: bpr_plain_bwd<64><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, scale, GU, GP, GN); break;
+    case 32: bpr_plain_bwd<8><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, d_gout, GU, GP, GN); break;
+    case 64: bpr_plain_bwd<16><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, d_gout, GU, GP, GN); break;
+    case 128: bpr_plain_bwd<32><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, d_gout, GU, GP, GN); break;
+    default: bpr_plain_bwd<64><<<blocks, 256, 0, st>>>(U, P, N, d_coef, (int)B, d_gout, GU, GP, GN); break;
   }
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }
 
-srh_status_t srh_sumsq(const float* d_x, int64_t n_elem, double* d_out, void* stream) {
-  SRH_REQUIRE(d_x && d_out && n_elem >= 0, "sumsq: bad argument");
-  if (n_elem == 0) return SRH_OK;
-  const int blocks = (int)std::min<int64_t>((n_elem + 255) / 256, 2048);
-  sumsq_kernel<<<blocks, 256, 0, srh::as_stream(stream)>>>(d_x, n_elem, d_out);
+static srh_status_t l2_args(const srh_l2_block_t* blocks, int32_t n_blocks, float reg, bool backward, L2Args& a) {
+  SRH_REQUIRE(blocks && n_blocks >= 1 && n_blocks <= kL2Blocks, "l2_reg: 1..%d blocks of rows per call", kL2Blocks);
+  a.count = n_blocks;
+  a.reg = reg;
+  a.first_wg[0] = 0;
+  for (int k = 0; k < n_blocks; ++k) {
+    const srh_l2_block_t& b = blocks[k];
+    SRH_REQUIRE(b.d_x && b.rows > 0 && b.cols > 0, "l2_reg: block %d is empty or null", k);
+    SRH_REQUIRE(!backward || b.d_gx, "l2_reg_bwd: block %d has no gradient buffer", k);
+    a.x[k] = b.d_x;
+    a.gx[k] = b.d_gx;
+    a.n[k] = b.rows * b.cols;
+    a.rows[k] = (float)b.rows;
+    a.first_wg[k + 1] = a.first_wg[k] + (int)std::min<int64_t>((a.n[k] + 1023) / 1024, kL2MaxWg);
+  }
+  return SRH_OK;
+}
+
+srh_status_t srh_l2_reg_fwd(const srh_l2_block_t* blocks, int32_t n_blocks, float reg, void* d_scalar_ws,
+                            float* d_norms, float* d_loss, void* stream) {
+  SRH_REQUIRE(d_scalar_ws && d_norms && d_loss, "l2_reg_fwd: null argument");
+  L2Args a{};
+  if (srh_status_t s = l2_args(blocks, n_blocks, reg, false, a)) return s;
+  l2_reg_fwd_kernel<<<a.first_wg[n_blocks], 256, 0, srh::as_stream(stream)>>>(a, reinterpret_cast<ScalarWs*>(d_scalar_ws),
+                                                                             d_norms, d_loss);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_l2_reg_bwd(const srh_l2_block_t* blocks, int32_t n_blocks, float reg, const float* d_norms,
+                            const float* d_gout, void* stream) {
+  SRH_REQUIRE(d_norms && d_gout, "l2_reg_bwd: null argument");
+  L2Args a{};
+  if (srh_status_t s = l2_args(blocks, n_blocks, reg, true, a)) return s;
+  l2_reg_bwd_kernel<<<a.first_wg[n_blocks], 256, 0, srh::as_stream(stream)>>>(a, d_norms, d_gout);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

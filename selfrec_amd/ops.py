@@ -484,21 +484,51 @@ def bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch
         _p(greg_item, torch.float32), _p(losses, torch.float64), _p(ws), _stream()), "srh_bpr_l2_fwd_bwd")
 
 
-def bpr_fwd(u, p, n, loss_sum, coef):
+_scalar_ws = {}
+
+
+def scalar_ws(device) -> torch.Tensor:
+    """The 64-byte workspace the single-launch loss kernels finish their scalars in (SRH_SCALAR_WS_BYTES): one per device,
+    zero before its first use, left zero by every call; the calls that share it are ordered on the current stream."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _scalar_ws.get(key)
+    if ws is None:
+        ws = _scalar_ws[key] = torch.zeros(_lib.SCALAR_WS_BYTES // 8, dtype=torch.float64, device=device)
+    return ws
+
+
+def bpr_fwd(u, p, n, loss, coef):
+    """loss (0-dim f32) = mean BPR loss of the rows; coef[b] = d loss / d (pos_b - neg_b).  One launch."""
     check(_lib.load().srh_bpr_fwd(_p(u, torch.float32), _p(p, torch.float32), _p(n, torch.float32), u.shape[0],
-                                  int(u.shape[1]), _p(loss_sum, torch.float64), _p(coef, torch.float32), _stream()),
-          "srh_bpr_fwd")
+                                  int(u.shape[1]), scalar_ws(u.device).data_ptr(), _p(loss, torch.float32),
+                                  _p(coef, torch.float32), _stream()), "srh_bpr_fwd")
 
 
-def bpr_bwd(u, p, n, coef, scale, gu, gp, gn):
+def bpr_bwd(u, p, n, coef, gout, gu, gp, gn):
+    """gout: the upstream gradient as a 0-dim f32 DEVICE tensor (read by the kernel: no host synchronisation)."""
     check(_lib.load().srh_bpr_bwd(_p(u, torch.float32), _p(p, torch.float32), _p(n, torch.float32),
-                                  _p(coef, torch.float32), u.shape[0], int(u.shape[1]), float(scale),
+                                  _p(coef, torch.float32), u.shape[0], int(u.shape[1]), _p(gout, torch.float32, "gout"),
                                   _p(gu, torch.float32), _p(gp, torch.float32), _p(gn, torch.float32), _stream()),
           "srh_bpr_bwd")
 
 
-def sumsq(x, out):
-    check(_lib.load().srh_sumsq(_p(x, torch.float32), x.numel(), _p(out, torch.float64), _stream()), "srh_sumsq")
+def _l2_blocks(xs, gxs=None):
+    arr = (_lib.L2Block * len(xs))()
+    for k, x in enumerate(xs):
+        arr[k].d_x, arr[k].rows, arr[k].cols = _p(x, torch.float32, "emb"), int(x.shape[0]), int(x.shape[1])
+        arr[k].d_gx = _p(gxs[k], torch.float32, "grad") if gxs is not None else None
+    return arr
+
+
+def l2_reg_fwd(xs, reg, norms, loss):
+    """loss (0-dim f32) = reg * sum_k ||xs[k]||_F / rows_k; norms[k] = ||xs[k]||_F.  1..4 blocks of rows, one launch."""
+    check(_lib.load().srh_l2_reg_fwd(_l2_blocks(xs), len(xs), float(reg), scalar_ws(xs[0].device).data_ptr(),
+                                     _p(norms, torch.float32), _p(loss, torch.float32), _stream()), "srh_l2_reg_fwd")
+
+
+def l2_reg_bwd(xs, reg, norms, gout, gxs):
+    check(_lib.load().srh_l2_reg_bwd(_l2_blocks(xs, gxs), len(xs), float(reg), _p(norms, torch.float32),
+                                     _p(gout, torch.float32, "gout"), _stream()), "srh_l2_reg_bwd")
 
 
 # SRH_NCE_SPLIT16, SRH_NCE_F32 (include/selfrec_hip.h); "bf16x3" is the round-1/2 name of the split mode, kept as an alias

@@ -38,28 +38,35 @@ def _padded(width_set, what, *tensors):
     return d, w
 
 
+def _dev_scalar(gout, like):
+    """the upstream gradient as the kernels read it: a 0-dim f32 tensor ON THE DEVICE (a float(gout) would be a
+    device-to-host sync in the middle of every backward pass -- the host could no longer run ahead of the device)"""
+    if gout.device != like.device or gout.dtype != torch.float32:
+        gout = gout.to(device=like.device, dtype=torch.float32)
+    return gout.contiguous()
+
+
 class _BprFn(torch.autograd.Function):
+    """one launch forward (the mean is finished on the device), one backward"""
+
     @staticmethod
     def forward(ctx, u, p, n):
         d, w = _padded(ops.ROW_WIDTHS, "bpr_loss", u)
         u, p, n = (ops.pad_cols(t, w) for t in (u, p, n))
-        rows = u.shape[0]
-        loss_sum = torch.zeros(1, dtype=torch.float64, device=u.device)
-        coef = torch.empty(rows, dtype=torch.float32, device=u.device)
-        ops.bpr_fwd(u, p, n, loss_sum, coef)
+        loss = torch.empty((), dtype=torch.float32, device=u.device)
+        coef = torch.empty(u.shape[0], dtype=torch.float32, device=u.device)
+        ops.bpr_fwd(u, p, n, loss, coef)
         ctx.save_for_backward(u, p, n, coef)
         ctx.d = d
-        return (loss_sum / rows).to(torch.float32).reshape(())
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
         u, p, n, coef = ctx.saved_tensors
-        gu, gp, gn = torch.empty_like(u), torch.empty_like(p), torch.empty_like(n)
-        # the upstream gradient stays ON THE DEVICE (folded into the per-row coefficients): a float(gout) here is a
-        # device-to-host sync in the middle of every backward pass -- the host could no longer run ahead of the device
-        ops.bpr_bwd(u, p, n, coef * (gout.to(torch.float32) / u.shape[0]), 1.0, gu, gp, gn)
+        g = torch.empty((3,) + tuple(u.shape), dtype=torch.float32, device=u.device)
+        ops.bpr_bwd(u, p, n, coef, _dev_scalar(gout, u), g[0], g[1], g[2])
         d = ctx.d
-        return gu[:, :d], gp[:, :d], gn[:, :d]
+        return g[0][:, :d], g[1][:, :d], g[2][:, :d]
 
 
 def _announce_wide(what, d, limit):
@@ -82,32 +89,37 @@ def bpr_loss(user_emb, pos_item_emb, neg_item_emb):
     return _BprFn.apply(user_emb, pos_item_emb, neg_item_emb)
 
 
-class _FrobNormFn(torch.autograd.Function):
-    """||x||_F of a 2-D block (torch.norm(emb, p=2) in the reference); zero gradient at 0."""
+class _L2RegFn(torch.autograd.Function):
+    """reg * sum_k ||emb_k||_F / rows_k over 1..4 blocks of rows: one launch forward, one backward (zero gradient where a
+    norm is zero, as torch.norm's)."""
+    MAX_BLOCKS = 4
 
     @staticmethod
-    def forward(ctx, x):
-        x = x.contiguous()
-        acc = torch.zeros(1, dtype=torch.float64, device=x.device)
-        ops.sumsq(x, acc)
-        norm = torch.sqrt(acc).to(torch.float32).reshape(())
-        ctx.save_for_backward(x, norm)
-        return norm
+    def forward(ctx, reg, *embs):
+        xs = [e.contiguous() for e in embs]
+        dev = xs[0].device
+        norms = torch.empty(len(xs), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ops.l2_reg_fwd(xs, reg, norms, loss)
+        ctx.save_for_backward(norms, *xs)
+        ctx.reg = float(reg)
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
-        x, norm = ctx.saved_tensors
-        # gout / ||x|| (0 at ||x|| = 0) as a DEVICE scalar: no float(...) -- every one of those is a device-to-host sync
-        # that stops the host from running ahead (four per step of the reference's XSimGCL.py before round 4)
-        coef = torch.where(norm > 0, gout.to(torch.float32) / norm, torch.zeros_like(norm))
-        return x * coef
+        norms, *xs = ctx.saved_tensors
+        gxs = [torch.empty_like(x) for x in xs]
+        ops.l2_reg_bwd(xs, ctx.reg, norms, _dev_scalar(gout, norms), gxs)
+        return (None, *gxs)
 
 
 def l2_reg_loss(reg, *args):
+    if args and len(args) <= _L2RegFn.MAX_BLOCKS and all(_on_hip_path(e) and e.numel() > 0 for e in args):
+        return _L2RegFn.apply(float(reg), *args)
     emb_loss = 0
     for emb in args:
-        if _on_hip_path(emb):
-            emb_loss = emb_loss + _FrobNormFn.apply(emb) / emb.shape[0]
+        if _on_hip_path(emb) and emb.numel() > 0:
+            emb_loss = emb_loss + _L2RegFn.apply(1.0, emb)                     # = ||emb|| / rows
         else:
             emb_loss = emb_loss + torch.norm(emb, p=2) / emb.shape[0]          # loss_torch.py:18-22
     return emb_loss * reg
@@ -120,19 +132,23 @@ class _InfoNceFn(torch.autograd.Function):
         v1, v2 = ops.pad_cols(v1, w), ops.pad_cols(v2, w)
         n = v1.shape[0]
         dev = v1.device
-        loss = torch.zeros(1, dtype=torch.float64, device=dev)
-        g1, g2 = torch.zeros_like(v1), torch.zeros_like(v2)
+        # [dL/dv1 | dL/dv2 | loss (one double)]: the kernels ADD into all three, so all three start at zero -- one fill
+        buf = torch.zeros(2 * n * w + 2, dtype=torch.float32, device=dev)
+        g = buf[:2 * n * w].view(2, n, w)
+        loss = buf[2 * n * w:].view(torch.float64)
         ws = ops.infonce_ws(n, w, dev)
         # forward and backward share every intermediate, so both are produced here with unit
         # upstream gradient and scaled in backward()
-        ops.infonce_fwd_bwd(v1, v2, None, n, tau=temperature, loss_scale=1.0, loss=loss, g1=g1, g2=g2, ws=ws)
-        ctx.save_for_backward(g1[:, :d], g2[:, :d])
+        ops.infonce_fwd_bwd(v1, v2, None, n, tau=temperature, loss_scale=1.0, loss=loss, g1=g[0], g2=g[1], ws=ws)
+        ctx.save_for_backward(g)
+        ctx.d = d
         return loss.to(torch.float32).reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        g1, g2 = ctx.saved_tensors
-        return g1 * gout, g2 * gout, None
+        (g,) = ctx.saved_tensors
+        g = g * gout
+        return g[0][:, :ctx.d], g[1][:, :ctx.d], None
 
 
 def _infonce_expression(view1, view2, temperature, b_cos=True):

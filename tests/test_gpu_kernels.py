@@ -417,6 +417,56 @@ def test_loss_functions_match_reference_outputs(golden_ops, n):
         assert rel_err(gn, g[f"ops_{n}_g_nce"]) < 1e-5
 
 
+@pytest.mark.parametrize("rows,d", [(1, 64), (2048, 64), (777, 32), (300, 100), (4099, 128)])
+def test_single_launch_losses_equal_the_torch_expressions(rows, d):
+    """bpr_loss / l2_reg_loss finish their scalars on the device (one launch forward, one backward, a shared 64-byte
+    workspace that every call leaves zero): values and gradients against the reference's expressions (loss_torch.py:6-22)
+    evaluated by ATen on the same device, with a NON-unit upstream gradient, an all-zero block (zero gradient, as
+    torch.norm's), four blocks of different sizes in one call, and the same call repeated."""
+    from selfrec_amd import ops
+    from selfrec_amd.util import loss_torch as L
+    gen = torch.Generator().manual_seed(rows * 31 + d)
+    mk = lambda r: (torch.randn(r, d, generator=gen) * 0.3).to(DEV).requires_grad_(True)
+    u, p, q = mk(rows), mk(rows), mk(rows)
+    z = torch.zeros(5, d, device=DEV, requires_grad=True)
+    small = mk(3)
+
+    def expression(u, p, q, z, small):
+        pos, neg = torch.mul(u, p).sum(dim=1), torch.mul(u, q).sum(dim=1)
+        bpr = torch.mean(-torch.log(10e-6 + torch.sigmoid(pos - neg)))
+        emb = 0
+        for e in (u, z, p, small):
+            emb = emb + torch.norm(e, p=2) / e.shape[0]
+        return bpr, emb * 0.37
+
+    for _ in range(3):                                  # (the workspace is shared: repeated calls must not leak into each other)
+        bpr, reg = L.bpr_loss(u, p, q), L.l2_reg_loss(0.37, u, z, p, small)
+        assert bpr.dtype == torch.float32 and bpr.dim() == 0 and reg.dtype == torch.float32 and reg.dim() == 0
+        got = torch.autograd.grad(bpr * 3.7 + reg * -2.5, (u, p, q, z, small))
+        wb, wr = expression(u, p, q, z, small)
+        want = torch.autograd.grad(wb * 3.7 + wr * -2.5, (u, p, q, z, small))
+        np.testing.assert_allclose([bpr.item(), reg.item()], [wb.item(), wr.item()], rtol=2e-6)
+        for g, w in zip(got, want):
+            assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 2e-6
+        assert not got[3].any()                                         # the zero block
+        assert not ops.scalar_ws(u.device).any()
+    # five blocks (one more than a launch takes) and a block on the CPU go block by block, same value
+    five = L.l2_reg_loss(0.37, u, z, p, small, small)
+    assert abs(five.item() - (wr.item() + 0.37 * (torch.norm(small) / 3).item())) < 2e-6 * abs(five.item())
+    mixed = L.l2_reg_loss(0.37, u, small.detach().cpu())
+    assert abs(mixed.item() - 0.37 * ((torch.norm(u) / rows).item() + (torch.norm(small) / 3).item())) < 2e-6 * abs(mixed.item())
+    # the number of launches: what the host pays per call in the op-level tier
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        bpr, reg = L.bpr_loss(u, p, q), L.l2_reg_loss(0.37, u, p)
+        (bpr + reg).backward()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    ours = [k for k in names if "bpr_plain" in k or "l2_reg" in k]
+    assert len(ours) == 4, names                                        # two forward, two backward
+
+
 @pytest.mark.parametrize("n,d,tau", [(2048, 64, 0.2), (1500, 64, 0.15), (700, 128, 0.2), (17, 64, 0.5), (900, 256, 0.2),
                                      (300, 256, 0.05)])
 def test_infonce_gathered_matches_oracle(n, d, tau):

@@ -78,6 +78,13 @@ determinism)
   timeout 600 python tools/determinism_probe.py > $OUT/determinism.txt 2>&1; echo "determinism exit $?"; grep -v amdgpu.ids $OUT/determinism.txt | tail -12;;
 nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
+hostprobeold)
+  PROBE_PKG_ROOT=$PWD/_refstage/old_pkg timeout 300 python tools/oplevel_host_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/oplevel_host_probe_before.txt; echo "hostprobeold exit $?"; cat $OUT/oplevel_host_probe_before.txt;;
+hostprobe)
+  timeout 300 python tools/oplevel_host_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/oplevel_host_probe${HOSTPROBE_TAG:-}.txt; echo "hostprobe exit $?"; cat $OUT/oplevel_host_probe${HOSTPROBE_TAG:-}.txt;;
+testslosses)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_dropin.py -m gpu -q --tb=short -p no:cacheprovider -k "loss or dropin or client or fast or reference or embedding" > $OUT/tests_losses.log 2>&1; echo "testslosses exit $?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_losses.log | head -40;;
 oplevel)
   # per-statement step time of the op-level models + whole 2-epoch runs through main
   : > $OUT/oplevel.txt
