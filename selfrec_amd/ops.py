@@ -64,6 +64,7 @@ class Sampler:
         h = C.c_void_p()
         check(self._lib.srh_sampler_create(C.byref(h), n_users, n_items, eu.size, pu, pi), "srh_sampler_create")
         self._h = h
+        self._pushed = None            # the words this object last handed to python's generator (set_state_from_python)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -73,30 +74,40 @@ class Sampler:
 
     # -- RNG state ------------------------------------------------------------------
     def set_state_from_python(self, state=None):
-        """Adopt ``random.getstate()`` (version 3 tuple: 624 words + position)."""
+        """Adopt ``random.getstate()`` (version 3 tuple: 624 words + position).  When python's generator still holds the
+        very state this object pushed last (nobody drew from ``random`` in between -- the per-batch case of
+        ``next_batch_pairwise``), the C++ generator is already there and nothing is converted: boxing 624 words into
+        a numpy array and back cost ~150 us per batch, a tenth of an op-level LightGCN step."""
         state = _pyrandom.getstate() if state is None else state
         if state[0] != 3 or len(state[1]) != 625:
             raise SelfrecHipError("unsupported random.getstate() layout")
-        words = np.asarray(state[1][:624], dtype=np.uint32)
-        check(self._lib.srh_sampler_set_state(self._h, words.ctypes.data_as(C.c_void_p), int(state[1][624])))
         self._gauss = state[2]
+        if self._pushed is not None and state[1] == self._pushed:
+            return
+        words = np.array(state[1][:624], dtype=np.uint32)
+        check(self._lib.srh_sampler_set_state(self._h, words.ctypes.data_as(C.c_void_p), int(state[1][624])))
+        self._pushed = None
 
     def python_state(self):
         """The generator state as a tuple ``random.setstate`` accepts."""
         words = np.empty(624, dtype=np.uint32)
         pos = C.c_int32()
         check(self._lib.srh_sampler_get_state(self._h, words.ctypes.data_as(C.c_void_p), C.byref(pos)))
-        return (3, tuple(int(x) for x in words) + (int(pos.value),), getattr(self, "_gauss", None))
+        return (3, tuple(words.tolist()) + (int(pos.value),), getattr(self, "_gauss", None))
 
     def push_state_to_python(self):
-        _pyrandom.setstate(self.python_state())
+        state = self.python_state()
+        _pyrandom.setstate(state)
+        self._pushed = state[1]
 
     def seed(self, seed: int):
         check(self._lib.srh_sampler_seed(self._h, int(seed)), "srh_sampler_seed")
         self._gauss = None
+        self._pushed = None
 
     # -- draws ----------------------------------------------------------------------
     def shuffle(self):
+        self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_shuffle(self._h), "srh_sampler_shuffle")
 
     def order(self) -> np.ndarray:
@@ -110,6 +121,7 @@ class Sampler:
         i = np.empty(cnt, dtype=np.int32)
         j = np.empty(cnt * n_negs, dtype=np.int32)
         out = C.c_int64()
+        self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_next_batch(self._h, ptr, batch_size, n_negs, u.ctypes.data_as(C.c_void_p),
                                                i.ctypes.data_as(C.c_void_p), j.ctypes.data_as(C.c_void_p),
                                                C.byref(out)), "srh_sampler_next_batch")
@@ -132,18 +144,21 @@ class Sampler:
             nui = np.zeros(nb, dtype=np.int32)
             res.update(uniq_u=uu, uniq_i=ui, n_uniq_u=nuu, n_uniq_i=nui)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_epoch(self._h, batch_size, n_negs, vp(u), vp(i), vp(j), vp(uu), vp(nuu),
                                           vp(ui), vp(nui)), "srh_sampler_epoch")
         return res
 
     def sample_range(self, n: int, k: int) -> np.ndarray:
         out = np.empty(k, dtype=np.int64)
+        self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_sample_range(self._h, n, k, out.ctypes.data_as(C.c_void_p)),
               "srh_sampler_sample_range")
         return out
 
     def next_u32(self) -> int:
         v = C.c_uint32()
+        self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_next_u32(self._h, C.byref(v)))
         return int(v.value)
 

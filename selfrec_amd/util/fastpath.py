@@ -1,13 +1,13 @@
 """Host-side fast paths of the OP-LEVEL tier: what a model file written the reference's way pays per step beyond its kernels.
 
 A step of the unmodified XSimGCL.py on this package's kernels spent 2.2 ms on the host and 1.46 ms on the device
-(profiles/r02_e_dropin_torch_profiler.txt, 189 launches).  Three idioms of the reference's model files account for the
+(profiles/r02_e_dropin_torch_profiler.txt, 189 launches).  Three idioms of the reference's model files (and one of its entry class) account for the
 avoidable part, and none of them needs the file to change (``dropin.install()`` switches these on, ``uninstall()`` off):
 
 1. ``table[python_list]`` (XSimGCL.py:30, LightGCN.py:24-25, MF.py:20): torch boxes the list into a CPU tensor, copies it to
    the device and gathers with advanced indexing, whose backward is ``index_put_(accumulate=True)`` -- a sort plus several
    launches (0.24 ms per step).  The lists ``next_batch_pairwise`` yields are REAL python lists (the reference's protocol),
-   but the generator also uploads all three streams -- and their sorted unique ids -- in ONE pinned copy and registers the
+   but the generator also uploads all three streams -- and, for models that ask for them, their sorted unique ids -- in ONE pinned copy and registers the
    device tensors under the lists' identities; ``Tensor.__getitem__`` with a registered list (or any 1-D int64 HIP index into
    a 2-D HIP tensor) becomes ``index_select``: one gather launch, backward = ``index_add_`` (atomics, no sort).  Same rows,
    same values; gradients equal up to fp32 summation order of duplicate rows.
@@ -19,6 +19,11 @@ avoidable part, and none of them needs the file to change (``dropin.install()`` 
    ``Adam`` (below) is a ``torch.optim.Adam`` whose ``step()`` runs ``srh_adam_step`` -- one launch per table, the
    arithmetic the engine's tests hold to ``torch.optim.Adam`` -- whenever the group uses the plain algorithm on fp32 HIP
    parameters, and torch's own step otherwise.
+
+4. ``FileIO.load_data_set(path, 'graph')`` (the reference's SELFRec.py:12-13) building 1.2 M python triples that only
+   ``Interaction`` reads -- and that ``shuffle()`` (util/sampler.py:7) then permutes every epoch.  With the fast paths on it
+   returns ``data/loader.TripleFile``: a list-like object the native loader parses, materialised as the ordinary list the
+   moment anything indexes, iterates or mutates it, its shuffles kept as one pending permutation until then.
 
 Everything here is an optimisation of identical semantics; a list the caller edited after it was yielded, an index that is
 not registered, a parameter group with weight decay -- each takes torch's own path.
@@ -36,18 +41,35 @@ hits = {"gather_list": 0, "gather_index": 0, "unique": 0, "adam": 0}       # how
 
 class _Stream:
     """one yielded list and what the generator knows about it"""
-    __slots__ = ("lst", "n", "first", "last", "max_id", "total", "dev", "uniq_host", "uniq_dev")
+    __slots__ = ("lst", "n", "first", "last", "host", "dev", "uniq_host", "uniq_dev", "_total", "_max")
 
-    def __init__(self, lst, dev, uniq_host, uniq_dev, max_id, total):
-        self.total = int(total)
+    def __init__(self, lst, host, dev):
         self.lst, self.n = lst, len(lst)
         self.first, self.last = (lst[0], lst[-1]) if lst else (None, None)
-        self.dev, self.uniq_host, self.uniq_dev, self.max_id = dev, uniq_host, uniq_dev, int(max_id)
+        self.host, self.dev, self.uniq_host, self.uniq_dev = host, dev, None, None
+        self._total = self._max = None
 
     def still(self, lst):
         """the caller has not edited the list since it was yielded (length and both ends: the generator's lists are fresh
         objects, so only an in-place edit by the caller could change them)"""
         return len(lst) == self.n and (self.n == 0 or (lst[0] == self.first and lst[-1] == self.last))
+
+    @property
+    def total(self):
+        if self._total is None:
+            self._total = int(self.host.sum())
+        return self._total
+
+    @property
+    def max_id(self):
+        if self._max is None:
+            self._max = int(self.host.max()) if self.n else 0
+        return self._max
+
+    def set_unique(self, ids_host, ids_dev):
+        hu = torch.from_numpy(ids_host).as_subclass(HostIds)
+        hu._srh_dev = ids_dev
+        self.uniq_host, self.uniq_dev = hu, ids_dev
 
 
 class HostIds(torch.Tensor):
@@ -73,20 +95,28 @@ def active() -> bool:
     return _state["on"]
 
 
+def _pinned(n):
+    pin = _state["pinned"]
+    if pin is None or pin.numel() < n:
+        pin = _state["pinned"] = torch.empty(max(n, 1 << 15), dtype=torch.int64).pin_memory()
+    return pin
+
+
 def register_batch(lists, arrays, device=None):
     """Called by ``next_batch_pairwise`` right before it yields ``lists`` = (u, i, j) python lists built from the int32
-    ``arrays``: one pinned host buffer [u | i | j | unique(u) | unique(i)] (int64), one asynchronous copy, views of the
-    device buffer registered under the lists' identities.  The previous batch's registrations are dropped."""
+    ``arrays``: one pinned host buffer [u | i | j (| unique(u) | unique(i))] (int64), one asynchronous copy, views of the
+    device buffer registered under the lists' identities.  The sorted unique ids ride along only when the model asked for
+    them on the previous batch (``torch.unique``: XSimGCL, SGL -- LightGCN and MF never do, and two host sorts per batch
+    were 3 % of their step); a first request is served on demand (``_unique_of``).  The previous batch's registrations
+    are dropped."""
     if not _state["on"] or not torch.cuda.is_available():
         return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    u, i, j = (np.asarray(a, dtype=np.int64) for a in arrays)
-    uu, ui = np.unique(u), np.unique(i)                      # sorted: torch.unique's order
-    parts = (u, i, j, uu, ui)
+    parts = [np.asarray(a, dtype=np.int64) for a in arrays]
+    if _state.get("want_unique"):
+        parts += [np.unique(parts[0]), np.unique(parts[1])]          # sorted: torch.unique's order
     total = sum(p.size for p in parts)
-    pin = _state["pinned"]
-    if pin is None or pin.numel() < total:
-        pin = _state["pinned"] = torch.empty(max(total, 1 << 15), dtype=torch.int64).pin_memory()
+    pin = _pinned(total)
     host = pin.numpy()
     at, views = 0, []
     for p in parts:
@@ -95,16 +125,21 @@ def register_batch(lists, arrays, device=None):
         at += p.size
     on_dev = torch.empty(total, dtype=torch.int64, device=dev)
     on_dev.copy_(pin[:total], non_blocking=True)
-    d = [on_dev[a:b] for a, b in views]
-    batch = {}
-    for lst, dv, (uh, ud) in zip(lists, d[:3], ((uu, d[3]), (ui, d[4]), (None, None))):
-        hu = None
-        if uh is not None:
-            hu = torch.from_numpy(uh.copy()).as_subclass(HostIds)
-            hu._srh_dev = ud
-        arr = parts[len(batch)]
-        batch[id(lst)] = _Stream(lst, dv, hu, ud, uh[-1] if uh is not None and uh.size else 0, arr.sum())
-    _state["batch"] = batch
+    streams = [_Stream(lst, parts[k], on_dev[views[k][0]:views[k][1]]) for k, lst in enumerate(lists)]
+    for k in range(len(parts) - 3):
+        streams[k].set_unique(parts[3 + k].copy(), on_dev[views[3 + k][0]:views[3 + k][1]])
+    _state["batch"] = {id(st.lst): st for st in streams}
+    _state["want_unique"] = False                                   # (set again by the first torch.unique of this batch)
+
+
+def _unique_of(s):
+    """sorted unique ids of a registered stream, host and device: from the batch's one copy when they rode along, else
+    computed and uploaded now (the model's first ``torch.unique``; later batches carry them)"""
+    _state["want_unique"] = True
+    if s.uniq_host is None:
+        ids = np.unique(s.host)
+        s.set_unique(ids, torch.from_numpy(ids).to(s.dev.device))
+    return s.uniq_host
 
 
 def _lookup(lst):
@@ -136,14 +171,14 @@ def _unique(input, *args, **kwargs):
     if not args and not kwargs and type(input) is torch.Tensor and input.device.type == "cpu" and input.dim() == 1 \
             and input.dtype in (torch.int64, torch.float32) and _state["batch"]:
         n = input.numel()
-        for s in _state["batch"].values():
+        for k, s in enumerate(_state["batch"].values()):
             # (ids above 2^24 do not survive the reference's torch.Tensor(list) float round trip: those keep torch's path,
             # so that this module never computes anything else than the model file's own expression would)
-            if s.uniq_host is not None and s.n == n and n > 0 and int(input[0]) == s.first and int(input[-1]) == s.last \
+            if k < 2 and s.n == n and n > 0 and int(input[0]) == s.first and int(input[-1]) == s.last \
                     and s.still(s.lst) and s.max_id < (1 << 24) and int(input.sum()) == s.total:
                 if input.dtype == torch.int64:
                     hits["unique"] += 1
-                    return s.uniq_host
+                    return _unique_of(s)
                 break                                        # (a float tensor: unique of floats is not what we hold)
     return orig(input, *args, **kwargs)
 
@@ -192,7 +227,7 @@ class Adam(torch.optim.Adam):
 
 
 def install():
-    """Switch the three fast paths on (idempotent).  ``torch.Tensor.__getitem__``, ``torch.unique`` and
+    """Switch the fast paths on (idempotent).  ``torch.Tensor.__getitem__``, ``torch.unique`` and
     ``torch.optim.Adam`` are wrapped process-wide until ``uninstall()``; every wrapper falls through to torch's own
     implementation for anything it does not recognise."""
     if _state["on"]:
@@ -204,6 +239,8 @@ def install():
     torch.Tensor.__getitem__ = _getitem
     torch.unique = _unique
     torch.optim.Adam = Adam
+    from ..data import loader
+    loader.LAZY_GRAPH_FILES[0] = True
     _state["on"] = True
 
 
@@ -216,4 +253,6 @@ def uninstall():
         del torch.Tensor.__getitem__                         # (back to the inherited slot of torch._C.TensorBase)
     torch.unique = _state["orig_unique"]
     torch.optim.Adam = _state["orig_adam"]
-    _state.update(on=False, batch={}, pinned=None)
+    from ..data import loader
+    loader.LAZY_GRAPH_FILES[0] = False
+    _state.update(on=False, batch={}, pinned=None, want_unique=False)

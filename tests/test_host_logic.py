@@ -422,6 +422,34 @@ def test_torch_cpu_generator_replay_is_bit_exact():
     print(f"keep mask of 2.47 M entries: replay {1e3 * fast:.1f} ms, ATen {1e3 * slow:.1f} ms")
 
 
+def test_dropin_fast_paths_make_the_entry_class_load_lazily(tmp_path):
+    """dropin.install(): ``data.loader.FileIO.load_data_set(path, 'graph')`` -- what the reference's SELFRec.py:12-13 calls --
+    returns the lazy TripleFile (equal to the list as soon as anybody reads it); without the fast paths, and after
+    uninstall(), the plain list of the reference."""
+    import importlib
+    from selfrec_amd import dropin
+    from selfrec_amd.data.loader import TripleFile
+    tu, ti, su, si, U, I = synth.make_dataset("tiny")
+    tr = tmp_path / "train.txt"
+    synth.write_text(str(tr), tu, ti)
+    want = FileIO.load_data_set(str(tr), "graph")
+    assert type(want) is list
+    for fast in (True, False):
+        dropin.install(fuse=False, fast=fast)
+        try:
+            got = importlib.import_module("data.loader").FileIO.load_data_set(str(tr), "graph")
+            assert isinstance(got, TripleFile) == fast
+            if fast:
+                assert got.unread() and Interaction({}, got, []).training_size()[2] == len(want) and got.unread()
+            assert list(got) == want
+            # (a sequential file, a missing file: the reference's behaviour)
+            with pytest.raises(FileNotFoundError):
+                importlib.import_module("data.loader").FileIO.load_data_set(str(tmp_path / "none.txt"), "graph")
+        finally:
+            dropin.uninstall()
+    assert type(FileIO.load_data_set(str(tr), "graph")) is list
+
+
 def test_lazy_training_file_keeps_the_shuffles_as_a_pending_permutation(tmp_path):
     """data/loader.TripleFile + util/sampler: on a dataset opened lazily the in-place shuffles of sampler.py:7 are carried
     as one permutation until somebody reads ``data.training_data``; batches, the list a reader then finds, and every later
