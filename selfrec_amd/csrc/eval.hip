@@ -214,7 +214,21 @@ __global__ __launch_bounds__(256) void cand_topk_kernel(const int32_t* __restric
 // A true top-K item has s >= t_u, hence s~ >= t_u - delta_u: it survives.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr float kFilterMargin = 4e-5f;
+// How many of the split products the filter evaluates (build-time: tools/spmm_lab/build_alt.sh builds the others for an A/B):
+//   3  u_hi.i_hi + u_hi.i_lo + u_lo.i_hi          delta = 4e-5   |u| max|i|   (round 3: three MFMAs per 16 dimensions)
+//   2  u_hi.i_hi + u_lo.i_hi                      delta = 1.98e-3 |u| max|i|  (the item side rounded to bf16: 2^-9 per element)
+//   1  u_hi.i_hi                                  delta = 3.93e-3 |u| max|i|  (both sides rounded: 2^-8 + 2^-18, Cauchy-Schwarz)
+// The margin only decides how many items reach the exact re-score; near a row's K-th best score the catalogue is thin
+// (K of 38 k items lie above it), so a 100x wider margin adds a handful of survivors per user while the filter's MFMA work
+// -- and the item image it stages through LDS -- drops to a third / a half.  Every margin is a BOUND, not an estimate:
+// |fl_bf16(x) - x| <= 2^-9 |x| (round to nearest even, 8 significant bits), the products are exact in f32, and the f32
+// accumulation of d <= 256 terms adds d * 2^-24 sum |u_k i_k| <= 1.6e-5 |u||i|.
+#ifndef SRH_F16_TERMS
+#define SRH_F16_TERMS 1
+#endif
+constexpr int kF16Terms = SRH_F16_TERMS;
+static_assert(kF16Terms >= 1 && kF16Terms <= 3, "SRH_F16_TERMS: 1, 2 or 3");
+constexpr float kFilterMargin = kF16Terms == 3 ? 4e-5f : (kF16Terms == 2 ? 1.98e-3f : 3.93e-3f);
 
 // rows of an f32 table as bf16 hi / lo images + the row's L2 norm; the table's largest norm in *max_norm (float bits
 // compare like unsigned ints for non-negative floats).  FRAG = false: row-major images (the query rows: each wave loads
@@ -313,10 +327,11 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
                                                        const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
                                                        Filter16Args f, float* __restrict__ C = nullptr) {
   constexpr int KS = D / 16;
-  constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile
-  constexpr int ST = 32768 / TILE_BYTES;             // tiles per stage: 4 (d = 64), 2 (d = 128)
+  constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile (the global image)
+  constexpr int FR = kF16Terms == 3 ? 2 * KS : KS;   // fragments of a tile this build stages: hi + lo, or hi only
+  constexpr int ST = 32768 / (FR * 1024);            // tiles per stage: 4 (d = 64; 8 hi-only), 2 (d = 128; 4 hi-only)
   extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
-  constexpr int STAGE_BYTES = ST * TILE_BYTES;       // 32 KB
+  constexpr int STAGE_BYTES = ST * FR * 1024;        // 32 KB
   constexpr int WAVES = 8 / UB, CAP = kF16StageCap * UB / 2;       // (same LDS either way: 8 shorter lists or 4 longer ones)
   int* s_col = reinterpret_cast<int*>(f16_smem + 2 * ST * TILE_BYTES);
   float* s_sc = reinterpret_cast<float*>(s_col + WAVES * CAP);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         ah[ub][s] = ld8(Uhi + (size_t)ar * D + 16 * s + 8 * h);
-        al[ub][s] = ld8(Ulo + (size_t)ar * D + 16 * s + 8 * h);
+        if (kF16Terms >= 2) al[ub][s] = ld8(Ulo + (size_t)ar * D + 16 * s + 8 * h);
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -371,9 +386,13 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   };
   const unsigned char* img = reinterpret_cast<const unsigned char*>(Ifrag);
   auto copy_stage = [&](int t0, unsigned char* dst) {           // tiles [t0, min(t0 + ST, t_end)) -> dst
-    const int frags = min(ST, t_end - t0) * 2 * KS;
+    const int frags = min(ST, t_end - t0) * FR;
     const unsigned char* src = img + (size_t)t0 * TILE_BYTES;
-    for (int k = wv; k < frags; k += WAVES) glds16_b(src + (size_t)k * 1024 + lane * 16, dst + k * 1024);
+    for (int k = wv; k < frags; k += WAVES) {
+      // (hi-only builds skip the lo half of every tile of the global image)
+      const size_t from = (FR == 2 * KS) ? (size_t)k * 1024 : (size_t)(k / KS) * TILE_BYTES + (size_t)(k % KS) * 1024;
+      glds16_b(src + from + lane * 16, dst + k * 1024);
+    }
   };
   copy_stage(t_begin, f16_smem);
   int cur = 0;
@@ -388,8 +407,8 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
         bf16x8 bh[KS], bl[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          bh[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + s) * 1024 + lane * 16));
-          bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * 2 * KS + KS + s) * 1024 + lane * 16));
+          bh[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * FR + s) * 1024 + lane * 16));
+          if (kF16Terms == 3) bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * FR + KS + s) * 1024 + lane * 16));
         }
         const int col = (t0 + tt) * 32 + r32;
 #pragma unroll
@@ -399,8 +418,8 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
           for (int t = 0; t < 16; ++t) acc[t] = 0.f;
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
+            if (kF16Terms >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
+            if (kF16Terms == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
           }
           if (SLAB) {

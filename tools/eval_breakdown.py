@@ -52,6 +52,11 @@ ms_host, _ = wall(lambda: gr._to_host(ids_dev, sc_dev))
 ms_pageable, _ = wall(lambda: (ids_dev.cpu().numpy(), sc_dev.cpu().numpy()))
 ms_all, _ = wall(lambda: rec.rank_on_device(uid))
 ms_emb, _ = wall(lambda: rec._device_embeddings())
+from selfrec_amd import ops  # noqa: E402
+_, _, counts, _ = ops.score_mask_topk_filtered(ue, uid_dev, ie, g.r_indptr, g.r_indices, 20, sample_items=gr.FILTER_SAMPLE_ITEMS,
+                                               cap=gr.FILTER_CAP, chunk_rows=gr.FILTER_CHUNK_ROWS)
+counts = counts.cpu().numpy()
+print(f"survivors of the filter per user: mean {counts.mean():.1f} max {counts.max()} over cap {(counts > gr.FILTER_CAP).sum()}", end=" | ")
 print(f"users {len(uid)}: _rank device time (events) {sorted(dev)[3]:.3f} ms | _rank wall {ms_rank_wall:.3f} | pinned D2H of ids + scores "
       f"{ms_host:.3f} (pageable .cpu(): {ms_pageable:.3f}) | _device_embeddings {ms_emb:.3f} | rank_on_device {ms_all:.3f} ms = "
       f"{len(uid) / ms_all / 1e3:.2f} M users/s")
