@@ -204,31 +204,47 @@ __global__ __launch_bounds__(256) void cand_topk_kernel(const int32_t* __restric
 
 
 // ---------------------------------------------------------------------------------------
-// The FILTER pass on the bf16 pipe (round 3).  The filter only has to decide "can this score reach the row's
-// bound?" -- it never has to report a score -- so it runs on split-bf16 operands (x = hi + lo, three MFMAs of
-// v_mfma_f32_32x32x16_bf16 per 16 dimensions: 5.3x the f32 MFMA's rate) against a bound lowered by a rigorous margin;
-// the few hundred survivors per user are then RE-SCORED with the very instruction sequence of gemm_nt_kernel (so
-// ids and scores stay bit-identical to the plain pipeline) and ranked.
-//   |s~ - s| <= 3 * 2^-18 * sum_k |u_k i_k| (dropped lo.lo, two operand representations) + f32 accumulation of either
-//   side (d * 2^-24 * sum |u_k i_k|) <= 4e-5 * |u| * max_i |i| for d <= 128 =: delta_u  (kFilterMargin)
-// A true top-K item has s >= t_u, hence s~ >= t_u - delta_u: it survives.
+// The FILTER pass on the bf16 pipe (round 3; margins per item and one-term products: round 4).  The filter only has to
+// decide "can this score reach the row's bound?" -- it never has to report a score -- so it runs on bf16 operands against
+// rigorous error bounds; the few dozen survivors per user are then RE-SCORED with the very instruction sequence of
+// gemm_nt_kernel (so ids and scores stay bit-identical to the plain pipeline) and ranked.
+//   s~_uj = the bf16 product the MFMAs form,  |s~_uj - s_uj| <= delta_uj = c |u| |i_j|,   c = kFilterMargin:
+//   SRH_F16_TERMS  products per 16 dimensions                 c
+//   3              u_hi.i_hi + u_hi.i_lo + u_lo.i_hi           5e-5     (dropped lo.lo: 3 * 2^-18)
+//   2              u_hi.i_hi + u_lo.i_hi                       1.99e-3  (the item side rounded to bf16: 2^-9 + 2^-18)
+//   1 (default)    u_hi.i_hi                                   3.94e-3  (both sides rounded: 2^-8 + 2^-18)
+//   -- |fl_bf16(x) - x| <= 2^-9 |x| (round to nearest even, 8 significant bits), the products are exact in f32, Cauchy-Schwarz
+//   over the d terms, and the f32 accumulation of d + 1 <= 129 addends (the accumulator starts at -T, see below) adds at most
+//   2 (d + 1) 2^-24 |u||i_j| = 1.6e-5 |u||i_j| wherever it matters (|T| <= |u||i_j| for any item that can reach T).
+// The margin is PER ITEM: with one bound for the whole catalogue (round 3: c |u| max_j |i_j|) a few popular items of large
+// norm -- trained tables have them: 100x the typical norm after 1300 steps -- widen everybody's margin, harmless at
+// c = 4e-5 and ruinous at 4e-3 (984 of 31.5 k users overflowed their candidate lists).  Per item the margin scales with the
+// score it guards.  The margin only decides how many items reach the exact re-score: near a row's K-th best score the
+// catalogue is thin, so a 100x wider one adds a handful of survivors per user (50 -> 60) while the MFMA work and the item
+// image staged through LDS drop to a third / a half.
+//   bound stage:  slab[u][j] = s~_uj - delta_uj <= s_uj for a leading slice of the catalogue; T_u = a lower bound of its
+//                 K-th largest entry (training items masked) <= the exact K-th best score of the row;
+//   filter:       a top-K item has s_uj >= T_u, hence s~_uj + delta_uj >= T_u: the accumulator starts at -T_u and the test
+//                 is fma(c |u|, |i_j|, acc) >= 0 -- one FMA per output and ONE comparison per 32 x 32 block (the maximum);
+//   re-score:     L_j = s~ - delta, U_j = s~ + delta; tau = the K-th largest L_j of the unmasked survivors <= the exact K-th
+//                 best; only survivors with U_j >= tau can be in the exact top-K: those are re-scored exactly and ranked.
+// Where a ranking's 1.05 ms go (31.5 k users, trained tables, tools/gpu_session.sh evalbreakab with -DSRH_F16_EXP=1 / 2 builds):
+// MFMAs + operand staging of the filter 0.17, its epilogue 0.25 (four blocks in five hold a survivor: 1.6 per 32 x 32 block),
+// writing the survivors out 0.10, the re-score 0.19, the bound stage (slab, mask, bound) 0.21, the rest 0.13.  Tried on top
+// and dropped, all within +-0.07 ms of this form: survivor lists private to (row, item range) with LDS slot counters instead
+// of device-scope atomics (the atomics are not what the flush costs), long staging lists flushed when half full (seven
+// waves wait at the stage barrier for the one that flushes), four returning atomics in flight per lane, wave-uniform
+// ballots per row quad and output instead of the bit mask + select loop.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// How many of the split products the filter evaluates (build-time: tools/spmm_lab/build_alt.sh builds the others for an A/B):
-//   3  u_hi.i_hi + u_hi.i_lo + u_lo.i_hi          delta = 4e-5   |u| max|i|   (round 3: three MFMAs per 16 dimensions)
-//   2  u_hi.i_hi + u_lo.i_hi                      delta = 1.98e-3 |u| max|i|  (the item side rounded to bf16: 2^-9 per element)
-//   1  u_hi.i_hi                                  delta = 3.93e-3 |u| max|i|  (both sides rounded: 2^-8 + 2^-18, Cauchy-Schwarz)
-// The margin only decides how many items reach the exact re-score; near a row's K-th best score the catalogue is thin
-// (K of 38 k items lie above it), so a 100x wider margin adds a handful of survivors per user while the filter's MFMA work
-// -- and the item image it stages through LDS -- drops to a third / a half.  Every margin is a BOUND, not an estimate:
-// |fl_bf16(x) - x| <= 2^-9 |x| (round to nearest even, 8 significant bits), the products are exact in f32, and the f32
-// accumulation of d <= 256 terms adds d * 2^-24 sum |u_k i_k| <= 1.6e-5 |u||i|.
 #ifndef SRH_F16_TERMS
 #define SRH_F16_TERMS 1
 #endif
 constexpr int kF16Terms = SRH_F16_TERMS;
 static_assert(kF16Terms >= 1 && kF16Terms <= 3, "SRH_F16_TERMS: 1, 2 or 3");
-constexpr float kFilterMargin = kF16Terms == 3 ? 4e-5f : (kF16Terms == 2 ? 1.98e-3f : 3.93e-3f);
+constexpr float kFilterMargin = kF16Terms == 3 ? 5e-5f : (kF16Terms == 2 ? 1.99e-3f : 3.94e-3f);
+// the survivor's score is handed on as acc + T (the accumulator held s~ - T): one more rounding of size 2^-24 (|T| + |s~|)
+constexpr float kFilterAbsSlack = 3e-7f;
 
 // rows of an f32 table as bf16 hi / lo images + the row's L2 norm; the table's largest norm in *max_norm (float bits
 // compare like unsigned ints for non-negative floats).  FRAG = false: row-major images (the query rows: each wave loads
@@ -290,7 +306,7 @@ struct Filter16Args {
   const float* thr;            // row r's exact bound = thr[r * thr_stride]
   int thr_stride;
   const float* u_norm;         // |u_r|
-  const unsigned int* max_item_norm;
+  const float* item_norm;      // |i_j| per item, whole 32-item tiles (0 beyond the catalogue)
   int32_t* cnt;
   int32_t* cand_id;
   float* cand_sc;              // the split-bf16 score of the candidate (within delta_u of the exact one)
@@ -305,7 +321,8 @@ __device__ __forceinline__ void glds16_b(const void* gsrc, void* ldst) {
 #define SRH_F16_EXP 0
 #endif
 constexpr int kF16StageCap = 256;   // survivors a wave collects in LDS between two flushes (one per stage of item tiles)
-constexpr int kF16Lds = 2 * 32768 + 4 * kF16StageCap * (4 + 4 + 2);   // two stages + the four waves' survivor lists
+constexpr int kF16NormBytes = 1024;  // the staged tiles' item norms: <= 8 tiles x 32 floats per stage
+constexpr int kF16Lds = 2 * (32768 + kF16NormBytes) + 4 * kF16StageCap * (4 + 4 + 2);   // two stages (+ norms) + the survivor lists
 #ifndef SRH_F16_UB
 #define SRH_F16_UB 1                // 32-row MFMA blocks per wave: 1 (8 waves per 256-row workgroup) or 2 (4 waves; the first version)
 #endif
@@ -331,9 +348,10 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   constexpr int FR = kF16Terms == 3 ? 2 * KS : KS;   // fragments of a tile this build stages: hi + lo, or hi only
   constexpr int ST = 32768 / (FR * 1024);            // tiles per stage: 4 (d = 64; 8 hi-only), 2 (d = 128; 4 hi-only)
   extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
-  constexpr int STAGE_BYTES = ST * FR * 1024;        // 32 KB
+  constexpr int STAGE_BYTES = ST * FR * 1024 + kF16NormBytes;      // 32 KB of fragments, then the tiles' item norms
+  static_assert(ST * 128 <= kF16NormBytes, "norm slot of a stage");
   constexpr int WAVES = 8 / UB, CAP = kF16StageCap * UB / 2;       // (same LDS either way: 8 shorter lists or 4 longer ones)
-  int* s_col = reinterpret_cast<int*>(f16_smem + 2 * ST * TILE_BYTES);
+  int* s_col = reinterpret_cast<int*>(f16_smem + 2 * STAGE_BYTES);
   float* s_sc = reinterpret_cast<float*>(s_col + WAVES * CAP);
   short* s_row = reinterpret_cast<short*>(s_sc + WAVES * CAP);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -345,9 +363,9 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   const bool live = m0 < m;                          // (a wave beyond the chunk's rows still copies and synchronises)
   auto ld8 = [](const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); };
   bf16x8 ah[UB][KS], al[UB][KS];
-  float thr[UB][16];             // lowered bounds of the rows this lane holds results for
+  float thr[UB][16];             // T_row of the rows this lane holds results for (+inf beyond the chunk: nothing passes)
+  float cu[UB][16];              // c |u_row|: times the item's norm = the margin of one score
   {
-    const float item_norm = __uint_as_float(*f.max_item_norm);
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       const int ar = min(m0 + 32 * ub + r32, m - 1);
@@ -359,9 +377,8 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
-        // (the bound itself came from split-bf16 scores: one delta to make it a bound, one for the score compared with it)
-        thr[ub][t] = (!SLAB && row < m) ? f.thr[(size_t)row * f.thr_stride] - 2.0f * kFilterMargin * f.u_norm[row] * item_norm
-                                        : INFINITY;
+        cu[ub][t] = (row < m) ? kFilterMargin * f.u_norm[row] : 0.f;
+        thr[ub][t] = SLAB ? 0.f : ((row < m) ? f.thr[(size_t)row * f.thr_stride] : INFINITY);
       }
     }
   }
@@ -393,6 +410,9 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
       const size_t from = (FR == 2 * KS) ? (size_t)k * 1024 : (size_t)(k / KS) * TILE_BYTES + (size_t)(k % KS) * 1024;
       glds16_b(src + from + lane * 16, dst + k * 1024);
     }
+    // the tiles' item norms (128 B per tile) behind the fragments: one 16-byte direct load per lane of one wave
+    if (wv == (frags % WAVES) && lane * 4 < min(ST, t_end - t0) * 32)
+      glds16_b(reinterpret_cast<const unsigned char*>(f.item_norm) + (size_t)t0 * 128 + lane * 16, dst + ST * FR * 1024);
   };
   copy_stage(t_begin, f16_smem);
   int cur = 0;
@@ -411,11 +431,12 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
           if (kF16Terms == 3) bl[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + (tt * FR + KS + s) * 1024 + lane * 16));
         }
         const int col = (t0 + tt) * 32 + r32;
+        const float nj = *reinterpret_cast<const float*>(buf + ST * FR * 1024 + (tt * 32 + r32) * 4);     // |i_col|
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) {
           floatx16 acc;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+          for (int t = 0; t < 16; ++t) acc[t] = -thr[ub][t];                 // (the slab stage: thr = 0)
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             if (kF16Terms >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ub][s], bh[s], acc, 0, 0, 0);
@@ -423,10 +444,11 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ub][s], bh[s], acc, 0, 0, 0);
           }
           if (SLAB) {
+            // a LOWER bound of every exact score of the slice: the bound stage ranks these
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
               const int row = m0 + 32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h;
-              if (row < m && col < n) C[(size_t)row * n + col] = acc[t];
+              if (row < m && col < n) C[(size_t)row * n + col] = __builtin_fmaf(-cu[ub][t], nj, acc[t]);
             }
             continue;
           }
@@ -439,22 +461,32 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
             continue;
           }
 #endif
-          // The common case -- nothing passes -- is straight-line code: every lane packs its 16 comparisons into a bit
-          // mask (two VALU operations per output, no branch), ONE ballot per 32 x 32 block decides.  (The first version
-          // tested a ballot per accumulator register: 32 taken branches per tile, each around an inlined flush loop --
-          // 65 cycles per ballot, 117-129 us per chunk against 52 us for the same kernel without an epilogue.)
+          // Nothing passes in one block of five: that case is straight-line code -- one FMA per output (the score's own
+          // margin added to s~ - T), their maximum by v_max3, ONE comparison and ONE ballot per 32 x 32 block.  (Round 3 packed
+          // 16 comparisons into a bit mask first: two VALU operations per output; its first version tested a ballot per
+          // accumulator register: 32 taken branches per tile.)
+          float e[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) e[t] = __builtin_fmaf(cu[ub][t], nj, acc[t]);
+          float mx = fmaxf(fmaxf(e[0], e[1]), e[2]);
+#pragma unroll
+          for (int t = 3; t < 15; t += 2) mx = fmaxf(fmaxf(mx, e[t]), e[t + 1]);
+          mx = fmaxf(mx, e[15]);
+          if (col >= n) mx = -1.f;
+          unsigned long long bal = __builtin_amdgcn_ballot_w64(mx >= 0.f);
+          if (bal == 0) continue;
           unsigned pm = 0;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) pm |= (acc[t] >= thr[ub][t] ? 1u : 0u) << t;           // (rows >= m carry +inf)
+          for (int t = 0; t < 16; ++t) pm |= (e[t] >= 0.f ? 1u : 0u) << t;           // (rows >= m: -inf)
           if (col >= n) pm = 0;
-          unsigned long long bal = __builtin_amdgcn_ballot_w64(pm != 0);
+          bal = __builtin_amdgcn_ballot_w64(pm != 0);
           while (bal != 0) {                                                 // wave-uniform; one pass per survivor of the
             const bool act = pm != 0;                                        // lane that has the most (almost always 1)
             const int t = act ? __builtin_ctz(pm) : 0;
             pm &= pm - 1u;
-            float sc = acc[0];
+            float sc = acc[0] + thr[ub][0];
 #pragma unroll
-            for (int k = 1; k < 16; ++k) sc = (t == k) ? acc[k] : sc;       // (registers cannot be indexed by t)
+            for (int k = 1; k < 16; ++k) sc = (t == k) ? acc[k] + thr[ub][k] : sc;       // (registers cannot be indexed by t)
             if (act) {
               const int at = staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
               stage_row[at] = (short)(32 * ub + (t & 3) + 8 * (t >> 2) + 4 * h);
@@ -472,11 +504,11 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   }
 }
 
-// Survivors of filter16_kernel -> the row's exact top-K.  The survivors carry their split-bf16 scores s~ (|s~ - s| <=
-// delta_u); only the few that can still be in the exact top-K are re-scored:
-//   tau~ = K-th largest s~ of the unmasked survivors.  The K survivors above it have s >= tau~ - delta, so the exact K-th
-//   score is >= tau~ - delta, and an exact top-K item has s~ >= s - delta >= tau~ - 2 delta: the candidates of the second
-//   round (K ... a few dozen per user instead of a few hundred -- their item rows are the only ones gathered again).
+// Survivors of filter16_kernel -> the row's exact top-K.  A survivor carries its bf16 score s~ with |s~ - s| <= delta_j =
+// c |u| |i_j| (+ the rounding of handing it on); only the few that can still be in the exact top-K are re-scored:
+//   L_j = s~ - delta_j <= s_j <= U_j = s~ + delta_j;  tau = the K-th largest L_j of the unmasked survivors: K items have
+//   s >= tau, so the exact K-th best is >= tau and an exact top-K item has U_j >= tau -- the candidates of the second round
+//   (K ... a few dozen per user: their item rows are the only ones gathered again).
 // The exact score is the fma chain  acc = fma(u[s], i[s], acc); acc = fma(u[D/2 + s], i[D/2 + s], acc), s = 0 .. D/2 - 1 --
 // BIT-IDENTICAL to what v_mfma_f32_32x32x2_f32 accumulates in gemm_nt_kernel with its operand assignment (measured on
 // gfx950: tools/microbench/mfma_chain.hip, 40 / 40 tiles; every other order, 0 / 40), so ids and scores equal the plain
@@ -487,7 +519,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                            int user_base, const float* __restrict__ I,
                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ cand_id,
                                                            const float* __restrict__ cand_sc, const float* __restrict__ u_norm,
-                                                           const unsigned int* __restrict__ max_item_norm,
+                                                           const float* __restrict__ item_norm,
+                                                           const float* __restrict__ thr, int thr_stride,
                                                            int cap, int k, int bitmap_words,
                                                            const int32_t* __restrict__ r_indptr,
                                                            const int32_t* __restrict__ r_indices,
@@ -497,6 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   float* s_val = reinterpret_cast<float*>(cand_smem);         // approximate scores, then exact ones of the second round
   int* s_idx = reinterpret_cast<int*>(cand_smem) + cap;
   int* s_sel = s_idx + cap;                                    // second-round candidates (positions in s_idx)
+  float* s_dl = reinterpret_cast<float*>(s_sel + cap);         // the survivors' margins: U_j - L_j
   __shared__ float s_u[D];
   __shared__ int s_n, s_m;
   __shared__ float s_tau;
@@ -516,7 +550,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // membership in the user's training row: a bitmap over the catalogue in LDS (bitmap_words > 0: catalogues up to 131 k
   // items) filled from the row with one coalesced pass -- a binary search per candidate is a chain of 6-7 dependent L2
   // round trips, ~10 us of this kernel's 40 per workgroup -- or the binary search for larger catalogues
-  unsigned int* s_bits = reinterpret_cast<unsigned int*>(s_sel + cap);
+  unsigned int* s_bits = reinterpret_cast<unsigned int*>(s_dl + cap);
+  // delta_j = cu |i_j| + slack: cu = c |u|; the slack covers the rounding of s~ = (s~ - T) + T in the filter's hand-off
+  const float cu = kFilterMargin * u_norm[row];
+  const float slack = kFilterAbsSlack * fabsf(thr[(size_t)row * thr_stride]);
   if (bitmap_words > 0) {
     for (int w = threadIdx.x; w < bitmap_words; w += 256) s_bits[w] = 0u;
     __syncthreads();
@@ -549,25 +586,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     base = __builtin_amdgcn_readfirstlane(base);
     if (keep) {
       const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      s_val[at] = cand_sc[(size_t)row * cap + t];
+      const float sc = cand_sc[(size_t)row * cap + t];
+      const float dl = __builtin_fmaf(cu, item_norm[id], __builtin_fmaf(kFilterAbsSlack, fabsf(sc), slack));
+      s_val[at] = sc - dl;                                     // L_j (rounded down by the slack's share)
+      s_dl[at] = 2.0f * dl;                                    // U_j = L_j + 2 delta_j
       s_idx[at] = id;
     }
   }
   __syncthreads();
   const int nv = s_n;
-  // tau~: the approximate score of rank min(K, nv) - 1
+  // tau: the lower bound of rank min(K, nv) - 1 (fewer than K survivors: everything is re-scored)
   for (int t = threadIdx.x; t < nv; t += 256) {
     const float v = s_val[t];
     const int id = s_idx[t];
     int rank = 0;
     for (int j = 0; j < nv; ++j) rank += (s_val[j] > v) || (s_val[j] == v && s_idx[j] < id);
-    if (rank == min(k, nv) - 1) s_tau = v;
+    if (rank == min(k, nv) - 1) s_tau = (nv >= k) ? v : -INFINITY;
   }
   __syncthreads();
-  const float floor2 = s_tau - 2.0f * kFilterMargin * u_norm[row] * __uint_as_float(*max_item_norm);
+  const float tau = s_tau;
   for (int t0 = 0; t0 < nv; t0 += 256) {
     const int t = t0 + threadIdx.x;
-    const bool keep = t < nv && s_val[t] >= floor2;
+    const bool keep = t < nv && s_val[t] + s_dl[t] >= tau;
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
     int base = 0;
     if (lane == 0 && bal) base = atomicAdd(&s_m, __builtin_popcountll(bal));
@@ -916,7 +956,7 @@ static bool filt_split_served(int32_t d) { return d == 64 || d == 128; }
 static int64_t filt_split_bytes(int64_t rows, int64_t n_items, int32_t d) {
   if (!filt_split_served(d)) return 0;
   const int64_t padded = (n_items + 31) / 32 * 32;               // the item images are whole 32-row tiles
-  return 2 * filt_align(padded * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + 256;
+  return 2 * filt_align(padded * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + filt_align(padded * 4);
 }
 
 int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
@@ -945,8 +985,7 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
   // split-bf16 filter (d = 64 / 128): operand images of the whole item table once, of each chunk's query rows per chunk
   const bool split = filt_split_served(d);
   uint16_t *i_hi = nullptr, *i_lo = nullptr, *u_hi = nullptr, *u_lo = nullptr;
-  float* u_norm = nullptr;
-  unsigned int* max_norm = nullptr;
+  float *u_norm = nullptr, *i_norm = nullptr;
   if (split) {
     ws += filt_align(chunk_rows * 4);            // (the chunk layout's counter slot: counts live in d_out_counts)
     const int64_t padded = (n_items + 31) / 32 * 32;
@@ -955,13 +994,14 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     u_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_norm = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * 4);
-    max_norm = reinterpret_cast<unsigned int*>(ws);
-    hipError_t err = hipMemsetAsync(max_norm, 0, sizeof(unsigned int), st);
+    i_norm = reinterpret_cast<float*>(ws);
+    // (the last tile's rows beyond the catalogue: norm 0 -- their scores are never looked at)
+    hipError_t err = padded > n_items ? hipMemsetAsync(i_norm + n_items, 0, sizeof(float) * (size_t)(padded - n_items), st) : hipSuccess;
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
     const int lpr = d / 4, g = 64 / lpr;
     const int blocks = (int)(((n_items + g - 1) / g + 3) / 4);
-    if (d == 64) split_rows_kernel<16, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
-    else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, nullptr, max_norm);
+    if (d == 64) split_rows_kernel<16, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, i_norm, nullptr);
+    else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, i_norm, nullptr);
     SRH_LAUNCH_CHECK();
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute((const void*)filter16_kernel<64, false, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
@@ -990,7 +1030,8 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int tpw = (s_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((s_tiles + tpw - 1) / tpw), (unsigned)gy);
       Filter16Args none{};
-      none.max_item_norm = max_norm;
+      none.u_norm = u_norm;
+      none.item_norm = i_norm;
       if (d == 64) {
         split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
         filter16_kernel<64, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
@@ -1026,21 +1067,21 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int gx = std::max(1, std::min(n_tiles, (512 + gy - 1) / gy));
       const int tiles_per_wg = (n_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
-      Filter16Args f16{s_sc + (k - 1), k, u_norm, max_norm, cnt, cand_id, cand_sc, cap};
+      Filter16Args f16{s_sc + (k - 1), k, u_norm, i_norm, cnt, cand_id, cand_sc, cap};
       if (d == 64) filter16_kernel<64, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       else filter16_kernel<128, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       SRH_LAUNCH_CHECK();
       // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
       // (training-row membership by an LDS bitmap over the catalogue while it fits: <= 16 KB, i.e. 131 k items)
       const int bitmap_words = (d_r_indptr && n_items <= 131072) ? (int)((n_items + 31) / 32) : 0;
-      const size_t rs_lds = (size_t)cap * 12 + (size_t)bitmap_words * 4;
+      const size_t rs_lds = (size_t)cap * 16 + (size_t)bitmap_words * 4;
       if (d == 64)
         rescore_topk_kernel<64><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                             max_norm, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                             i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
                                                              d_out_ids + lo * k, d_out_scores + lo * k);
       else
         rescore_topk_kernel<128><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                              max_norm, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                              i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
                                                               d_out_ids + lo * k, d_out_scores + lo * k);
       SRH_LAUNCH_CHECK();
       continue;
