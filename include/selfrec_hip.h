@@ -434,10 +434,12 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
  *      >= t_u -- a few hundred (item, score) pairs per user, appended to a list of `cap` slots;
  *   3. training items of u are dropped from its list (binary search in the mask CSR) and the rest is
  *      put in exact (score desc, id asc) order.
- *   d = 64 / 128 (round 3): passes 1 and 2 only have to DECIDE, so they run on split-bf16 operands (3 bf16 MFMAs per
- *   16 dimensions, 5.3x the f32 MFMA's rate): |s~ - s| <= delta_u = 4e-5 |u| max|i|, the bound from pass 1's approximate
- *   scores is t~_u - delta_u, pass 2 keeps (id, s~) with s~ >= t~_u - 2 delta_u, and pass 3 re-scores exactly -- by the scalar
- *   fma chain that is bit-identical to the f32 MFMA's accumulation -- the survivors within 2 delta_u of the K-th s~.
+ *   d = 64 / 128: passes 1 and 2 only have to DECIDE, so they run on bf16 operands (one v_mfma_f32_32x32x16_bf16 per 16
+ *   dimensions: 16x the f32 MFMA's rate) against rigorous PER-ITEM error bounds: |s~_uj - s_uj| <= delta_uj = 3.94e-3 |u| |i_j|
+ *   (both operands rounded to bf16).  Pass 1 ranks LOWER bounds s~ - delta of the sample's scores, so t_u is a lower bound of
+ *   the exact K-th best; pass 2 keeps (id, s~) with s~ + delta >= t_u; pass 3 takes tau = the K-th largest s~ - delta of the
+ *   unmasked survivors and re-scores exactly -- by the scalar fma chain that is bit-identical to the f32 MFMA's accumulation --
+ *   the survivors with s~ + delta >= tau.  (Round 3: three split-bf16 products and one margin 4e-5 |u| max_j|i_j| per user.)
  * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
  * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
  * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with

@@ -591,8 +591,8 @@ def test_filtered_ranking_equals_exact_ranking(d):
 
 @pytest.mark.parametrize("d,scale", [(64, 30.0), (64, 1e-3), (128, 5.0)])
 def test_split_bf16_filter_never_loses_a_top_k_item(d, scale):
-    """Round 3: at d = 64 / 128 the filter pass of srh_score_mask_topk_filtered decides on split-bf16 products against a
-    bound lowered by 4e-5 |u| max|i|, and the survivors are re-scored exactly.  Stress for that margin: large and tiny
+    """At d = 64 / 128 the filter pass of srh_score_mask_topk_filtered decides on bf16 products against per-item error
+    bounds (3.94e-3 |u| |i_j|: csrc/eval.hip), and the survivors are re-scored exactly.  Stress for those margins: large and tiny
     magnitudes, a catalogue of near-duplicates (thousands of items within 1e-6 relative of each other, i.e. inside the
     bf16 products' error of the bound), items of very unequal norms -- ids AND scores must still be bit-identical to the
     plain pipeline's on every row that fits."""
