@@ -459,6 +459,7 @@ def eval_throughput(trainer, data, k=20):
     gemm_tflops = 2.0 * q.shape[0] * data.item_num * q.shape[1] * 10 / (a.elapsed_time(b) * 1e-3) / 1e12
     del slab
     return {"users": len(uid), "k": k, "timing": "median of 5 calls", "device_users_per_s": round(len(uid) / t_kernel, 1),
+            "rows_redone_in_reference_heap_order": getattr(rec, "_last_tie_rows", None),
             "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
             "end_to_end_what": "test() + ranking_evaluation(); test() returns a lazy Mapping over the (users x K) arrays",
             "end_to_end_materialised_users_per_s": round(len(out) / t_mat, 1),
@@ -473,8 +474,8 @@ def eval_throughput(trainer, data, k=20):
                                  "(exact-f32 MFMA chain, masks, top-K, ids + scores to the host)",
                          "gemm_alone_tflops": round(gemm_tflops, 2),
                          "gemm_alone_frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                         # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of filter16_kernel (the dominant ranking kernel, 3-term split-bf16
-                         # products): how busy the matrix pipe is, NOT the algorithmic fraction above
+                         # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of filter16_kernel (the ranking's largest kernel; one bf16 product per 16 dimensions since round 4, three before
+                         # -- a third of the MFMAs in about the same time: the pipe is not what bounds it): NOT the algorithmic fraction above
                          "mfma_busy": eval_mfma_busy()[0], "mfma_busy_source": eval_mfma_busy()[1]}}
 
 

@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 24
+#define SRH_ABI_VERSION 25
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -90,6 +90,13 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
 srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out);
 /* random.getrandbits(32) -- lets tests pin how much of the stream was consumed. */
 srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out);
+
+/* find_k_largest(K, candidates) of reference util/algorithm.py:144-156 on the host, with the reference's order among EQUAL
+ * scores: python's heapq on (score, position) tuples restated step for step (heapify, heapreplace on a strictly larger score,
+ * a stable descending sort of the heap array).  The device ranking orders ties (score desc, id asc); base/graph_recommender.py
+ * redoes the rows whose best K + 1 scores hold a tie through this call.  *out_count = min(K, n) entries written. */
+srh_status_t srh_find_k_largest_host(int64_t k, const float* h_candidates, int64_t n, int64_t* h_out_ids,
+                                     float* h_out_scores, int64_t* out_count);
 
 /* `torch.rand(n)` of the CPU generator (ATen: mt19937, one 32-bit word per float32, value = (word & 0xFFFFFF) * 2^-24),
  * replayed on the host from the generator's own words: what model/graph/BUIR.py:118-121 draws per forward pass for its
@@ -456,6 +463,11 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
                                           int64_t sample_items, int32_t cap, int64_t chunk_rows, void* d_ws,
                                           int32_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
                                           void* stream);
+/* (n_query, k1) ranked ids / scores (k1 = K + 1) -> their first K columns; a row in which two NEIGHBOURS of the K + 1 scores are
+ * EQUAL is marked d_out_ids[row][0] = -1 - id: its order among the equal scores is the reference's heap walk's
+ * (util/algorithm.py:144-156), which the caller restores on the host (srh_find_k_largest_host). */
+srh_status_t srh_topk_trim_mark_ties(const int32_t* d_ids, const float* d_scores, int64_t n_query, int32_t k1,
+                                     int32_t* d_out_ids, float* d_out_scores, void* stream);
 /* The scoring GEMM alone: C (m, n) = A (m, d) B (n, d)^T, fp32 MFMA. */
 srh_status_t srh_gemm_nt_f32(const float* d_a, const float* d_b, float* d_c, int64_t m,
                              int64_t n, int32_t d, void* stream);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -96,6 +96,8 @@ SIGNATURES = {
     "srh_abi_version": (_i32, []),
     "srh_last_error_string": (C.c_char_p, []),
     "srh_device_count": (_i32, []),
+    "srh_topk_trim_mark_ties": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "srh_find_k_largest_host": (_i32, [_i64, _vp, _i64, _vp, _vp, _vp]),
     "srh_sampler_create": (_i32, [C.POINTER(_vp), _i64, _i64, _i64, _vp, _vp]),
     "srh_sampler_destroy": (None, [_vp]),
     "srh_sampler_set_state": (_i32, [_vp, _vp, _i32]),

@@ -122,6 +122,40 @@ class GraphRecommender(Recommender):
             ids[redo], sc[redo] = ids_r, sc_r
         return ids, sc
 
+    def _rank_marking_ties(self, ue, uid, ie, g, k):
+        """ids, scores (device, k columns); a row whose best K + 1 scores hold two EQUAL neighbours carries ids[row, 0] =
+        -1 - id (``marked`` False: the kernels have no spare column to rank -- K + 1 > 128 or > the catalogue).
+
+        The device kernels order (score desc, id asc); the reference's ``find_k_largest`` (util/algorithm.py:144-156)
+        walks a size-K min-heap, and which of several equal scores it keeps, and in what order, is a property of that walk.
+        Equal scores among a user's best are not exotic: 20 neighbouring pairs x 31,504 users of scores a few hundred
+        thousand ulps apart tie once or twice per ranking at the Yelp2018 shape (and every row of a degenerate table does).
+        So the device ranks K + 1 -- an equality anywhere else cannot touch the first K places -- marks those rows in the
+        same launch that drops the spare column, and only they are redone the reference's way (``_heap_order_rows``).
+        Cost when nothing ties: one more ranked column and one small launch; no synchronisation of its own."""
+        if k + 1 > min(128, int(ie.shape[0])):
+            ids, sc = self._rank(ue, uid, ie, g, k)
+            return ids, sc, False
+        ids, sc = ops.topk_trim_mark_ties(*self._rank(ue, uid, ie, g, k + 1))
+        return ids, sc, True
+
+    def _heap_order_rows(self, rows, ue, uid_host, ie, g, k, chunk=256):
+        """ids (int32), scores (float32) numpy (len(rows), k) of the given query rows in the reference's heap order: their
+        score rows by the ranking's own fma chain (srh_gemm_nt_f32), the training items at -10e8
+        (graph_recommender.py:49-50), python's heapq walk restated in C++ (srh_find_k_largest_host, pinned to the
+        reference's outputs by tests/golden)."""
+        out_ids = np.empty((len(rows), k), dtype=np.int32)
+        out_sc = np.empty((len(rows), k), dtype=np.float32)
+        users = np.asarray(uid_host)[rows].astype(np.int64)
+        for lo in range(0, len(rows), chunk):
+            u = users[lo:lo + chunk]
+            scores = ops.gemm_nt(ue[torch.from_numpy(u).to(ue.device)].contiguous(), ie).cpu().numpy()
+            for j, uu in enumerate(u.tolist()):
+                cand = scores[j]
+                cand[g.h_r_indices[g.h_r_indptr[uu]:g.h_r_indptr[uu + 1]]] = -10e8
+                out_ids[lo + j], out_sc[lo + j] = ops.find_k_largest_host(k, cand)
+        return out_ids, out_sc
+
     @staticmethod
     def _filter_chunk_rows(device):
         """Users per chunk of the filtered ranking: FILTER_CHUNK_ROWS, halved while the chunk's workspace -- chunk x (sample +
@@ -144,8 +178,15 @@ class GraphRecommender(Recommender):
         ue, ie = self._device_embeddings()
         g = self.data.device_graph(ie.device)
         uid = self._device_user_ids(user_ids, ie.device)
-        ids_dev, sc_dev = self._rank(ue, uid, ie, g, k)
+        ids_dev, sc_dev, marked = self._rank_marking_ties(ue, uid, ie, g, k)
         if with_hits:
+            if marked:                                           # (the flags below are taken from the ids: settle ties first)
+                rows = torch.nonzero(ids_dev[:, 0] < 0).flatten()
+                self._last_tie_rows = int(rows.numel())
+                if rows.numel():
+                    ids_fix, sc_fix = self._heap_order_rows(rows.cpu().numpy(), ue, user_ids, ie, g, k)
+                    ids_dev[rows] = torch.from_numpy(ids_fix).to(ids_dev.device)
+                    sc_dev[rows] = torch.from_numpy(sc_fix).to(sc_dev.device)
             t_indptr, t_indices, _ = self._test_csr(ie.device)
             flags = ops.topk_hit_flags(ids_dev, uid, t_indptr, t_indices)
             if metric_cuts:
@@ -154,7 +195,13 @@ class GraphRecommender(Recommender):
                 got = _to_host(ids_dev, sc_dev, flags, *[t for c in range(len(metric_cuts)) for t in (hits[c], ndcg[c])])
                 return (got[0], got[1], got[2], {int(n): (got[3 + 2 * c], got[4 + 2 * c]) for c, n in enumerate(metric_cuts)})
             return _to_host(ids_dev, sc_dev, flags)
-        return _to_host(ids_dev, sc_dev)
+        ids, sc = _to_host(ids_dev, sc_dev)
+        if marked:
+            rows = np.flatnonzero(ids[:, 0] < 0)                 # (the marks ride in the ids: no extra copy, no extra sync)
+            self._last_tie_rows = int(rows.size)
+            if rows.size:
+                ids[rows], sc[rows] = self._heap_order_rows(rows, ue, user_ids, ie, g, k)
+        return ids, sc
 
     def _device_user_ids(self, user_ids, device):
         """The int32 ids on the device; test() passes the SAME cached array every epoch, so the upload happens once."""

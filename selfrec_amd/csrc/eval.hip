@@ -841,6 +841,29 @@ srh_status_t gemm_dispatch(const float* a, const int32_t* a_rows, const float* b
 // (f-3) hit flags for the metric tail: flag[q][r] = 1 iff ranked id ids[q][r] is a test item of the
 // query's user (binary search in that user's sorted test row) -- what Metric.hits / Metric.NDCG
 // (reference util/evaluation.py:7-16,66-78) find by python set membership.
+// (rows, k + 1) ranked ids / scores -> their first k columns, with a mark on the rows in which two NEIGHBOURS of the k + 1
+// scores are equal: ids_out[row][0] = -1 - id.  Such a row's order is the reference's heap walk's, not (score, id)'s
+// (util/algorithm.py:144-156): the caller redoes it on the host.  One thread per row.
+__global__ __launch_bounds__(256) void trim_mark_ties_kernel(const int32_t* __restrict__ ids, const float* __restrict__ sc,
+                                                             int64_t rows, int k1, int32_t* __restrict__ ids_out,
+                                                             float* __restrict__ sc_out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int k = k1 - 1;
+  bool tie = false;
+  float prev = sc[r * k1];
+  for (int c = 1; c < k1; ++c) {
+    const float v = sc[r * k1 + c];
+    tie |= (v == prev);
+    prev = v;
+  }
+  for (int c = 0; c < k; ++c) {
+    ids_out[r * k + c] = ids[r * k1 + c];
+    sc_out[r * k + c] = sc[r * k1 + c];
+  }
+  if (tie) ids_out[r * k] = -1 - ids_out[r * k];
+}
+
 __global__ __launch_bounds__(256) void hit_flags_kernel(const int32_t* __restrict__ ids, int64_t total, int k,
                                                         const int32_t* __restrict__ user_ids,
                                                         const int32_t* __restrict__ t_indptr,
@@ -1105,6 +1128,16 @@ srh_status_t srh_topk_hit_flags(const int32_t* d_ids, int64_t n_query, int32_t k
   const int64_t total = n_query * k;
   hit_flags_kernel<<<(unsigned)((total + 255) / 256), 256, 0, srh::as_stream(stream)>>>(d_ids, total, k, d_user_ids,
                                                                                          d_t_indptr, d_t_indices, d_flags);
+  SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+srh_status_t srh_topk_trim_mark_ties(const int32_t* d_ids, const float* d_scores, int64_t n_query, int32_t k1,
+                                     int32_t* d_out_ids, float* d_out_scores, void* stream) {
+  SRH_REQUIRE(d_ids && d_scores && d_out_ids && d_out_scores, "topk_trim_mark_ties: null argument");
+  SRH_REQUIRE(n_query > 0 && k1 >= 2, "topk_trim_mark_ties: bad shape");
+  trim_mark_ties_kernel<<<(unsigned)((n_query + 255) / 256), 256, 0, srh::as_stream(stream)>>>(d_ids, d_scores, n_query, k1,
+                                                                                               d_out_ids, d_out_scores);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }

@@ -374,6 +374,76 @@ srh_status_t srh_sampler_next_u32(srh_sampler_t* s, uint32_t* out) {
   return SRH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// find_k_largest (reference util/algorithm.py:144-156) on the host, tie order included.  The reference keeps a min-heap of
+// (score, position) pairs -- python's heapq on tuples -- seeded with the first K candidates, replaces the root whenever a
+// later score is STRICTLY larger, and finally sorts the heap by score, descending and stable.  Which of several equal scores
+// survive, and in what order they come out, is therefore a property of heapq's sift routines; they are restated here step
+// for step (CPython Lib/heapq.py: heapify, _siftup, _siftdown, heapreplace), so that the few rows of a ranking whose best
+// scores tie come out as the reference's would without walking 38 k python floats (6 ms per row).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct HeapItem {
+  float score;
+  int64_t pos;
+};
+inline bool heap_less(const HeapItem& a, const HeapItem& b) {          // tuple comparison: score, then position
+  return a.score < b.score || (a.score == b.score && a.pos < b.pos);
+}
+void heap_siftdown(HeapItem* heap, int64_t startpos, int64_t pos) {
+  const HeapItem item = heap[pos];
+  while (pos > startpos) {
+    const int64_t parent = (pos - 1) >> 1;
+    if (!heap_less(item, heap[parent])) break;
+    heap[pos] = heap[parent];
+    pos = parent;
+  }
+  heap[pos] = item;
+}
+void heap_siftup(HeapItem* heap, int64_t n, int64_t pos) {
+  const int64_t startpos = pos;
+  const HeapItem item = heap[pos];
+  int64_t child = 2 * pos + 1;
+  while (child < n) {                                                   // bubble the smaller child up until a leaf ...
+    const int64_t right = child + 1;
+    if (right < n && !heap_less(heap[child], heap[right])) child = right;
+    heap[pos] = heap[child];
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  heap[pos] = item;                                                     // ... then sift the item down from there
+  heap_siftdown(heap, startpos, pos);
+}
+}  // namespace
+
+srh_status_t srh_find_k_largest_host(int64_t k, const float* h_candidates, int64_t n, int64_t* h_out_ids, float* h_out_scores,
+                                     int64_t* out_count) {
+  SRH_REQUIRE(h_candidates && h_out_ids && h_out_scores && out_count, "find_k_largest_host: null argument");
+  SRH_REQUIRE(k >= 1 && n >= 0, "find_k_largest_host: bad K or length");
+  const int64_t m = std::min(k, n);                                     // (candidates[:K] of a shorter list: all of it)
+  std::vector<HeapItem> heap((size_t)m);
+  for (int64_t i = 0; i < m; ++i) heap[(size_t)i] = {h_candidates[i], i};
+  for (int64_t i = m / 2 - 1; i >= 0; --i) heap_siftup(heap.data(), m, i);            // heapq.heapify
+  HeapItem* hp = heap.data();
+  float root = m > 0 ? hp[0].score : 0.f;
+  for (int64_t i = k; i < n; ++i) {
+    const float c = h_candidates[i];
+    if (c > root) {                                                     // heapq.heapreplace
+      hp[0] = {c, i};
+      heap_siftup(hp, m, 0);
+      root = hp[0].score;
+    }
+  }
+  // heap.sort(key=score, reverse=True): stable, equal scores keep their order in the heap array
+  std::stable_sort(heap.begin(), heap.end(), [](const HeapItem& a, const HeapItem& b) { return a.score > b.score; });
+  for (int64_t i = 0; i < m; ++i) {
+    h_out_ids[i] = heap[(size_t)i].pos;
+    h_out_scores[i] = heap[(size_t)i].score;
+  }
+  *out_count = m;
+  return SRH_OK;
+}
+
 srh_status_t srh_mt19937_uniform_f32(uint32_t* h_mt624, int32_t* pos, int64_t n, float* h_out,
                                      float keep_addend, uint8_t* h_keep) {
   SRH_REQUIRE(h_mt624 && pos, "mt19937_uniform_f32: null state");

@@ -48,6 +48,20 @@ def _np(a, dtype):
     return a, a.ctypes.data_as(C.c_void_p)
 
 
+def find_k_largest_host(k: int, candidates) -> tuple[np.ndarray, np.ndarray]:
+    """ids (int64), scores (float32) of reference util/algorithm.py:144-156 ``find_k_largest`` -- the heap's own order among
+    equal scores -- for a float32 vector on the host (srh_find_k_largest_host: python's heapq restated in C++)."""
+    cand = np.ascontiguousarray(candidates, dtype=np.float32)
+    m = min(int(k), int(cand.size))
+    ids, sc = np.empty(m, dtype=np.int64), np.empty(m, dtype=np.float32)
+    n_out = C.c_int64()
+    check(_lib.load().srh_find_k_largest_host(int(k), cand.ctypes.data_as(C.c_void_p), int(cand.size),
+                                              ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(n_out)),
+          "srh_find_k_largest_host")
+    assert n_out.value == m
+    return ids, sc
+
+
 # ----------------------------------------------------------------------------------------
 # (a-1) sampler
 # ----------------------------------------------------------------------------------------
@@ -698,6 +712,17 @@ def score_mask_topk_filtered(user_emb, user_ids, item_emb, r_indptr, r_indices, 
                                            _p(ws), _p(ids, torch.int32), _p(sc, torch.float32),
                                            _p(counts, torch.int32), _stream()), "srh_score_mask_topk_filtered")
     return ids, sc, counts, ws
+
+
+def topk_trim_mark_ties(ids_k1, scores_k1):
+    """(rows, K + 1) ranked ids / scores -> (rows, K) with rows holding a tie among their K + 1 scores marked ids[:, 0] < 0
+    (= -1 - id): one launch (srh_topk_trim_mark_ties)."""
+    rows, k1 = int(ids_k1.shape[0]), int(ids_k1.shape[1])
+    ids = torch.empty((rows, k1 - 1), dtype=torch.int32, device=ids_k1.device)
+    sc = torch.empty((rows, k1 - 1), dtype=torch.float32, device=ids_k1.device)
+    check(_lib.load().srh_topk_trim_mark_ties(_p(ids_k1, torch.int32), _p(scores_k1, torch.float32), rows, k1,
+                                              _p(ids, torch.int32), _p(sc, torch.float32), _stream()), "srh_topk_trim_mark_ties")
+    return ids, sc
 
 
 def gemm_nt(a, b, out=None):

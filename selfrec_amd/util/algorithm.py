@@ -32,6 +32,10 @@ def find_k_largest(K, candidates):
     order = np.argsort(-vals, kind='stable')
     top = vals[order]
     if np.any(top[1:] == top[:-1]):          # a tie among the K+1 best: order is heap-specific
+        if cand.dtype == np.float32:         # (the same walk in C++: 36 us instead of 3 ms per 38 k candidates)
+            from .. import ops
+            ids, sc = ops.find_k_largest_host(K, cand)
+            return ids.tolist(), sc.astype(float).tolist()
         return _heap_walk(K, cand)
     sel = part[order[:K]]
     return sel.tolist(), cand[sel].astype(float).tolist()

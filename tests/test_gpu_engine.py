@@ -125,6 +125,77 @@ def test_engine_backed_model_class_ranks_like_reference(golden_models, golden_me
     assert np.allclose(model.predict(u)[model.data.item[rec[u][0][0]]], rec[u][0][1], rtol=1e-5)
 
 
+def _bare_recommender(data, user_emb, item_emb, max_n):
+    from selfrec_amd.base import graph_recommender as gr
+    rec = gr.GraphRecommender.__new__(gr.GraphRecommender)
+    rec.data, rec.max_N, rec.topN = data, max_n, [max_n]
+    rec.user_emb, rec.item_emb = user_emb.cuda(), item_emb.cuda()
+    return rec
+
+
+def test_device_ranking_orders_ties_like_the_reference_heap(golden_ops):
+    """reference util/algorithm.py:144-156 keeps a size-K min-heap: WHICH of several equal scores stay, and in what order,
+    is a property of that walk (tests/golden: candidates with three 0.9s, three 0.5s and a masked entry -> ids
+    [2, 10, 5, 8, 7], not the lowest-id order [2, 5, 10, 8, 0]).  rank_on_device ranks K + 1 on the device, flags rows with
+    equal neighbours and redoes exactly those the reference's way."""
+    g = golden_ops
+    cand = g["topk_ties_in"]
+    n = len(cand)
+    masked = int(np.argmin(cand))                                       # the entry the golden holds at -10e8
+    # items named by their column, appearing in column order; user "q" rated only the masked item
+    train = [["p" if j != masked else "q", str(j), 1.0] for j in range(n)]
+    data = Interaction({}, train, [["q", "0", 1.0]])
+    assert [data.item[str(j)] for j in range(n)] == list(range(n))
+    d = 64
+    ue = torch.zeros(data.user_num, d); ue[:, 0] = 1.0
+    ie = torch.zeros(n, d); ie[:, 0] = torch.from_numpy(np.where(cand < -1e8, 2.0, cand).astype(np.float32))
+    rec = _bare_recommender(data, ue, ie, 5)
+    ids, sc = rec.rank_on_device(np.asarray([data.user["q"]], dtype=np.int32))
+    assert ids[0].tolist() == g["topk_ties_ids"].tolist()
+    assert np.array_equal(sc[0], g["topk_ties_scores"])
+    # the other user rated everything but the masked item: only that one is left, then masked entries at -10e8 in heap order
+    from selfrec_amd.util.algorithm import find_k_largest
+    ids_p, sc_p = rec.rank_on_device(np.asarray([data.user["p"]], dtype=np.int32))
+    c2 = np.full(n, -10e8, dtype=np.float32); c2[masked] = 2.0
+    want_ids, want_sc = find_k_largest(5, c2)
+    assert ids_p[0].tolist() == want_ids and np.array_equal(sc_p[0], np.asarray(want_sc, dtype=np.float32))
+
+
+def test_filtered_ranking_orders_planted_ties_like_the_reference_heap():
+    """The same through the filtered pipeline (catalogue >= 4 x the bound slice): duplicate item rows planted among some
+    users' best -- some straddling the K-th place -- against util.algorithm.find_k_largest (pinned to the reference's
+    outputs by the goldens) on the ranking's own scores; rows without ties are untouched."""
+    from selfrec_amd.util.algorithm import find_k_largest
+    rng = np.random.default_rng(12)
+    U, I, K, d = 300, 20000, 20, 64
+    tu, ti = synth.generate_edges(U, I, 60000, 5)
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    U, I = data.user_num, data.item_num
+    assert I >= 4 * 4096
+    ue = (rng.standard_normal((U, d)) * 0.3).astype(np.float32)
+    ie = (rng.standard_normal((I, d)) * 0.3).astype(np.float32)
+    tied_users = [3, 77, 150]
+    for n_dup, u in zip((2, 5, 30), tied_users):                        # 30 > K: the tie straddles the K-th place
+        dup = rng.choice(I, size=n_dup, replace=False)
+        ie[dup] = ue[u] * 3.0                                            # equal rows, far above everything else for user u
+    rec = _bare_recommender(data, torch.from_numpy(ue), torch.from_numpy(ie), K)
+    users = np.arange(U, dtype=np.int32)
+    ids, sc = rec.rank_on_device(users)
+    g = data.device_graph(torch.device("cuda"))
+    scores = ops.gemm_nt(rec.user_emb, rec.item_emb).cpu().numpy()
+    indptr, indices = g.r_indptr.cpu().numpy(), g.r_indices.cpu().numpy()
+    n_heap = 0
+    for u in range(U):
+        c = scores[u].copy()
+        c[indices[indptr[u]:indptr[u + 1]]] = -10e8
+        want_ids, want_sc = find_k_largest(K, c)
+        assert ids[u].tolist() == want_ids, u
+        assert np.array_equal(sc[u], np.asarray(want_sc, dtype=np.float32))
+        top = np.sort(c)[::-1][:K + 1]
+        n_heap += bool((top[1:] == top[:-1]).any())
+    assert n_heap >= len(tied_users)
+
+
 @pytest.mark.parametrize("name", ["XSimGCL", "SGL", "LightGCN"])
 def test_hipgraph_replay_equals_eager(golden_models, golden_meta, tiny_data, name):
     """Same RNG stream, same batches: a captured step replayed == the eager launch sequence."""

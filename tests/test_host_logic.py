@@ -43,6 +43,23 @@ def test_drop_in_generator_is_bit_exact(golden_ops):
     assert np.array_equal([data.user[t[0]] for t in data.training_data], g["sampler_a_final_order_u"])
 
 
+def test_native_heap_walk_is_pythons_heapq(golden_ops):
+    """srh_find_k_largest_host restates CPython's heapq (heapify, heapreplace, the stable descending sort) step for step:
+    the reference's golden, and tie-heavy random vectors against the literal python walk -- ids in the same ORDER."""
+    from selfrec_amd import ops
+    g = golden_ops
+    ids, sc = ops.find_k_largest_host(5, g["topk_ties_in"])
+    assert ids.tolist() == g["topk_ties_ids"].tolist() and np.array_equal(sc, g["topk_ties_scores"])
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        n, k = int(rng.integers(1, 400)), int(rng.integers(1, 50))
+        c = (rng.integers(0, 6, n) * 0.25).astype(np.float32)            # six distinct values: ties everywhere
+        if trial % 4 == 0:
+            c[rng.integers(0, n, 3)] = -10e8                                # masked entries
+        got, want = ops.find_k_largest_host(k, c), algorithm._heap_walk(k, c)
+        assert got[0].tolist() == want[0] and np.array_equal(got[1], np.asarray(want[1], dtype=np.float32)), (trial, n, k)
+
+
 def test_find_k_largest_equals_reference_heap(golden_ops):
     g = golden_ops
     ids, sc = algorithm.find_k_largest(5, g["topk_ties_in"])

@@ -79,7 +79,7 @@ determinism)
 nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
 testseval)
-  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider -k "rank or filter or topk or score or eval or metric" > $OUT/tests_eval.log 2>&1; echo "testseval exit $?"
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider -k "rank or filter or topk or score or eval or metric or ties or heap" > $OUT/tests_eval.log 2>&1; echo "testseval exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_eval.log | head -40;;
 hostprobeold)
   PROBE_PKG_ROOT=$PWD/_refstage/old_pkg timeout 300 python tools/oplevel_host_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/oplevel_host_probe_before.txt; echo "hostprobeold exit $?"; cat $OUT/oplevel_host_probe_before.txt;;
