@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                            int cap, int k, int bitmap_words,
                                                            const int32_t* __restrict__ r_indptr,
                                                            const int32_t* __restrict__ r_indices,
-                                                           int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+                                                           int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                           int skip_upto) {
   constexpr int DH = D / 2;
   extern __shared__ unsigned char cand_smem[];
   float* s_val = reinterpret_cast<float*>(cand_smem);         // approximate scores, then exact ones of the second round
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   __shared__ float s_tau;
   const int row = blockIdx.x;
   const int c = cnt[row];
-  if (c > cap) return;
+  if (c > cap || c <= skip_upto) return;                       // (short lists: rescore_wave_kernel has ranked them)
   if (threadIdx.x == 0) { s_n = 0; s_m = 0; s_tau = -INFINITY; }
   const int u = user_ids ? user_ids[row] : user_base + row;          // the user's id: mask CSR row
   const int urow = user_ids ? u : row;
@@ -633,6 +634,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
   __syncthreads();
   for (int e = threadIdx.x; e < ns; e += 256) {
+    const int t = s_sel[e];
+    const float v = s_val[t];
+    const int id = s_idx[t];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j) {
+      const int tj = s_sel[j];
+      rank += (s_val[tj] > v) || (s_val[tj] == v && s_idx[tj] < id);
+    }
+    if (rank < k) {
+      out_ids[(size_t)row * k + rank] = id;
+      out_scores[(size_t)row * k + rank] = v;
+    }
+  }
+}
+
+// The same re-score with ONE WAVE per row, for the rows whose list is short (<= CW survivors: all but a few per cent).
+// rescore_topk_kernel spends a 256-thread workgroup, seven barriers and a catalogue-wide bitmap on ~60 survivors: its
+// 20 us per row are a chain of dependent round trips with seven rows in flight per CU.  Here a row is a wave: no barrier
+// (a wave's LDS operations complete in order), the counters of the compactions are wave-uniform registers, membership in
+// the user's training row is a binary search in an LDS copy of that row (rows longer than TRW: in global memory), and
+// 24 rows are in flight per CU.  Same arithmetic, same order of the exact fma chain, same (score desc, id asc) ranking.
+template <int D, int CW>
+__global__ __launch_bounds__(256) void rescore_wave_kernel(const float* __restrict__ U, const int32_t* __restrict__ user_ids, int user_base,
+                                                           const float* __restrict__ I, int rows, const int32_t* __restrict__ cnt,
+                                                           const int32_t* __restrict__ cand_id, const float* __restrict__ cand_sc,
+                                                           const float* __restrict__ u_norm, const float* __restrict__ item_norm,
+                                                           const float* __restrict__ thr, int thr_stride, int cap, int k,
+                                                           const int32_t* __restrict__ r_indptr, const int32_t* __restrict__ r_indices,
+                                                           int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+  constexpr int DH = D / 2, TRW = 512;
+  __shared__ float s_val_[4][CW];
+  __shared__ float s_dl_[4][CW];
+  __shared__ int s_idx_[4][CW];
+  __shared__ short s_sel_[4][CW];
+  __shared__ int s_tr_[4][TRW];
+  __shared__ float s_u_[4][D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const int c = cnt[row];
+  if (c > CW) return;                                             // (long or overflowed lists: rescore_topk_kernel)
+  float* s_val = s_val_[w];
+  float* s_dl = s_dl_[w];
+  int* s_idx = s_idx_[w];
+  short* s_sel = s_sel_[w];
+  int* s_tr = s_tr_[w];
+  float* s_u = s_u_[w];
+  const int u = user_ids ? user_ids[row] : user_base + row;
+  const int urow = user_ids ? u : row;
+  for (int q = lane; q < D; q += 64) s_u[q] = U[(size_t)urow * D + q];
+  const int rs = r_indptr ? r_indptr[u] : 0, re = r_indptr ? r_indptr[u + 1] : 0;
+  const int ntr = re - rs;
+  const bool cached = ntr <= TRW;
+  if (cached) for (int p = lane; p < ntr; p += 64) s_tr[p] = r_indices[rs + p];
+  const float cu = kFilterMargin * u_norm[row];
+  const float slack = kFilterAbsSlack * fabsf(thr[(size_t)row * thr_stride]);
+  __builtin_amdgcn_wave_barrier();
+  // 1. the unmasked survivors with their bounds: L_j in s_val, U_j - L_j in s_dl
+  int nv = 0;                                                     // wave-uniform
+  for (int t0 = 0; t0 < c; t0 += 64) {
+    const int t = t0 + lane;
+    bool keep = t < c;
+    int id = 0;
+    if (keep) {
+      id = cand_id[(size_t)row * cap + t];
+      int lo = 0, hi = ntr;
+      if (cached) {
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_tr[mid] < id) lo = mid + 1; else hi = mid;
+        }
+        keep = !(lo < ntr && s_tr[lo] == id);
+      } else {
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (r_indices[rs + mid] < id) lo = mid + 1; else hi = mid;
+        }
+        keep = !(lo < ntr && r_indices[rs + lo] == id);
+      }
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    if (keep) {
+      const int at = nv + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      const float sc = cand_sc[(size_t)row * cap + t];
+      const float dl = __builtin_fmaf(cu, item_norm[id], __builtin_fmaf(kFilterAbsSlack, fabsf(sc), slack));
+      s_val[at] = sc - dl;
+      s_dl[at] = 2.0f * dl;
+      s_idx[at] = id;
+    }
+    nv += __builtin_popcountll(bal);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // 2. tau: the lower bound of rank min(K, nv) - 1 (fewer than K survivors: everything is re-scored)
+  float tau = -INFINITY;
+  if (nv >= k) {
+    for (int t0 = 0; t0 < nv; t0 += 64) {
+      const int t = t0 + lane;
+      bool hit = false;
+      float v = 0.f;
+      if (t < nv) {
+        v = s_val[t];
+        const int id = s_idx[t];
+        int rank = 0;
+        for (int j = 0; j < nv; ++j) rank += (s_val[j] > v) || (s_val[j] == v && s_idx[j] < id);
+        hit = rank == k - 1;
+      }
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+      if (bal) tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)__builtin_ctzll(bal)));
+    }
+  }
+  // 3. the candidates of the second round: U_j >= tau
+  int ns = 0;                                                     // wave-uniform
+  for (int t0 = 0; t0 < nv; t0 += 64) {
+    const int t = t0 + lane;
+    const bool keep = t < nv && s_val[t] + s_dl[t] >= tau;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    if (keep) s_sel[ns + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = (short)t;
+    ns += __builtin_popcountll(bal);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // 4. their exact scores, in place: a lane per candidate, the fma chain of gemm_nt_kernel's MFMA in its order
+  for (int e = lane; e < ns; e += 64) {
+    const int t = s_sel[e];
+    const float4* ip = reinterpret_cast<const float4*>(I + (size_t)s_idx[t] * D);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < DH / 4; ++q) {
+      const float4 x0 = ip[q], x1 = ip[DH / 4 + q];
+      acc = __builtin_fmaf(s_u[4 * q + 0], x0.x, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 0], x1.x, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 1], x0.y, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 1], x1.y, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 2], x0.z, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 2], x1.z, acc);
+      acc = __builtin_fmaf(s_u[4 * q + 3], x0.w, acc); acc = __builtin_fmaf(s_u[DH + 4 * q + 3], x1.w, acc);
+    }
+    s_val[t] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // 5. (score desc, id asc) among them
+  for (int e = lane; e < ns; e += 64) {
     const int t = s_sel[e];
     const float v = s_val[t];
     const int id = s_idx[t];
@@ -1098,14 +1237,24 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       // (training-row membership by an LDS bitmap over the catalogue while it fits: <= 16 KB, i.e. 131 k items)
       const int bitmap_words = (d_r_indptr && n_items <= 131072) ? (int)((n_items + 31) / 32) : 0;
       const size_t rs_lds = (size_t)cap * 16 + (size_t)bitmap_words * 4;
-      if (d == 64)
+      // short lists (all but a few per cent of the rows) by a wave each, the rest by a workgroup each
+      constexpr int kWaveRows = 128;               // (longer lists: the O(n^2) rank counts want the 256 threads of the workgroup form)
+      const int wg = (int)((m + 3) / 4);
+      if (d == 64) {
+        rescore_wave_kernel<64, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, i_norm,
+                                                               s_sc + (k - 1), k, cap, k, d_r_indptr, d_r_indices,
+                                                               d_out_ids + lo * k, d_out_scores + lo * k);
         rescore_topk_kernel<64><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
                                                              i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
-                                                             d_out_ids + lo * k, d_out_scores + lo * k);
-      else
+                                                             d_out_ids + lo * k, d_out_scores + lo * k, kWaveRows);
+      } else {
+        rescore_wave_kernel<128, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, i_norm,
+                                                                s_sc + (k - 1), k, cap, k, d_r_indptr, d_r_indices,
+                                                                d_out_ids + lo * k, d_out_scores + lo * k);
         rescore_topk_kernel<128><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
                                                               i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
-                                                              d_out_ids + lo * k, d_out_scores + lo * k);
+                                                              d_out_ids + lo * k, d_out_scores + lo * k, kWaveRows);
+      }
       SRH_LAUNCH_CHECK();
       continue;
     }
