@@ -812,11 +812,26 @@ __device__ __forceinline__ float wave_max_f(float v) {
                fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }
 
-__global__ __launch_bounds__(256) void bound_rows_kernel(const float* __restrict__ scores, int rows, int n, int k,
-                                                         float* __restrict__ out, int out_stride) {
+// mask_indptr != NULL: the row's wave first writes -10e8 over the user's training items in the slice (mask_kernel's job:
+// graph_recommender.py:49-50) -- one launch and one pass over the masks less per chunk; the wave reads its own stores back
+// after they have left it (s_waitcnt vmcnt(0): the vector L1 is write-through and holds none of these lines yet).
+__global__ __launch_bounds__(256) void bound_rows_kernel(float* __restrict__ scores, int rows, int n, int k,
+                                                         float* __restrict__ out, int out_stride,
+                                                         const int32_t* __restrict__ user_ids, int user_base,
+                                                         const int32_t* __restrict__ mask_indptr,
+                                                         const int32_t* __restrict__ mask_indices) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (mask_indptr) {
+    const int u = user_ids ? user_ids[row] : user_base + row;
+    const int ms = mask_indptr[u], me = mask_indptr[u + 1];
+    for (int p = ms + lane; p < me; p += 64) {
+      const int item = mask_indices[p];
+      if (item < n) scores[(size_t)row * n + item] = -10e8f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   const float* x = scores + (size_t)row * n;
   const int n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -1206,13 +1221,15 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       rc = gemm_dispatch(emb, ids, d_item_emb, slab, m, sample_items, d, st);
       if (rc) return rc;
     }
-    if (d_r_indptr) {
+    if (d_r_indptr && !split) {
       mask_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(ids, (int)m, d_r_indptr, d_r_indices, slab, (int)sample_items, (int)lo);
       SRH_LAUNCH_CHECK();
     }
     if (split) {
-      // (the split path needs the bound only, not the sample's ranked list: one pass, one wave per row)
-      bound_rows_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(slab, (int)m, (int)sample_items, k, s_sc + (k - 1), k);
+      // (the split path needs the bound only, not the sample's ranked list: one pass, one wave per row, the row's masks
+      // applied by the same wave)
+      bound_rows_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(slab, (int)m, (int)sample_items, k, s_sc + (k - 1), k, ids, (int)lo,
+                                                            d_r_indptr, d_r_indices);
       SRH_LAUNCH_CHECK();
     } else {
       rc = srh_topk_rows(slab, m, sample_items, k, s_ids, s_sc, stream);
