@@ -447,13 +447,17 @@ srh_status_t srh_score_mask_topk(const float* d_user_emb, const int32_t* d_user_
  *   the exact K-th best; pass 2 keeps (id, s~) with s~ + delta >= t_u; pass 3 takes tau = the K-th largest s~ - delta of the
  *   unmasked survivors and re-scores exactly -- by the scalar fma chain that is bit-identical to the f32 MFMA's accumulation --
  *   the survivors with s~ + delta >= tau.  (Round 3: three split-bf16 products and one margin 4e-5 |u| max_j|i_j| per user.)
+ *   In this path the bound slice of pass 1 is the `sample_items` items of LARGEST NORM, not the first ones: the item image is
+ *   built in norm order (norms, one radix sort of (norm, id) pairs, the permutation and its inverse), a user's best scores sit
+ *   on the items training has pushed outwards, and the K-th best over such a slice is a far tighter bound: 39 instead of 60
+ *   survivors per user on trained tables (tools/sample_choice_probe.py).
  * Scores come from the same fma chain, so ids and scores are identical to srh_score_mask_topk.
  * d_out_counts[q] = number of survivors of row q, training items included: when it exceeds `cap`
  * (tie-heavy rows, users with thousands of training items) that row of the outputs is NOT valid and the caller ranks it with
  * srh_score_mask_topk.  d_ws: srh_score_mask_topk_filtered_ws_bytes(chunk_rows, ...) bytes.
  * Shape constants measured on the Yelp2018 shape (profiles/r03_m_*): chunk_rows 16384 (larger chunks fill the chip: 4096 ->
- * 16384 users per chunk is +20 %), sample_items 4096 (within 7 % of the best for trained tables, 1.5x better than 2048 for
- * untrained ones), cap 1024.  In the split path, pass 1 derives t~_u as the K-th largest of 256 disjoint group maxima of
+ * 16384 users per chunk is +20 %), sample_items 3072 in norm order (2048 .. 4096 are within 3 % of each other on trained
+ * tables; round 3, catalogue order: 4096), cap 1024.  In the split path, pass 1 derives t~_u as the K-th largest of 256 disjoint group maxima of
  * the masked sample scores (a lower bound of their K-th largest: K distinct items attain it). */
 int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
                                               int64_t n_items, int32_t d);

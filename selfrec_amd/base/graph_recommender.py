@@ -29,7 +29,8 @@ SCORE_SLAB_BYTES = 96 << 20
 # (tools/eval_sweep.py on trained embeddings, 31.5 k users: chunks of 4096 / 8192 / 16384 / 32768 users rank at 15.8 / 17.9 /
 #  19.0 / 19.0 M users/s -- a chunk's six launches fill the chip better and there are fewer of them; its workspace is
 #  chunk x (sample + 2 cap) x 4 B = 400 MB at 16384.  A 2048- or 8192-item sample, or 512 slots, move it by < 3 %.)
-FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 4096, 1024, 16384
+FILTER_SAMPLE_ITEMS, FILTER_CAP, FILTER_CHUNK_ROWS = 3072, 1024, 16384
+FILTER_MIN_ITEMS = 16384            # smaller catalogues: the exact slab pipeline
 DEVICE_TOPK_MAX = 128          # srh_topk_rows / srh_score_mask_topk(_filtered): k <= 128
 FILTER_WS_KEEP_BYTES = 1 << 30  # the filtered ranking's workspace is cached on the model up to this size
 
@@ -103,7 +104,7 @@ class GraphRecommender(Recommender):
         """Large catalogues: the score matrix is never stored (srh_score_mask_topk_filtered: a bound from a
         slice of the catalogue, then a filtering pass); the few rows whose survivor list overflowed
         (tie-heavy scores) are re-ranked by the exact path.  Same ids and scores either way."""
-        if ie.shape[0] < 4 * FILTER_SAMPLE_ITEMS:
+        if ie.shape[0] < FILTER_MIN_ITEMS:
             return self._rank_exact(ue, uid, ie, g, k)
         chunk = self._filter_chunk_rows(ie.device)
         ws = getattr(self, '_filter_ws', None)

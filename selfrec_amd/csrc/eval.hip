@@ -8,6 +8,7 @@
 //   Output tile traffic (4 B per 2*d flops) keeps the kernel at the MFMA/HBM ridge for d=64,
 //   which is why callers chunk the users so the score slab stays in the 256 MiB Infinity Cache.
 #include "common.h"
+#include <hipcub/hipcub.hpp>
 
 namespace {
 using namespace srh;
@@ -246,6 +247,37 @@ constexpr float kFilterMargin = kF16Terms == 3 ? 5e-5f : (kF16Terms == 2 ? 1.99e
 // the survivor's score is handed on as acc + T (the accumulator held s~ - T): one more rounding of size 2^-24 (|T| + |s~|)
 constexpr float kFilterAbsSlack = 3e-7f;
 
+// The bound slice is the S items of LARGEST NORM, not the first S of the catalogue: a user's best scores sit on popular items,
+// popular items are the ones training has pushed outwards, and the K-th best score over such a slice is a far tighter bound
+// (trained XSimGCL tables, Yelp2018 shape, tools/sample_choice_probe.py: 2048 largest-norm items leave 27.7 items per user at or
+// above the bound, the first 4096 of the catalogue 38.6, the first 2048 66.7).  So the item image is built in norm order --
+// norms, a radix sort of (norm bits, item id) pairs, the permutation and its inverse: four small launches per ranking -- and
+// everything downstream works on image rows; only the survivors' ids are translated back, when they are written out.
+template <int LPR>
+__global__ __launch_bounds__(256) void item_norms_kernel(const float* __restrict__ X, int n, uint32_t* __restrict__ norm_bits,
+                                                         int32_t* __restrict__ iota) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int r = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
+  const bool valid = r < n;
+  const float4 v = reinterpret_cast<const float4*>(X)[(size_t)(valid ? r : 0) * LPR + sub];
+  const float ss = group_sum<LPR>(f4_dot(v, v));
+  if (valid && sub == 0) {
+    norm_bits[r] = __float_as_uint(sqrtf(ss));                  // (non-negative floats order like their bit patterns)
+    iota[r] = r;
+  }
+}
+__global__ __launch_bounds__(256) void invert_order_kernel(const int32_t* __restrict__ order, int n, int32_t* __restrict__ column_of_item) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n) column_of_item[order[r]] = r;
+}
+static size_t filt_sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                                     (int32_t*)nullptr, (int)n);
+  return bytes;
+}
+
 // rows of an f32 table as bf16 hi / lo images + the row's L2 norm; the table's largest norm in *max_norm (float bits
 // compare like unsigned ints for non-negative floats).  FRAG = false: row-major images (the query rows: each wave loads
 // its A operands once).  FRAG = true: FRAGMENT-LINEAR images of the item table -- per 32-row tile, per image, per MFMA
@@ -306,7 +338,8 @@ struct Filter16Args {
   const float* thr;            // row r's exact bound = thr[r * thr_stride]
   int thr_stride;
   const float* u_norm;         // |u_r|
-  const float* item_norm;      // |i_j| per item, whole 32-item tiles (0 beyond the catalogue)
+  const float* item_norm;      // |i_j| per IMAGE row, whole 32-item tiles (0 beyond the catalogue)
+  const int32_t* order;        // image row -> item id (the image holds the items by norm, largest first)
   int32_t* cnt;
   int32_t* cand_id;
   float* cand_sc;              // the split-bf16 score of the candidate (within delta_u of the exact one)
@@ -395,7 +428,7 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
       const int row = m0 + stage_row[e];
       const int slot = atomicAdd(f.cnt + row, 1);
       if (slot < f.cap) {
-        f.cand_id[(size_t)row * f.cap + slot] = stage_col[e];
+        f.cand_id[(size_t)row * f.cap + slot] = f.order[stage_col[e]];        // image row -> item id
         f.cand_sc[(size_t)row * f.cap + slot] = stage_sc[e];
       }
     }
@@ -819,7 +852,8 @@ __global__ __launch_bounds__(256) void bound_rows_kernel(float* __restrict__ sco
                                                          float* __restrict__ out, int out_stride,
                                                          const int32_t* __restrict__ user_ids, int user_base,
                                                          const int32_t* __restrict__ mask_indptr,
-                                                         const int32_t* __restrict__ mask_indices) {
+                                                         const int32_t* __restrict__ mask_indices,
+                                                         const int32_t* __restrict__ column_of_item) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -827,7 +861,7 @@ __global__ __launch_bounds__(256) void bound_rows_kernel(float* __restrict__ sco
     const int u = user_ids ? user_ids[row] : user_base + row;
     const int ms = mask_indptr[u], me = mask_indptr[u + 1];
     for (int p = ms + lane; p < me; p += 64) {
-      const int item = mask_indices[p];
+      const int item = column_of_item[mask_indices[p]];           // (the slab's columns are image rows: items by norm)
       if (item < n) scores[(size_t)row * n + item] = -10e8f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1133,7 +1167,10 @@ static bool filt_split_served(int32_t d) { return d == 64 || d == 128; }
 static int64_t filt_split_bytes(int64_t rows, int64_t n_items, int32_t d) {
   if (!filt_split_served(d)) return 0;
   const int64_t padded = (n_items + 31) / 32 * 32;               // the item images are whole 32-row tiles
-  return 2 * filt_align(padded * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + filt_align(padded * 4);
+  // + the norm order of the catalogue: norms by item (the sort's keys), sorted keys, 0 .. n-1, the order, its inverse, the
+  //   sort's scratch
+  return 2 * filt_align(padded * d * 2) + 2 * filt_align(rows * d * 2) + filt_align(rows * 4) + filt_align(padded * 4) +
+         5 * filt_align(padded * 4) + filt_align((int64_t)filt_sort_temp_bytes(n_items));
 }
 
 int64_t srh_score_mask_topk_filtered_ws_bytes(int64_t chunk_rows, int64_t sample_items, int32_t k, int32_t cap,
@@ -1163,6 +1200,8 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
   const bool split = filt_split_served(d);
   uint16_t *i_hi = nullptr, *i_lo = nullptr, *u_hi = nullptr, *u_lo = nullptr;
   float *u_norm = nullptr, *i_norm = nullptr;
+  const float* norm_by_item = nullptr;
+  int32_t *order = nullptr, *column_of_item = nullptr;
   if (split) {
     ws += filt_align(chunk_rows * 4);            // (the chunk layout's counter slot: counts live in d_out_counts)
     const int64_t padded = (n_items + 31) / 32 * 32;
@@ -1171,14 +1210,30 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
     u_hi = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_lo = reinterpret_cast<uint16_t*>(ws); ws += filt_align(chunk_rows * d * 2);
     u_norm = reinterpret_cast<float*>(ws); ws += filt_align(chunk_rows * 4);
-    i_norm = reinterpret_cast<float*>(ws);
+    i_norm = reinterpret_cast<float*>(ws); ws += filt_align(padded * 4);
+    uint32_t* norm_bits = reinterpret_cast<uint32_t*>(ws); ws += filt_align(padded * 4);       // = norms by ITEM, as floats
+    uint32_t* sorted_bits = reinterpret_cast<uint32_t*>(ws); ws += filt_align(padded * 4);
+    int32_t* iota = reinterpret_cast<int32_t*>(ws); ws += filt_align(padded * 4);
+    order = reinterpret_cast<int32_t*>(ws); ws += filt_align(padded * 4);
+    column_of_item = reinterpret_cast<int32_t*>(ws); ws += filt_align(padded * 4);
+    void* sort_temp = ws;
+    size_t sort_bytes = filt_sort_temp_bytes(n_items);
+    norm_by_item = reinterpret_cast<const float*>(norm_bits);
     // (the last tile's rows beyond the catalogue: norm 0 -- their scores are never looked at)
     hipError_t err = padded > n_items ? hipMemsetAsync(i_norm + n_items, 0, sizeof(float) * (size_t)(padded - n_items), st) : hipSuccess;
     if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
     const int lpr = d / 4, g = 64 / lpr;
     const int blocks = (int)(((n_items + g - 1) / g + 3) / 4);
-    if (d == 64) split_rows_kernel<16, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, i_norm, nullptr);
-    else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, nullptr, (int)n_items, i_hi, i_lo, i_norm, nullptr);
+    // the catalogue in norm order, largest first (see item_norms_kernel), then its operand image in that order
+    if (d == 64) item_norms_kernel<16><<<blocks, 256, 0, st>>>(d_item_emb, (int)n_items, norm_bits, iota);
+    else item_norms_kernel<32><<<blocks, 256, 0, st>>>(d_item_emb, (int)n_items, norm_bits, iota);
+    SRH_LAUNCH_CHECK();
+    err = hipcub::DeviceRadixSort::SortPairsDescending(sort_temp, sort_bytes, norm_bits, sorted_bits, iota, order, (int)n_items, 0, 32, st);
+    if (err != hipSuccess) { srh::set_error("score_mask_topk_filtered: sort: %s", hipGetErrorString(err)); return SRH_ERR_HIP; }
+    invert_order_kernel<<<(int)((n_items + 255) / 256), 256, 0, st>>>(order, (int)n_items, column_of_item);
+    SRH_LAUNCH_CHECK();
+    if (d == 64) split_rows_kernel<16, true><<<blocks, 256, 0, st>>>(d_item_emb, order, (int)n_items, i_hi, i_lo, i_norm, nullptr);
+    else split_rows_kernel<32, true><<<blocks, 256, 0, st>>>(d_item_emb, order, (int)n_items, i_hi, i_lo, i_norm, nullptr);
     SRH_LAUNCH_CHECK();
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute((const void*)filter16_kernel<64, false, SRH_F16_UB>, hipFuncAttributeMaxDynamicSharedMemorySize, kF16Lds);
@@ -1209,6 +1264,7 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       Filter16Args none{};
       none.u_norm = u_norm;
       none.item_norm = i_norm;
+      none.order = order;
       if (d == 64) {
         split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
         filter16_kernel<64, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
@@ -1229,7 +1285,7 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       // (the split path needs the bound only, not the sample's ranked list: one pass, one wave per row, the row's masks
       // applied by the same wave)
       bound_rows_kernel<<<(int)((m + 3) / 4), 256, 0, st>>>(slab, (int)m, (int)sample_items, k, s_sc + (k - 1), k, ids, (int)lo,
-                                                            d_r_indptr, d_r_indices);
+                                                            d_r_indptr, d_r_indices, column_of_item);
       SRH_LAUNCH_CHECK();
     } else {
       rc = srh_topk_rows(slab, m, sample_items, k, s_ids, s_sc, stream);
@@ -1246,7 +1302,7 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int gx = std::max(1, std::min(n_tiles, (512 + gy - 1) / gy));
       const int tiles_per_wg = (n_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
-      Filter16Args f16{s_sc + (k - 1), k, u_norm, i_norm, cnt, cand_id, cand_sc, cap};
+      Filter16Args f16{s_sc + (k - 1), k, u_norm, i_norm, order, cnt, cand_id, cand_sc, cap};
       if (d == 64) filter16_kernel<64, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       else filter16_kernel<128, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
       SRH_LAUNCH_CHECK();
@@ -1258,18 +1314,18 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       constexpr int kWaveRows = 128;               // (longer lists: the O(n^2) rank counts want the 256 threads of the workgroup form)
       const int wg = (int)((m + 3) / 4);
       if (d == 64) {
-        rescore_wave_kernel<64, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, i_norm,
+        rescore_wave_kernel<64, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, norm_by_item,
                                                                s_sc + (k - 1), k, cap, k, d_r_indptr, d_r_indices,
                                                                d_out_ids + lo * k, d_out_scores + lo * k);
         rescore_topk_kernel<64><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                             i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                             norm_by_item, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
                                                              d_out_ids + lo * k, d_out_scores + lo * k, kWaveRows);
       } else {
-        rescore_wave_kernel<128, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, i_norm,
+        rescore_wave_kernel<128, kWaveRows><<<wg, 256, 0, st>>>(emb, ids, (int)lo, d_item_emb, (int)m, cnt, cand_id, cand_sc, u_norm, norm_by_item,
                                                                 s_sc + (k - 1), k, cap, k, d_r_indptr, d_r_indices,
                                                                 d_out_ids + lo * k, d_out_scores + lo * k);
         rescore_topk_kernel<128><<<(int)m, 256, rs_lds, st>>>(emb, ids, (int)lo, d_item_emb, cnt, cand_id, cand_sc, u_norm,
-                                                              i_norm, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
+                                                              norm_by_item, s_sc + (k - 1), k, cap, k, bitmap_words, d_r_indptr, d_r_indices,
                                                               d_out_ids + lo * k, d_out_scores + lo * k, kWaveRows);
       }
       SRH_LAUNCH_CHECK();

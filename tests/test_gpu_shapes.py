@@ -244,7 +244,7 @@ def test_yelp_shape_two_steps_match_reference_run(yelp_data, shapes, smeta, tag)
     rec = gr.GraphRecommender.__new__(gr.GraphRecommender)
     rec.data, rec.max_N, rec.topN = yelp_data, 20, [20]
     rec.user_emb, rec.item_emb = fu.contiguous(), fi.contiguous()
-    assert fi.shape[0] >= 4 * gr.FILTER_SAMPLE_ITEMS                # (this catalogue takes the filtered pipeline)
+    assert fi.shape[0] >= gr.FILTER_MIN_ITEMS                # (this catalogue takes the filtered pipeline)
     ids_f, sc_f = rec.rank_on_device(shapes[f"{tag}_eval_users"].astype(np.int32))
     assert getattr(rec, "_filter_ws", None) is not None            # (... and it did)
     assert (ids_f == want_ids).mean() > 0.995

@@ -78,6 +78,11 @@ determinism)
   timeout 600 python tools/determinism_probe.py > $OUT/determinism.txt 2>&1; echo "determinism exit $?"; grep -v amdgpu.ids $OUT/determinism.txt | tail -12;;
 nceprec)
   timeout 300 python tools/nce_precision.py > $OUT/nce_precision.txt 2>&1; echo "nceprec exit $?"; grep -v amdgpu.ids $OUT/nce_precision.txt;;
+evaltrainedprof)
+  # per-kernel times of the ranking on TRAINED tables (the kernels of the 1300 training steps are in the same trace: ignore them)
+  rm -rf $OUT/evaltrained; (cd /tmp && EVAL_TRAIN_STEPS=1300 timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/evaltrained -o trace -- python $OLDPWD/tools/eval_breakdown.py > $OLDPWD/$OUT/evaltrained.log 2>&1); echo "evaltrainedprof exit $?"
+  stats $OUT/evaltrained | grep -E "kernel  |filter16|rescore|bound_rows|mask_kernel|split_rows|item_norms|invert_order|trim_mark|DeviceRadix|radix|onesweep|histogram|hit_flags" | tee $OUT/evaltrained_kernel_stats.txt; grep -v amdgpu.ids $OUT/evaltrained.log | tail -1
+  find $OUT/evaltrained -name "*.db" -size +30M -delete;;
 testseval)
   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider -k "rank or filter or topk or score or eval or metric or ties or heap" > $OUT/tests_eval.log 2>&1; echo "testseval exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_eval.log | head -40;;
