@@ -379,7 +379,9 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   constexpr int KS = D / 16;
   constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile (the global image)
   constexpr int FR = kF16Terms == 3 ? 2 * KS : KS;   // fragments of a tile this build stages: hi + lo, or hi only
-  constexpr int ST = 32768 / (FR * 1024);            // tiles per stage: 4 (d = 64; 8 hi-only), 2 (d = 128; 4 hi-only)
+  // tiles per stage: 8 (d = 64 hi-only; 4 with the lo fragments), 4 (d = 128; 2).  The slab launch -- a slice of ~100 tiles dealt
+  // round-robin over 8 workgroups per row block -- takes half-size stages so that the deal comes out even.
+  constexpr int ST = (SLAB ? 16384 : 32768) / (FR * 1024);
   extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
   constexpr int STAGE_BYTES = ST * FR * 1024 + kF16NormBytes;      // 32 KB of fragments, then the tiles' item norms
   static_assert(ST * 128 <= kF16NormBytes, "norm slot of a stage");
@@ -391,7 +393,13 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   const int r32 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * 256 + wv * 32 * UB;
   const int n_tiles = (n + 31) / 32;
-  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+  // The item image is in NORM order (largest first), and that is where a row's survivors are: the workgroups of one row block
+  // take the STAGES of item tiles round-robin -- x, x + X, x + 2 X, ... -- so that each of them sees large and small norms
+  // alike.  (Contiguous ranges gave the first workgroup of every row block nearly all of the survivor work, and with one wave
+  // of 512 workgroups on the chip the slowest one IS the kernel's time.)  tiles_per_wg: unused since.
+  (void)tiles_per_wg;
+  const int t_end = n_tiles;
+  const int t_begin = blockIdx.x * ST, t_step = gridDim.x * ST;
   if (t_begin >= t_end) return;
   const bool live = m0 < m;                          // (a wave beyond the chunk's rows still copies and synchronises)
   auto ld8 = [](const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); };
@@ -449,10 +457,10 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   };
   copy_stage(t_begin, f16_smem);
   int cur = 0;
-  for (int t0 = t_begin; t0 < t_end; t0 += ST, cur ^= 1) {
+  for (int t0 = t_begin; t0 < t_end; t0 += t_step, cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of stage t0 (and its flush) landed
     __syncthreads();                                             // ... everyone's; and the other buffer has been read
-    if (t0 + ST < t_end) copy_stage(t0 + ST, f16_smem + (cur ^ 1) * STAGE_BYTES);   // in flight under this stage's MFMAs
+    if (t0 + t_step < t_end) copy_stage(t0 + t_step, f16_smem + (cur ^ 1) * STAGE_BYTES);   // in flight under this stage's MFMAs
     if (live) {
       const unsigned char* buf = f16_smem + cur * STAGE_BYTES;
       const int nt = min(ST, t_end - t0);
