@@ -445,7 +445,7 @@ def eval_throughput(trainer, data, k=20):
     t_mat = sorted(times)[len(times) // 2]
     assert len(rec_list) == len(out) and len(rec_list[users[0]]) == k and report_m == report
     flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
-    # how hard the filter has to work on THESE embeddings: survivors per user of the bound from the first 4096 items
+    # how hard the filter has to work on THESE embeddings: survivors per user of the bound from the slice (the FILTER_SAMPLE_ITEMS items of largest norm)
     # (training items included), rows whose list overflowed the 1024 slots (re-ranked by the exact slab pipeline)
     from selfrec_amd.base import graph_recommender as _gr
     ue_p, ie_p = rec._device_embeddings()

@@ -374,7 +374,7 @@ constexpr int kF16Lds = 2 * (32768 + kF16NormBytes) + 4 * kF16StageCap * (4 + 4 
 // derived from approximate scores is lowered by one more delta_u (see srh_score_mask_topk_filtered).
 template <int D, bool SLAB = false, int UB = 2>
 __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __restrict__ Uhi, const uint16_t* __restrict__ Ulo,
-                                                       const uint16_t* __restrict__ Ifrag, int m, int n, int tiles_per_wg,
+                                                       const uint16_t* __restrict__ Ifrag, int m, int n,
                                                        Filter16Args f, float* __restrict__ C = nullptr) {
   constexpr int KS = D / 16;
   constexpr int TILE_BYTES = 2 * KS * 1024;          // hi fragments then lo fragments of one 32-item tile (the global image)
@@ -396,8 +396,7 @@ __global__ __launch_bounds__(512 / UB) void filter16_kernel(const uint16_t* __re
   // The item image is in NORM order (largest first), and that is where a row's survivors are: the workgroups of one row block
   // take the STAGES of item tiles round-robin -- x, x + X, x + 2 X, ... -- so that each of them sees large and small norms
   // alike.  (Contiguous ranges gave the first workgroup of every row block nearly all of the survivor work, and with one wave
-  // of 512 workgroups on the chip the slowest one IS the kernel's time.)  tiles_per_wg: unused since.
-  (void)tiles_per_wg;
+  // of 512 workgroups on the chip the slowest one IS the kernel's time.)
   const int t_end = n_tiles;
   const int t_begin = blockIdx.x * ST, t_step = gridDim.x * ST;
   if (t_begin >= t_end) return;
@@ -1275,10 +1274,10 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       none.order = order;
       if (d == 64) {
         split_rows_kernel<16, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<64, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+        filter16_kernel<64, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, none, slab);
       } else {
         split_rows_kernel<32, false><<<sb, 256, 0, st>>>(emb, ids, (int)m, u_hi, u_lo, u_norm, nullptr);
-        filter16_kernel<128, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, tpw, none, slab);
+        filter16_kernel<128, true, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)sample_items, none, slab);
       }
       SRH_LAUNCH_CHECK();
     } else {
@@ -1311,8 +1310,8 @@ srh_status_t srh_score_mask_topk_filtered(const float* d_user_emb, const int32_t
       const int tiles_per_wg = (n_tiles + gx - 1) / gx;
       dim3 grid((unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)gy);
       Filter16Args f16{s_sc + (k - 1), k, u_norm, i_norm, order, cnt, cand_id, cand_sc, cap};
-      if (d == 64) filter16_kernel<64, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
-      else filter16_kernel<128, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, tiles_per_wg, f16);
+      if (d == 64) filter16_kernel<64, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, f16);
+      else filter16_kernel<128, false, SRH_F16_UB><<<grid, 512 / SRH_F16_UB, kF16Lds, st>>>(u_hi, u_lo, i_hi, (int)m, (int)n_items, f16);
       SRH_LAUNCH_CHECK();
       // 3'. ... and the survivors re-scored by gemm_nt_kernel's own instruction sequence, masked, ranked
       // (training-row membership by an LDS bitmap over the catalogue while it fits: <= 16 KB, i.e. 131 k items)

@@ -690,7 +690,7 @@ def score_mask_topk(user_emb, user_ids, item_emb, r_indptr, r_indices, k, scores
     return ids, sc
 
 
-def score_mask_topk_filtered(user_emb, user_ids, item_emb, r_indptr, r_indices, k, *, sample_items=4096, cap=1024,
+def score_mask_topk_filtered(user_emb, user_ids, item_emb, r_indptr, r_indices, k, *, sample_items=3072, cap=1024,
                              chunk_rows=4096, ws=None):
     """ids, scores, counts (device).  Rows with counts > cap are not valid (see include/selfrec_hip.h):
     rank those with score_mask_topk."""
