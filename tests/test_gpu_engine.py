@@ -153,6 +153,10 @@ def test_device_ranking_orders_ties_like_the_reference_heap(golden_ops):
     ids, sc = rec.rank_on_device(np.asarray([data.user["q"]], dtype=np.int32))
     assert ids[0].tolist() == g["topk_ties_ids"].tolist()
     assert np.array_equal(sc[0], g["topk_ties_scores"])
+    # the path test() takes (hit flags and metric rows from the ids): the ties are settled on the device first
+    ids_h, sc_h, flags, cuts = rec.rank_on_device(np.asarray([data.user["q"]], dtype=np.int32), with_hits=True, metric_cuts=[5])
+    assert ids_h[0].tolist() == g["topk_ties_ids"].tolist() and np.array_equal(sc_h[0], g["topk_ties_scores"])
+    assert flags[0].tolist() == [int(i == data.item["0"]) for i in ids_h[0]] and int(cuts[5][0][0]) == int(flags[0].sum())
     # the other user rated everything but the masked item: only that one is left, then masked entries at -10e8 in heap order
     from selfrec_amd.util.algorithm import find_k_largest
     ids_p, sc_p = rec.rank_on_device(np.asarray([data.user["p"]], dtype=np.int32))
