@@ -75,6 +75,11 @@ def profile_steps(mod, model, n, name, skip=20):
     print(f"{name}: {n} profiled steps, {state['dt'] / n * 1e3:.2f} ms/step under the profiler")
     print(ka.table(sort_by="self_cpu_time_total", row_limit=28, max_name_column_width=60))
     print(ka.table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=60))
+    # calls in which the HOST waits for the device (a synchronous copy drains the stream: the host can no longer run ahead)
+    print("# host-side waits per step (calls, ms of host time in them):")
+    for e in ka:
+        if any(w in e.key for w in ("Memcpy", "Synchronize", "aten::item", "_local_scalar_dense", "aten::nonzero", "hipMalloc", "hipFree")):
+            print(f"#   {e.key[:60]:60s} {e.count / n:6.1f} calls  {e.self_cpu_time_total / n / 1e3:8.3f} ms")
 
 
 def main():
