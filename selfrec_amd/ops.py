@@ -517,9 +517,10 @@ _scalar_ws = {}
 
 
 def scalar_ws(device) -> torch.Tensor:
-    """The 64-byte workspace the single-launch loss kernels finish their scalars in (SRH_SCALAR_WS_BYTES): one per device,
-    zero before its first use, left zero by every call; the calls that share it are ordered on the current stream."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """The 64-byte workspace the single-launch loss kernels finish their scalars in (SRH_SCALAR_WS_BYTES): one per device and
+    stream, zero before its first use, left zero by every call."""
+    # (one per device AND stream: the calls that share a workspace must be ordered, and a stream is what orders them)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _scalar_ws.get(key)
     if ws is None:
         ws = _scalar_ws[key] = torch.zeros(_lib.SCALAR_WS_BYTES // 8, dtype=torch.float64, device=device)

@@ -28,3 +28,17 @@ for sample in (2048, 4096, 8192):
         surv = (S >= T[:, None]).sum(dim=1).float()
         print(f"slice {sample:5d} {name:13s}: survivors mean {surv.mean():7.1f} median {surv.median():6.0f} max {int(surv.max()):5d}; "
               f"rows whose bound IS the exact K-th best: {(T == true_kth).float().mean() * 100:.1f} %")
+
+# Cauchy-Schwarz cut-off: an item can reach the bound T_u only if |i_j| >= T_u / |u|.  With the catalogue in norm order a
+# 32-row block of the filter could stop at the first tile whose largest norm is below the block's smallest T_u / |u|.
+un = ue[users].norm(dim=1)
+T = S[:, order[:3072]].topk(K, dim=1).values[:, -1]
+q = torch.where(T > 0, T / un, torch.zeros_like(T))                 # required norm per user (0: no cut-off possible)
+sorted_norms = norms[order]
+needed = torch.searchsorted(-sorted_norms, -q)                       # items with norm >= q, per user
+print("fraction of the catalogue a user's row has to look at (norm >= T/|u|): mean %.3f median %.3f" %
+      (needed.float().mean() / ie.shape[0], needed.float().median() / ie.shape[0]))
+for blk in (32, 256):
+    qb = q[: (q.numel() // blk) * blk].view(-1, blk).min(dim=1).values
+    nb = torch.searchsorted(-sorted_norms, -qb)
+    print(f"  per {blk}-row block (its weakest user decides): mean {nb.float().mean() / ie.shape[0]:.3f} median {nb.float().median() / ie.shape[0]:.3f}")
