@@ -8,8 +8,8 @@ avoidable part, and none of them needs the file to change (``dropin.install()`` 
    the device and gathers with advanced indexing, whose backward is ``index_put_(accumulate=True)`` -- a sort plus several
    launches (0.24 ms per step).  The lists ``next_batch_pairwise`` yields are REAL python lists (the reference's protocol),
    but the generator also uploads all three streams -- and, for models that ask for them, their sorted unique ids -- in ONE pinned copy and registers the
-   device tensors under the lists' identities; ``Tensor.__getitem__`` with a registered list (or any 1-D int64 HIP index into
-   a 2-D HIP tensor) becomes ``index_select``: one gather launch, backward = ``index_add_`` (atomics, no sort).  Same rows,
+   device tensors under the lists' identities; ``Tensor.__getitem__`` with a registered list (or with one of the device index
+   tensors this module handed out: a stream, its unique ids) on a 2-D HIP tensor becomes ``index_select``: one gather launch, backward = ``index_add_`` (atomics, no sort).  Same rows,
    same values; gradients equal up to fp32 summation order of duplicate rows.
 2. ``torch.unique(torch.Tensor(idx).type(torch.long)).cuda()`` (XSimGCL.py:46-47, SGL.py:116-117): a float round trip, a
    host sort and a synchronous H2D copy per side.  The C++ sampler already knows the sorted unique ids of the batch:
@@ -35,7 +35,8 @@ import torch
 
 from .. import ops
 
-_state = {"on": False, "orig_getitem": None, "orig_unique": None, "orig_adam": None, "batch": {}, "pinned": None, "dev": None}
+_state = {"on": False, "orig_getitem": None, "orig_unique": None, "orig_adam": None, "batch": {}, "pinned": None, "dev": None,
+          "safe_idx": {}}
 hits = {"gather_list": 0, "gather_index": 0, "unique": 0, "adam": 0}       # how often each fast path was taken (tests, profiles)
 
 
@@ -70,6 +71,7 @@ class _Stream:
         hu = torch.from_numpy(ids_host).as_subclass(HostIds)
         hu._srh_dev = ids_dev
         self.uniq_host, self.uniq_dev = hu, ids_dev
+        _state["safe_idx"][id(ids_dev)] = ids_dev
 
 
 class HostIds(torch.Tensor):
@@ -126,6 +128,7 @@ def register_batch(lists, arrays, device=None):
     on_dev = torch.empty(total, dtype=torch.int64, device=dev)
     on_dev.copy_(pin[:total], non_blocking=True)
     streams = [_Stream(lst, parts[k], on_dev[views[k][0]:views[k][1]]) for k, lst in enumerate(lists)]
+    _state["safe_idx"] = {id(st.dev): st.dev for st in streams}       # (the previous batch's tensors are dropped with it)
     for k in range(len(parts) - 3):
         streams[k].set_unique(parts[3 + k].copy(), on_dev[views[3 + k][0]:views[3 + k][1]])
     _state["batch"] = {id(st.lst): st for st in streams}
@@ -159,7 +162,10 @@ def _getitem(self, idx):
             hits["gather_list"] += 1
             return torch.index_select(self, 0, s.dev)
         return orig(self, idx)
-    if type(idx) is torch.Tensor and idx.dim() == 1 and idx.dtype == torch.int64 and idx.device == self.device:
+    # a device index is taken only when it IS one of the tensors this module handed out (a batch stream or its sorted unique
+    # ids: non-negative by construction) -- advanced indexing wraps negative indices, index_select does not, and whether an
+    # arbitrary device tensor holds one cannot be asked without a synchronisation
+    if type(idx) is torch.Tensor and _state["safe_idx"].get(id(idx)) is idx and idx.device == self.device:
         hits["gather_index"] += 1
         return torch.index_select(self, 0, idx)
     return orig(self, idx)
@@ -255,4 +261,4 @@ def uninstall():
     torch.optim.Adam = _state["orig_adam"]
     from ..data import loader
     loader.LAZY_GRAPH_FILES[0] = False
-    _state.update(on=False, batch={}, pinned=None, want_unique=False)
+    _state.update(on=False, batch={}, pinned=None, want_unique=False, safe_idx={})

@@ -123,6 +123,16 @@ def test_fast_paths_take_the_reference_idioms_and_the_same_steps(golden_models, 
         assert torch.equal(table[u_idx], want)
         u_idx[0] = (u_idx[0] + 1) % data.user_num
         assert torch.equal(table[u_idx], table[torch.tensor(u_idx, device="cuda")])
+        # a device index the module did not hand out keeps torch's semantics -- negative indices wrap -- and torch's path
+        before = dict(fastpath.hits)
+        neg = torch.tensor([-1, 0, -2], device="cuda")
+        assert torch.equal(table[neg], torch.stack([table[data.user_num - 1], table[0], table[data.user_num - 2]]))
+        assert fastpath.hits == before
+        # ... the sorted unique ids it did hand out take index_select
+        uu = torch.unique(torch.Tensor(i_idx).type(torch.long)).cuda()
+        items = torch.arange(data.item_num * 4, dtype=torch.float32, device="cuda").reshape(data.item_num, 4)
+        assert torch.equal(items[uu], items[torch.from_numpy(np.unique(i_idx)).cuda()[:, None], torch.arange(4, device="cuda")])
+        assert fastpath.hits["gather_index"] == before["gather_index"] + 1
     finally:
         dropin.uninstall()
 

@@ -64,7 +64,7 @@ def main():
         idx = torch.randint(0, U, (B,), device=DEV)
         lists = ([int(x) for x in np.random.randint(0, U, B)],) * 3
         fastpath.register_batch(lists, [np.asarray(lists[0], dtype=np.int32)] * 3)
-        timed("table[device int64 index] (fast path: index_select)", lambda: table[idx])
+        timed("table[device int64 index of the caller's] (torch's own path)", lambda: table[idx])
         timed("table[registered python list] (fast path)", lambda: table[lists[0]])
         timed("table[idx] forward + backward", lambda: table[idx].backward(u.detach()))
         opt = torch.optim.Adam([table, torch.nn.Parameter(torch.randn(I, d, device=DEV))], lr=1e-3)
