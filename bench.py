@@ -851,7 +851,8 @@ def main():
             use_graph = not args.no_graph and not eager
             if layout is False:
                 from selfrec_amd.engine import FusedTrainer
-                return FusedTrainer(data, args.emb, use_graph=use_graph, **kw)
+                # (the first epoch is drawn on a thread while the trainer is built: Runner seeds with the same value)
+                return FusedTrainer(data, args.emb, use_graph=use_graph, sampler_seed=args.seed, **kw)
             from selfrec_amd.dist import ShardedTrainer
             return ShardedTrainer(data, args.emb, layout=layout, use_graph=use_graph, **kw)
         return build

@@ -52,7 +52,7 @@ class FusedTrainer:
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
                  noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False, comm=None,
-                 nce_precision=None):
+                 nce_precision=None, sampler_seed=None):
         if model not in MODELS:
             raise SelfrecHipError(f"FusedTrainer: unknown model {model!r}")
         ops.require_gpu()
@@ -101,6 +101,17 @@ class FusedTrainer:
         self.rows.bind(N, self.U, dev)
         self.w, self.col0 = self.colx.w, self.colx.col0     # width / first column of this rank's tables
         self.n_pad, self.P = self.rows.n_pad, self.rows.P   # rows this rank owns / rows of a whole table
+        # The sampler needs the interaction arrays only: with `sampler_seed` given, the FIRST epoch is drawn on a host thread
+        # from here on -- under the graph upload, the SpMM plans and the XCD calibration below (all of them C++ / device work
+        # that releases the GIL) -- instead of after them: 3.6 of 13.3 s to the first trained step at 1 M x 500 k.
+        # (SGL draws its edge-dropped views from the same stream and needs the graph for them: sampled after construction.)
+        self.sampler = ops.Sampler(data.train_u, data.train_i, self.U, self.I)
+        self._first_epoch, self._first_epoch_seed = None, None
+        if sampler_seed is not None and model != "SGL":
+            self._first_epoch_seed = int(sampler_seed)
+            self.sampler.seed(self.sync.sampler_seed(int(sampler_seed)))
+            self._first_epoch = EpochPrefetcher(self, first=True)
+            self._first_epoch.start()
         self.graph = self.rows.build_graph(data, dev, column_classes=not self.colx.split)
         self.adj = self.graph.adj
         g = self.graph
@@ -183,7 +194,6 @@ class FusedTrainer:
         if model in ("XSimGCL", "SimGCL", "SGL"):       # user side + item side share one workspace / launch set
             one = ops.infonce_ws(2 * B if model == "SGL" else B, d, dev)
             self.nce_ws = torch.empty(one.numel() * (1 if model == "SGL" else 2), dtype=torch.uint8, device=dev)
-        self.sampler = ops.Sampler(data.train_u, data.train_i, self.U, self.I)
         E = self.sampler.n_edges
         self.epoch_batches = (E + B - 1) // B
         sizes = {"u": E, "i": E, "j": E, "uniq_u": self.epoch_batches * B, "uniq_i": self.epoch_batches * B,
@@ -344,13 +354,26 @@ class FusedTrainer:
     def seed_sampler(self, seed: int):
         """Seed the batch sampler.  Replicated layouts (rows / cols / 2-D) need the SAME stream on every rank; data
         parallel needs a DIFFERENT one per rank (seed + rank): every rank trains on its own batches."""
+        if self._first_epoch is not None:
+            if int(seed) == self._first_epoch_seed:
+                return                                     # (the epoch being drawn since construction IS this seed's first)
+            self._drop_first_epoch()                       # another seed after all
         self.sampler.seed(self.sync.sampler_seed(int(seed)))
+
+    def _drop_first_epoch(self):
+        """The epoch drawn since construction is not wanted: let its thread finish, and start from a FRESH sampler -- the
+        discarded shuffle has permuted the sampler's edge order, which the next seed's stream must not inherit."""
+        self._first_epoch.take()
+        self._first_epoch = None
+        self.sampler = ops.Sampler(self.data.train_u, self.data.train_i, self.U, self.I)
 
     def seed_sampler_from_python(self):
         """Adopt the global ``random`` state (bit-exact mode, as the reference consumes it).  Data parallel over more than
         one rank has no reference stream to be exact to -- every rank needs ITS OWN batches -- so there one 63-bit draw of
         the (replicated) global stream seeds the sampler, offset by the rank (adopting the state itself would
         hand every rank the same batches)."""
+        if self._first_epoch is not None:
+            self._drop_first_epoch()
         if self.sync.active and self.sync.world > 1:
             import random
             self.sampler.seed(self.sync.sampler_seed(random.getrandbits(63)) & ((1 << 63) - 1))
@@ -359,7 +382,14 @@ class FusedTrainer:
 
     def sample_epoch_host(self):
         """Host part of an epoch: SGL's two edge-dropped views are drawn first (SGL.py:28-29),
-        then shuffle + batches.  Pure host work -- safe to run on a worker thread."""
+        then shuffle + batches.  Pure host work -- safe to run on a worker thread.  (The epoch that has been in the making
+        since construction -- ``sampler_seed`` -- is handed out first.)"""
+        if self._first_epoch is not None:
+            pre, self._first_epoch = self._first_epoch, None
+            return pre.take()
+        return self._sample_epoch_host_now()
+
+    def _sample_epoch_host_now(self):
         out = {}
         if self.model == "SGL":
             masks = []
@@ -912,15 +942,16 @@ class EpochPrefetcher:
     works on epoch e.  The sampler is sequential by construction (one MT19937 stream with
     data-dependent rejection), so a single producer is all there is to overlap."""
 
-    def __init__(self, trainer: FusedTrainer):
+    def __init__(self, trainer: FusedTrainer, first: bool = False):
         self.trainer = trainer
         self._thread = None
         self._result = None
         self._error = None
+        self._first = first           # the trainer's own early start: draws directly (sample_epoch_host hands THIS one out)
 
     def _work(self):
         try:
-            self._result = self.trainer.sample_epoch_host()
+            self._result = self.trainer._sample_epoch_host_now() if self._first else self.trainer.sample_epoch_host()
         except BaseException as e:  # surfaced on the consumer side
             self._error = e
 

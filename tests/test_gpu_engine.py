@@ -125,6 +125,30 @@ def test_engine_backed_model_class_ranks_like_reference(golden_models, golden_me
     assert np.allclose(model.predict(u)[model.data.item[rec[u][0][0]]], rec[u][0][1], rtol=1e-5)
 
 
+def test_first_epoch_sampled_during_construction_is_the_seeds_first_epoch(golden_models, golden_meta, tiny_data):
+    """FusedTrainer(sampler_seed=s) draws its first epoch on a host thread while the graph, plans and calibration are built:
+    same epochs as seeding after construction; another seed afterwards drops that epoch AND the permuted edge order."""
+    def epochs(tr, n=2):
+        out = []
+        for _ in range(n):
+            tr.begin_epoch()
+            out.append(tuple(a.copy() for a in tr.epoch_node_ids()))
+        return out
+    plain = make_trainer("XSimGCL", golden_models, golden_meta, tiny_data, noise_fn=None)
+    plain.seed_sampler(5)
+    want5 = epochs(plain)
+    early = make_trainer("XSimGCL", golden_models, golden_meta, tiny_data, noise_fn=None, sampler_seed=5)
+    assert early._first_epoch is not None
+    early.seed_sampler(5)                                   # (what bench.Runner does: the same seed keeps the epoch)
+    got5 = epochs(early)
+    assert early._first_epoch is None and all(np.array_equal(a, b) for e, w in zip(got5, want5) for a, b in zip(e, w))
+    other = make_trainer("XSimGCL", golden_models, golden_meta, tiny_data, noise_fn=None, sampler_seed=5)
+    other.seed_sampler(7)
+    fresh = make_trainer("XSimGCL", golden_models, golden_meta, tiny_data, noise_fn=None)
+    fresh.seed_sampler(7)
+    assert all(np.array_equal(a, b) for e, w in zip(epochs(other), epochs(fresh)) for a, b in zip(e, w))
+
+
 def _bare_recommender(data, user_emb, item_emb, max_n):
     from selfrec_amd.base import graph_recommender as gr
     rec = gr.GraphRecommender.__new__(gr.GraphRecommender)

@@ -59,11 +59,12 @@ def main():
         t = stage("device graph (normalised CSR, column-class order, SpMM plans)", t)
         torch.manual_seed(0)
         tr = FusedTrainer(data, args.emb, model="XSimGCL", n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2,
-                          layer_cl=1, batch_size=2048, use_graph=True)
-        t = stage("FusedTrainer (tables, workspaces, sampler, replanned CSR, XCD calibration)", t)
+                          layer_cl=1, batch_size=2048, use_graph=True,
+                          sampler_seed=None if os.environ.get("STARTUP_NO_EARLY_SAMPLING") else 1)
+        t = stage("FusedTrainer (tables, workspaces, replanned CSR, XCD calibration; the first epoch is being sampled on a thread)", t)
         tr.seed_sampler(1)
         host = tr.sample_epoch_host()
-        t = stage("first epoch sampled on the host (shuffle + batches + unique ids)", t)
+        t = stage("first epoch: what of its sampling was not hidden under the construction", t)
         tr.upload_epoch(host)
         t = stage("epoch upload", t)
         tr.step()
