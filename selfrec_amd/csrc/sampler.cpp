@@ -178,8 +178,9 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
     const uint32_t b = s->sig_bit(u, s->edge_i[e]);
     s->sig[(size_t)s->sig_off[u] + (b >> 6)] |= 1ULL << (b & 63);
   }
-  s->seen_u.assign((size_t)(n_users + 63) / 64, 0);
-  s->seen_i.assign((size_t)(n_items + 63) / 64, 0);
+  // (two levels each: one bit per id, then one bit per 64-bit word of those -- sorted_unique)
+  s->seen_u.assign((size_t)(n_users + 63) / 64 + ((size_t)(n_users + 63) / 64 + 63) / 64, 0);
+  s->seen_i.assign((size_t)(n_items + 63) / 64 + ((size_t)(n_items + 63) / 64 + 63) / 64, 0);
   *out = s;
   return SRH_OK;
 }
@@ -290,22 +291,35 @@ srh_status_t srh_sampler_next_batch(srh_sampler_t* s, int64_t ptr, int64_t batch
   return SRH_OK;
 }
 
-// sorted unique ids of one batch: mark a bitmap, then sweep the touched 64-bit words in order
-static int32_t sorted_unique(const int32_t* src, int64_t n, int32_t* dst, std::vector<uint64_t>& seen) {
-  int32_t lo = INT32_MAX, hi = -1;
+// sorted unique ids of one batch: mark a bitmap, then visit its non-empty 64-bit words in order.  The words are found
+// through a SECOND bitmap with one bit per word of the first: a batch of 2048 ids touches at most 2048 of the 15.6 k words a
+// million users span, and sweeping all of them for every batch was a third of an epoch's sampling at the 1 M x 500 k shape
+// (2.7 of 7.6 s on the build host; with the summary 0.3).  `seen` holds both levels: [words of ids | words of words].
+static int32_t sorted_unique(const int32_t* src, int64_t n, int32_t* dst, std::vector<uint64_t>& seen, size_t n_words) {
+  uint64_t* l0 = seen.data();
+  uint64_t* l1 = seen.data() + n_words;
+  int32_t lo = INT32_MAX, hi = -1;                 // range of touched level-1 words
   for (int64_t k = 0; k < n; ++k) {
     const int32_t v = src[k];
-    seen[(size_t)v >> 6] |= 1ULL << (v & 63);
-    lo = std::min(lo, v >> 6);
-    hi = std::max(hi, v >> 6);
+    const int32_t w = v >> 6;
+    l0[w] |= 1ULL << (v & 63);
+    l1[w >> 6] |= 1ULL << (w & 63);
+    lo = std::min(lo, w >> 6);
+    hi = std::max(hi, w >> 6);
   }
   int32_t m = 0;
-  for (int32_t wd = lo; wd <= hi; ++wd) {
-    uint64_t bits = seen[wd];
-    seen[wd] = 0;
-    while (bits) {
-      dst[m++] = (wd << 6) + __builtin_ctzll(bits);
-      bits &= bits - 1;
+  for (int32_t w1 = lo; w1 <= hi; ++w1) {
+    uint64_t words = l1[w1];
+    l1[w1] = 0;
+    while (words) {
+      const int32_t wd = (w1 << 6) + __builtin_ctzll(words);
+      words &= words - 1;
+      uint64_t bits = l0[wd];
+      l0[wd] = 0;
+      while (bits) {
+        dst[m++] = (wd << 6) + __builtin_ctzll(bits);
+        bits &= bits - 1;
+      }
     }
   }
   return m;
@@ -328,8 +342,8 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
   for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
     int64_t cnt = batch_into(s, ptr, batch_size, n_negs, h_u + ptr, h_i + ptr, h_j + ptr * n_negs);
     if (want_uniq) {
-      h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, s->seen_u);
-      h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, s->seen_i);
+      h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, s->seen_u, (size_t)(s->n_users + 63) / 64);
+      h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, s->seen_i, (size_t)(s->n_items + 63) / 64);
     }
     ptr += cnt;
   }
