@@ -81,6 +81,15 @@ struct MT19937 {
     y ^= (y >> 18);
     return y;
   }
+  // the k-th output AFTER the next one, without drawing it (k < N - pos: outputs of the current block only)
+  inline uint32_t peek_u32(int at) const {
+    uint32_t y = mt[at];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= (y >> 18);
+    return y;
+  }
   // n in [1, 2^32)
   inline uint32_t randbelow(uint32_t n) {
     const int shift = __builtin_clz(n);  // 32 - bit_length(n)
@@ -94,7 +103,8 @@ struct MT19937 {
 
 struct srh_sampler {
   int64_t n_users = 0, n_items = 0, n_edges = 0;
-  std::vector<int32_t> edge_u, edge_i;      // as given at create time
+  struct Edge { int32_t u, i; };
+  std::vector<Edge> edges;                  // as given at create time (one cache line per edge, not one per array)
   std::vector<uint32_t> order;              // persistent order of training_data (edge numbers)
   std::vector<int64_t> row_ptr;             // user -> sorted positive items
   std::vector<int32_t> row_items;
@@ -102,20 +112,23 @@ struct srh_sampler {
   // few MB in total, cache resident).  A clear bit proves "not rated" without touching the user's
   // item list -- the common case by far; once the bitmap is as large as the catalogue it is exact.
   std::vector<uint64_t> sig;
-  std::vector<uint32_t> sig_off;            // first 64-bit word of user u's bitmap
-  std::vector<uint8_t> sig_log2;            // log2(bits) of user u's bitmap; 255 = exact item bitmap
+  // per user, in ONE word (the sampler's inner loop misses the cache on every array it touches per pair: 5 -> 3 lines):
+  //   info >> 8  = first 64-bit word of user u's bitmap;  info & 255 = log2(bits) of it, 255 = exact item bitmap
+  std::vector<uint64_t> sig_info;
   std::vector<uint64_t> seen_u, seen_i;     // scratch bitmaps for the per-batch sorted unique ids
   MT19937 rng;
   bool seeded = false;
 
-  inline uint32_t sig_bit(int32_t u, int32_t item) const {
-    const uint8_t lg = sig_log2[u];
+  static inline uint32_t sig_bit_of(uint64_t info, int32_t item) {
+    const uint32_t lg = (uint32_t)(info & 255);
     return lg == 255 ? (uint32_t)item : ((uint32_t)item * 0x9E3779B1U) >> (32 - lg);
   }
+  inline uint32_t sig_bit(int32_t u, int32_t item) const { return sig_bit_of(sig_info[u], item); }
   inline bool rated(int32_t u, int32_t item) const {
-    const uint32_t b = sig_bit(u, item);
-    if (!((sig[(size_t)sig_off[u] + (b >> 6)] >> (b & 63)) & 1ULL)) return false;
-    if (sig_log2[u] == 255) return true;
+    const uint64_t info = sig_info[u];
+    const uint32_t b = sig_bit_of(info, item);
+    if (!((sig[(size_t)(info >> 8) + (b >> 6)] >> (b & 63)) & 1ULL)) return false;
+    if ((info & 255) == 255) return true;
     const int32_t* lo = row_items.data() + row_ptr[u];
     const int32_t* hi = row_items.data() + row_ptr[u + 1];
     return std::binary_search(lo, hi, item);
@@ -134,15 +147,13 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
   srh_sampler* s = new (std::nothrow) srh_sampler();
   if (!s) { srh::set_error("sampler_create: out of memory"); return SRH_ERR_NOMEM; }
   s->n_users = n_users; s->n_items = n_items; s->n_edges = n_edges;
-  if (n_edges > 0) {
-    s->edge_u.assign(h_edge_user, h_edge_user + n_edges);
-    s->edge_i.assign(h_edge_item, h_edge_item + n_edges);
-  }
+  s->edges.resize((size_t)n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) s->edges[(size_t)e] = {h_edge_user[e], h_edge_item[e]};
   s->order.resize(n_edges);
   for (int64_t e = 0; e < n_edges; ++e) s->order[e] = (uint32_t)e;
   s->row_ptr.assign(n_users + 1, 0);
   for (int64_t e = 0; e < n_edges; ++e) {
-    int32_t u = s->edge_u[e], it = s->edge_i[e];
+    int32_t u = s->edges[e].u, it = s->edges[e].i;
     if (u < 0 || u >= n_users || it < 0 || it >= n_items) {
       delete s;
       srh::set_error("sampler_create: edge %lld (%d,%d) out of range", (long long)e, u, it);
@@ -153,30 +164,28 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
   for (int64_t u = 0; u < n_users; ++u) s->row_ptr[u + 1] += s->row_ptr[u];
   s->row_items.resize(n_edges);
   std::vector<int64_t> fill(s->row_ptr.begin(), s->row_ptr.end() - 1);
-  for (int64_t e = 0; e < n_edges; ++e) s->row_items[fill[s->edge_u[e]]++] = s->edge_i[e];
+  for (int64_t e = 0; e < n_edges; ++e) s->row_items[fill[s->edges[e].u]++] = s->edges[e].i;
   for (int64_t u = 0; u < n_users; ++u)
     std::sort(s->row_items.begin() + s->row_ptr[u], s->row_items.begin() + s->row_ptr[u + 1]);
-  s->sig_off.resize(n_users);
-  s->sig_log2.resize(n_users);
+  s->sig_info.resize(n_users);
   size_t words = 0;
   for (int64_t u = 0; u < n_users; ++u) {
     const int64_t deg = s->row_ptr[u + 1] - s->row_ptr[u];
     int lg = 8;
     while ((int64_t(1) << lg) < 16 * deg) ++lg;
-    s->sig_off[u] = (uint32_t)words;
     if ((int64_t(1) << lg) >= n_items) {                  // as large as the catalogue: make it exact
-      s->sig_log2[u] = 255;
+      s->sig_info[u] = ((uint64_t)words << 8) | 255u;
       words += (size_t)(n_items + 63) / 64;
     } else {
-      s->sig_log2[u] = (uint8_t)lg;
+      s->sig_info[u] = ((uint64_t)words << 8) | (uint64_t)lg;
       words += (size_t)1 << (lg - 6);
     }
   }
   s->sig.assign(words, 0);
   for (int64_t e = 0; e < n_edges; ++e) {
-    const int32_t u = s->edge_u[e];
-    const uint32_t b = s->sig_bit(u, s->edge_i[e]);
-    s->sig[(size_t)s->sig_off[u] + (b >> 6)] |= 1ULL << (b & 63);
+    const int32_t u = s->edges[e].u;
+    const uint32_t b = s->sig_bit(u, s->edges[e].i);
+    s->sig[(size_t)(s->sig_info[u] >> 8) + (b >> 6)] |= 1ULL << (b & 63);
   }
   // (two levels each: one bit per id, then one bit per 64-bit word of those -- sorted_unique)
   s->seen_u.assign((size_t)(n_users + 63) / 64 + ((size_t)(n_users + 63) / 64 + 63) / 64, 0);
@@ -255,26 +264,61 @@ static inline int64_t batch_into(srh_sampler_t* s, int64_t ptr, int64_t batch_si
   const uint32_t n_items = (uint32_t)s->n_items;
   int64_t w = 0;
   constexpr int64_t kAhead = 32;
+  // The membership test of a candidate reads one word of the user's signature: cache resident at the Yelp2018 shape, a miss
+  // per draw once the signatures are tens of MB (1 M users).  The candidate of pair p + kSpec is known before it is drawn:
+  // the generator's coming outputs can be LOOKED AT (peek_u32: the current block of 624 words, nothing is consumed), and unless
+  // an earlier candidate is rejected as rated -- rare -- the pair will draw exactly those.  So a cursor runs kSpec pairs ahead,
+  // replays randbelow on the peeked outputs and prefetches the word the real test will read.  Purely a hint: the draws
+  // themselves are the loop below, unchanged; a rejection just restarts the cursor at the real position.
+  constexpr int64_t kSpec = 8;
+  const int shift = __builtin_clz(n_items);
+  int64_t spec_p = ptr;              // next pair the cursor will look at
+  int spec_pos = s->rng.pos;         // generator position that pair is expected to start at
+  bool spec_ok = true;               // (false: ran into the end of the block; resumes after the refill)
+  int prev_pos = s->rng.pos;
+  auto speculate = [&](int64_t upto) {
+    while (spec_ok && spec_p < upto && spec_p < end) {
+      const int32_t un = s->edges[s->order[spec_p]].u;
+      const uint64_t info = s->sig_info[un];
+      int q = spec_pos;
+      for (int32_t m = 0; m < n_negs; ++m) {
+        uint32_t r;
+        do {
+          if (q >= MT19937::N) { spec_ok = false; return; }
+          r = s->rng.peek_u32(q++) >> shift;
+        } while (r >= n_items);
+        const uint32_t b = srh_sampler::sig_bit_of(info, (int32_t)r);
+        __builtin_prefetch(s->sig.data() + (size_t)(info >> 8) + (b >> 6));
+      }
+      spec_pos = q;
+      ++spec_p;
+    }
+  };
   for (int64_t p = ptr; p < end; ++p) {
     if (p + kAhead < end) {                       // hide the two dependent random accesses
       const uint32_t ea = s->order[p + kAhead];
-      __builtin_prefetch(s->edge_u.data() + ea);
-      __builtin_prefetch(s->edge_i.data() + ea);
+      __builtin_prefetch(s->edges.data() + ea);
     }
     if (p + kAhead / 2 < end) {
-      const int32_t un = s->edge_u[s->order[p + kAhead / 2]];
-      __builtin_prefetch(s->sig_off.data() + un);
-      __builtin_prefetch(s->sig_log2.data() + un);
+      const int32_t un = s->edges[s->order[p + kAhead / 2]].u;
+      __builtin_prefetch(s->sig_info.data() + un);
     }
+    if (s->rng.pos < prev_pos) spec_ok = true, spec_p = p, spec_pos = s->rng.pos;    // (a new block of outputs: look ahead again)
+    prev_pos = s->rng.pos;
+    if (spec_p <= p) spec_p = p, spec_pos = s->rng.pos;                              // (never behind the real position)
+    speculate(p + kSpec);
     const int64_t e = s->order[p];
-    const int32_t uu = s->edge_u[e];
+    const srh_sampler::Edge ed = s->edges[e];
+    const int32_t uu = ed.u;
     u[p - ptr] = uu;
-    it[p - ptr] = s->edge_i[e];
+    it[p - ptr] = ed.i;
+    bool rejected = false;
     for (int32_t m = 0; m < n_negs; ++m) {
       int32_t cand = (int32_t)s->rng.randbelow(n_items);
-      while (s->rated(uu, cand)) cand = (int32_t)s->rng.randbelow(n_items);
+      while (s->rated(uu, cand)) { cand = (int32_t)s->rng.randbelow(n_items); rejected = true; }
       neg[w++] = cand;
     }
+    if (rejected) spec_p = p + 1, spec_pos = s->rng.pos;       // the outputs moved on: the cursor's guesses are stale
   }
   return end - ptr;
 }
