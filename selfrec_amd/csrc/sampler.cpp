@@ -16,8 +16,10 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -165,8 +167,25 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
   s->row_items.resize(n_edges);
   std::vector<int64_t> fill(s->row_ptr.begin(), s->row_ptr.end() - 1);
   for (int64_t e = 0; e < n_edges; ++e) s->row_items[fill[s->edges[e].u]++] = s->edges[e].i;
-  for (int64_t u = 0; u < n_users; ++u)
-    std::sort(s->row_items.begin() + s->row_ptr[u], s->row_items.begin() + s->row_ptr[u + 1]);
+  // the per-user work below (sorting a user's items, filling a user's bitmap) touches disjoint memory: user ranges of about
+  // equal numbers of edges, one host thread each
+  int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                         n_edges / (1 << 20)));
+  if (const char* forced = std::getenv("SRH_SAMPLER_THREADS")) n_thr = std::max(1, std::min(64, std::atoi(forced)));   // (tests)
+  std::vector<int64_t> cut((size_t)n_thr + 1, n_users);
+  cut[0] = 0;
+  for (int t = 1; t < n_thr; ++t)
+    cut[(size_t)t] = std::lower_bound(s->row_ptr.begin(), s->row_ptr.end(), n_edges * t / n_thr) - s->row_ptr.begin();
+  auto over_users = [&](auto&& body) {
+    if (n_thr == 1) { body((int64_t)0, n_users); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) pool.emplace_back([&, t] { body(cut[(size_t)t], std::min<int64_t>(cut[(size_t)t + 1], n_users)); });
+    for (auto& th : pool) th.join();
+  };
+  over_users([&](int64_t u0, int64_t u1) {
+    for (int64_t u = u0; u < u1; ++u)
+      std::sort(s->row_items.begin() + s->row_ptr[u], s->row_items.begin() + s->row_ptr[u + 1]);
+  });
   s->sig_info.resize(n_users);
   size_t words = 0;
   for (int64_t u = 0; u < n_users; ++u) {
@@ -182,11 +201,16 @@ srh_status_t srh_sampler_create(srh_sampler_t** out, int64_t n_users, int64_t n_
     }
   }
   s->sig.assign(words, 0);
-  for (int64_t e = 0; e < n_edges; ++e) {
-    const int32_t u = s->edges[e].u;
-    const uint32_t b = s->sig_bit(u, s->edges[e].i);
-    s->sig[(size_t)(s->sig_info[u] >> 8) + (b >> 6)] |= 1ULL << (b & 63);
-  }
+  over_users([&](int64_t u0, int64_t u1) {            // (by user, from the grouped item lists: a user's bitmap stays in cache)
+    for (int64_t u = u0; u < u1; ++u) {
+      const uint64_t info = s->sig_info[u];
+      uint64_t* bits = s->sig.data() + (size_t)(info >> 8);
+      for (int64_t p = s->row_ptr[u]; p < s->row_ptr[u + 1]; ++p) {
+        const uint32_t b = srh_sampler::sig_bit_of(info, s->row_items[p]);
+        bits[b >> 6] |= 1ULL << (b & 63);
+      }
+    }
+  });
   // (two levels each: one bit per id, then one bit per 64-bit word of those -- sorted_unique)
   s->seen_u.assign((size_t)(n_users + 63) / 64 + ((size_t)(n_users + 63) / 64 + 63) / 64, 0);
   s->seen_i.assign((size_t)(n_items + 63) / 64 + ((size_t)(n_items + 63) / 64 + 63) / 64, 0);

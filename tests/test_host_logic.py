@@ -43,6 +43,27 @@ def test_drop_in_generator_is_bit_exact(golden_ops):
     assert np.array_equal([data.user[t[0]] for t in data.training_data], g["sampler_a_final_order_u"])
 
 
+def test_sampler_construction_on_several_threads_gives_the_same_streams(monkeypatch):
+    """srh_sampler_create sorts the users' item lists and fills their membership bitmaps on host threads (user ranges of
+    equal edge counts; large graphs only -- SRH_SAMPLER_THREADS forces a count): the epochs do not depend on it."""
+    from selfrec_amd import ops
+    rng = np.random.default_rng(3)
+    U, I, E = 5000, 700, 120000
+    u = (rng.random(E) ** 2 * U).astype(np.int32); i = (rng.random(E) ** 2 * I).astype(np.int32)
+    key = np.unique(u.astype(np.int64) * I + i)
+    u, i = (key // I).astype(np.int32), (key % I).astype(np.int32)
+    perm = rng.permutation(len(u)); u, i = u[perm], i[perm]
+    runs = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("SRH_SAMPLER_THREADS", threads)
+        smp = ops.Sampler(u, i, U, I)
+        smp.seed(11)
+        eps = [smp.epoch(512, 2, with_unique=True) for _ in range(2)]
+        runs.append([e[k].copy() for e in eps for k in ("u", "i", "j", "uniq_u", "n_uniq_i")])
+    for other in runs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0], other))
+
+
 def test_native_heap_walk_is_pythons_heapq(golden_ops):
     """srh_find_k_largest_host restates CPython's heapq (heapify, heapreplace, the stable descending sort) step for step:
     the reference's golden, and tie-heavy random vectors against the literal python walk -- ids in the same ORDER."""
