@@ -125,7 +125,7 @@ class GraphRecommender(Recommender):
 
     def _rank_marking_ties(self, ue, uid, ie, g, k):
         """ids, scores (device, k columns); a row whose best K + 1 scores hold two EQUAL neighbours carries ids[row, 0] =
-        -1 - id (``marked`` False: the kernels have no spare column to rank -- K + 1 > 128 or > the catalogue).
+        -1 - id (K + 1 > 128 or > the catalogue: no spare column to rank -- ``_mark_ties_without_spare`` finds them).
 
         The device kernels order (score desc, id asc); the reference's ``find_k_largest`` (util/algorithm.py:144-156)
         walks a size-K min-heap, and which of several equal scores it keeps, and in what order, is a property of that walk.
@@ -136,9 +136,34 @@ class GraphRecommender(Recommender):
         Cost when nothing ties: one more ranked column and one small launch; no synchronisation of its own."""
         if k + 1 > min(128, int(ie.shape[0])):
             ids, sc = self._rank(ue, uid, ie, g, k)
-            return ids, sc, False
+            return self._mark_ties_without_spare(ids, sc, ue, uid, ie, g, k), sc, True
         ids, sc = ops.topk_trim_mark_ties(*self._rank(ue, uid, ie, g, k + 1))
         return ids, sc, True
+
+    def _mark_ties_without_spare(self, ids, sc, ue, uid, ie, g, k, chunk=2048):
+        """ids with the tied rows marked (ids[row, 0] = -1 - id) when the kernels have no spare column for the (K + 1)-th
+        score (K = 128, or K = the catalogue): a row is tied when two neighbours among its K scores are equal, or when MORE
+        masked scores of its catalogue row equal its K-th score than its K places hold -- the second test re-scores the
+        rows chunk by chunk (srh_gemm_nt_f32, the ranking's own fma chain, training items at -10e8), i.e. it costs a second
+        scoring pass, paid only by this one K."""
+        tied = (sc[:, 1:] == sc[:, :-1]).any(dim=1) if k > 1 else torch.zeros(sc.shape[0], dtype=torch.bool, device=sc.device)
+        n_items = int(ie.shape[0])
+        if k < n_items:
+            kth = sc[:, k - 1]
+            held = (sc == kth[:, None]).sum(dim=1)
+            uid_l = uid.long()
+            lo, cnt = g.r_indptr[:-1].long()[uid_l], (g.r_indptr[1:] - g.r_indptr[:-1]).long()[uid_l]
+            for at in range(0, int(uid.numel()), chunk):
+                rows = slice(at, min(at + chunk, int(uid.numel())))
+                scores = ops.gemm_nt(ue[uid_l[rows]].contiguous(), ie)
+                c = cnt[rows]
+                owner = torch.repeat_interleave(torch.arange(c.numel(), device=c.device), c)
+                within = torch.arange(int(c.sum()), device=c.device) - torch.repeat_interleave(torch.cumsum(c, 0) - c, c)
+                scores[owner, g.r_indices.long()[lo[rows][owner] + within]] = MASKED_SCORE
+                tied[rows] |= (scores == kth[rows, None]).sum(dim=1) > held[rows]
+        ids = ids.clone()
+        ids[tied, 0] = -1 - ids[tied, 0]
+        return ids
 
     def _heap_order_rows(self, rows, ue, uid_host, ie, g, k, chunk=256):
         """ids (int32), scores (float32) numpy (len(rows), k) of the given query rows in the reference's heap order: their
@@ -205,15 +230,18 @@ class GraphRecommender(Recommender):
         return ids, sc
 
     def _device_user_ids(self, user_ids, device):
-        """The int32 ids on the device; test() passes the SAME cached array every epoch, so the upload happens once."""
-        cached = getattr(self, '_uid_dev_cache', None)
-        ends = (len(user_ids), int(user_ids[0]), int(user_ids[-1])) if len(user_ids) else (0, 0, 0)
-        if cached is not None and cached[0] is user_ids and cached[2] == ends and cached[1].device == torch.device(device):
-            return cached[1]
-        uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=device)
-        if isinstance(user_ids, np.ndarray):
-            self._uid_dev_cache = (user_ids, uid, ends)
-        return uid
+        """The int32 ids on the device.  The upload is cached only for the array this class owns -- the test users'
+        ids test() passes every epoch (``_test_users``: never handed out for writing); a caller's array is uploaded on every
+        call: whether it was edited in place since the last one cannot be known without reading all of it."""
+        owned = getattr(self, '_test_users_cache', None)
+        if owned is not None and user_ids is owned[2]:
+            cached = getattr(self, '_uid_dev_cache', None)
+            if cached is not None and cached[0] is user_ids and cached[1].device == torch.device(device):
+                return cached[1]
+            uid = torch.as_tensor(user_ids, device=device)
+            self._uid_dev_cache = (user_ids, uid)
+            return uid
+        return torch.as_tensor(np.asarray(user_ids, dtype=np.int32), device=device)
 
     def _test_users(self):
         """Test users in test-set order with their ids, test-set sizes and the item-name table (built once)."""
@@ -223,11 +251,11 @@ class GraphRecommender(Recommender):
             uid = np.fromiter((self.data.user[u] for u in users), dtype=np.int32, count=len(users))
             id2item = self.data.id2item
             names = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)
-            cached = self._test_users_cache = (self.data.test_set, users, uid, names)
+            cached = self._test_users_cache = (self.data.test_set, users, uid, names, dict.fromkeys(users))
         return cached[1:]
 
     def test(self):
-        users, uid, names = self._test_users()
+        users, uid, names, keys = self._test_users()
         # (the device top-K kernels keep K <= 128 candidates per user in LDS: a longer list, or one longer than the
         # catalogue, takes the reference's per-user loop below -- slow, but every config the reference runs, runs)
         on_device = self.max_N <= min(DEVICE_TOPK_MAX, self.data.item_num)
@@ -241,7 +269,7 @@ class GraphRecommender(Recommender):
             # reads like the reference's {user: [(item, score), ...]}; rows are built on access and
             # ranking_evaluation works on the arrays (same strings)
             return RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=self.data.test_set,
-                               per_user=got[3] if len(got) > 3 else None)
+                               per_user=got[3] if len(got) > 3 else None, keys=keys)
         rec_list = {}
         for user in users:                                   # models with a custom predict()
             candidates = self.predict(user)

@@ -13,6 +13,18 @@ void set_error(const char* fmt, ...) {
 }
 const std::string& last_error() { return g_last_error; }
 
+int cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 srh_status_t check_fetch_args(const srh_batch_fetch_args_t* in, srh_batch_fetch_args_t& out) {
   SRH_REQUIRE(in, "batch_fetch: null argument");
   SRH_REQUIRE(in->d_epoch_u && in->d_epoch_i && in->d_epoch_j && in->d_cursor && in->d_stage_u && in->d_stage_i &&

@@ -39,6 +39,9 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // lanes per embedding row when each lane owns one float4 of it
 inline bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
+// compute units of the current device (cached per device; 256 on MI355X)
+int cu_count();
+
 // the checks srh_batch_fetch promises; `out` = the args as the kernels take them (optional groups normalised)
 srh_status_t check_fetch_args(const srh_batch_fetch_args_t* in, srh_batch_fetch_args_t& out);
 

@@ -6,6 +6,7 @@
 // (v_mfma_f32_16x16x4_f32: exact f32 fma chains, so the 1e-4 parity budget is untouched).
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -348,10 +349,64 @@ constexpr int kNceMaxProblems = 4;
 struct NceBatch {
   NceWs w[kNceMaxProblems];
   int count;
-  int splits;      // key-range splits per query tile (1..kNceSplits)
+  int splits;      // key-range splits per query tile (1..kNceSplits): the split-16 passes' fixed setting
+  int slots;       // > 0: the tile passes are PERSISTENT -- `slots` workgroups share the (query block, key range) tasks of
+                   // nce_plan, cut on the device from the live row counts (the all-f32 passes)
+  int f32_only;    // the prep kernel leaves the 16-bit operand images unwritten
 };
 
 __host__ __device__ inline int64_t nce_pad(int64_t n) { return (n + 63) / 64 * 64; }
+
+// ---- the all-f32 passes' work list ---------------------------------------------------------------------------------------
+// The row counts n_k of a step (unique users / items of the batch: ~1880 and ~1620 of 2048 on the Yelp shape) exist only on
+// the device, and the passes' work goes with n_k^2: a grid cut on the host for n_max runs 36 % more key blocks than the
+// batch holds and leaves a sixth of the CUs without a workgroup.  So the f32 passes launch one workgroup per CU and every
+// workgroup derives the SAME task list from the device counts: problem k is cut into qb_k = ceil(np_k / 128) query blocks
+// (8 waves x 16 queries) times splits_k key ranges of per_k 32-key blocks, with the block budget T per task the one that
+// minimises rounds(T) x T (rounds = tasks over workgroups; T >= kb_k / 16: the split partials' workspace holds 16).
+struct NcePlan {
+  int n[kNceMaxProblems], per[kNceMaxProblems], splits[kNceMaxProblems], first[kNceMaxProblems + 1];
+};
+constexpr int kNceQueryBlock = 128, kNceKeyBlock = 32, kNceMaxPer = 128;
+
+
+__device__ __forceinline__ void nce_plan(const NceBatch& b, NcePlan& p) {
+  int qb[kNceMaxProblems], kb[kNceMaxProblems];
+  int t_min = 1;
+  long long work = 0;
+#pragma unroll
+  for (int k = 0; k < kNceMaxProblems; ++k) {
+    int n = 0;
+    if (k < b.count) n = max(0, b.w[k].d_n ? min(*b.w[k].d_n, b.w[k].n_max) : b.w[k].n_max);
+    p.n[k] = n;
+    const int np = (int)nce_pad(n);
+    qb[k] = (np + kNceQueryBlock - 1) / kNceQueryBlock;
+    kb[k] = np / kNceKeyBlock;
+    t_min = max(t_min, (kb[k] + kNceSplits - 1) / kNceSplits);
+    work += (long long)qb[k] * kb[k];
+  }
+  int t = max(t_min, (int)((work + b.slots - 1) / b.slots));
+  int best_t = t;
+  long long best_cost = -1;
+  for (int it = 0; it < 32; ++it, ++t) {
+    int tasks = 0;
+#pragma unroll
+    for (int k = 0; k < kNceMaxProblems; ++k) tasks += qb[k] * ((kb[k] + t - 1) / t);
+    const int rounds = (tasks + b.slots - 1) / b.slots;
+    const long long cost = (long long)rounds * t;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_t = t; }
+    if (rounds <= 1) break;
+  }
+  p.first[0] = 0;
+#pragma unroll
+  for (int k = 0; k < kNceMaxProblems; ++k) {
+    const int sp = kb[k] > 0 ? (kb[k] + best_t - 1) / best_t : 0;
+    p.splits[k] = sp;
+    p.per[k] = sp > 0 ? (kb[k] + sp - 1) / sp : 0;       // the even cut of kb_k over its splits (<= best_t)
+    p.first[k + 1] = p.first[k] + qb[k] * sp;
+  }
+}
+
 
 inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
   NceWs w;
@@ -415,6 +470,7 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
     // an exact power of two: hi = f16(32 x), lo = f16(32 x - hi) represents x to 2^-22 -- |x| <= 1, so hi <= 32 and lo
     // stays a normal f16 down to |x| ~ 1e-3, below which its absolute error is < 2^-25 / 32), V operand of the P.V
     // product as bf16 hi + lo (its partner, the weights, needs f32's exponent range)
+    if (batch.f32_only) return;
     const int view = second ? 1 : 0;
     constexpr int D = LPR * 4;
     const float f[4] = {o.x, o.y, o.z, o.w};
@@ -471,110 +527,6 @@ __global__ __launch_bounds__(256) void nce_prep_bpr1(NceBatch batch, BprArgs bpr
 }
 
 
-// One wave = 16 "query" rows against a slice of the "key" rows.
-//   PASS2 == false : Q = v1n, K = V = v2n, w_ij = exp(s_ij - c)              -> O1, l
-//   PASS2 == true  : Q = v2n, K = V = v1n, w_ij = exp(s_ji - c) / l_(key)    -> O2
-// with s = <q,k>/tau and c = 1/tau >= max s (rows are unit vectors), so no running max.
-// Swapped product (S^T = K Q^T) puts a query's weights for keys 4g+r in lane (q, g), which
-// is exactly the A-operand layout of the following  P V  product -- no LDS, no permutes.
-template <int D, bool PASS2>
-__global__ __launch_bounds__(256) void nce_tile(NceBatch batch, float inv_tau) {
-  constexpr int DQ = D / 4;      // floats of a row per lane for the S product (k-steps)
-  constexpr int NT = D / 16;     // 16-column n-tiles of the PV product
-  const NceWs& w = batch.w[blockIdx.z];
-  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
-  const int np = (int)w.np;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c16 = lane & 15, g = lane >> 4;
-  const int q0 = (blockIdx.x * 4 + wv) * 16;
-  const int ks = blockIdx.y;
-  if (q0 >= np) return;
-  const float* Q = PASS2 ? w.v2n : w.v1n;
-  const float* K = PASS2 ? w.v1n : w.v2n;
-  const int per = ((np + batch.splits - 1) / batch.splits + 31) / 32 * 32;
-  const int kb = ks * per, ke = min(np, kb + per);
-
-  float qreg[DQ];
-  {
-    const float4* src = reinterpret_cast<const float4*>(Q + (size_t)(q0 + c16) * D + g * DQ);
-#pragma unroll
-    for (int t = 0; t < DQ / 4; ++t) {
-      float4 v = src[t];
-      qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
-    }
-  }
-  floatx4 O[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) O[t] = (floatx4){0.f, 0.f, 0.f, 0.f};
-  float lsum = 0.f;
-
-  for (int j0 = kb; j0 < ke; j0 += 32) {     // two 16-key tiles per iteration
-    float k0[DQ], k1[DQ];
-    {
-      const float4* s0 = reinterpret_cast<const float4*>(K + (size_t)(j0 + c16) * D + g * DQ);
-      const float4* s1 = reinterpret_cast<const float4*>(K + (size_t)(j0 + 16 + c16) * D + g * DQ);
-#pragma unroll
-      for (int t = 0; t < DQ / 4; ++t) {
-        float4 a = s0[t], b = s1[t];
-        k0[4 * t + 0] = a.x; k0[4 * t + 1] = a.y; k0[4 * t + 2] = a.z; k0[4 * t + 3] = a.w;
-        k1[4 * t + 0] = b.x; k1[4 * t + 1] = b.y; k1[4 * t + 2] = b.z; k1[4 * t + 3] = b.w;
-      }
-    }
-    float vv[2][4][NT];   // value rows for the PV product: key j0 + 16*h + 4g + s
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float4* vs = reinterpret_cast<const float4*>(K + (size_t)(j0 + 16 * h + 4 * g + s) * D + c16 * NT);
-#pragma unroll
-        for (int t = 0; t < NT / 4; ++t) {
-          float4 x = vs[t];
-          vv[h][s][4 * t + 0] = x.x; vv[h][s][4 * t + 1] = x.y; vv[h][s][4 * t + 2] = x.z; vv[h][s][4 * t + 3] = x.w;
-        }
-      }
-    floatx4 a0 = (floatx4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-    for (int s = 0; s < DQ; ++s) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[s], qreg[s], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[s], qreg[s], a1, 0, 0, 0);
-    }
-    float wgt[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = j0 + 16 * h + 4 * g + r;
-        const float sraw = (h == 0) ? a0[r] : a1[r];
-        float e = expf(sraw * inv_tau - inv_tau);
-        if (PASS2) e *= w.invl[min(key, np - 1)];
-        wgt[h][r] = (key < n) ? e : 0.f;
-        lsum += wgt[h][r];
-      }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          O[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[h][s], vv[h][s][t], O[t], 0, 0, 0);
-  }
-
-  // O[t][r] = out[query q0 + 4g + r][column NT*c16 + t]
-  float* op = w.opart + ((size_t)ks * np + q0) * D;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float* rowp = op + (size_t)(4 * g + r) * D + c16 * NT;
-#pragma unroll
-    for (int t = 0; t < NT / 4; ++t)
-      reinterpret_cast<float4*>(rowp)[t] = make_float4(O[4 * t + 0][r], O[4 * t + 1][r], O[4 * t + 2][r], O[4 * t + 3][r]);
-  }
-  if (!PASS2) {
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    if (g == 0) w.lpart[(size_t)ks * np + q0 + c16] = lsum;
-  }
-}
-
 // Split 16-bit arithmetic of nce_tile_lds (the default path).  An f32 operand x is carried as a short sum of 16-bit
 // pieces and a product a.b as the cross terms that matter, each one MFMA at 16x the f32-MFMA rate, f32 accumulation:
 //   similarity product S = Q K^T (the logits, and through them the loss): f16 pieces of 32 x -- hi = f16(32 x),
@@ -620,7 +572,8 @@ __device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, floa
 // gradients of both views through the normalisation and scatter them.  Returns the row's loss term
 // (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
 template <int LPR>
-__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub, float4* scr) {
+__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub, float4* scr,
+                                                 int splits) {
   const bool valid = i < n;
   const int ii = valid ? i : 0;
   const size_t at = (size_t)ii * LPR + sub;
@@ -632,15 +585,18 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const int dst = w.idx ? w.idx[ii] : ii;
   float4 O1 = f4_zero(), O2 = f4_zero();
   float l = 0.f;
-#pragma unroll
-  for (int k0 = 0; k0 < kNceUsedSplits; k0 += 8) {     // eight splits' loads in flight at a time
+  for (int k0 = 0; k0 < splits; k0 += 8) {             // eight splits' loads in flight at a time
     float4 p1[8], p2[8];
     float lp[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      p1[k] = reinterpret_cast<const float4*>(w.opart + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
-      p2[k] = reinterpret_cast<const float4*>(w.opart2 + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
-      lp[k] = w.lpart[(size_t)(k0 + k) * w.np + ii];
+      p1[k] = p2[k] = f4_zero();
+      lp[k] = 0.f;
+      if (k0 + k < splits) {
+        p1[k] = reinterpret_cast<const float4*>(w.opart + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
+        p2[k] = reinterpret_cast<const float4*>(w.opart2 + (size_t)(k0 + k) * w.np * (LPR * 4))[at];
+        lp[k] = w.lpart[(size_t)(k0 + k) * w.np + ii];
+      }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                      // split order: the order pass 2 folded 1 / l in
@@ -898,68 +854,320 @@ __global__ __launch_bounds__(64 * WAVES) void nce_tile_lds(NceBatch batch, float
   }
 }
 
-template <int LPR, bool PASS2>
-__global__ __launch_bounds__(256) void nce_finish(NceBatch batch, NceFinishArgs a) {
-  constexpr int G = 64 / LPR;
-  const NceWs& w = batch.w[blockIdx.z];
-  const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
-  if (n <= 0) return;
-  const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
-  const int i = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + g;
-  const bool valid = i < n;
-  const int ii = valid ? i : 0;
-  const size_t at = (size_t)ii * LPR + sub;
-  float4 O = f4_zero();
-  float l = 0.f;
-  for (int ks = 0; ks < batch.splits; ++ks) {
-    O = f4_add(O, reinterpret_cast<const float4*>(w.opart + (size_t)ks * w.np * (LPR * 4))[at]);
-    if (!PASS2) l += w.lpart[(size_t)ks * w.np + ii];
-  }
-  const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
-  const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
-  const float coef = a.loss_scale * a.inv_tau / (float)n;
-  float4 dn;                      // gradient w.r.t. the normalised row
-  float norm;
-  float4 self;
-  if (!PASS2) {
-    const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
-    const float lse = a.inv_tau + logf(l);
-    double part = wave_sum_d((valid && sub == 0) ? (double)(lse - sii) : 0.0);
-    if (lane == 0) w.losspart[(blockIdx.x * 256u + threadIdx.x) >> 6] = part;   // folded by the PASS2 launch
-    const float il = 1.0f / l;
-    if (valid && sub == 0) w.invl[i] = il;
-    dn = make_float4(coef * (O.x * il - vb.x), coef * (O.y * il - vb.y), coef * (O.z * il - vb.z), coef * (O.w * il - vb.w));
-    norm = w.norm1[ii];
-    self = va;
+
+// ---- SRH_NCE_F32: both n x n x d products of a pass on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds) -----------------
+// Same dataflow and conventions as nce_tile_lds (swapped S^T = K Q^T so a lane's weights ARE its A fragment of the P.V
+// product; the pair's own weight kept out of the sums, e_ii left in w.ediag), on the f32 rows v1n / v2n themselves.
+// The matrix pipe is the bound (2 x 2 n^2 d flops per pass at 64 flop / clk / SIMD), so the kernel is built to keep it
+// issuing:
+//   * one PERSISTENT workgroup per CU, 8 waves x 16 queries, tasks cut on the device from the live row counts (nce_plan);
+//   * the task's key rows arrive through a ring of eight 32-key blocks in LDS, filled by direct global->LDS loads two
+//     chunks (4 blocks) ahead -- one barrier per 64 keys; ONE f32 image serves both products: rows are stored with their
+//     16-byte chunks XOR-swizzled by the row number, the S product reads chunk g + 4 t of row c16 and the P.V product chunk
+//     (c16 + 4) % 16 of row 4 g + r: both conflict-free under ds_read_b128's lane groups {0-3, 12-15, 20-27}, ...;
+//   * a wave's own stream is software-pipelined: S(j + 1)'s 32 MFMAs are issued with block j's exp / mask VALU work in
+//     their shadow, then P.V(j)'s 32 MFMAs with the LDS reads of block j + 2's operands in theirs.
+template <int D>
+struct NceF32 {
+  static constexpr int kBlockBytes = kNceKeyBlock * D * 4;       // one 32-key block of f32 rows
+  static constexpr int kSlots = 8;
+  static constexpr int kLoadsPerBlock = kBlockBytes / 1024 / 8;  // direct-load instructions per wave per block
+  static constexpr int kLds = kSlots * kBlockBytes + kNceMaxPer * kNceKeyBlock * 4;
+};
+
+// LDS reads the compiler does not see as LDS reads.  Every ds_read the compiler emits itself after a direct global->LDS
+// load waits for vmcnt(0) -- it cannot tell which bytes the load fills -- which would drain the ring's run-ahead at every
+// block.  These are issued as opaque instructions; lds_wait() is the lgkmcnt(0) their consumers sit behind (the operands
+// pass through it, so no use can be scheduled above it).
+template <int OFFSET>
+__device__ __forceinline__ floatx4 lds_read_f4_async(unsigned addr) {
+  static_assert(OFFSET >= 0 && OFFSET < 65536 && OFFSET % 16 == 0, "ds_read_b128 offset field");
+  floatx4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFFSET));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(floatx4 (&x)[N]);
+// two operand sets behind one wait (the wait covers every outstanding read, but only the registers it NAMES are ordered
+// behind it for the compiler: a set left out may be consumed above it)
+__device__ __forceinline__ void lds_wait(floatx4 (&x)[4], floatx4 (&y)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(floatx4 (&x)[N]) {
+  static_assert(N == 4 || N == 8 || N == 16, "lds_wait: 4, 8 or 16 registers quads");
+  if constexpr (N == 4) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+  } else if constexpr (N == 8) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
   } else {
-    if (blockIdx.x == 0 && threadIdx.x < 64) {     // fixed-order fold of the per-wave loss partials
-      const int n_waves = (int)(w.np / G);
-      double t = 0.0;
-      for (int k = threadIdx.x; k < n_waves; k += 64) t += w.losspart[k];
-      t = wave_sum_d(t);
-      if (threadIdx.x == 0) atomicAdd(a.loss, (double)a.loss_scale * t / (double)n);   // one per problem
-    }
-    dn = make_float4(coef * (O.x - va.x), coef * (O.y - va.y), coef * (O.z - va.z), coef * (O.w - va.w));
-    norm = w.norm2[ii];
-    self = vb;
-  }
-  // backward of v / max(||v||, 1e-12)
-  const float proj = group_sum<LPR>(f4_dot(self, dn));
-  float4 dv;
-  if (norm > 1e-12f) {
-    dv = make_float4((dn.x - self.x * proj) / norm, (dn.y - self.y * proj) / norm,
-                     (dn.z - self.z * proj) / norm, (dn.w - self.w * proj) / norm);
-  } else {
-    dv = f4_scale(dn, 1e12f);
-  }
-  if (valid) {
-    const int dst = w.idx ? w.idx[i] : i;
-    // atomic: BPR's scatter adds to the same rows
-    __shared__ float4 s_scr[4][64];
-    atomic_add_row<LPR>((PASS2 ? w.g2 : w.g1) + (size_t)dst * LPR * 4, dv, sub, s_scr[threadIdx.x >> 6]);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
   }
 }
 
+// 16 bytes per lane from `base` + lane_off + wave_off (raw buffer of `bytes` bytes) into LDS at `lds` + 16 lane: one
+// buffer_load_dwordx4 ... lds.  (A __device__ function of its own: with the buffer-resource type in a __global__ body the
+// host pass of hipcc 7.2 silently drops the kernel's stub.)
+__device__ __forceinline__ void buffer_to_lds16(const void* base, int bytes, void* lds, int lane_off, int wave_off) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, lane_off, wave_off, 0, 0);
+}
+
+template <int D, bool PASS2>
+__global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_tau) {
+  constexpr int DQ = D / 4;            // k-steps of the S product (dims per lane)
+  constexpr int NT = D / 16;           // 16-column n-tiles of the P.V product
+  constexpr int NV = NT / 4;           // 16-byte chunks of a row a lane reads for the P.V product
+  constexpr int KQ = DQ / 4;           // 16-byte chunks of a row a lane reads for the S product
+  constexpr int RB = D * 4;            // bytes per row
+  using Cfg = NceF32<D>;
+  constexpr int LPB = Cfg::kLoadsPerBlock;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* invl_s = reinterpret_cast<float*>(smem + Cfg::kSlots * Cfg::kBlockBytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  NcePlan plan;
+  nce_plan(batch, plan);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int cidx = (c16 + 4) & 15;
+
+  // per-lane LDS byte offsets inside a block (the swizzle: chunk c of row r sits at chunk (c & ~15) | ((c ^ r) & 15));
+  // the tile half h and the chunk's high bit are immediates of the reads
+  unsigned off_s[4], off_v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) off_s[t] = lds0 + c16 * RB + (((g + 4 * t) ^ c16) & 15) * 16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) off_v[r] = lds0 + (4 * g + r) * RB + ((cidx ^ (4 * g + r)) & 15) * 16;
+  // the direct loads of one block: instruction i of this wave fills LDS bytes [1024 (LPB wv + i), +1024) of the slot
+  int ld_off[LPB];
+#pragma unroll
+  for (int i = 0; i < LPB; ++i) {
+    const int pos = (LPB * wv + i) * 1024 + lane * 16;
+    const int row = pos / RB, phys = (pos % RB) >> 4;
+    ld_off[i] = row * RB + ((phys & ~15) | ((phys ^ row) & 15)) * 16;
+  }
+
+  const int n_tasks = plan.first[kNceMaxProblems];
+  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    int k = 0, first = 0, per = plan.per[0], splits = plan.splits[0], n = plan.n[0];
+#pragma unroll
+    for (int q = 1; q < kNceMaxProblems; ++q)
+      if (task >= plan.first[q]) { k = q; first = plan.first[q]; per = plan.per[q]; splits = plan.splits[q]; n = plan.n[q]; }
+    const NceWs& w = batch.w[k];
+    const int np = (int)nce_pad(n);
+    const size_t stride = (size_t)w.np;
+    const float* lpart = w.lpart;
+    float* ediag = w.ediag;
+    const int local = task - first;
+    const int qblk = local / splits, split = local % splits;
+    const int b0 = split * per;
+    const int nblk = min(per, np / kNceKeyBlock - b0);     // >= 1
+    const int q0 = qblk * kNceQueryBlock + wv * 16;
+    const bool wave_live = q0 < np;
+    const float* Qv = PASS2 ? w.v2n : w.v1n;
+    const unsigned char* Kv = reinterpret_cast<const unsigned char*>(PASS2 ? w.v1n : w.v2n) + (size_t)b0 * Cfg::kBlockBytes;
+    float* opart = (PASS2 ? w.opart2 : w.opart) + ((size_t)split * stride + q0) * D;
+    if (task != (int)blockIdx.x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous task's ring and 1 / l are read out
+
+    float qreg[DQ];
+    {
+      const float* src = Qv + (size_t)min(q0 + c16, np - 1) * D + 4 * g;
+#pragma unroll
+      for (int t = 0; t < KQ; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 16 * t);
+        qreg[4 * t + 0] = x.x; qreg[4 * t + 1] = x.y; qreg[4 * t + 2] = x.z; qreg[4 * t + 3] = x.w;
+      }
+    }
+    if (PASS2) {
+      // 1 / l(key) from pass 1's split partials, in split order (lpart holds the off-diagonal sums; rows >= n: unused)
+      for (int t = threadIdx.x; t < nblk * kNceKeyBlock; t += 512) {
+        const int key = b0 * kNceKeyBlock + t;
+        float l = 0.f;
+        for (int sp = 0; sp < splits; ++sp) l += lpart[(size_t)sp * stride + key];
+        invl_s[t] = 1.0f / (l + ediag[key]);
+      }
+    }
+    // (buffer_load ... lds, not global_load_lds: the compiler files the FLAT-encoded form under "may return out of
+    // order" and turns every vmcnt it inserts itself into vmcnt(0) while one is in flight -- the ring's run-ahead gone)
+    const int k_bytes = nblk * Cfg::kBlockBytes;
+    auto issue_chunk = [&](int c) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int b = min(2 * c + jj, nblk - 1);                    // (past the range: a harmless re-load, never read)
+        unsigned char* dst = smem + ((2 * c + jj) & (Cfg::kSlots - 1)) * Cfg::kBlockBytes + LPB * wv * 1024;
+#pragma unroll
+        for (int i = 0; i < LPB; ++i)
+          buffer_to_lds16(Kv, k_bytes, dst + i * 1024, ld_off[i], b * Cfg::kBlockBytes);
+      }
+    };
+    issue_chunk(0);
+    issue_chunk(1);
+    issue_chunk(2);
+    // chunk 0 has landed once all but the 4 LPB youngest loads are back (lgkmcnt: the 1 / l stores)
+    if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // S operands of one block: K rows 16 h + c16, chunks g + 4 t   (kq[KQ h + t], element e <-> k-step 4 t + e)
+    floatx4 kq[2 * KQ];
+    // (address = one add per operand set and slot: the tile half and the chunk's high bit ride in the offset field --
+    //  the f32 MFMA and the vector ALU do not overlap on this chip, tools/microbench/mfma_f32_valu.hip: every VALU
+    //  instruction of the key loop is paid in full)
+    auto issue_k = [&](int j) {
+      const unsigned base = (unsigned)((j & (Cfg::kSlots - 1)) * Cfg::kBlockBytes);
+      unsigned a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = off_s[t] + base;
+      kq[0] = lds_read_f4_async<0>(a[0]); kq[1] = lds_read_f4_async<0>(a[1]);
+      kq[2] = lds_read_f4_async<0>(a[2]); kq[3] = lds_read_f4_async<0>(a[3]);
+      if constexpr (KQ == 8) {
+        kq[4] = lds_read_f4_async<256>(a[0]); kq[5] = lds_read_f4_async<256>(a[1]);
+        kq[6] = lds_read_f4_async<256>(a[2]); kq[7] = lds_read_f4_async<256>(a[3]);
+      }
+      kq[KQ + 0] = lds_read_f4_async<16 * RB>(a[0]); kq[KQ + 1] = lds_read_f4_async<16 * RB>(a[1]);
+      kq[KQ + 2] = lds_read_f4_async<16 * RB>(a[2]); kq[KQ + 3] = lds_read_f4_async<16 * RB>(a[3]);
+      if constexpr (KQ == 8) {
+        kq[KQ + 4] = lds_read_f4_async<16 * RB + 256>(a[0]); kq[KQ + 5] = lds_read_f4_async<16 * RB + 256>(a[1]);
+        kq[KQ + 6] = lds_read_f4_async<16 * RB + 256>(a[2]); kq[KQ + 7] = lds_read_f4_async<16 * RB + 256>(a[3]);
+      }
+    };
+    // P.V operands of half a block: V rows 16 h + 4 g + r, chunks cidx + 16 v   (vv[NV r + v], element u' <-> n-tile 4 v + u')
+    auto issue_v = [&](int j, auto half_tag, floatx4 (&vv)[4 * NV]) {
+      constexpr int H = decltype(half_tag)::value;
+      const unsigned base = (unsigned)((j & (Cfg::kSlots - 1)) * Cfg::kBlockBytes);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned a = off_v[r] + base;
+        vv[NV * r] = lds_read_f4_async<16 * H * RB>(a);
+        if constexpr (NV == 2) vv[NV * r + 1] = lds_read_f4_async<16 * H * RB + 256>(a);
+      }
+    };
+    floatx4 acc[2];
+    auto s_product = [&]() {
+      acc[0] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      acc[1] = acc[0];
+#pragma unroll
+      for (int s = 0; s < DQ; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[s >> 2][s & 3], qreg[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[KQ + (s >> 2)][s & 3], qreg[s], acc[1], 0, 0, 0);
+      }
+    };
+    floatx4 O[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) O[u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    const int qrow = q0 + c16;                                      // the query whose weights this lane holds
+
+    // one block: [P.V operands of half 0 | S(j + 1) beside block j's weights] then [P.V half 0 | operands of half 1]
+    // then [P.V half 1 | S operands of block j + 2]
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+    // weight of a logit: exp(s / tau - 1 / tau) as one fma and one v_exp_f32 (2^x)
+    const float ex_scale = inv_tau * 1.44269504088896340736f;
+    auto block_step = [&](int j, auto more_tag, auto edge_tag) {
+      constexpr bool kMore = decltype(more_tag)::value;             // block j + 1 exists: its S product runs here
+      constexpr bool kEdge = decltype(edge_tag)::value;             // the block holds keys >= n or this wave's own pairs
+      constexpr bool kHalves = D > 64;                              // d = 128: the second half's operands follow the first's MFMAs
+      floatx4 v0[4 * NV], v1[4 * NV];
+      const floatx4 a0 = acc[0], a1 = acc[1];
+      issue_v(j, Half0{}, v0);
+      if constexpr (!kHalves) issue_v(j, Half1{}, v1);
+      if constexpr (kMore) s_product();
+      float wgt[2][4];
+      float own_e = 0.f;
+      bool has_own = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = kNceKeyBlock * j + 16 * h + 4 * g + r;
+          float e = __builtin_amdgcn_exp2f(fmaf(h == 0 ? a0[r] : a1[r], ex_scale, -ex_scale));
+          if constexpr (kEdge) {
+            const int key = kNceKeyBlock * b0 + kl;
+            const bool own = key == qrow;
+            if (!PASS2) { own_e = own ? e : own_e; has_own |= own; }
+            if (PASS2) e *= invl_s[kl];
+            e = (key < n && !own) ? e : 0.f;
+          } else {
+            if (PASS2) e *= invl_s[kl];
+          }
+          lsum += e;
+          wgt[h][r] = e;
+        }
+      if constexpr (kEdge) {
+        if (!PASS2 && has_own && qrow < n) ediag[qrow] = own_e;     // the pair's own weight: nce_finish_row folds it in
+      }
+      if constexpr (kHalves) {
+        lds_wait(v0);
+        issue_v(j, Half1{}, v1);
+      } else {
+        lds_wait(v0, v1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          O[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[0][r], v0[NV * r + (u >> 2)][u & 3], O[u], 0, 0, 0);
+      if constexpr (kHalves) lds_wait(v1);
+      if constexpr (kMore) issue_k(j + 2);                          // (past the range: stale bytes, never used)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          O[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[1][r], v1[NV * r + (u >> 2)][u & 3], O[u], 0, 0, 0);
+      // the S operands are settled HERE, in the block that issued their reads, not at their use in the next iteration: a
+      // value that crosses the loop edge may pass through compiler-made copies, and a copy of a register whose read is
+      // still in flight copies stale bytes (tests/test_isa_async_lds.py checks the built kernel for exactly that)
+      if constexpr (kMore) lds_wait(kq);
+    };
+
+    if (wave_live) {
+      issue_k(0);
+      lds_wait(kq);
+      s_product();
+      issue_k(1);                                                   // (chunk 0 = blocks 0 and 1 has landed; one block: unused)
+      lds_wait(kq);
+    }
+    for (int j = 0; j < nblk; ++j) {
+      if ((j & 1) == 0) {
+        // chunks <= c + 1 have landed once only chunk c + 2's loads are out; then every wave is past chunk c - 1 and its
+        // slots take chunk c + 3
+        if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        issue_chunk((j >> 1) + 3);
+      }
+      if (!wave_live) continue;
+      // masks only where they can bite: a block reaching past the live rows, or one that holds this wave's own pairs
+      const int key0 = kNceKeyBlock * (b0 + j);
+      const bool edge = key0 + kNceKeyBlock > n || (key0 < q0 + 16 && key0 + kNceKeyBlock > q0);
+      if (j + 1 < nblk) {
+        if (edge) block_step(j, std::true_type{}, std::true_type{});
+        else block_step(j, std::true_type{}, std::false_type{});
+      } else {
+        if (edge) block_step(j, std::false_type{}, std::true_type{});
+        else block_step(j, std::false_type{}, std::false_type{});
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the ring's run-ahead loads: nothing may land later)
+    if (!wave_live) continue;
+
+    // O[4 v + u'][r] = out[query q0 + 4 g + r][column 4 (cidx + 16 v) + u']
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        st_f4<kNceWT>(reinterpret_cast<float4*>(opart + (size_t)(4 * g + r) * D + 4 * (cidx + 16 * v)),
+                      make_float4(O[4 * v + 0][r], O[4 * v + 1][r], O[4 * v + 2][r], O[4 * v + 3][r]));
+    if (!PASS2) {
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+      if (g == 0) const_cast<float*>(lpart)[(size_t)split * stride + qrow] = lsum;
+    }
+  }
+}
 
 // One finish for both passes (used with nce_tile_lds): folds the split partials, turns them into the
 // gradients of both views (through the normalisation) and scatters them; the loss partials are folded
@@ -976,7 +1184,13 @@ __device__ __forceinline__ void nce_finish_both_body(const NceBatch& batch, cons
   if (n <= 0 || wave >= n_waves) return;
   const int lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
   __shared__ float4 s_scr[4][64];
-  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub, s_scr[threadIdx.x >> 6]));
+  int splits = batch.splits;
+  if (batch.slots > 0) {            // the persistent passes' cut of this problem (nce_plan: same counts, same answer)
+    NcePlan plan;
+    nce_plan(batch, plan);
+    splits = plan.splits[bz];
+  }
+  const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub, s_scr[threadIdx.x >> 6], splits));
   // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
   __shared__ double wg_part[4];
   if (lane == 0) wg_part[threadIdx.x >> 6] = part;
@@ -1029,6 +1243,26 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     np_max = std::max(np_max, (int)w.np);
   }
   const float inv_tau = 1.0f / tau;
+  const bool f32 = precision == SRH_NCE_F32;
+  int grid_f32 = 0;
+  if (f32) {
+    if constexpr (D > 128) {
+      srh::set_error("infonce_fwd_bwd: the all-f32 MFMA path serves d = 64 / 128");
+      return SRH_ERR_UNSUPPORTED;
+    }
+    // one persistent workgroup per CU (the 80+ KB ring admits one); never more than the largest cut nce_plan can make
+    int64_t most = 0;
+    for (int k = 0; k < count; ++k) {
+      if (batch.w[k].np / kNceKeyBlock > (int64_t)kNceSplits * kNceMaxPer) {
+        srh::set_error("infonce_fwd_bwd: the all-f32 MFMA path serves n <= %d", kNceSplits * kNceMaxPer * kNceKeyBlock);
+        return SRH_ERR_UNSUPPORTED;
+      }
+      most += (batch.w[k].np + kNceQueryBlock - 1) / kNceQueryBlock * kNceSplits;
+    }
+    batch.slots = srh::cu_count();
+    batch.f32_only = 1;
+    grid_f32 = (int)std::min<int64_t>(batch.slots, most);
+  }
   dim3 gp((np_max / G + 3) / 4, 2, count);
   BprArgs bp{};
   int n_bpr = 0;
@@ -1042,7 +1276,7 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
   SRH_LAUNCH_CHECK();
   NceFinishArgs fa{inv_tau, loss_scale, loss};
   dim3 fb((np_max / G + 3) / 4, 1, count);
-  if (precision == SRH_NCE_SPLIT16) {
+  if (!f32) {
     constexpr int kLds = nce_lds_bytes<D, kNcePvTerms>();
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute((const void*)nce_tile_lds<D, false, 1, 8, kNcePvTerms>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
@@ -1055,31 +1289,24 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     SRH_LAUNCH_CHECK();
     nce_tile_lds<D, true, 1, 8, kNcePvTerms><<<gl, 512, kLds, st>>>(batch, inv_tau);
     SRH_LAUNCH_CHECK();
-    if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
-    else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
+  } else if constexpr (D <= 128) {
+    // ---- SRH_NCE_F32: both products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds), same four launches ----
+    constexpr int kLds = NceF32<D>::kLds;
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      return true;
+    }();
+    (void)attr_set;
+    nce_tile_f32<D, false><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
     SRH_LAUNCH_CHECK();
-    return SRH_OK;
-  }
-  // ---- SRH_NCE_F32: both products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds), one finish per pass ----
-  if constexpr (D > 128) {
-    srh::set_error("infonce_fwd_bwd: the all-f32 MFMA path serves d = 64 / 128");
-    return SRH_ERR_UNSUPPORTED;
-  } else {
-  if (bpr) {
-    bpr_phase2<LPR><<<n_bpr, 256, 0, st>>>(bp);
+    nce_tile_f32<D, true><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
     SRH_LAUNCH_CHECK();
   }
-  dim3 gt(np_max / 64, batch.splits, count);
-  nce_tile<D, false><<<gt, 256, 0, st>>>(batch, inv_tau);
-  SRH_LAUNCH_CHECK();
-  nce_finish<LPR, false><<<fb, 256, 0, st>>>(batch, fa);
-  SRH_LAUNCH_CHECK();
-  nce_tile<D, true><<<gt, 256, 0, st>>>(batch, inv_tau);
-  SRH_LAUNCH_CHECK();
-  nce_finish<LPR, true><<<fb, 256, 0, st>>>(batch, fa);
+  if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
+  else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
-  }
 }
 
 template <int LPR>

@@ -4,45 +4,138 @@
 ``origin``: {user: {item: 1}}; ``res``: {user: [(item, score), ...]} best first.
 """
 import math
-from collections.abc import Mapping
-
 import numpy as np
 
 
-class RankedLists(Mapping):
-    """The ``{user: [(item, score), ...]}`` result of ``GraphRecommender.test()`` held as the arrays the
-    device ranking returned: (users x K) item ids and scores plus, when the ranking also produced them,
-    the per-position hit flags and the users' test-set sizes.  It reads like the reference's dict (same
-    keys in test-set order, rows materialised as lists of (item name, score) on access) so
-    ``evaluate()`` and any user code keep working, while ``ranking_evaluation`` takes the arrays.
+class RankedLists(dict):
+    """The ``{user: [(item, score), ...]}`` result of ``GraphRecommender.test()`` (reference
+    base/graph_recommender.py:44-58) -- a ``dict`` -- held as the arrays the device ranking returned until somebody
+    looks inside: (users x K) item ids and scores plus, when the ranking also produced them, the per-position hit flags
+    and the users' test-set sizes.  ``ranking_evaluation`` takes the arrays; anything that treats the object as the
+    dictionary it is -- indexing, iteration, ``items()``, ``json.dump``, ``pickle``, ``dict(x)``, ``==`` -- makes it
+    build every row once (two bulk conversions, ``materialise``) into its own storage, after which it IS that plain dict.
+    From then on ``ranking_evaluation`` reads the rows as well (they are plain lists their holder may have edited), as
+    the reference's does; an in-place edit of the mapping drops the arrays outright.
     """
 
-    def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None, per_user=None):
+    def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None, per_user=None,
+                 keys=None):
+        # The KEYS are in the storage from the start (`keys`: a {user: None} dict of these users to copy -- the caller's
+        # cached one -- else built here): C code that sizes a dict without asking it (json's encoder short-cuts an empty
+        # one to "{}") sees the right length, and everything that then reads entries goes through the methods below.
+        super().__init__(keys if keys is not None else dict.fromkeys(users))
         self.users = users if isinstance(users, list) else list(users)
-        self._row = None                       # user -> row, built on first lookup
+        self._filled = False                   # the values are still placeholders
         self.item_names, self.ids, self.scores = item_names, ids, scores
         self.hit_flags, self.truth_sizes, self.origin = hit_flags, truth_sizes, origin
         # {N: (hits per user int32, DCG / IDCG per user float64)} when the ranking computed them (srh_metric_rows)
         self.per_user = per_user or {}
 
-    def __len__(self):
-        return len(self.users)
-
-    def __iter__(self):
-        return iter(self.users)
-
-    def __getitem__(self, user):
-        if self._row is None:
-            self._row = {u: r for r, u in enumerate(self.users)}
-        r = self._row[user]
-        return list(zip(self.item_names[self.ids[r]].tolist(), self.scores[r].tolist()))
-
+    # ---- lazily filled storage -----------------------------------------------------------------------------------------
     def materialise(self):
         """The reference's return value as a plain dict -- {user: [(item name, score), ...]} for every user, every tuple
         built (graph_recommender.py:52-53) -- in two bulk conversions instead of one row at a time."""
+        if self._filled:
+            return dict(dict.items(self))
         names = self.item_names[self.ids].tolist()          # (users x K) python strings
         scores = self.scores.tolist()                       # (users x K) python floats
         return {u: list(zip(n, s)) for u, n, s in zip(self.users, names, scores)}
+
+    def _fill(self):
+        if not self._filled:
+            rows = self.materialise()
+            self._filled = True
+            dict.update(self, rows)
+        return self
+
+    def _edited(self):
+        """the rows no longer are what the device ranked: the arrays (and the fast report they feed) are dropped"""
+        self._fill()
+        self.hit_flags, self.per_user = None, {}
+
+    @property
+    def arrays_valid(self):
+        """the arrays still ARE the result: nobody has been handed the rows (a row is a plain list its holder may edit)"""
+        return self.hit_flags is not None and not self._filled
+
+    # (len(), `in`: dict's own -- the keys are there)
+    def __getitem__(self, user):
+        return dict.__getitem__(self._fill(), user)
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __reversed__(self):
+        return dict.__reversed__(self._fill())
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def get(self, user, default=None):
+        return dict.get(self._fill(), user, default)
+
+    def copy(self):
+        return dict(dict.items(self._fill()))
+
+    def __eq__(self, other):
+        return dict.__eq__(self._fill(), other)
+
+    def __ne__(self, other):
+        return dict.__ne__(self._fill(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self._fill())
+
+    def __or__(self, other):
+        return dict.__or__(self._fill(), other)
+
+    def __ror__(self, other):
+        return dict.__ror__(self._fill(), other)
+
+    def __reduce__(self):                                    # pickle / copy: the plain dict the reference returns
+        return (dict, (self.materialise(),))
+
+    # writes
+    def __setitem__(self, user, row):
+        self._edited()
+        dict.__setitem__(self, user, row)
+
+    def __delitem__(self, user):
+        self._edited()
+        dict.__delitem__(self, user)
+
+    def __ior__(self, other):
+        self._edited()
+        dict.update(self, other)
+        return self
+
+    def pop(self, *args):
+        self._edited()
+        return dict.pop(self, *args)
+
+    def popitem(self):
+        self._edited()
+        return dict.popitem(self)
+
+    def setdefault(self, user, default=None):
+        self._edited()
+        return dict.setdefault(self, user, default)
+
+    def update(self, *args, **kwargs):
+        self._edited()
+        dict.update(self, *args, **kwargs)
+
+    def clear(self):
+        self._edited()
+        dict.clear(self)
 
 
 def _left_to_right_sum(x):
@@ -129,7 +222,7 @@ def ranking_evaluation(origin, res, N):
     if len(origin) != len(res):
         print('The Lengths of test set and predicted set do not match!')
         raise SystemExit(-1)
-    if isinstance(res, RankedLists) and res.hit_flags is not None and res.origin is origin:
+    if isinstance(res, RankedLists) and res.arrays_valid and res.origin is origin:
         return _fast_report(res, N)
     report = []
     for n in N:

@@ -137,6 +137,45 @@ def test_fast_paths_take_the_reference_idioms_and_the_same_steps(golden_models, 
         dropin.uninstall()
 
 
+def test_fast_path_staging_survives_a_host_that_runs_ahead():
+    """The generator stages every batch through pinned memory with an ASYNCHRONOUS copy and the op-level loop does not
+    synchronise per step: with the device busy (here: a queue of large products) the host registers batches N + 1 ... N + 4
+    before the copy of batch N has run.  Each batch's device ids -- and an edit in the MIDDLE of a yielded list -- must
+    still be its own (one pinned buffer was rewritten under the pending copy)."""
+    from selfrec_amd import dropin
+    from selfrec_amd.util import fastpath
+    dropin.install(fuse=False)
+    try:
+        rng = np.random.default_rng(5)
+        a = torch.randn(4096, 4096, device="cuda")
+        table = torch.arange(50000 * 4, dtype=torch.float32, device="cuda").reshape(50000, 4)
+        batches = [[rng.integers(0, 50000, 2048).astype(np.int32) for _ in range(3)] for _ in range(6)]
+        torch.cuda.synchronize()
+        for _ in range(60):                       # ~0.1 s of queued device work: every registration below runs ahead of it
+            a = (a @ a).clamp_(-1, 1)
+        got = []
+        for arrays in batches:
+            lists = tuple(x.tolist() for x in arrays)
+            fastpath.register_batch(lists, arrays)
+            got.append(tuple(table[l] for l in lists))           # index_select with the staged device ids, queued
+        torch.cuda.synchronize()
+        for arrays, rows in zip(batches, got):
+            for x, r in zip(arrays, rows):
+                assert torch.equal(r[:, 0].cpu(), torch.from_numpy(x.astype(np.float32)) * 4)
+        lists = tuple(x.tolist() for x in batches[0])
+        fastpath.register_batch(lists, batches[0])
+        before = fastpath.hits["gather_list"]
+        lists[0][1000] = (lists[0][1000] + 1) % 50000            # an interior edit: torch's own path, the edited rows
+        assert torch.equal(table[lists[0]], table[torch.tensor(lists[0], device="cuda")])
+        assert fastpath.hits["gather_list"] == before
+        # a CPU tensor that only LOOKS like a stream (same length, ends and sum) is not answered from the registry
+        fake = torch.tensor(lists[1], dtype=torch.int64)
+        fake[10] += 1; fake[11] -= 1
+        assert torch.equal(torch.unique(fake), torch.from_numpy(np.unique(fake.numpy())))
+    finally:
+        dropin.uninstall()
+
+
 def test_handle_rectangular_backward_uses_transpose():
     import scipy.sparse as sp
     rng = np.random.default_rng(0)

@@ -224,6 +224,40 @@ def test_filtered_ranking_orders_planted_ties_like_the_reference_heap():
     assert n_heap >= len(tied_users)
 
 
+@pytest.mark.parametrize("I", [20000, 3000])
+def test_top128_without_a_spare_column_still_orders_ties_like_the_heap(I):
+    """K = 128 leaves the device kernels no (K + 1)-th column to see a tie across the K-th place with
+    (_mark_ties_without_spare: equal neighbours among the K, or more catalogue scores equal to the K-th than the K places
+    hold).  Planted duplicates inside the best 128 and straddling the 128-th place, both pipelines (filtered / exact slab),
+    against find_k_largest on the ranking's own scores."""
+    from selfrec_amd.util.algorithm import find_k_largest
+    rng = np.random.default_rng(128)
+    U, K, d = 60, 128, 64
+    tu, ti = synth.generate_edges(U, I, 6000, 9)
+    data = Interaction({}, synth.as_triples(tu, ti), [])
+    U, I = data.user_num, data.item_num
+    ue = (rng.standard_normal((U, d)) * 0.3).astype(np.float32)
+    ie = (rng.standard_normal((I, d)) * 0.3).astype(np.float32)
+    ie[rng.choice(I, size=3, replace=False)] = ue[5] * 3.0               # a tie at the top of user 5's list
+    base = ue[9] / np.linalg.norm(ue[9])
+    rows = rng.choice(I, size=140, replace=False)
+    ie[rows[:120]] = base * np.linspace(9.0, 5.0, 120, dtype=np.float32)[:, None]     # 120 distinct leaders for user 9 ...
+    ie[rows[120:]] = base * 4.0                                                         # ... then 20 equal: 8 places for them
+    rec = _bare_recommender(data, torch.from_numpy(ue), torch.from_numpy(ie), K)
+    users = np.arange(U, dtype=np.int32)
+    ids, sc = rec.rank_on_device(users)
+    assert rec._last_tie_rows >= 2
+    g = data.device_graph(torch.device("cuda"))
+    scores = ops.gemm_nt(rec.user_emb, rec.item_emb).cpu().numpy()
+    indptr, indices = g.r_indptr.cpu().numpy(), g.r_indices.cpu().numpy()
+    for u in range(U):
+        c = scores[u].copy()
+        c[indices[indptr[u]:indptr[u + 1]]] = -10e8
+        want_ids, want_sc = find_k_largest(K, c)
+        assert ids[u].tolist() == want_ids, u
+        assert np.array_equal(sc[u], np.asarray(want_sc, dtype=np.float32))
+
+
 @pytest.mark.parametrize("name", ["XSimGCL", "SGL", "LightGCN"])
 def test_hipgraph_replay_equals_eager(golden_models, golden_meta, tiny_data, name):
     """Same RNG stream, same batches: a captured step replayed == the eager launch sequence."""

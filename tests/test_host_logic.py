@@ -233,13 +233,47 @@ def test_ranked_lists_reads_like_the_dict_and_reports_the_same_strings():
     sizes = np.array([len(origin[u]) for u in users])
     ranked = evaluation.RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=origin)
     as_dict = {u: [(names[i], float(s)) for i, s in zip(ids[r], scores[r])] for r, u in enumerate(users)}
-    assert list(ranked) == users and len(ranked) == n_users
-    assert dict(ranked) == as_dict and ranked[users[7]] == as_dict[users[7]]
+    make = lambda: evaluation.RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=origin)
+    # untouched: the vectorised branch, no row built
+    assert len(ranked) == n_users and users[3] in ranked and "nobody" not in ranked
     for N in ([20], [10, 20], [1, 5, 20]):
         assert evaluation.ranking_evaluation(origin, ranked, N) == evaluation.ranking_evaluation(origin, as_dict, N)
+    assert ranked.arrays_valid and dict.get(ranked, users[0]) is None
+    # looked into: it is the dict, and the report then reads the rows (same strings)
+    assert list(ranked) == users and len(ranked) == n_users
+    assert dict(ranked) == as_dict and ranked[users[7]] == as_dict[users[7]] and ranked == as_dict
+    assert not ranked.arrays_valid
+    assert evaluation.ranking_evaluation(origin, ranked, [10, 20]) == evaluation.ranking_evaluation(origin, as_dict, [10, 20])
     # without flags (or against another test set) it goes through the loops like any mapping
     plain = evaluation.RankedLists(users, names, ids, scores)
     assert evaluation.ranking_evaluation(origin, plain, [10, 20]) == evaluation.ranking_evaluation(origin, as_dict, [10, 20])
+    # the reference returns a dict (base/graph_recommender.py:44-58): whatever takes a dict takes this
+    import copy
+    import json
+    import pickle
+    for how in (lambda r: json.loads(json.dumps(r)), lambda r: pickle.loads(pickle.dumps(r)), copy.deepcopy, copy.copy,
+                lambda r: {**r}, lambda r: dict(r.items()), lambda r: r | {}, lambda r: {} | r, lambda r: r.copy(), dict,
+                lambda r: json.loads(json.JSONEncoder().encode(r)), lambda r: json.loads("".join(json.JSONEncoder().iterencode(r)))):
+        got = how(make())
+        assert type(got) is dict
+        assert {u: [tuple(c) for c in row] for u, row in got.items()} == as_dict
+    fresh = make()
+    assert isinstance(fresh, dict) and list(fresh.keys()) == users and list(fresh.values())[5] == as_dict[users[5]]
+    assert fresh.get("nobody") is None and fresh.get(users[2]) == as_dict[users[2]] and list(reversed(fresh)) == users[::-1]
+    assert repr(make()) == repr(as_dict)
+    # in-place edits behave as on the reference's dict, and the report follows them
+    edited, want = make(), {u: list(r) for u, r in as_dict.items()}
+    edited[users[0]] = want[users[0]] = as_dict[users[1]]
+    edited[users[4]].reverse(); want[users[4]].reverse()
+    assert edited.pop(users[9]) == want.pop(users[9]) and edited == want and len(edited) == n_users - 1
+    cut = {u: t for u, t in origin.items() if u != users[9]}
+    assert evaluation.ranking_evaluation(cut, edited, [10, 20]) == evaluation.ranking_evaluation(cut, want, [10, 20])
+    other = make()
+    del other[users[1]]
+    other.update({"x": []}); other.setdefault("y", [1]); other |= {"z": []}
+    assert "x" in other and other["y"] == [1] and "z" in other and users[1] not in other and len(other) == n_users + 2
+    other.clear()
+    assert not other and len(other) == 0
 
 
 def test_xcd_share_calibration_controller(monkeypatch):

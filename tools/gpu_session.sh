@@ -51,6 +51,38 @@ lossprobe)
   rm -rf $OUT/lossprobe; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/lossprobe -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/lossprobe.log 2>&1); echo "lossprobe exit $?"
   stats $OUT/lossprobe | grep -E "kernel  |bpr_|nce_" > $OUT/lossprobe_kernel_stats.txt; cat $OUT/lossprobe_kernel_stats.txt; tail -1 $OUT/lossprobe.log
   find $OUT/lossprobe -name "*.db" -size +40M -delete;;
+lossprobef32)
+  rm -rf $OUT/lossprobef32; (cd /tmp && LOSS_PROBE_PRECISION=f32 timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/lossprobef32 -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/lossprobef32.log 2>&1); echo "lossprobef32 exit $?"
+  stats $OUT/lossprobef32 | grep -E "kernel  |bpr_|nce_" > $OUT/lossprobef32_kernel_stats.txt; cat $OUT/lossprobef32_kernel_stats.txt; tail -1 $OUT/lossprobef32.log
+  find $OUT/lossprobef32 -name "*.db" -size +40M -delete;;
+losspmc)
+  # counters of the loss section's kernels (one --pmc group per pass), per-dispatch means
+  : > $OUT/loss_pmc.txt
+  for G in "${LOSSPMC_A:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE}" "${LOSSPMC_B:-SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE}"; do
+    rm -rf $OUT/losspmc; (cd /tmp && LOSS_PROBE_ITERS=30 LOSS_PROBE_PRECISION=${LOSSPMC_PRECISION:-f32} timeout 400 rocprofv3 --kernel-trace --pmc $G -d $OLDPWD/$OUT/losspmc -o pmc -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/losspmc.log 2>&1); echo "losspmc exit $?"
+    f=$(find $OUT/losspmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "nce_|bpr_" | tee -a $OUT/loss_pmc.txt
+  done
+  rm -rf $OUT/losspmc;;
+mfmavalu)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/microbench/mfma_f32_valu.hip -o /tmp/mfma_f32_valu.out && timeout 120 /tmp/mfma_f32_valu.out > $OUT/mfma_f32_valu.txt 2>&1; echo "mfmavalu exit $?"; cat $OUT/mfma_f32_valu.txt;;
+ncef32ab)
+  # the f32 InfoNCE passes under other compile-time switches (ALT_SRC=losses tools/spmm_lab/build_alt.sh <name> "<flags>")
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so
+  : > $OUT/ncef32ab.txt
+  for N in ${NCE_LIBS:-base}; do
+    [ "$N" = base ] || cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so
+    rm -rf $OUT/ncef32ab_$N; (cd /tmp && LOSS_PROBE_ITERS=100 LOSS_PROBE_PRECISION=f32 timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/ncef32ab_$N -o trace -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/ncef32ab_$N.log 2>&1); echo "ncef32ab $N exit $?"
+    echo "== $N" >> $OUT/ncef32ab.txt; stats $OUT/ncef32ab_$N | grep -E "nce_tile" | tee -a $OUT/ncef32ab.txt
+    rm -rf $OUT/ncef32ab_$N
+    cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so
+  done;;
+testsk)
+  # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
+  timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_k.log | head -60;;
+testsnce)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "infonce" > $OUT/tests_nce.log 2>&1; echo "testsnce exit $?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_nce.log | head -40;;
 nceab)
   # InfoNCE shape constants: per alt library (tools/spmm_lab/alt/libselfrec_hip_<name>.so, built by
   # ALT_SRC=losses tools/spmm_lab/build_alt.sh ...) the loss section's per-kernel times + its error against float64
@@ -86,8 +118,6 @@ evaltrainedprof)
 testseval)
   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_shapes.py -m gpu -q --tb=short -p no:cacheprovider -k "rank or filter or topk or score or eval or metric or ties or heap" > $OUT/tests_eval.log 2>&1; echo "testseval exit $?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/tests_eval.log | head -40;;
-hostprobeold)
-  PROBE_PKG_ROOT=$PWD/_refstage/old_pkg timeout 300 python tools/oplevel_host_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/oplevel_host_probe_before.txt; echo "hostprobeold exit $?"; cat $OUT/oplevel_host_probe_before.txt;;
 hostprobe)
   timeout 300 python tools/oplevel_host_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/oplevel_host_probe${HOSTPROBE_TAG:-}.txt; echo "hostprobe exit $?"; cat $OUT/oplevel_host_probe${HOSTPROBE_TAG:-}.txt;;
 testslosses)

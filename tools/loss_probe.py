@@ -28,6 +28,9 @@ bpr = dict(batch=B, n_rows_dev=rows_dev, reg_coef=1e-4, reg_include_neg=False, l
            greg_user=tr.gF, greg_item=tr.gF, losses=tr.losses[0:2])
 bpr_in = (F, F, F, F, st["u"], st["i"], st["j"])
 problems = [(F, CL, st["uniq_u"], B, nuu, tr.gF, tr.gCL), (F, CL, st["uniq_i"], B, nui, tr.gF, tr.gCL)]
+PREC = os.environ.get("LOSS_PROBE_PRECISION") or None     # 'split' | 'f32' | unset = the process default
+if PREC:
+    ops.set_infonce_precision(PREC)
 for _ in range(int(os.environ.get("LOSS_PROBE_ITERS", "200"))):
     ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=tr.bpr_ws)                                     # bpr_phase1 + bpr_phase2
     ops.infonce_multi(problems, d=64, tau=0.2, loss_scale=0.2, loss=tr.losses[2:3], ws=tr.nce_ws)   # prep, 2 tiles, finish_both
