@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: XSimGCL training throughput (user-item pairs/s) on a synthetic
-Yelp2018-shaped graph (BASELINE.json config 3: 31,668 x 38,048, ~1.26 M train edges, d=64,
-B=2048, L=3, l*=1, eps=0.2, lambda=0.2, tau=0.2), plus full-rank eval users/s.
+"""Headline benchmark: XSimGCL training throughput (user-item pairs/s) on a synthetic Yelp2018-shaped graph
+(BASELINE.json config 3: 31,668 x 38,048, ~1.26 M train edges, d=64, B=2048, L=3, l*=1, eps=0.2, lambda=0.2,
+tau=0.2), plus full-rank eval users/s.
 
     python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU via torchrun)
 
-A "step" is one pass of the whole hot path over one batch: host sampling of that batch (C++
-MT19937 replay, on a worker thread, one epoch ahead), index staging, L propagation SpMMs with
-fused perturbation/mean, BPR + L2 + 2 x InfoNCE forward/backward, L backward SpMMs, dense Adam.
-Inputs (graph, tables, sampled epoch) are resident in HBM when the timed region starts; the
-region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is reported.
+A "step" is one pass of the whole hot path over one batch: host sampling of that batch (C++ MT19937 replay, on a
+worker thread, one epoch ahead), index staging, L propagation SpMMs with fused perturbation / mean, BPR + L2 +
+2 x InfoNCE forward / backward, L backward SpMMs, dense Adam.  Inputs (graph, tables, sampled epoch) are resident in
+HBM when the timed region starts; the region is EXACTLY --steps steps between barrier + torch.cuda.synchronize() on
+both sides, positioned (by extra untimed steps) so that it holds an epoch boundary -- sampler hand-over and index
+upload are inside the metric -- and the max over ranks is reported.
 
-One JSON line on rank 0 with the contract fields plus
-  "roofline":     dominant kernel (CSR SpMM, HBM-bound): algorithmic bytes per launch / mean
-                  launch duration measured with HIP events on the launch stream
-  "cpu_baseline": the CPU oracle ("port" of the reference's torch-CPU step) timed on this box's
-                  host cores on a bounded sample of the same workload (rank 0, N=1 only)
-  "eval":         full-rank top-20 throughput over the test users (kernels only / end to end)
-"""
-import argparse
+The arithmetic of the headline is fp32 throughout: InfoNCE's two n x n x d products run on the f32 MFMA
+(v_mfma_f32_16x16x4_f32, exact f32 multiply-adds), like the reference's fp32 matmul (util/loss_torch.py:46-47).
+The library's faster mode for those two products (16-bit split operands, f32 accumulation) is timed beside it and
+reported as `value_split16`; it is not the headline.
+
+N > 1: the headline keeps the global batch at B = 2048 pairs per step and divides that batch's work over the ranks
+(tables / graph sharded: "scaling": "strong", north_star's partition); the data-parallel run (N x B pairs per step,
+weak) is the `dp` sub-record.
+
+One JSON line on rank 0: the contract fields, `roofline` (dominant kernel: CSR SpMM, HBM-bound, algorithmic bytes per
+launch / mean launch duration from HIP events on the launch stream), `cpu_baseline` (the reference's own train() step
+when a checkout is staged on this box, else the oracle port, on this host's cores), `eval`.  The parts live in
+benchlib/: workload (flags, data, step driver), launch (N ranks, watchdog), probes (roofline), evalbench, baseline,
+dropin_bench."""
 import json
 import os
 import sys
@@ -27,749 +34,67 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-MFMA_F32_PEAK_TFLOPS = 157.3
-
-
-def parse(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1300)     # > 2 epochs of 616 batches
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--shape", default="yelp2018")
-    ap.add_argument("--model", default="XSimGCL")
-    ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--emb", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=2048)
-    ap.add_argument("--tau", type=float, default=0.2)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-eval", action="store_true")
-    ap.add_argument("--no-dropin", action="store_true")
-    ap.add_argument("--seed", type=int, default=2024)
-    return ap.parse_args(argv)
-
-
-def build_data(shape, seed):
-    from selfrec_amd import synth
-    from selfrec_amd.data.ui_graph import Interaction
-    tu, ti, su, si, U, I = synth.make_dataset(shape, seed=seed)
-    if len(tu) > 5_000_000:
-        # (the 1 M x 500 k graph: 40 M python triples would be 25 GB of host objects -- what the reference needs for it;
-        # the id arrays go straight in, with a bounded test set)
-        data = Interaction.from_id_arrays({}, tu, ti, su[:200_000], si[:200_000], U, I)
-    else:
-        data = Interaction({}, synth.as_triples(tu, ti), synth.as_triples(su, si))
-    return data, (tu, ti, su, si, U, I)
-
-
-def spmm_alg_bytes(nnz, n_rows, n_cols, d):
-    """compulsory traffic of one CSR SpMM with perfect reuse of x."""
-    return nnz * 8 + (n_rows + 1) * 4 + n_cols * d * 4 + n_rows * d * 4
-
-
-def step_alg_bytes(model, nnz, N, d, L, B):
-    passes = {"MF": 0, "LightGCN": 1, "XSimGCL": 1, "SimGCL": 3, "SGL": 3}[model]
-    bwd = {"MF": 0, "LightGCN": 1, "XSimGCL": 1, "SimGCL": 1, "SGL": 3}[model]
-    spmm = (passes + bwd) * L * spmm_alg_bytes(nnz, N, N, d)
-    return spmm + 7 * N * d * 4 + N * d * 4 + 2 * 3 * B * d * 4 + 4 * 2 * B * d * 4
-
-
-def git_blob_hash(path):
-    """`git hash-object path` without git: the id of the file's contents."""
-    import hashlib
-    with open(path, "rb") as f:
-        body = f.read()
-    return hashlib.sha1(b"blob %d\0" % len(body) + body).hexdigest()
-
-
-def pmc_traffic(args):
-    """HBM-side bytes per dense SpMM launch from the committed PMC passes (bench.py cannot run under rocprofv3 --pmc
-    itself): profiles/spmm_dense_traffic[_<shape>_d<emb>].json, written by tools/pmc_to_json.py from a counter session
-    over tools/spmm_pmc.py.  The record carries the git blob id of the csrc/spmm.hip it was measured on: a record taken
-    from another kernel source is REFUSED (traffic = null, with the reason), not quoted."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    default = args.shape == "yelp2018" and args.emb == 64
-    name = "spmm_dense_traffic.json" if default else f"spmm_dense_traffic_{args.shape}_d{args.emb}.json"
-    path = os.path.join(here, "profiles", name)
-    if not os.path.exists(path):
-        return None, f"no PMC pass committed for this workload (profiles/{name})"
-    with open(path) as f:
-        rec = json.load(f)
-    want, have = rec.get("spmm_hip_blob"), git_blob_hash(os.path.join(here, "selfrec_amd", "csrc", "spmm.hip"))
-    if want != have:
-        return None, (f"profiles/{name} was measured on csrc/spmm.hip blob {str(want)[:12]}, this tree has {have[:12]}: stale "
-                      f"record refused (re-run tools/gpu_session.sh pmc)")
-    return rec["traffic_bytes_per_launch"], f"{rec['summary']}: {rec['how']}"
-
-
-def eval_mfma_busy():
-    """MFMA-pipe utilisation of the ranking's filter kernel from the committed counter pass (profiles/eval_mfma_busy.json,
-    written from tools/gpu_session.sh evalpmc; bench.py cannot run under rocprofv3 --pmc itself).  Stamped with the git blob of
-    the csrc/eval.hip it was measured on: a record of another kernel source is refused (None + the reason)."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "profiles", "eval_mfma_busy.json")
-    if not os.path.exists(path):
-        return None, "no counter pass committed (profiles/eval_mfma_busy.json)"
-    with open(path) as f:
-        rec = json.load(f)
-    have = git_blob_hash(os.path.join(here, "selfrec_amd", "csrc", "eval.hip"))
-    if rec.get("eval_hip_blob") != have:
-        return None, (f"profiles/eval_mfma_busy.json was measured on csrc/eval.hip blob {str(rec.get('eval_hip_blob'))[:12]}, this tree "
-                      f"has {have[:12]}: stale record refused (re-run tools/gpu_session.sh evalpmc)")
-    return rec["mfma_busy_filter16"], f"{rec['summary']}: {rec['how']}"
-
-
-def pmc_traffic_cols(args, w):
-    """Same for one rank's launch on (N, w) tables in the column-sharded layout: profiles/spmm_cols_traffic.json."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "spmm_cols_traffic.json")
-    if not (args.shape == "yelp2018" and args.emb == 64) or not os.path.exists(path):
-        return None, "no PMC pass committed for this workload"
-    with open(path) as f:
-        rec = json.load(f)
-    t = rec["traffic_bytes_per_launch"].get(str(w))
-    return t, f"{rec['summary']}: {rec['how']}"
-
-
-def slice_kernel_name(w):
-    """The SpMM kernel that serves (N, w) tables (csrc/spmm.hip)."""
-    return {8: "spmm_pair_kernel", 16: "spmm_slice_kernel<4>", 32: "spmm_slice_kernel<8>"}.get(w, f"spmm_rows_kernel<{w // 4}>")
-
-
-def time_spmm_kernel(trainer, iters=50):
-    """Mean duration (s) of the propagation SpMM launch in the three flavours a step issues, HIP events on
-    the launch stream: dense (forward layers / inner backward layers: all rows, perturb epilogue),
-    row-masked (last forward layer: batch rows only) and column-masked (first backward layer: batch
-    columns only).  An XSimGCL step with L layers issues 2L launches: 2L-2 dense + 1 + 1."""
-    from selfrec_amd import ops
-    adj = trainer.adj                                         # (this rank's rows when the graph is sharded)
-    x, y = trainer.E0, trainer._loc(trainer.Ha)
-    stamp = (trainer.cursor[1:2] - 1).contiguous()            # the marks of the batch that just ran
-    sl = trainer._slice_kw()                                  # (column-sharded: where the slice sits in the row)
-    flavours = {
-        "dense": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0, **sl),
-        "row_masked": ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0,
-                                        row_mark=trainer._loc(trainer.mark), mark_stamp=stamp, **sl),
-        "col_masked": ops.make_epilogue(col_mark=trainer.mark, mark_stamp=stamp, **sl),
-    }
-    pattern = {}
-    if getattr(trainer, "vfree", False):
-        # value-free launches (layers >= 2 and every backward product but the first): pattern + row scale
-        sc = dict(row_scale=trainer.dinv, scale_in=True, scale_out=True)
-        flavours["dense_value_free"] = ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0, **sc)
-        flavours["row_masked_value_free"] = ops.make_epilogue(perturb_eps=trainer.eps, rng_seed=1, rng_offset=0,
-                                                              row_mark=trainer.mark, mark_stamp=stamp, **sc)
-        pattern = {"dense_value_free": True, "row_masked_value_free": True}
-    out = {}
-    adj_cm = getattr(trainer, "adj_cm", None) or adj          # (the column-masked launch runs on its own plan: engine.py)
-    for name, ep in flavours.items():
-        kw = {"pattern": True} if pattern.get(name) else {}
-        m = adj_cm if name == "col_masked" else adj
-        for _ in range(5):
-            ops.spmm(m, x, out=y, epilogue=ep, **kw)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        a.record()
-        for _ in range(iters):
-            ops.spmm(m, x, out=y, epilogue=ep, **kw)
-        b.record()
-        torch.cuda.synchronize()
-        out[name] = a.elapsed_time(b) / iters * 1e-3
-    n = 2 * max(trainer.L, 1)
-    if pattern and n >= 4:
-        # L layers: forward = 1 dense (values) + (L-2) dense value-free + 1 row-masked value-free;
-        # backward = 1 column-masked (values) + (L-1) dense value-free
-        out["step_mix"] = (out["dense"] + (n - 4) * out["dense_value_free"] + out["row_masked_value_free"] + out["col_masked"]
-                           + out["dense_value_free"]) / n
-    else:
-        out["step_mix"] = ((n - 2) * out["dense"] + out["row_masked"] + out["col_masked"]) / n if n >= 2 else out["dense"]
-    return out
-
-
-def cpu_baseline(args, raw, seconds):
-    """The CPU oracle's XSimGCL step (torch-CPU fp32, python sampler) on this host's cores."""
-    import random
-    from oracle import selfrec_oracle as O
-    tu, ti, su, si, U, I = raw
-    torch.manual_seed(args.seed)
-    kw = dict(n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau, layer_cl=1,
-              batch_size=args.batch)
-    tr = O.OracleTrainer(args.model, tu, ti, U, I, args.emb, **kw)
-    smp = O.PairwiseSampler(tu, ti, U, I)
-    random.seed(args.seed)
-    t0 = time.time()
-    it = smp.epoch(args.batch)
-    first = next(it)                                  # includes the once-per-epoch python shuffle
-    t_first = time.time() - t0
-    tr.step(*first)                                   # warm-up
-    n, t_steps, t_sample = 0, 0.0, 0.0
-    t_begin = time.time()
-    while time.time() - t_begin < seconds or n < 3:
-        t1 = time.time(); batch = next(it); t2 = time.time()
-        tr.step(*batch)
-        t3 = time.time()
-        t_sample += t2 - t1; t_steps += t3 - t2; n += 1
-    per_batch_sample = t_sample / n
-    shuffle_amortised = max(t_first - per_batch_sample, 0.0) / max(1, (len(tu) + args.batch - 1) // args.batch)
-    step_s = t_steps / n + per_batch_sample + shuffle_amortised
-    return {"value": round(args.batch / step_s, 1), "unit": "pairs/s", "cores": torch.get_num_threads(),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{n} XSimGCL steps (B={args.batch}, L={args.layers}) of the oracle on the same graph, "
-                      f"{t_steps / n * 1e3:.0f} ms compute + {per_batch_sample * 1e3:.1f} ms python sampling per step, "
-                      f"shuffle {t_first:.2f} s amortised over the epoch",
-            "port_vs_reference": "the reference's own model/graph/XSimGCL.py train() step was timed beside this port on the GPU "
-                                 "box's host, same process and thread count (tools/cpu_reference_vs_port.py, profiles/"
-                                 "r04_b_cpu_reference_vs_port.txt): reference 641 / 692 ms per step, port 739 / 639 / 531 -- "
-                                 "indistinguishable inside the 128-thread host's run-to-run spread (+-15 %)"}
-
-
-def eval_cpu_baseline(trainer, data, k=20, n_users=300):
-    """The reference's evaluation loop (graph_recommender.py:46-53: one mat-vec, a python mask loop over the
-    user's training items and a heap top-K per user) as the CPU oracle restates it, on a bounded sample of the
-    test users; numba is not in this image, so `find_k_largest` runs as python ("as shipped here") -- the
-    second figure leaves the top-K out so the comparison is not inflated by that."""
-    from oracle import selfrec_oracle as O
-    ue, ie = (t.float().cpu().numpy() for t in trainer.embeddings())
-    users = [data.user[u] for u in list(data.test_set)[:n_users]]
-    rated = {u: [data.item[i] for i in data.training_set_u[data.id2user[u]]] for u in users}
-    t0 = time.time()
-    O.full_rank_topk(ue, ie, users, lambda u: rated[u], k)
-    t_full = time.time() - t0
-    t0 = time.time()
-    for u in users:                                      # scores + mask only
-        cand = (ie @ ue[u]).astype(np.float32)
-        for i in rated[u]:
-            cand[i] = -10e8
-    t_nok = time.time() - t0
-    return {"as_shipped_users_per_s": round(len(users) / t_full, 1), "topk_excluded_users_per_s": round(len(users) / t_nok, 1),
-            "kind": "port", "cores": torch.get_num_threads(),
-            "sample": f"{len(users)} test users through the oracle's per-user loop (python heap top-{k}; numba absent)"}
-
-
-def dropin_throughput(args, raw, steps=60, warmup=8):
-    """pairs/s of the OP-LEVEL drop-in tier: what a SELFRec user gets without switching to selfrec_amd's model
-    classes -- a model file written the reference's way (torch.sparse.mm on the uploaded adjacency, rand_like /
-    normalize / sign perturbation, stack + mean, fancy-index gathers, util.loss_torch losses, torch.optim.Adam,
-    the next_batch_pairwise generator pulled synchronously: XSimGCL.py:23-50,83-101) running on this package's
-    sampler, SpMM handle and loss kernels.  The unmodified reference files were run the same way in a gpurun
-    session (profiles/r02_a_dropin_reference_models.txt); /root/reference does not exist where bench.py runs."""
-    import random
-    import torch.nn.functional as F
-    from selfrec_amd import dropin, synth
-    dropin.install(fuse=False)         # the mirrors under the reference's module names + the host-side fast paths (util/fastpath.py)
-    from selfrec_amd.base.torch_interface import TorchGraphInterface
-    from selfrec_amd.data.ui_graph import Interaction
-    from selfrec_amd.util.loss_torch import InfoNCE, bpr_loss, l2_reg_loss
-    from selfrec_amd.util.sampler import next_batch_pairwise
-    tu, ti, su, si, U, I = raw
-    data = Interaction({}, synth.as_triples(tu, ti), [])
-    adj = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj).cuda()
-    torch.manual_seed(args.seed)
-    emb = torch.nn.ParameterDict({
-        "user_emb": torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(U, args.emb))),
-        "item_emb": torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(I, args.emb)))}).cuda()
-    opt = torch.optim.Adam(emb.parameters(), lr=1e-3)
-    eps, lam, tau, l_star, reg = 0.2, 0.2, args.tau, 1, 1e-4
-
-    def encode(perturbed):
-        h = torch.cat([emb["user_emb"], emb["item_emb"]], 0)
-        layers, view = [], None
-        for k in range(args.layers):
-            h = torch.sparse.mm(adj, h)
-            if perturbed:
-                h = h + torch.sign(h) * F.normalize(torch.rand_like(h), dim=-1) * eps
-            layers.append(h)
-            if k == l_star - 1:
-                view = h
-        out = torch.stack(layers, dim=1).mean(dim=1)
-        return torch.split(out, [U, I]) + torch.split(view, [U, I])
-
-    random.seed(args.seed)
-    done, t0 = 0, None
-    for u_idx, i_idx, j_idx in next_batch_pairwise(data, args.batch):
-        if done == warmup:
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-        ue, ie, cu, ci = encode(True)
-        u, p, n = ue[u_idx], ie[i_idx], ie[j_idx]
-        uu = torch.unique(torch.Tensor(u_idx).type(torch.long)).cuda()          # (XSimGCL.py:46-47, as the file spells it)
-        ui = torch.unique(torch.Tensor(i_idx).type(torch.long)).cuda()
-        cl = InfoNCE(ue[uu], cu[uu], tau) + InfoNCE(ie[ui], ci[ui], tau)
-        loss = bpr_loss(u, p, n) + l2_reg_loss(reg, u, p) + lam * cl
-        opt.zero_grad(); loss.backward(); opt.step()
-        done += 1
-        if done == warmup + steps:
-            break
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dropin.uninstall()
-    return {"pairs_per_s": round(steps * args.batch / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "what": "XSimGCL written against SELFRec's API (raw torch.sparse.mm on the handle, torch autograd, torch.optim.Adam, "
-                    "python generator sampler pulled synchronously, table[list] gathers, torch.unique(torch.Tensor(list))) under "
-                    "dropin.install(): HIP SpMM / loss / sampler / Adam kernels underneath, ids uploaded once per batch",
-            "final_loss": float(loss.item())}
-
-
-def dropin_fused_throughput(args, raw, epochs=3):
-    """pairs/s of the THIRD tier: the reference's own, unmodified model/graph/XSimGCL.py with dropin.install(fuse=True)
-    -- the file's SHA-256 is checked and its train() is served by engine.FusedTrainer (selfrec_amd/dropin.py).  Needs
-    the reference's model/ directory: it is staged untracked under _refstage/ for a GPU session (reference sources are
-    never committed; /root/reference does not exist on the bench box) -- without it this returns the committed
-    measurement's location instead of a number."""
-    import importlib
-    import random
-    import tempfile
-    stage = os.path.join(REPO, "_refstage")
-    if not os.path.isfile(os.path.join(stage, "model", "graph", "XSimGCL.py")):
-        return {"pairs_per_s": None, "note": "no staged reference checkout on this box (_refstage/model/graph/XSimGCL.py); "
-                "measured in a gpurun session: profiles/r03_b_dropin_fused_reference_models.txt (6.31 M pairs/s over 5 epochs)"}
-    from selfrec_amd import dropin, synth
-    from selfrec_amd.util.conf import ModelConf
-    tu, ti, su, si, U, I = raw
-    dropin.install(fuse=True)
-    sys.path.insert(0, stage)
-    cwd = os.getcwd()
-    try:
-        mod = importlib.import_module("model.graph.XSimGCL")
-        if "XSimGCL" not in dropin._state["fused"]:
-            return {"pairs_per_s": None, "note": "the staged XSimGCL.py is not byte-for-byte the reference's: not fused"}
-        with tempfile.TemporaryDirectory() as tmp:
-            os.chdir(tmp)
-            conf = ModelConf({"model": {"name": "XSimGCL", "type": "graph"}, "item.ranking.topN": [10, 20],
-                              "embedding.size": args.emb, "max.epoch": epochs, "batch.size": args.batch, "learning.rate": 0.001,
-                              "reg.lambda": 0.0001, "output": "./results/", "training.set": "x", "test.set": "y",
-                              "XSimGCL": {"n_layer": args.layers, "l_star": 1, "lambda": 0.2, "eps": 0.2, "tau": args.tau}})
-            torch.manual_seed(args.seed); random.seed(args.seed)
-            model = mod.XSimGCL(conf, [list(t) for t in synth.as_triples(tu, ti)], [list(t) for t in synth.as_triples(su, si)])
-            t_eval = [0.0]
-            real_eval = model.fast_evaluation
-
-            def timed_eval(epoch):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                r = real_eval(epoch)
-                torch.cuda.synchronize(); t_eval[0] += time.perf_counter() - t0
-                return r
-            model.fast_evaluation = timed_eval
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            model.train()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0 - t_eval[0]
-    finally:
-        os.chdir(cwd)
-        sys.path.remove(stage)
-        dropin.uninstall()
-    return {"pairs_per_s": round(epochs * len(tu) / dt, 1), "epochs": epochs, "seconds": round(dt, 3),
-            "fast_evaluation_seconds": round(t_eval[0], 3),
-            "what": "model/graph/XSimGCL.py of the reference, unmodified (SHA-256 checked), dropin.install(fuse=True): "
-                    "train() on engine.FusedTrainer; engine construction, XCD calibration, graph capture, sampling included"}
-
-
-def stream_bandwidth(dev):
-    """Measured streaming rates of this GPU with the library's own elementwise kernel, y = a*x + b*y
-    (srh_axpby: 2 reads + 1 write per element): arrays that stay in the 256 MiB Infinity Cache (the regime
-    of the engine's 17.8 MB tables) and arrays far beyond it (HBM proper) -- the achievable counterparts
-    of the 8 TB/s spec (tools/stream_bw.py prints the same for Adam's 7-stream pattern)."""
-    from selfrec_amd import ops
-    out = {}
-    for label, mib in (("infinity_cache_64MiB_arrays", 64), ("hbm_1GiB_arrays", 1024)):
-        n = mib * (1 << 20) // 4
-        x, y = torch.ones(n, device=dev), torch.ones(n, device=dev)
-        for _ in range(3):
-            ops.axpby(0.5, x, 0.5, y)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); a.record()
-        for _ in range(10):
-            ops.axpby(0.5, x, 0.5, y)
-        b.record(); torch.cuda.synchronize()
-        out[label] = round(3.0 * n * 4 * 10 / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
-        del x, y
-    return out
-
-
-def ops_filtered(ue, uid_dev, ie, g, k, gr):
-    from selfrec_amd import ops
-    return ops.score_mask_topk_filtered(ue, uid_dev, ie, g.r_indptr, g.r_indices, k, sample_items=gr.FILTER_SAMPLE_ITEMS,
-                                        cap=gr.FILTER_CAP, chunk_rows=gr.FILTER_CHUNK_ROWS)
-
-
-def eval_throughput(trainer, data, k=20):
-    from selfrec_amd.base.graph_recommender import GraphRecommender
-    users = list(data.test_set)
-    if not users:
-        return None
-    rec = GraphRecommender.__new__(GraphRecommender)
-    rec.data, rec.max_N, rec.topN = data, k, [k]
-    rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())
-    uid = np.asarray([data.user[u] for u in users], dtype=np.int32)      # (test() caches this array: _test_users)
-    rec.rank_on_device(uid)                                               # warm-up at the measured shape (workspace, module load)
-    times = []
-    for _ in range(5):                                                    # (2 ms each: the median of five, not one sample)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        ids, sc = rec.rank_on_device(uid)
-        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-    t_kernel = sorted(times)[len(times) // 2]
-    # the ranking's kernels alone (HIP events around _rank: K columns, no copy to the host, no tie rows redone)
-    ue_k, ie_k = rec._device_embeddings()
-    g_k = data.device_graph(ie_k.device)
-    uid_k = rec._device_user_ids(uid, ie_k.device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    t_dev = []
-    for _ in range(5):
-        torch.cuda.synchronize(); ev[0].record()
-        rec._rank(ue_k, uid_k, ie_k, g_k, k)
-        ev[1].record(); torch.cuda.synchronize(); t_dev.append(ev[0].elapsed_time(ev[1]) * 1e-3)
-    t_dev = sorted(t_dev)[2]
-    from selfrec_amd.util.evaluation import ranking_evaluation
-    rec.test()                                                            # builds the test-set CSR / name table once
-    times = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        out = rec.test()                                                  # what fast_evaluation() runs every epoch:
-        report = ranking_evaluation(data.test_set, out, [k])              # ranking + the metric strings
-        times.append(time.perf_counter() - t0)
-    t_e2e = sorted(times)[len(times) // 2]
-    assert len(report) == 5
-    # SURVEY.md 8(d): "up to and including the python rec_list" -- the same call with the reference's return value fully
-    # built: {user: [(item name, score), ...]} for every test user, every tuple a python object (630 k of them here);
-    # test() itself returns a lazy Mapping over the arrays (rows are built on access) and the figure above times that
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        out = rec.test()
-        rec_list = out.materialise() if hasattr(out, "materialise") else dict(out)
-        report_m = ranking_evaluation(data.test_set, out, [k])
-        times.append(time.perf_counter() - t0)
-    t_mat = sorted(times)[len(times) // 2]
-    assert len(rec_list) == len(out) and len(rec_list[users[0]]) == k and report_m == report
-    flops = 2.0 * len(uid) * data.item_num * rec.item_emb.shape[1]
-    # how hard the filter has to work on THESE embeddings: survivors per user of the bound from the slice (the FILTER_SAMPLE_ITEMS items of largest norm)
-    # (training items included), rows whose list overflowed the 1024 slots (re-ranked by the exact slab pipeline)
-    from selfrec_amd.base import graph_recommender as _gr
-    ue_p, ie_p = rec._device_embeddings()
-    g = data.device_graph(ie_p.device)
-    uid_dev = torch.as_tensor(uid, device=ie_p.device)
-    _, _, counts, _ = ops_filtered(ue_p, uid_dev, ie_p, g, k, _gr)
-    survivors = {"mean": round(float(counts.float().mean()), 1), "max": int(counts.max()),
-                 "rows_over_cap": int((counts > _gr.FILTER_CAP).sum()), "cap": _gr.FILTER_CAP}
-    # the scoring GEMM alone (srh_gemm_nt_f32: the same MFMA kernel without the filter epilogue, one 4096-user chunk
-    # into a slab): its rate against the fp32 MFMA peak is the kernel-quality figure; `achieved` below is the whole
-    # ranking pipeline (bound pass + filter GEMM + candidate ranking + D2H of ids and scores) against the same peak
-    from selfrec_amd import ops
-    q = rec.user_emb[torch.as_tensor(uid[:4096].astype(np.int64), device=rec.user_emb.device)].contiguous()
-    slab = torch.empty((q.shape[0], data.item_num), dtype=torch.float32, device=q.device)
-    for _ in range(3):
-        ops.gemm_nt(q, rec.item_emb, out=slab)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); a.record()
-    for _ in range(10):
-        ops.gemm_nt(q, rec.item_emb, out=slab)
-    b.record(); torch.cuda.synchronize()
-    gemm_tflops = 2.0 * q.shape[0] * data.item_num * q.shape[1] * 10 / (a.elapsed_time(b) * 1e-3) / 1e12
-    del slab
-    return {"users": len(uid), "k": k, "timing": "median of 5 calls", "device_users_per_s": round(len(uid) / t_kernel, 1),
-            "device_what": "rank_on_device: K + 1 columns ranked, rows with tied scores redone in the reference's heap order, ids + "
-                           "scores on the host",
-            "rows_redone_in_reference_heap_order": getattr(rec, "_last_tie_rows", None),
-            "kernels_users_per_s": round(len(uid) / t_dev, 1), "kernels_ms": round(t_dev * 1e3, 3),
-            "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
-            "end_to_end_what": "test() + ranking_evaluation(); test() returns a lazy Mapping over the (users x K) arrays",
-            "end_to_end_materialised_users_per_s": round(len(out) / t_mat, 1),
-            "end_to_end_materialised_what": "the same plus the reference's rec_list built in full: a dict of every user's "
-                                            "list of (item name, score) tuples (SURVEY 8d's definition of eval time)",
-            "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
-            "filter_survivors_per_user": survivors,
-            "roofline": {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
-                         "achieved": round(flops / t_kernel / 1e12, 2),
-                         "frac": round(flops / t_kernel / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                         "what": "2 * users * items * d flops of full-catalogue scoring / the whole device-side ranking "
-                                 "(exact-f32 MFMA chain, masks, top-K, ids + scores to the host)",
-                         "gemm_alone_tflops": round(gemm_tflops, 2),
-                         "gemm_alone_frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                         # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of filter16_kernel (the ranking's largest kernel; one bf16 product per 16 dimensions since round 4, three before
-                         # -- a third of the MFMAs in about the same time: the pipe is not what bounds it): NOT the algorithmic fraction above
-                         "mfma_busy": eval_mfma_busy()[0], "mfma_busy_source": eval_mfma_busy()[1]}}
-
-
-def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):
-    """Full-rank evaluation over N GPUs: the item table is replicated (`embeddings()` gathers it),
-    the test users are dealt over the ranks, every rank scores / masks / ranks its share, and the ranked ids meet on
-    every rank with one all-gather.  users/s = all test users / the slowest rank's time, D2H of its share included."""
-    import numpy as np
-    from selfrec_amd.base.graph_recommender import GraphRecommender
-    users = list(data.test_set)
-    if not users:
-        return None
-    rec = GraphRecommender.__new__(GraphRecommender)
-    rec.data, rec.max_N = data, k
-    rec.user_emb, rec.item_emb = (t.contiguous() for t in trainer.embeddings())      # (a collective when sharded)
-    from selfrec_amd.dist import deal_users, gather_ranked
-    uid = [data.user[u] for u in users]
-    mine, n_max = deal_users(uid, rank, world)
-    rec.rank_on_device(mine)                                                         # warm-up at the measured shape
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.time()
-    ids, _ = rec.rank_on_device(mine)
-    table = gather_ranked(ids, len(uid), rank, world, "cuda")
-    torch.cuda.synchronize()
-    t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ranked = int((table[:, 0] >= 0).sum().item())
-    return {"users": len(uid), "k": k, "users_ranked_and_gathered": ranked,
-            "device_users_per_s": round(len(uid) / float(t.item()), 1),
-            "note": f"test users dealt over {world} ranks, item table replicated, ranked ids all-gathered; slowest rank's time"}
-
-
-def default_layout_is_dp(nnz):
-    """bench.py --gpus N > 1 on this graph: data parallel unless SRH_SHARD_LAYOUT says otherwise or the graph is gather-bound"""
-    from selfrec_amd.dist import GATHER_BOUND_NNZ
-    return (os.environ.get("SRH_SHARD_LAYOUT") or "dp") == "dp" and nnz < GATHER_BOUND_NNZ
-
-
-def free_port():
-    """A TCP port nobody listens on right now (rendezvous of a self-launched job: never a fixed number -- two jobs on one
-    node, or a stale listener of a crashed one, would collide on it)."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def visible_gpus():
-    """HIP devices this process can open (0 without a GPU: never an error)."""
-    try:
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
-
-
-def refuse_gpu_count(n, backend):
-    """`--gpus N` with N above the visible devices: say so and leave with exit code 2 instead of letting N ranks fight over
-    fewer GPUs (RCCL refuses two ranks per device with an error that names neither N nor the device count).  The CPU
-    launch check ("gloo") and the shared-device test mode ("gloo:device") do not need N devices."""
-    have = visible_gpus()
-    if backend in ("gloo", "gloo:device") or n <= have:
-        return
-    msg = (f"bench.py --gpus {n}: only {have} HIP device(s) visible on this node (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
-           f"= {os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES') or 'unset'}); run with "
-           f"--gpus <= {have}")
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(json.dumps({"error": msg, "n_gpus": n, "visible_gpus": have}), flush=True)
-    raise SystemExit(2)
-
-
-def relaunch_under_torchrun(n):
-    """`python bench.py --gpus N` (no launcher, the way the driver's single-GPU command line is spelled): start
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` -- one rank per GPU over
-    RCCL -- and hand its exit code back.  Rank 0 of the child job prints the JSON line on the inherited stdout."""
-    import subprocess
-    refuse_gpu_count(n, os.environ.get("SRH_DIST_BACKEND", "nccl"))
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool's hosts (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    print(f"[bench] --gpus {n} without a launcher: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
-
-
-class Watchdog:
-    """First-contact safety of the N > 1 run (no line of it has met more than one real GPU): a daemon thread that ends the
-    PROCESS -- message on stderr, an error JSON line on rank 0, exit code 3 -- when the main thread has not reported progress
-    for `seconds`.  A collective that never returns cannot be recovered from inside the process that is stuck in it; what can
-    be done is to stop within a bounded time, say where, and leave the GPU free (a job that hangs until the driver's own
-    limit is a strike against the box).  `beat(phase)` after every phase that contains a collective."""
-
-    def __init__(self, seconds, rank=0, enabled=True):
-        import threading
-        self.seconds, self.rank = float(seconds), rank
-        self.phase, self.last = "start", time.monotonic()
-        self._stop = threading.Event()
-        self.thread = None
-        if enabled and self.seconds > 0:
-            self.thread = threading.Thread(target=self._watch, daemon=True)
-            self.thread.start()
-
-    def beat(self, phase):
-        self.phase, self.last = phase, time.monotonic()
-
-    def stop(self):
-        self._stop.set()
-
-    def _watch(self):
-        while not self._stop.wait(min(1.0, self.seconds / 4)):
-            idle = time.monotonic() - self.last
-            if idle > self.seconds:
-                msg = (f"watchdog: rank {self.rank} made no progress for {idle:.0f} s in phase '{self.phase}' "
-                       f"(limit SRH_BENCH_WATCHDOG_S = {self.seconds:.0f} s) -- a collective or a captured graph around one "
-                       f"did not return; rerun with SRH_SHARDED_GRAPH=0 (eager launches) or SRH_SHARD_LAYOUT=rows|cols to "
-                       f"narrow it down")
-                print(f"[bench] {msg}", file=sys.stderr, flush=True)
-                if self.rank == 0:
-                    print(json.dumps({"error": msg, "phase": self.phase}), flush=True)
-                os._exit(3)
-
-
-class Runner:
-    """A trainer driven the way a training run drives it: the host samples epoch e + 1 on a worker thread while the device
-    works on epoch e; an epoch boundary = hand-over of the sampled arrays + a 25 MB index upload."""
-
-    def __init__(self, trainer, seed, dist=None, watchdog=None):
-        from selfrec_amd.engine import EpochPrefetcher
-        self.trainer, self.dist, self.watchdog = trainer, dist, watchdog
-        trainer.seed_sampler(seed)                 # (data parallel: seed + rank -- every rank its own batches)
-        self.pre = EpochPrefetcher(trainer)
-        self.pre.start()
-        self.left, self.uploads = 0, 0
-
-    def run(self, n_steps):
-        done = 0
-        while done < n_steps:
-            if self.left == 0:
-                self.uploads += 1
-                self.trainer.upload_epoch(self.pre.take())
-                self.pre.start()                       # host samples the next epoch while this one runs
-                self.left = self.trainer.epoch_batches
-            take = min(self.left, n_steps - done)
-            for _ in range(take):
-                self.trainer.step()
-            self.left -= take
-            done += take
-
-    def fence(self):
-        torch.cuda.synchronize()
-        if self.dist is not None:
-            self.dist.barrier()
-            torch.cuda.synchronize()
-
-    def timed(self, n_steps, phase):
-        """(seconds, epoch boundaries inside) of exactly n_steps steps between two fences; the MAX over the ranks."""
-        self.fence()
-        up0 = self.uploads
-        t0 = time.perf_counter()
-        self.run(n_steps)
-        self.fence()
-        dt = time.perf_counter() - t0
-        if self.dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            dt = float(t.item())
-        if self.watchdog is not None:
-            self.watchdog.beat(phase)
-        return dt, self.uploads - up0
-
-
-def first_steps_guarded(make_trainer, runner_of, watchdog, what):
-    """The first steps of a multi-rank trainer (capture of the two graphs around the collective, the first replays): if
-    they RAISE -- an RCCL timeout, a capture error next to a live communicator, the engine's replay-vs-eager check -- fall
-    back to eager launches ONCE; a second failure ends the run with exit code 4 and the message.  (A hang that raises
-    nothing is the watchdog's.)  Returns (trainer, runner, note)."""
-    note = None
-    for attempt in (0, 1):
-        trainer = make_trainer(eager=attempt == 1)
-        runner = runner_of(trainer)
-        try:
-            runner.run(2)
-            runner.fence()
-            if watchdog is not None:
-                watchdog.beat(f"{what}: first steps")
-            return trainer, runner, note
-        except (RuntimeError, ValueError) as e:
-            note = f"{what}: {type(e).__name__} in the first steps ({str(e)[:300]})"
-            print(f"[bench] {note}; " + ("falling back to eager launches once" if attempt == 0 else "giving up"),
-                  file=sys.stderr, flush=True)
-            if attempt == 1:
-                if int(os.environ.get("RANK", "0")) == 0:
-                    print(json.dumps({"error": note}), flush=True)
-                os._exit(4)
-    raise AssertionError("unreachable")
-
-
-def spmm_roofline(args, trainer, sharded, dp, step_s, g):
-    """The roofline block of one trainer: its dominant propagation launch against HBM on algorithmic bytes,
-    the counters' traffic where a PMC pass of this kernel source is committed, and the bare gather stream on the live
-    graph's column array (ops.gather_floor_probe) -- the floor of the vector-memory path for the launch's row fetches."""
-    from selfrec_amd import ops
-    if trainer.L < 1:
-        return None
-    stream = stream_bandwidth(trainer.dev)      # (first: it allocates and frees 2 GiB -- the chip idles through the frees)
-    t_spmm = time_spmm_kernel(trainer)
-    alg = spmm_alg_bytes(trainer.adj.nnz, trainer.adj.shape[0], trainer.adj.shape[1], trainer.w)
-    # the dominant launch: the value-free dense product when the engine uses it (2L - 3 of the 2L launches of a
-    # step), else the dense product with values.  Algorithmic bytes stay SURVEY 8(d)'s CSR figure either way.
-    dom = "dense_value_free" if "dense_value_free" in t_spmm else "dense"
-    t_spmm["dominant"] = t_spmm[dom]
-    ach = alg / t_spmm[dom] / 1e9
-    cols = bool(getattr(trainer, "cols", False))
-    if not sharded or dp:              # (data parallel: every rank runs the single-GPU launch)
-        traffic, traffic_note = pmc_traffic(args)
-    elif cols and trainer.w != args.emb:
-        traffic, traffic_note = pmc_traffic_cols(args, trainer.w)
-    else:
-        traffic, traffic_note = None, "PMC passes exist for the unsharded and the column-sharded launches only"
-    floor = None
-    if trainer.w in (64, 128, 256):
-        try:
-            floor_us = ops.gather_floor_probe(trainer.adj.indices, trainer.E0)
-            floor = {"gather_floor_us": round(floor_us, 2),
-                     "gather_floor_what": (f"srh_gather_floor_probe: the {trainer.adj.nnz} row fetches of one launch "
-                                           f"({trainer.adj.nnz * trainer.w * 4 / 1e6:.0f} MB through the vector-memory path) "
-                                           "over the live graph's CSR column array, 8 in flight per row-group, no values / "
-                                           "epilogue / output; HIP events, 30 passes"),
-                     "gather_floor_TBps": round(trainer.adj.nnz * trainer.w * 4 / (floor_us * 1e-6) / 1e12, 2),
-                     "launch_over_gather_floor": round(t_spmm[dom] * 1e6 / floor_us, 3),
-                     "frac_of_attainable": round(floor_us / (t_spmm[dom] * 1e6), 4)}
-        except Exception as e:          # (a footnote never costs the line)
-            floor = {"gather_floor_us": None, "gather_floor_error": f"{type(e).__name__}: {e}"}
-    step_bytes = step_alg_bytes(args.model, 2 * g.n_edges, g.n_nodes, args.emb, args.layers, args.batch)
-    return {"bound": "hbm",
-            "kernel": (f"{slice_kernel_name(trainer.w)} "
-                       f"(one propagation layer over the whole graph for this rank's {trainer.w} of "
-                       f"{args.emb} columns, perturb epilogue)") if cols else
-                      (f"spmm_rows_kernel<{args.emb // 4}> (one propagation layer over "
-                       f"{'the rows of one rank of the' if sharded and not dp else 'the whole'} graph, "
-                       "perturb epilogue; split rows finished in-kernel"
-                       + ("; value-free form: pattern of A over a table pre-scaled by D^-1/2, row scale in "
-                          "the epilogue" if "dense_value_free" in t_spmm else "") + ")"),
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-            **(floor or {}),
-            "measured_stream_GBps": stream,
-            "traffic_source": traffic_note,
-            "traffic_GBps": round(traffic / t_spmm["dominant"] / 1e9, 1) if traffic else None,
-            "alg_bytes_per_launch": alg, "launch_us": round(t_spmm["dominant"] * 1e6, 2),
-            # ADVICE r02: the value-free launch streams no value array -- the same launch priced by the
-            # bytes ITS formulation has to move (indices + indptr + D^-1/2 + x + y), next to SURVEY
-            # 8(d)'s figure for the problem (CSR with values) that `achieved` / `frac` use
-            **({"value_free_byte_model": {
-                "bytes_per_launch": alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4,
-                "achieved": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9, 1),
-                "frac": round((alg - trainer.adj.nnz * 4 + trainer.adj.shape[0] * 4) / t_spmm[dom] / 1e9 / HBM_PEAK_GBS, 4)}}
-               if dom == "dense_value_free" else {}),
-            "with_values": ({"launch_us": round(t_spmm["dense"] * 1e6, 2),
-                             "achieved": round(alg / t_spmm["dense"] / 1e9, 1),
-                             "frac": round(alg / t_spmm["dense"] / 1e9 / HBM_PEAK_GBS, 4)}
-                            if "dense" in t_spmm else None),
-            "launch_us_by_flavour": {k: round(v * 1e6, 2) for k, v in t_spmm.items()},
-            "note": "rocprofv3's per-kernel average mixes the three flavours: compare it with "
-                    "launch_us_by_flavour.step_mix (profiles/)",
-            "step_alg_bytes": step_bytes,
-            "step_GBps": round(step_bytes / step_s / 1e9, 1) if step_s else None}
-
-
-def steady_state(runner, step_s, pairs_per_step):
-    """>= 2 epochs (>= 1 epoch boundary: sampler hand-over + 25 MB index upload inside the region) and >= 0.6 s of
-    device time, whatever --steps the driver passed.  SURVEY.md 8(d): sampling and the index upload are INSIDE the metric."""
-    tr = runner.trainer
-    n = max(2 * tr.epoch_batches, int(0.6 / step_s))
-    if n * step_s > 30.0:          # (the 1 M x 500 k shape: an epoch is 19,657 steps of 25 ms -- bounded instead)
-        n = max(20, int(5.0 / step_s))
-    dt, bounds = runner.timed(n, "steady state")
-    return {"steps": n, "seconds": round(dt, 4), "ms_per_step": round(dt / n * 1e3, 4),
-            "pairs_per_s": round(n * pairs_per_step / dt, 1), "epoch_boundaries_inside": bounds}
+from benchlib.baseline import cpu_baseline  # noqa: E402
+from benchlib.dropin_bench import dropin_fused_throughput, dropin_throughput  # noqa: E402
+from benchlib.evalbench import eval_cpu_baseline, eval_throughput, eval_throughput_sharded, ops_filtered  # noqa: E402,F401
+from benchlib.launch import (Watchdog, default_layout_is_dp, first_steps_guarded, free_port,  # noqa: E402,F401
+                             refuse_gpu_count, relaunch_under_torchrun)
+from benchlib.probes import (git_blob_hash, pmc_traffic_cols, spmm_roofline, time_spmm_kernel)  # noqa: E402,F401
+from benchlib.workload import (Runner, build_data, parse, spmm_alg_bytes, steady_state, step_alg_bytes)  # noqa: E402,F401
+
+NCE_MODELS = ("XSimGCL", "SimGCL", "SGL")
+
+
+def launch_check(args, rank, world, backend, wd_seconds, coll_timeout):
+    """`SRH_DIST_BACKEND=gloo`: the launch path without GPUs (tests/test_dist_cpu.py) -- rendezvous, one collective, the
+    layouts this world size would take -- then stop; everything after it needs the HIP library and a device."""
+    import torch.distributed as dist
+    from selfrec_amd.dist import describe_layout, pick_layout
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=coll_timeout)
+    wd = Watchdog(wd_seconds, rank)
+    if os.environ.get("SRH_BENCH_TEST_STALL"):          # (tests/test_dist_cpu.py: the watchdog's exit path)
+        time.sleep(float(os.environ["SRH_BENCH_TEST_STALL"]))
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    wd.beat("launch check")
+    if rank == 0:
+        head = headline_layout(args, world)
+        print(json.dumps({"launch_check": True, "backend": backend, "world": world, "rank_sum": float(t.item()),
+                          "ranks_in_collective": int(ones.item()), "master_port": int(os.environ["MASTER_PORT"]),
+                          "headline": {"layout": pick_layout(args.emb, world, head, None), "scaling": scaling_of(head),
+                                       "global_batch": args.batch * (world if head == "dp" else 1),
+                                       "parallelism": describe_layout(args.emb, world, head)},
+                          "sub_records": sub_record_layouts(args, world, head)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    wd.stop()
+
+
+def headline_layout(args, world):
+    """The layout `--gpus N` reports first: north_star's -- one batch of B pairs, tables / graph divided over the ranks
+    (pick_layout's cols / rows / 2-D choice: "auto") -- unless SRH_SHARD_LAYOUT names another."""
+    return (os.environ.get("SRH_SHARD_LAYOUT") or "auto").lower()
+
+
+def scaling_of(layout):
+    return "weak" if layout == "dp" else "strong"
+
+
+def sub_record_layouts(args, world, head):
+    """Layouts timed after the headline: data parallel (weak scaling) always; on the gather-bound 1 M x 500 k graph also
+    the plain row partition BASELINE.json names, beside pick_layout's 2-D grid."""
+    if os.environ.get("SRH_SUB_RECORDS", "1") == "0" or world < 2:
+        return []
+    subs = [s for s in (os.environ.get("SRH_SUB_LAYOUTS") or "").split(",") if s]
+    if not subs:
+        subs = ["dp"] if head != "dp" else ["auto"]
+        if args.shape == "1m-500k" and head not in ("rows",):
+            subs.append("rows")
+    return subs
 
 
 def main():
@@ -797,35 +122,14 @@ def main():
         if "MASTER_PORT" not in os.environ:                # (one process standing in for a job: SRH_FORCE_SHARDED)
             os.environ["MASTER_PORT"] = str(free_port())
     if sharded and backend not in ("nccl", "gloo:device"):
-        # launch-path check without GPUs (tests/test_dist_cpu.py): rendezvous, one collective, the layout this world
-        # size would take -- then stop; everything after this point needs the HIP library and a device
-        import torch.distributed as dist
-        from selfrec_amd.dist import describe_layout
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=coll_timeout)
-        wd = Watchdog(wd_seconds, rank)
-        if os.environ.get("SRH_BENCH_TEST_STALL"):          # (tests/test_dist_cpu.py: the watchdog's exit path)
-            time.sleep(float(os.environ["SRH_BENCH_TEST_STALL"]))
-        t = torch.tensor([rank + 1.0])
-        dist.all_reduce(t)
-        wd.beat("launch check")
-        if rank == 0:
-            strong = os.environ.get("SRH_STRONG_LAYOUT") or None
-            print(json.dumps({"launch_check": True, "backend": backend, "world": world, "rank_sum": float(t.item()),
-                              "master_port": int(os.environ["MASTER_PORT"]),
-                              "parallelism": describe_layout(args.emb, world, os.environ.get("SRH_SHARD_LAYOUT") or
-                                                             ("dp" if args.shape != "1m-500k" else None)),
-                              "strong_parallelism": describe_layout(args.emb, world, strong)}), flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
-        wd.stop()
-        return
+        return launch_check(args, rank, world, backend, wd_seconds, coll_timeout)
     refuse_gpu_count(world, backend)
     from selfrec_amd import _lib
     _lib.require_gpu()
     if shared_device:
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    watchdog = None
+    watchdog, dist, comm = None, None, None
     if sharded:
         import torch.distributed as dist
         if shared_device:
@@ -834,15 +138,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
                                     timeout=coll_timeout)
         watchdog = Watchdog(wd_seconds, rank, enabled=world > 1)
-    else:
-        dist = None
+        # the communicator's own account of itself, after a real collective on device memory: how many ranks added their 1
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        comm = {"backend": "gloo (TEST MODE: ranks share GPUs, figures are not measurements)" if shared_device
+                else f"{dist.get_backend()} (RCCL)", "ranks_in_collective": int(ones.item()), "world_size": dist.get_world_size()}
+        watchdog.beat("first collective")
 
     data, raw = build_data(args.shape, args.seed)
     if watchdog is not None:
         watchdog.beat("data built")
     nnz_adj = 2 * data.interaction_mat.nnz
+    has_nce = args.model in NCE_MODELS
     kw = dict(model=args.model, n_layers=args.layers, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=args.tau,
-              layer_cl=1, batch_size=args.batch)
+              layer_cl=1, batch_size=args.batch, nce_precision=("f32" if has_nce else None))
 
     def make(layout):
         """a trainer of this layout on the SAME initial tables (torch.manual_seed before every construction)"""
@@ -857,33 +167,47 @@ def main():
             return ShardedTrainer(data, args.emb, layout=layout, use_graph=use_graph, **kw)
         return build
 
+    def parallelism_of(tr):
+        from selfrec_amd.dist import describe_layout
+        return describe_layout(args.emb, world, str(tr.layout) if (world > 1 or tr.dp) else ("cols" if tr.cols else "rows"),
+                               2 * tr.graph.n_edges)
+
+    def timed_record(trainer, runner, label):
+        """warm-up to --warmup, then exactly --steps steps over an epoch boundary; the fields every record carries"""
+        runner.run(max(0, args.warmup - runner.steps_done))
+        extra = runner.align_to_epoch_boundary(args.steps)
+        dt, bounds, per_rank = runner.timed(args.steps, f"{label}: timed region")
+        dp = bool(getattr(trainer, "dp", False))
+        pairs = args.batch * (world if dp else 1)
+        return {"value": round(args.steps * pairs / dt, 1), "unit": "pairs/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "steps": args.steps, "global_batch": pairs, "scaling": "weak" if dp else "strong",
+                "epoch_boundaries_inside": bounds, "untimed_steps_before": runner.steps_done - args.steps,
+                "aligned_by_extra_steps": extra,
+                "ms_per_step_by_rank": [round(t / args.steps * 1e3, 4) for t in per_rank] if per_rank else None,
+                "launch": "hipGraph replay" if trainer.use_graph else "eager"}, dt
+
     notes = []
+    head = headline_layout(args, world)
     if sharded:
-        # N > 1 on a graph this small: the headline is data parallel (every rank its own batches, one all-reduce of the
-        # dense gradient per step: weak scaling, global batch N x B) unless SRH_SHARD_LAYOUT asks for a strong-scaling
-        # layout of ONE batch; gather-bound graphs take pick_layout's choice (2-D grid / column blocks).  The line ALSO
-        # carries a `strong` record: a layout that divides one batch of B pairs over the ranks (north_star's partition).
-        layout = os.environ.get("SRH_SHARD_LAYOUT") or ("dp" if default_layout_is_dp(nnz_adj) else None)
-        trainer, runner, note = first_steps_guarded(make(layout), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
-                                                    f"layout {layout or 'auto'}")
+        from selfrec_amd.dist import pick_layout
+        chosen = pick_layout(args.emb, world, head, nnz_adj)
+        trainer, runner, note = first_steps_guarded(make(chosen), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
+                                                    f"layout {chosen}")
         if note:
             notes.append(note)
-        warm_done = 2                              # (first_steps_guarded ran two steps: they count towards --warmup)
     else:
         trainer = make(False)()
         runner = Runner(trainer, args.seed, None, None)
-        warm_done = min(2, args.warmup)
-        runner.run(warm_done)                      # epoch upload, hipGraph capture, first replays
+        runner.run(min(2, max(args.warmup, 1)))    # epoch upload, hipGraph capture, first replays
         runner.fence()
-    dp = bool(getattr(trainer, "dp", False))
     g = trainer.graph
-    # The roofline probes (per-flavour launch times, the gather floor, the stream rates: ~30 ms of launches the line needs
+    dp = bool(getattr(trainer, "dp", False))
+    # The roofline probes (per-flavour launch times, the gather bound, the stream rates: ~30 ms of launches the line needs
     # anyway) run HERE, between the first warm-up steps and the rest: the timed region then starts on a chip that has been
-    # busy, not on one that idled through graph capture.  tools/step_timeline.py (profiles/r04_b_step_timeline.txt): after
-    # >= 0.3 s of idle the first 60 steps run 4 / 2.5 / 1.5 % slow (DVFS ramp; 0.2963, 0.2903, 0.2864 ms per 20-step region
-    # against 0.2816 sustained) whatever the host does -- a 20-step region timed straight from idle measures that ramp.
+    # busy, not on one that idled through graph capture (profiles/r04_b_step_timeline.txt: after >= 0.3 s of idle the first
+    # 60 steps run 4 / 2.5 / 1.5 % slow -- DVFS ramp).
     roof = None
-    if rank == 0 and warm_done >= 1:
+    if rank == 0:
         try:
             roof = spmm_roofline(args, trainer, sharded, dp, None, g)
         except RuntimeError as e:             # (never lose a multi-GPU line to its footnotes)
@@ -892,121 +216,84 @@ def main():
             roof = {"error": str(e)}
     if watchdog is not None:
         watchdog.beat("roofline")
-    runner.run(max(0, args.warmup - warm_done))
-    elapsed, epochs_in_region = runner.timed(args.steps, "timed region")
+    rec, elapsed = timed_record(trainer, runner, "headline")
     losses = trainer.read_losses()
+    step_s = max(elapsed / args.steps, 1e-6)
 
-    # rows / cols / 2-D: the global batch is fixed at B pairs per step for every N (strong scaling).  Data parallel: every
-    # rank trains on its own B pairs per step (weak scaling): N x B pairs per step.
-
-    def parallelism_of(tr):
-        from selfrec_amd.dist import describe_layout
-        return (describe_layout(args.emb, world, str(tr.layout) if (world > 1 or tr.dp) else
-                                ("cols" if tr.cols else "rows"), 2 * tr.graph.n_edges)
-                + (f"; torch.distributed backend nccl (RCCL), {dist.get_world_size()} rank(s), one per GPU" if not shared_device
-                   else f"; TEST MODE gloo:device -- {dist.get_world_size()} ranks sharing {torch.cuda.device_count()} GPU(s): "
-                        "the figures of this line are not measurements"))
-    pairs_per_step = args.batch * (world if dp else 1)
-    value = args.steps * pairs_per_step / elapsed
     out = {
         "metric": f"train pairs/sec ({args.model}, {'Yelp2018' if args.shape == 'yelp2018' else args.shape}-shape)",
-        "value": round(value, 1), "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        # the mode of the layout `--gpus N` takes for this graph (N = 1 reports the mode its N > 1 companions will run in,
-        # so that one SCALE series carries one label): data parallel = weak, the table / graph splits = strong
-        "scaling": "weak" if (dp or (not sharded and default_layout_is_dp(2 * trainer.graph.n_edges))) else "strong",
-        "vs_baseline": None,
-        "dtype": "f32" + (" (InfoNCE's two n x n x d products on 16-bit MFMA operands with f32 accumulation: the logits on "
-                          "split f16 hi+lo = 2^-22, the accuracy of an f32 dot product; P.V on split bf16 = 2^-18 per "
-                          "product, gradients 1e-6 rel; all-f32-MFMA path timed in ms_per_step_nce_f32)"
-                          if args.model in ("XSimGCL", "SimGCL", "SGL") else ""),
-        "data": "synthetic",
-        "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau} on synthetic "
-                               f"{args.shape}-shape graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), "
-                               f"d={args.emb}, B={args.batch}, Adam lr=1e-3; epochs are sampled by a host thread one epoch ahead and "
-                               f"uploaded at epoch boundaries: {epochs_in_region} boundary(ies) inside this timed region "
-                               f"(value_steady_state is the same quantity over a region that always spans >= 1)",
-                   "global_batch": pairs_per_step, "parallelism": parallelism_of(trainer) if sharded else "single",
-                   "rccl_ranks": (dist.get_world_size() if sharded and not shared_device else None),
-                   "launch": "hipGraph replay" if trainer.use_graph else "eager",
+        "value": rec["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+        # N = 1 carries the label of its N > 1 companions, so that one SCALE series reads as one mode
+        "scaling": rec["scaling"] if sharded else scaling_of(head), "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} L={args.layers} l*=1 eps=0.2 lambda=0.2 tau={args.tau}, synthetic {args.shape}-shape "
+                               f"graph ({g.n_users} users x {g.n_items} items, {g.n_edges} train edges), d={args.emb}, "
+                               f"B={args.batch}, Adam lr=1e-3",
+                   "global_batch": rec["global_batch"],
+                   "parallelism": parallelism_of(trainer) if sharded else "single",
+                   "rccl_ranks": comm["ranks_in_collective"] if comm and not shared_device else None,
+                   "comm": comm, "launch": rec["launch"],
+                   "epoch_boundaries_in_region": rec["epoch_boundaries_inside"],
+                   "nce_products": "f32 MFMA (v_mfma_f32_16x16x4_f32)" if has_nce else None,
+                   "perturbation_rng": "counter-based integer hash in the SpMM epilogue (not Philox): moments / decorrelation tested",
                    # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration
-                   # (engine._calibrate_xcd_shares; null: equal dealing)
                    "xcd_shares": (None if getattr(trainer, "xcd_shares", None) is None
                                   else [int(v) for v in trainer.xcd_shares])},
+        "ms_per_step_by_rank": rec["ms_per_step_by_rank"],
         "final_losses": {"bpr": losses[0], "reg": losses[1], "cl": losses[2]},
     }
-    if notes:
-        out["notes"] = notes
-    step_s = max(elapsed / args.steps, 1e-6)
-    out["steady_state"] = steady_state(runner, step_s, pairs_per_step)
-    # SURVEY.md 8(d) puts sampling and the index upload inside the metric: `value` times exactly --steps steps (the driver's
-    # contract; a short region holds no epoch boundary), value_steady_state is the same quantity with >= 1 boundary inside
+    if watchdog is not None:
+        watchdog.partial = out                     # (from here on a hang in a later leg still leaves this line)
+    out["steady_state"] = steady_state(runner, step_s, rec["global_batch"])
     out["value_steady_state"] = out["steady_state"]["pairs_per_s"]
-    out["ms_per_step_steady_state"] = out["steady_state"]["ms_per_step"]
-    if not sharded and args.model in ("XSimGCL", "SimGCL", "SGL"):
-        # the same step with InfoNCE's products on the exact-f32 MFMA path (re-captured graph)
-        trainer.set_nce_precision("f32")
-        runner.run(20); runner.fence()
-        t0 = time.perf_counter(); runner.run(300); runner.fence()
-        out["ms_per_step_nce_f32"] = round((time.perf_counter() - t0) / 300 * 1e3, 4)
+    if has_nce and not sharded:
+        # the same step with InfoNCE's two products on 16-bit split operands (the library's faster mode; re-captured graph)
         trainer.set_nce_precision("split")
+        runner.run(20); runner.fence()
+        n16 = max(300, args.steps)
+        dt16, _, _ = runner.timed(n16, "split16 region")
+        out["value_split16"] = round(n16 * args.batch / dt16, 1)
+        out["ms_per_step_split16"] = round(dt16 / n16 * 1e3, 4)
+        out["config"]["value_split16"] = out["value_split16"]
+        trainer.set_nce_precision("f32")
         runner.run(5); runner.fence()
-    if rank == 0:
-        if roof is None:                       # (--warmup 0: no batch had run when the probes were due)
-            try:
-                roof = spmm_roofline(args, trainer, sharded, dp, None, g)
-            except RuntimeError as e:
-                if not sharded:
-                    raise
-                roof = {"error": str(e)}
-        if roof:
-            if "step_alg_bytes" in roof:
-                roof["step_GBps"] = round(roof["step_alg_bytes"] / step_s / 1e9, 1)
-            out["roofline"] = roof
+    if rank == 0 and roof:
+        if "step_alg_bytes" in roof:
+            roof["step_GBps"] = round(roof["step_alg_bytes"] / step_s / 1e9, 1)
+        out["roofline"] = roof
 
-    # ---- N > 1: the strong-scaling record -- ONE batch of B pairs divided over the ranks (north_star / SURVEY 8e: tables
-    # and graph sharded, the global batch fixed), next to the data-parallel headline.  Column blocks where d / N is a
-    # width the kernels serve (one all-gather of the batch rows per step), else row blocks (an all-gather per product).
-    if sharded and dp and os.environ.get("SRH_STRONG_RECORD", "1") != "0":
+    # ---- N > 1: the other layouts, each a record of its own next to the headline
+    for sub in sub_record_layouts(args, world, head) if sharded else []:
         dist.barrier()
-        strong_layout = os.environ.get("SRH_STRONG_LAYOUT") or None        # None: pick_layout's cols / rows / 2-D choice
         try:
             from selfrec_amd.dist import pick_layout
-            chosen = pick_layout(args.emb, world, strong_layout or "auto", nnz_adj)     # ("auto": never SRH_SHARD_LAYOUT's dp)
-            if chosen == "dp":
-                raise ValueError("SRH_STRONG_LAYOUT=dp is not a strong-scaling layout (rows, cols, 2d[:GCxGR] or auto)")
+            chosen = pick_layout(args.emb, world, sub, nnz_adj)
             s_tr, s_run, s_note = first_steps_guarded(make(chosen), lambda t: Runner(t, args.seed, dist, watchdog), watchdog,
-                                                      f"strong layout {chosen}")
-            s_run.run(args.warmup)
-            s_dt, s_bounds = s_run.timed(args.steps, "strong timed region")
-            s_step = max(s_dt / args.steps, 1e-6)
-            rec = {"layout": chosen, "scaling": "strong", "global_batch": args.batch,
-                   "value": round(args.steps * args.batch / s_dt, 1), "unit": "pairs/s", "n_gpus": world,
-                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(s_step * 1e3, 4),
-                   "epoch_boundaries_inside": s_bounds, "parallelism": parallelism_of(s_tr),
-                   "rccl_ranks": dist.get_world_size() if not shared_device else None,
-                   "launch": "hipGraph replay" if s_tr.use_graph else "eager",
-                   "steady_state": steady_state(s_run, s_step, args.batch)}
+                                                      f"sub-record {chosen}")
+            s_rec, s_dt = timed_record(s_tr, s_run, f"sub-record {chosen}")
+            s_rec.update(layout=chosen, n_gpus=world, parallelism=parallelism_of(s_tr))
+            s_rec["steady_state"] = steady_state(s_run, max(s_dt / args.steps, 1e-6), s_rec["global_batch"])
             if s_note:
-                rec["note"] = s_note
-            if rank == 0:
-                try:
-                    rec["roofline"] = spmm_roofline(args, s_tr, True, False, s_step, s_tr.graph)
-                except RuntimeError as e:
-                    rec["roofline"] = {"error": str(e)}
-            out["strong"] = rec
+                s_rec["note"] = s_note
+            out["dp" if chosen == "dp" else f"layout_{chosen.replace(':', '_')}"] = s_rec
             del s_tr, s_run
-        except Exception as e:                    # (never lose the headline to its companion record)
-            out["strong"] = {"error": f"{type(e).__name__}: {e}"}
+        except Exception as e:                    # (never lose the headline to a companion record)
+            out[f"layout_{sub}_error"] = f"{type(e).__name__}: {e}"
         if watchdog is not None:
-            watchdog.beat("strong record")
+            watchdog.beat(f"sub-record {sub}")
         dist.barrier()
 
     if rank == 0:
         small = len(raw[0]) <= 5_000_000
         if not args.no_eval and not sharded and small:
             out["eval"] = eval_throughput(trainer, data)
+            if out["eval"]:
+                # eval time runs "up to and including the python rec_list" -- the materialised figure is the
+                # metric; the lazy one is what fast_evaluation() pays per epoch
+                out["eval_users_per_s"] = out["eval"]["end_to_end_materialised_users_per_s"]
+                out["eval_users_per_s_lazy"] = out["eval"]["end_to_end_users_per_s"]
+                out["config"]["eval_users_per_s"] = out["eval_users_per_s"]
         if not sharded and not args.no_dropin and args.model == "XSimGCL" and small:
             out["dropin"] = dropin_throughput(args, raw)
             out["dropin_pairs_per_s"] = out["dropin"]["pairs_per_s"]
@@ -1016,15 +303,12 @@ def main():
         if not args.no_cpu_baseline and not small:
             out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "kind": "port", "cores": torch.get_num_threads(),
                                    "sample": "not run at this shape: the reference's step needs ~25 GB of python objects and "
-                                             "~10 min per step here (tests/golden/make_golden_shapes.py section B ran it once: "
-                                             "216 s for one step on 8 threads = 9.5 pairs/s)"}
+                                             "minutes per step (tests/golden/make_golden_shapes.py ran it once: 216 s on 8 threads)"}
         elif not args.no_cpu_baseline:
             if watchdog is not None:
                 watchdog.beat("cpu baseline (rank 0 alone)")
             out["cpu_baseline"] = cpu_baseline(args, raw, min(args.cpu_seconds, max(5.0, wd_seconds / 4)) if sharded
                                                else args.cpu_seconds)
-            if "strong" in out and "error" not in out["strong"]:
-                out["strong"]["cpu_baseline"] = out["cpu_baseline"]
             if out.get("eval"):
                 out["eval"]["cpu_baseline"] = eval_cpu_baseline(trainer, data)
     if watchdog is not None:
@@ -1044,6 +328,8 @@ def main():
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.stop()
+    if notes:
+        out["notes"] = notes
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)        # RCCL's banner goes through C stdio: keep the JSON line last

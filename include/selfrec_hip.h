@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 25
+#define SRH_ABI_VERSION 26
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -548,6 +548,14 @@ srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t*
 srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals,
                                 const float* d_x, float* d_y, int32_t d, const srh_spmm_epilogue_t* epi,
                                 uint64_t* d_stamps, void* stream);
+/* The propagation launch's own lower bound, measured (bench.py's roofline.gather_bound_us): the task list of `plan` for d-
+ * column tables on its workgroup -> XCD placement, the (col) stream and the eight-in-flight gathers of x rows with their
+ * multiply-adds -- and nothing after them: no values (pattern), no cross-group reduction, no split-row hand-off, no epilogue,
+ * no y (d_scratch: one (d)-float row, never written for finite sums).  A strict subset of srh_spmm_f32's work on its schedule:
+ * it cannot come out slower than the product it bounds.  The XSimGCL_Encoder.forward product it prices:
+ * model/graph/XSimGCL.py:83-101.  d = 64 / 128 / 256.  Measurement only. */
+srh_status_t srh_spmm_gather_bound(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_x, float* d_scratch,
+                                   int32_t d, void* stream);
 /* The bare gather stream of a propagation launch, for the roofline block of bench.py (the step's dominant
  * kernel is priced against HBM on ALGORITHMIC bytes; this probe says what the chip's vector-memory path needs for the row
  * fetches alone).  Walks d_indices[0 .. n_idx) -- the live graph's CSR column array, as data/ui_graph.py:47-56 orders it --

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -115,6 +115,7 @@ SIGNATURES = {
     "srh_spmm_plan_set_xcd_shares": (_i32, [_vp, _i32, _vp]),
     "srh_spmm_plan_run_tasks": (_i32, [_vp, _i32]),
     "srh_spmm_f32_probe": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "srh_spmm_gather_bound": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "srh_gather_floor_probe": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "srh_spmm_plan_destroy": (None, [_vp]),
     "srh_spmm3_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

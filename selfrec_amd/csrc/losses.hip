@@ -329,6 +329,9 @@ struct NceWs {
                         // the accumulated sums: see nce_tile_lds)
   double* losspart;     // one partial per finish wave
   int32_t* ticket;      // np/16 + 1 arrival counters (zeroed by nce_prep, re-armed by the last arriver)
+  struct NcePlan* plan; // problem 0's: the persistent passes' task list for this step (written by nce_prep)
+  float* etile;         // all-f32 passes, n <= kNceReuseMax: pass 1's weights e_ij, stored [key j][query i] (row stride np),
+                        // so that pass 2 reads its A fragments back instead of recomputing the logits (NULL: recompute)
   // split-bf16 operand images of the two normalised views (hi = bf16(x), lo = bf16(x - hi)):
   // both stored FRAGMENT-LINEAR: the 64 lanes of one MFMA operand load read one contiguous 1 KB
   //   kq_*[view]  [row/16][k-slice s][lane][8]: lane (c16 = lane&15, g = lane>>4) holds row 16*tile + c16,
@@ -368,6 +371,7 @@ struct NcePlan {
   int n[kNceMaxProblems], per[kNceMaxProblems], splits[kNceMaxProblems], first[kNceMaxProblems + 1];
 };
 constexpr int kNceQueryBlock = 128, kNceKeyBlock = 32, kNceMaxPer = 128;
+constexpr int kNceReuseMax = 8192;      // pass 1 keeps its n x n weights for pass 2 up to this n (256 MB per problem)
 
 
 __device__ __forceinline__ void nce_plan(const NceBatch& b, NcePlan& p) {
@@ -432,6 +436,9 @@ inline NceWs carve_nce(void* ws, int64_t n_max, int d) {
     w.vt_lo[v] = h; h += np * d;
   }
   w.ticket = reinterpret_cast<int32_t*>(h);
+  // (np / 16 + 1 counters, then the plan record on the next 128-byte line: the trailing 512 bytes of srh_infonce_ws_bytes)
+  w.plan = reinterpret_cast<NcePlan*>(reinterpret_cast<char*>(h) + ((4 * (np / 16 + 1) + 127) / 128) * 128);
+  w.etile = np <= kNceReuseMax ? reinterpret_cast<float*>(reinterpret_cast<char*>(h) + 4 * (np / 16) + 512) : nullptr;
   return w;
 }
 
@@ -451,6 +458,14 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
   const bool second = by == 1;
   if (bx == 0 && by == 0)
     for (int k = threadIdx.x; k <= (int)(w.np / 16); k += 256) w.ticket[k] = 0;
+  // the persistent passes' task list, cut ONCE per step from the live row counts: the passes and the finish read the record
+  // (in every workgroup of the passes the same cut cost 4.9 k cycles of scalar divisions and dependent loads -- a tenth of
+  // the kernel; tools/nce_stamps.py)
+  if (batch.slots > 0 && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) {
+    NcePlan plan;
+    nce_plan(batch, plan);
+    *batch.w[0].plan = plan;
+  }
   const float* V = second ? V2 : V1;
   float* out = second ? w.v2n : w.v1n;
   float* nrm = second ? w.norm2 : w.norm1;
@@ -917,7 +932,27 @@ __device__ __forceinline__ void buffer_to_lds16(const void* base, int bytes, voi
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, lane_off, wave_off, 0, 0);
 }
 
-template <int D, bool PASS2>
+#ifdef SRH_NCEF32_STAMPS
+// (laboratory builds only: tools/spmm_lab/build_alt.sh stamps "-DSRH_NCEF32_STAMPS"; per wave {start, planned, first chunk in,
+//  key loop done, stores done, blocks, task} on the shader clock -- read by tools/nce_stamps.py through srh_debug_nce_stamps)
+__device__ unsigned long long g_nce_stamps[2][512 * 8 * 8];
+#define SRH_STAMP(k) do { if (lane == 0) g_nce_stamps[PASS2 ? 1 : 0][((size_t)blockIdx.x * 8 + wv) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define SRH_STAMP_VAL(k, v) do { if (lane == 0) g_nce_stamps[PASS2 ? 1 : 0][((size_t)blockIdx.x * 8 + wv) * 8 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define SRH_STAMP(k) do {} while (0)
+#define SRH_STAMP_VAL(k, v) do {} while (0)
+#endif
+
+// REUSE (every problem of the batch has its n x n weight array: n <= kNceReuseMax): pass 1 also stores the weight of every
+// (query i, key j) pair -- masked: 0 for the pair's own, for keys >= n and for queries >= n -- transposed, so that the lane
+// holding query j of pass 2 finds its four keys 4 g .. 4 g + 3 in ONE 16-byte load; pass 2 then runs no S product, no exp
+// and no masks: half its MFMAs.  (The f32 MFMA and the VALU do not overlap on this chip, so what a pass costs is the SUM of
+// the two: 64 MFMAs x 32 cycles per block and wave against 32 in pass 2 now.)
+__device__ __forceinline__ void st_f1_wt(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int D, bool PASS2, bool REUSE>
 __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_tau) {
   constexpr int DQ = D / 4;            // k-steps of the S product (dims per lane)
   constexpr int NT = D / 16;           // 16-column n-tiles of the P.V product
@@ -929,9 +964,10 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* invl_s = reinterpret_cast<float*>(smem + Cfg::kSlots * Cfg::kBlockBytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  NcePlan plan;
-  nce_plan(batch, plan);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  SRH_STAMP(0);
+  const NcePlan plan = *batch.w[0].plan;
+  SRH_STAMP(1);
   const int c16 = lane & 15, g = lane >> 4;
   const int cidx = (c16 + 4) & 15;
 
@@ -971,26 +1007,12 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
     const float* Qv = PASS2 ? w.v2n : w.v1n;
     const unsigned char* Kv = reinterpret_cast<const unsigned char*>(PASS2 ? w.v1n : w.v2n) + (size_t)b0 * Cfg::kBlockBytes;
     float* opart = (PASS2 ? w.opart2 : w.opart) + ((size_t)split * stride + q0) * D;
+    // pass 1 writes etile[key][query q0 + c16]; pass 2 (queries = pass 1's keys) reads etile[query q0 + c16][key .. key + 3]
+    float* et = REUSE ? (PASS2 ? w.etile + (size_t)min(q0 + c16, np - 1) * stride + (size_t)b0 * kNceKeyBlock + 4 * g
+                               : w.etile + ((size_t)b0 * kNceKeyBlock + 4 * g) * stride + q0 + c16)
+                      : nullptr;
     if (task != (int)blockIdx.x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous task's ring and 1 / l are read out
 
-    float qreg[DQ];
-    {
-      const float* src = Qv + (size_t)min(q0 + c16, np - 1) * D + 4 * g;
-#pragma unroll
-      for (int t = 0; t < KQ; ++t) {
-        const float4 x = *reinterpret_cast<const float4*>(src + 16 * t);
-        qreg[4 * t + 0] = x.x; qreg[4 * t + 1] = x.y; qreg[4 * t + 2] = x.z; qreg[4 * t + 3] = x.w;
-      }
-    }
-    if (PASS2) {
-      // 1 / l(key) from pass 1's split partials, in split order (lpart holds the off-diagonal sums; rows >= n: unused)
-      for (int t = threadIdx.x; t < nblk * kNceKeyBlock; t += 512) {
-        const int key = b0 * kNceKeyBlock + t;
-        float l = 0.f;
-        for (int sp = 0; sp < splits; ++sp) l += lpart[(size_t)sp * stride + key];
-        invl_s[t] = 1.0f / (l + ediag[key]);
-      }
-    }
     // (buffer_load ... lds, not global_load_lds: the compiler files the FLAT-encoded form under "may return out of
     // order" and turns every vmcnt it inserts itself into vmcnt(0) while one is in flight -- the ring's run-ahead gone)
     const int k_bytes = nblk * Cfg::kBlockBytes;
@@ -1004,7 +1026,33 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
           buffer_to_lds16(Kv, k_bytes, dst + i * 1024, ld_off[i], b * Cfg::kBlockBytes);
       }
     };
+    // the ring's first chunk first: the longest latency of the prologue; the query rows and (pass 2) the 1 / l fold go under
+    // it, the run-ahead chunks after them (so that "all but the 4 LPB youngest" below names exactly chunk 0 and these)
     issue_chunk(0);
+    constexpr bool kLogits = !(PASS2 && REUSE);                     // this pass forms the logits itself
+    float qreg[DQ];
+    if constexpr (kLogits) {
+      const float* src = Qv + (size_t)min(q0 + c16, np - 1) * D + 4 * g;
+#pragma unroll
+      for (int t = 0; t < KQ; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 16 * t);
+        qreg[4 * t + 0] = x.x; qreg[4 * t + 1] = x.y; qreg[4 * t + 2] = x.z; qreg[4 * t + 3] = x.w;
+      }
+    }
+    if (PASS2) {
+      // 1 / l(key) from pass 1's split partials, in split order (lpart holds the off-diagonal sums; rows >= n: unused)
+      for (int t = threadIdx.x; t < nblk * kNceKeyBlock; t += 512) {
+        const int key = b0 * kNceKeyBlock + t;
+        float lp[kNceSplits];
+#pragma unroll
+        for (int sp = 0; sp < kNceSplits; ++sp) lp[sp] = sp < splits ? lpart[(size_t)sp * stride + key] : 0.f;   // all in flight
+        const float ed = ediag[key];
+        float l = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < kNceSplits; ++sp) l += lp[sp];       // split order (adding 0 for the splits that do not exist)
+        invl_s[t] = 1.0f / (l + ed);
+      }
+    }
     issue_chunk(1);
     issue_chunk(2);
     // chunk 0 has landed once all but the 4 LPB youngest loads are back (lgkmcnt: the 1 / l stores)
@@ -1055,6 +1103,9 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[KQ + (s >> 2)][s & 3], qreg[s], acc[1], 0, 0, 0);
       }
     };
+    SRH_STAMP(2);
+    SRH_STAMP_VAL(5, nblk);
+    SRH_STAMP_VAL(6, task);
     floatx4 O[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) O[u] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -1100,6 +1151,14 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       if constexpr (kEdge) {
         if (!PASS2 && has_own && qrow < n) ediag[qrow] = own_e;     // the pair's own weight: nce_finish_row folds it in
       }
+      if constexpr (REUSE && !PASS2) {
+        // the weights pass 2 will read back (write-through: another XCD reads them next, nobody here does)
+        float* row = et + (size_t)(kNceKeyBlock * j) * stride;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st_f1_wt(row + (size_t)(16 * h + r) * stride, wgt[h][r]);
+      }
       if constexpr (kHalves) {
         lds_wait(v0);
         issue_v(j, Half1{}, v1);
@@ -1124,12 +1183,68 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       if constexpr (kMore) lds_wait(kq);
     };
 
-    if (wave_live) {
-      issue_k(0);
-      lds_wait(kq);
-      s_product();
-      issue_k(1);                                                   // (chunk 0 = blocks 0 and 1 has landed; one block: unused)
-      lds_wait(kq);
+    // pass 2 on pass 1's weights: [V operands out of LDS | weights of block j + 2 out of memory] then the block's 32 P.V
+    // MFMAs.  The weights arrive masked (own pairs, keys >= n of pass 1 = queries here); what pass 2 still masks is ITS keys
+    // >= n (pass 1's padding queries), in the one block that can hold them.
+    floatx4 e_now[2], e_next[2], e_far[2];
+    auto load_e = [&](int j, floatx4 (&e)[2]) {
+      const int jj = min(j, nblk - 1);                              // (past the range: a re-load, never used)
+      const float* src = et + (size_t)kNceKeyBlock * jj;
+      e[0] = *reinterpret_cast<const floatx4*>(src);
+      e[1] = *reinterpret_cast<const floatx4*>(src + 16);
+    };
+    auto reuse_step = [&](int j, auto edge_tag) {
+      constexpr bool kEdge = decltype(edge_tag)::value;
+      constexpr bool kHalves = D > 64;
+      floatx4 v0[4 * NV], v1[4 * NV];
+      issue_v(j, Half0{}, v0);
+      if constexpr (!kHalves) issue_v(j, Half1{}, v1);
+      load_e(j + 2, e_far);
+      float wgt[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const floatx4 il = *reinterpret_cast<const floatx4*>(invl_s + kNceKeyBlock * j + 16 * h + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float wt = e_now[h][r] * il[r];
+          if constexpr (kEdge) wt = (kNceKeyBlock * (b0 + j) + 16 * h + 4 * g + r < n) ? wt : 0.f;
+          wgt[h][r] = wt;
+        }
+      }
+      if constexpr (kHalves) {
+        lds_wait(v0);
+        issue_v(j, Half1{}, v1);
+      } else {
+        lds_wait(v0, v1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          O[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[0][r], v0[NV * r + (u >> 2)][u & 3], O[u], 0, 0, 0);
+      if constexpr (kHalves) lds_wait(v1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          O[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt[1][r], v1[NV * r + (u >> 2)][u & 3], O[u], 0, 0, 0);
+      e_now[0] = e_next[0]; e_now[1] = e_next[1];
+      e_next[0] = e_far[0]; e_next[1] = e_far[1];
+    };
+
+    if constexpr (kLogits) {
+      if (wave_live) {
+        issue_k(0);
+        lds_wait(kq);
+        s_product();
+        issue_k(1);                                                 // (chunk 0 = blocks 0 and 1 has landed; one block: unused)
+        lds_wait(kq);
+      }
+    } else {
+      if (wave_live) {
+        load_e(0, e_now);
+        load_e(1, e_next);
+      }
     }
     for (int j = 0; j < nblk; ++j) {
       if ((j & 1) == 0) {
@@ -1142,6 +1257,11 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       if (!wave_live) continue;
       // masks only where they can bite: a block reaching past the live rows, or one that holds this wave's own pairs
       const int key0 = kNceKeyBlock * (b0 + j);
+      if constexpr (!kLogits) {
+        if (key0 + kNceKeyBlock > n) reuse_step(j, std::true_type{});
+        else reuse_step(j, std::false_type{});
+        continue;
+      }
       const bool edge = key0 + kNceKeyBlock > n || (key0 < q0 + 16 && key0 + kNceKeyBlock > q0);
       if (j + 1 < nblk) {
         if (edge) block_step(j, std::true_type{}, std::true_type{});
@@ -1152,6 +1272,7 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the ring's run-ahead loads: nothing may land later)
+    SRH_STAMP(3);
     if (!wave_live) continue;
 
     // O[4 v + u'][r] = out[query q0 + 4 g + r][column 4 (cidx + 16 v) + u']
@@ -1166,6 +1287,7 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       lsum += __shfl_xor(lsum, 32);
       if (g == 0) const_cast<float*>(lpart)[(size_t)split * stride + qrow] = lsum;
     }
+    SRH_STAMP(4);
   }
 }
 
@@ -1186,9 +1308,7 @@ __device__ __forceinline__ void nce_finish_both_body(const NceBatch& batch, cons
   __shared__ float4 s_scr[4][64];
   int splits = batch.splits;
   if (batch.slots > 0) {            // the persistent passes' cut of this problem (nce_plan: same counts, same answer)
-    NcePlan plan;
-    nce_plan(batch, plan);
-    splits = plan.splits[bz];
+    splits = batch.w[0].plan->splits[bz];
   }
   const double part = wave_sum_d(nce_finish_row<LPR>(w, a, n, wave * G + g, sub, s_scr[threadIdx.x >> 6], splits));
   // ---- loss: one partial per workgroup; the workgroup that arrives last folds them in order
@@ -1293,14 +1413,24 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     // ---- SRH_NCE_F32: both products on v_mfma_f32_16x16x4_f32 (exact f32 multiply-adds), same four launches ----
     constexpr int kLds = NceF32<D>::kLds;
     static const bool attr_set = [] {
-      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+      (void)hipFuncSetAttribute((const void*)nce_tile_f32<D, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
       return true;
     }();
     (void)attr_set;
-    nce_tile_f32<D, false><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
-    SRH_LAUNCH_CHECK();
-    nce_tile_f32<D, true><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
+    bool reuse = true;                     // pass 1 keeps its weights for pass 2 (every problem has the n x n array)
+    for (int k = 0; k < count; ++k) reuse = reuse && batch.w[k].etile != nullptr;
+    if (reuse) {
+      nce_tile_f32<D, false, true><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
+      SRH_LAUNCH_CHECK();
+      nce_tile_f32<D, true, true><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
+    } else {
+      nce_tile_f32<D, false, false><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
+      SRH_LAUNCH_CHECK();
+      nce_tile_f32<D, true, false><<<grid_f32, 512, kLds, st>>>(batch, inv_tau);
+    }
     SRH_LAUNCH_CHECK();
   }
   if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
@@ -1438,7 +1568,8 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
   if (n <= 0 || d <= 0) return 0;
   const int64_t np = nce_pad(n);
   return 4 * (2 * np * d + 2 * (int64_t)kNceSplits * np * d + 4 * np + (int64_t)kNceSplits * np) + 8 * np +
-         20 * np * d + 4 * (np / 16) + 256;       // (2 views x 5 sixteen-bit operand images)
+         20 * np * d + 4 * (np / 16) + 512 +      // (2 views x 5 sixteen-bit operand images; counters; the plan record)
+         (np <= kNceReuseMax ? 4 * np * np : 0);  // (pass 1's weights for pass 2: NceWs::etile)
 }
 
 static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d, float tau,
@@ -1466,6 +1597,14 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
   if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
   return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
 }
+
+#ifdef SRH_NCEF32_STAMPS
+srh_status_t srh_debug_nce_stamps(unsigned long long* h_out /* 2 x 512 x 8 x 8 */) {
+  SRH_HIP(hipDeviceSynchronize());
+  SRH_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_nce_stamps), sizeof(g_nce_stamps)));
+  return SRH_OK;
+}
+#endif
 
 srh_status_t srh_infonce_set_precision(int32_t mode) {
   SRH_REQUIRE(mode == SRH_NCE_SPLIT_BF16 || mode == SRH_NCE_F32, "infonce_set_precision: unknown mode %d", mode);

@@ -463,7 +463,12 @@ struct alignas(64) Task64 {
 // A/B of the whole library settled where it belongs (profiles/r03_b_late_prefetch_ab.txt): the dense launches lose 0.4-0.6
 // us with it (their waves overlap enough for the early prefetch to be free), the ROW-MASKED launch -- a few thousand live
 // cooperative waves on a chain of dependent gather batches -- gains 1.5-1.8 us: instantiated for that flavour only.
-template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false>
+// FLOOR (srh_spmm_gather_bound): the launch's own lower bound, measured -- the SAME task list on the SAME workgroup ->
+// XCD placement, the same (col) stream and the same eight-in-flight gathers of x rows with their multiply-adds, and
+// nothing after them: no values (pattern), no cross-group reduction, no split-row hand-off, no epilogue, no y.  A strict
+// subset of the product's work on the product's schedule, so it cannot come out slower than the product it bounds
+// (round 4's stand-alone gather probe walked the index array in its own order and did: 48 us against 40).
+template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false, bool FLOOR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
@@ -613,6 +618,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       else if (more) fetch(coop_at(base + CH), e, cs, v);
     }
     float4 a4 = total();
+    if constexpr (FLOOR) {
+      if (a4.x == 123456.789f) Y[0] = a4;                    // (never: keeps the sums observable)
+      leave();
+      return;
+    }
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
@@ -661,7 +671,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (prefetch) { cs = csn; v = vn; }
     else if (more) fetch(short_at(q + 1, maxlen), e, cs, v);
   }
-  row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
+  if constexpr (FLOOR) {
+    const float4 a4 = total();
+    if (a4.x == 123456.789f) Y[0] = a4;
+  } else {
+    row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
+  }
   leave();
 }
 
@@ -1579,7 +1594,7 @@ srh_status_t srh_spmm_f32(const srh_spmm_plan_t* plan, const int32_t* d_indptr,
 
 static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
                                 float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch,
-                                unsigned long long* d_stamps, void* stream);
+                                unsigned long long* d_stamps, void* stream, bool floor_only = false);
 
 srh_status_t srh_spmm_f32_with_fetch(const srh_spmm_plan_t* plan, const int32_t* d_indptr, const int32_t* d_indices,
                                      const float* d_vals, const float* d_x, float* d_y, int32_t d,
@@ -1593,6 +1608,13 @@ srh_status_t srh_spmm_f32_probe(const srh_spmm_plan_t* plan, const int32_t* d_in
   SRH_REQUIRE(d_stamps, "spmm_f32_probe: null stamp buffer");
   SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_f32_probe: d=%d unsupported (64, 128 or 256)", d);
   return spmm_launch(plan, d_indices, d_vals, d_x, d_y, d, epi, nullptr, reinterpret_cast<unsigned long long*>(d_stamps), stream);
+}
+
+srh_status_t srh_spmm_gather_bound(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_x, float* d_scratch,
+                                   int32_t d, void* stream) {
+  SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_gather_bound: d=%d unsupported (64, 128 or 256)", d);
+  SRH_REQUIRE(d_scratch, "spmm_gather_bound: null scratch row");
+  return spmm_launch(plan, d_indices, nullptr, d_x, d_scratch, d, nullptr, nullptr, nullptr, stream, true);
 }
 
 srh_status_t srh_gather_floor_probe(const int32_t* d_indices, int64_t n_idx, const float* d_x, int64_t n_x_rows, int32_t d,
@@ -1670,7 +1692,7 @@ srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, cons
 
 static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_indices, const float* d_vals, const float* d_x,
                                 float* d_y, int32_t d, const srh_spmm_epilogue_t* epi, const srh_batch_fetch_args_t* fetch,
-                                unsigned long long* d_stamps, void* stream) {
+                                unsigned long long* d_stamps, void* stream, bool floor_only) {
   srh_batch_fetch_args_t fetch_args{};
   int n_fetch = 0;
   if (fetch) {
@@ -1709,7 +1731,11 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)
       ep.stamps = d_stamps;
-      if (d_stamps) {
+      if (floor_only) {
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, false, false, true);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, false, false, true);
+        else SRH_LAUNCH_ROWS(64, 3, false, false, false, true);
+      } else if (d_stamps) {
         SRH_REQUIRE(!ep.col_mark, "spmm_f32_probe: no column marks");
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, true);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, true);

@@ -444,6 +444,28 @@ def spmm_probe(csr: DeviceCSR, x: torch.Tensor, out: torch.Tensor, epilogue: Spm
     return finish, begin, end, xcd
 
 
+def spmm_gather_bound(csr, x: torch.Tensor, iters: int = 30) -> float:
+    """us per launch of srh_spmm_gather_bound on `csr`'s plan: the product's own gathers on the product's own schedule and
+    nothing after them -- a measured lower bound of ``spmm(csr, x)`` (HIP events on the launch stream).  Measurement only."""
+    d = int(x.shape[1])
+    scratch = torch.zeros(d, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+
+    def once():
+        check(lib.srh_spmm_gather_bound(csr._plan, _p(csr.indices, torch.int32), _p(x, torch.float32, "x"), scratch.data_ptr(),
+                                        d, _stream()), "srh_spmm_gather_bound")
+    for _ in range(5):
+        once()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        once()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
 def gather_floor_probe(indices: torch.Tensor, x: torch.Tensor, blocks: int = 4096, iters: int = 30) -> float:
     """us per pass of the bare gather stream over `indices` into the (rows, d) table `x` (srh_gather_floor_probe: the row
     fetches of one propagation launch and nothing else), HIP events on the launch stream.  Measurement only."""

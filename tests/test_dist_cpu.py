@@ -296,13 +296,33 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0
-    assert rec["parallelism"].startswith("data parallel x2")
-    # the companion record of the same line: ONE batch divided over the ranks (d / 2 = 32 columns per rank)
-    assert rec["strong_parallelism"].startswith("column-sharded tables x2")
+    assert rec["launch_check"] and rec["world"] == 2 and rec["rank_sum"] == 3.0 and rec["ranks_in_collective"] == 2
+    # the HEADLINE of `--gpus N` is north_star's configuration: ONE batch of 2048 pairs divided over the ranks (d / 2 = 32
+    # columns per rank), strong scaling; data parallel (N x 2048 pairs per step) is the sub-record
+    assert rec["headline"]["global_batch"] == 2048 and rec["headline"]["scaling"] == "strong"
+    assert rec["headline"]["layout"] == "cols" and rec["headline"]["parallelism"].startswith("column-sharded tables x2")
+    assert rec["sub_records"] == ["dp"]
     assert "torch.distributed.run" in p.stderr
     # the rendezvous port is picked free per launch, never a fixed number
     assert rec["master_port"] != 29511 and f"--master-port {rec['master_port']}" in p.stderr
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_headline_keeps_the_global_batch_at_2048(world):
+    """whatever N, the first record of `bench.py --gpus N` is the fixed-batch partition (B = 2048, strong);
+    on the 1 M x 500 k graph the plain row partition BASELINE.json names is timed beside pick_layout's grid."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from selfrec_amd.dist import pick_layout
+    for shape, emb in (("yelp2018", 64), ("1m-500k", 128)):
+        args = bench.parse(["--gpus", str(world), "--shape", shape, "--emb", str(emb)])
+        head = bench.headline_layout(args, world)
+        chosen = pick_layout(args.emb, world, head, 100_000_000 if shape == "1m-500k" else 2_500_000)
+        assert chosen != "dp" and bench.scaling_of(chosen) == "strong"
+        assert args.batch * (world if chosen == "dp" else 1) == 2048
+        subs = bench.sub_record_layouts(args, world, head)
+        assert subs[0] == "dp" and (("rows" in subs) == (shape == "1m-500k"))
 
 
 def _bench(args, **env_extra):
@@ -372,8 +392,14 @@ def test_bench_runner_counts_epoch_boundaries_and_takes_the_max_over_ranks():
 
     r = NoFence(Stub(), 7)
     r.run(3)
-    dt, bounds = r.timed(9, "x")
-    assert r.trainer.steps == 12 and r.trainer.uploads == 3 and bounds == 2 and dt >= 0
+    dt, bounds, per_rank = r.timed(9, "x")
+    assert r.trainer.steps == 12 and r.trainer.uploads == 3 and bounds == 2 and dt >= 0 and per_rank is None
+    assert r.steps_done == 12
+    # a short region is moved (untimed steps) to where it straddles an epoch boundary: 5-batch epochs, 3 left now
+    assert r.left == 3 and r.align_to_epoch_boundary(2) == 2 and r.left == 1
+    _, bounds, _ = r.timed(2, "y")
+    assert bounds == 1
+    assert r.align_to_epoch_boundary(9) == 0                     # (longer than an epoch: nothing to align)
     built = []
 
     def make(eager=False):

@@ -28,10 +28,10 @@ def test_checker_sees_a_copy_of_a_pending_register():
 @pytest.mark.skipif(not os.path.exists(device_isa.LIB), reason="library not built")
 def test_f32_infonce_passes_never_touch_an_unsettled_lds_read():
     ks = device_isa.kernels(name_filter="nce_tile_f32")
-    assert len(ks) == 4, sorted(ks)                                   # d = 64 / 128 x pass 1 / 2
+    assert len(ks) == 8, sorted(ks)                                   # d = 64 / 128 x pass 1 / 2 x weights kept / recomputed
     for name, body in ks.items():
-        assert sum(i.startswith("ds_read_b128") for i in body) >= 32, name
-        assert sum(i.startswith("v_mfma_f32_16x16x4_f32") for i in body) >= 128, name
+        assert sum(i.startswith("ds_read_b128") for i in body) >= 16, name
+        assert sum(i.startswith("v_mfma_f32_16x16x4_f32") for i in body) >= 64, name
         bad = device_isa.async_lds_violations(body)
         assert not bad, (name, bad[:5])
         # the ring's loads are buffer_load ... lds (not the FLAT-encoded global_load_lds, which turns every compiler-made

@@ -76,6 +76,23 @@ ncef32ab)
     rm -rf $OUT/ncef32ab_$N
     cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so
   done;;
+blockedab)
+  # column-blocked / relabelled propagation product at the 1 M x 500 k, d = 128 shape (tools/spmm_blocked_ab.py)
+  timeout ${BLOCKEDAB_TIMEOUT:-1500} python tools/spmm_blocked_ab.py > $OUT/spmm_blocked_ab.txt 2>&1; echo "blockedab exit $?"; grep -v amdgpu.ids $OUT/spmm_blocked_ab.txt | tail -30;;
+blockedpmc)
+  # fabric traffic + L2 hit rate of chosen variants: BLOCKED_PMC="ids:full ids:blocks6 relabel:full"
+  : > $OUT/spmm_blocked_pmc.txt
+  for V in ${BLOCKED_PMC:-ids:full}; do
+    for G in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum WRITE_SIZE"; do
+      rm -rf $OUT/blockedpmc; (cd /tmp && SPMM_AB_ONLY=$V SPMM_AB_ITERS=3 timeout 900 rocprofv3 --kernel-trace --pmc $G -d $OLDPWD/$OUT/blockedpmc -o pmc -- python $OLDPWD/tools/spmm_blocked_ab.py > $OLDPWD/$OUT/blockedpmc.log 2>&1); echo "blockedpmc $V [$G] exit $?"
+      f=$(find $OUT/blockedpmc -name "*.db" | head -1); echo "== $V" >> $OUT/spmm_blocked_pmc.txt; [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "spmm_rows" | tee -a $OUT/spmm_blocked_pmc.txt
+    done
+  done
+  rm -rf $OUT/blockedpmc;;
+ncestamps)
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so; cp tools/spmm_lab/alt/libselfrec_hip_stamps.so selfrec_amd/lib/libselfrec_hip.so
+  timeout 300 python tools/nce_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/nce_stamps.txt; echo "ncestamps exit $?"; cat $OUT/nce_stamps.txt
+  cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
 testsk)
   # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
   timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
