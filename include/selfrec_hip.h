@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 26
+#define SRH_ABI_VERSION 27
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -531,6 +531,11 @@ typedef struct {
   int32_t* d_n_cat;                /* optional: n_uniq_u + n_uniq_i */
   int64_t* d_now;                  /* optional int64[2]: copy of d_cursor taken by this launch -- what a kernel that runs
                                       CONCURRENTLY with the cursor advance (Adam beside srh_zero_rows) reads its step from */
+  int64_t half_batches;            /* 0: the arrays hold one epoch.  nb > 0: they hold TWO epochs back to back, nb batch
+                                      slots each (d_epoch_u/i/j and the unique-id lists: 2 nb batch_size entries, the counts:
+                                      2 nb) -- batch no b >= nb is batch b - nb of the second: its rows are cut against
+                                      n_edges with b - nb, its data sits at b.  The engine fills one half (a copy on its own
+                                      stream) while the steps read the other: an epoch boundary costs a cursor write. */
 } srh_batch_fetch_args_t;
 srh_status_t srh_batch_fetch(const srh_batch_fetch_args_t* args, void* stream);
 /* srh_spmm_f32 for d = 64, 128, 256 (no column marks) that ALSO performs srh_batch_fetch(fetch): eight more workgroups at

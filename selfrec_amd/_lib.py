@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
@@ -33,7 +33,8 @@ class BatchFetchArgs(C.Structure):
                 ("d_stage_u", C.c_void_p), ("d_stage_i", C.c_void_p), ("d_stage_j", C.c_void_p),
                 ("d_stage_uniq_u", C.c_void_p), ("d_stage_uniq_i", C.c_void_p), ("d_meta", C.c_void_p),
                 ("d_row_mark", C.c_void_p), ("mark_item_offset", C.c_int32), ("cat_item_offset", C.c_int32),
-                ("d_zero4", C.c_void_p), ("d_stage_cat", C.c_void_p), ("d_n_cat", C.c_void_p), ("d_now", C.c_void_p)]
+                ("d_zero4", C.c_void_p), ("d_stage_cat", C.c_void_p), ("d_n_cat", C.c_void_p), ("d_now", C.c_void_p),
+                ("half_batches", C.c_int64)]
 
 
 class InfonceProblem(C.Structure):

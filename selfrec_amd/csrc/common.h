@@ -60,7 +60,9 @@ __device__ __forceinline__ void batch_fetch_body(const srh_batch_fetch_args_t& f
   const int64_t b = f.d_cursor[0];
   const int32_t stamp = (int32_t)f.d_cursor[1];
   const int64_t bs = f.batch_size, ptr = b * bs;
-  const int64_t rows = (ptr >= f.n_edges) ? 0 : ((ptr + bs < f.n_edges) ? bs : f.n_edges - ptr);
+  // (two epochs back to back: batch b >= half_batches is batch b - half_batches of the second one)
+  const int64_t in_epoch = ((f.half_batches > 0 && b >= f.half_batches) ? b - f.half_batches : b) * bs;
+  const int64_t rows = (in_epoch >= f.n_edges) ? 0 : ((in_epoch + bs < f.n_edges) ? bs : f.n_edges - in_epoch);
   const int64_t tid = (int64_t)block * 256 + threadIdx.x, nth = (int64_t)n_blocks * 256;
   for (int64_t i = tid; i < rows; i += nth) {
     const int32_t u = f.d_epoch_u[ptr + i], p = f.d_epoch_i[ptr + i], n = f.d_epoch_j[ptr + i];

@@ -196,10 +196,18 @@ class FusedTrainer:
             self.nce_ws = torch.empty(one.numel() * (1 if model == "SGL" else 2), dtype=torch.uint8, device=dev)
         E = self.sampler.n_edges
         self.epoch_batches = (E + B - 1) // B
-        sizes = {"u": E, "i": E, "j": E, "uniq_u": self.epoch_batches * B, "uniq_i": self.epoch_batches * B,
-                 "n_uniq_u": self.epoch_batches, "n_uniq_i": self.epoch_batches}
-        # fixed addresses: a captured hipGraph keeps pointing at them across epochs
-        self._epoch_dev = {k: torch.zeros(n, dtype=torch.int32, device=dev) for k, n in sizes.items()}
+        # The device holds TWO epochs back to back (srh_batch_fetch_args_t::half_batches): the steps read one half while the
+        # next epoch's arrays are copied into the other on a stream of their own (stage_epoch, run by the prefetch thread),
+        # so an epoch boundary costs one cursor write instead of a 25 MB upload in front of the next step (1.5 ms at the
+        # Yelp2018 shape -- five steps).  Fixed addresses: a captured hipGraph keeps pointing at them across epochs.
+        nb = self.epoch_batches
+        self._epoch_slot = {"u": nb * B, "i": nb * B, "j": nb * B, "uniq_u": nb * B, "uniq_i": nb * B,
+                            "n_uniq_u": nb, "n_uniq_i": nb}                       # entries of ONE half
+        self._epoch_dev = {k: torch.zeros(2 * n, dtype=torch.int32, device=dev) for k, n in self._epoch_slot.items()}
+        self._live_half = None                 # the half the steps read (None: nothing uploaded yet)
+        self._half_free = [None, None]         # event on the step stream: every step that read this half has been enqueued
+        self._copy_stream = None
+        self._pinned = [None, None]
         self._epoch_ready = False
         self.step_count = 0
         # (a sharded step is captured only on request: RCCL collectives inside a hipGraph could not be
@@ -420,13 +428,59 @@ class FusedTrainer:
         host = self._epoch_host if host is None else host
         return self.rows.epoch_node_ids(host, self.P)
 
+    def _next_half(self):
+        return 0 if self._live_half is None else 1 - self._live_half
+
+    def stage_epoch(self, host):
+        """Start copying a sampled epoch into the half of the device arrays the steps are NOT reading, on the copy stream,
+        from pinned memory; `upload_epoch(host)` later only waits for it.  Called by the prefetch thread right after
+        sampling (GPU only; without it upload_epoch copies in line).  The target half was last read by the epoch before the
+        live one: the copy is ordered behind the event recorded when that epoch's last step had been enqueued."""
+        if self.dev.type != "cuda" or "_staged" in host:
+            return host
+        torch.cuda.set_device(self.dev)                                   # (a worker thread starts on device 0)
+        half = self._next_half()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.dev)
+        if self._pinned[half] is None:
+            self._pinned[half] = {k: torch.empty(n, dtype=torch.int32).pin_memory() for k, n in self._epoch_slot.items()}
+        pin = self._pinned[half]
+        if "_pin_done" in pin:
+            pin["_pin_done"].synchronize()                              # (two epochs ago: long complete)
+        for k, n in self._epoch_slot.items():
+            src = torch.from_numpy(host[k])
+            pin[k][:src.numel()].copy_(src)
+        with torch.cuda.stream(self._copy_stream):
+            if self._half_free[half] is not None:
+                self._copy_stream.wait_event(self._half_free[half])
+            for k, n in self._epoch_slot.items():
+                m = int(host[k].size)
+                self._epoch_dev[k][half * n:half * n + m].copy_(pin[k][:m], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        pin["_pin_done"] = done
+        host["_staged"] = (half, done)
+        return host
+
     def upload_epoch(self, host):
         dev = self.dev
         if "masks" in host:
             for v, mk in enumerate(host["masks"]):
                 self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
-        for k, t in self._epoch_dev.items():
-            t.copy_(torch.from_numpy(host[k]), non_blocking=True)
+        half = self._next_half()
+        staged = host.pop("_staged", None)
+        if staged is not None and staged[0] == half:
+            torch.cuda.current_stream().wait_event(staged[1])           # the copy stream's work, ordered before the next step
+        else:
+            # in line, on the step stream (in order behind every step that read this half): tests, begin_epoch(), the CPU
+            # stand-ins -- or a staged copy that went to the other half (an epoch was uploaded in between)
+            for k, n in self._epoch_slot.items():
+                src = torch.from_numpy(host[k])
+                self._epoch_dev[k][half * n:half * n + src.numel()].copy_(src, non_blocking=True)
+        if dev.type == "cuda" and self._live_half is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                                   # every step of the epoch that read the old half
+            self._half_free[self._live_half] = ev
         if self.place.replicated_batches:   # same seed => same batches on every rank; one tiny collective per epoch says so
             # (data parallel: every rank samples ITS OWN batches by design)
             w3 = np.arange(1, 4, dtype=np.int64)
@@ -436,7 +490,8 @@ class FusedTrainer:
                                      for k in ("u", "i", "j")])
         self._epoch_host = host
         self._epoch_ready = True
-        self.cursor[0:1].zero_()
+        self._live_half = half
+        self.cursor[0:1].fill_(half * self.epoch_batches)
 
     def begin_epoch(self):
         self.upload_epoch(self.sample_epoch_host())
@@ -654,7 +709,8 @@ class FusedTrainer:
         # the staged ids are table rows (items already offset / permuted): one table, one index space
         cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
         fetch = ((self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta),
-                 dict(row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now, **cat))
+                 dict(row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now,
+                      half_batches=self.epoch_batches, **cat))
         # The first product of the step does not depend on the batch (marks and staged ids enter at the last forward
         # layer and at the losses), so the fetch rides on its launch as eight extra workgroups instead of being a 5 us
         # launch of its own at the head of the step (srh_spmm_f32_with_fetch).
@@ -952,6 +1008,9 @@ class EpochPrefetcher:
     def _work(self):
         try:
             self._result = self.trainer._sample_epoch_host_now() if self._first else self.trainer.sample_epoch_host()
+            stage = getattr(self.trainer, "stage_epoch", None)
+            if stage is not None and not self._first:      # (the early first epoch is drawn while the trainer is still being built)
+                self._result = stage(self._result)
         except BaseException as e:  # surfaced on the consumer side
             self._error = e
 

@@ -828,8 +828,9 @@ def zero_rows(lists, d, cursor_advance=None):
 
 
 def batch_fetch_args(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
-                     stage_cat=None, cat_item_offset=0, n_cat=None, now=None):
-    """srh_batch_fetch_args_t.  ep: dict of device int32 arrays for the epoch; stage: dict of staging buffers."""
+                     stage_cat=None, cat_item_offset=0, n_cat=None, now=None, half_batches=0):
+    """srh_batch_fetch_args_t.  ep: dict of device int32 arrays for the epoch (two epochs back to back when half_batches >
+    0); stage: dict of staging buffers."""
     a = _lib.BatchFetchArgs()
     a.d_epoch_u, a.d_epoch_i, a.d_epoch_j = (_p(ep[k], torch.int32) for k in ("u", "i", "j"))
     a.d_epoch_uniq_u, a.d_epoch_uniq_i = _p(ep.get("uniq_u"), torch.int32), _p(ep.get("uniq_i"), torch.int32)
@@ -841,6 +842,7 @@ def batch_fetch_args(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None
     a.mark_item_offset, a.cat_item_offset = int(mark_item_offset), int(cat_item_offset)
     a.d_zero4, a.d_stage_cat, a.d_n_cat = _p(zero4, torch.float64), _p(stage_cat, torch.int32), _p(n_cat, torch.int32)
     a.d_now = _p(now, torch.int64)
+    a.half_batches = int(half_batches)
     a._keepalive = [ep, cursor, stage, meta, row_mark, zero4, stage_cat, n_cat, now]
     return a
 

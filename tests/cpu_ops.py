@@ -112,12 +112,13 @@ def axpby(a, x, b, y):
 
 
 def batch_fetch(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
-                stage_cat=None, cat_item_offset=0, n_cat=None, now=None):
+                stage_cat=None, cat_item_offset=0, n_cat=None, now=None, half_batches=0):
     b, stamp = int(cursor[0]), int(cursor[1])
     if now is not None:
         now.copy_(cursor)
     lo = b * batch_size
-    rows = max(0, min(batch_size, n_edges - lo))
+    in_epoch = (b - half_batches if half_batches and b >= half_batches else b) * batch_size
+    rows = max(0, min(batch_size, n_edges - in_epoch))
     for k in ("u", "i", "j"):
         stage[k][:rows] = ep[k][lo:lo + rows]
     if row_mark is not None and rows:

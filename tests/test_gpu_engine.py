@@ -258,6 +258,41 @@ def test_top128_without_a_spare_column_still_orders_ties_like_the_heap(I):
         assert np.array_equal(sc[u], np.asarray(want_sc, dtype=np.float32))
 
 
+def test_epochs_staged_by_the_prefetch_thread_train_like_epochs_uploaded_in_line(golden_models, golden_meta, tiny_data):
+    """The device holds two epochs back to back: the prefetch thread copies epoch e + 1 into the half epoch e is not reading
+    (pinned memory, its own stream) and the boundary is a cursor write.  Four epochs driven that way -- hipGraph replay, the
+    host never waiting for the device -- against the same four uploaded in line (begin_epoch): same batches, same
+    parameters up to the order of the batch-gradient atomics."""
+    from selfrec_amd.engine import EpochPrefetcher
+    outs = []
+    for staged in (False, True):
+        tr = make_trainer("XSimGCL", golden_models, golden_meta, tiny_data, noise_fn=None, use_graph=True)
+        tr.sampler.seed(5)
+        halves = []
+        if staged:
+            pre = EpochPrefetcher(tr)
+            pre.start()
+            for _ in range(4):
+                host = pre.take()
+                assert "_staged" in host                                     # the copy is already on its way
+                tr.upload_epoch(host)
+                pre.start()                                                  # epoch e + 1 is drawn and staged under epoch e
+                halves.append(tr._live_half)
+                for _ in range(tr.epoch_batches):
+                    tr.step()
+        else:
+            for _ in range(4):
+                for _ in range(tr.begin_epoch()):
+                    tr.step()
+                halves.append(tr._live_half)
+        assert halves == [0, 1, 0, 1]
+        torch.cuda.synchronize()
+        outs.append((tr.E0.cpu().numpy(), tr.read_losses()))
+    assert np.isfinite(outs[0][0]).all()
+    assert rel_err(outs[1][0], outs[0][0]) < 2e-6
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["XSimGCL", "SGL", "LightGCN"])
 def test_hipgraph_replay_equals_eager(golden_models, golden_meta, tiny_data, name):
     """Same RNG stream, same batches: a captured step replayed == the eager launch sequence."""

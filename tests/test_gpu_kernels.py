@@ -355,6 +355,39 @@ def test_product_with_batch_fetch_rider_equals_the_two_launches(tiny_data):
         ops.spmm(g.adj, x, epilogue=ops.make_epilogue(row_mark=one["mark"], mark_stamp=cursor[1:2]), fetch=args(one))
 
 
+def test_batch_fetch_over_two_epochs_back_to_back():
+    """srh_batch_fetch_args_t::half_batches: the arrays hold two epochs of nb batch slots each; batch no b >= nb is batch
+    b - nb of the second epoch -- cut against n_edges with b - nb (the last batch of EITHER epoch is short), read at b.
+    Every batch of both halves against the CPU stand-in of the same call (tests/cpu_ops.py)."""
+    from tests import cpu_ops
+    rng = np.random.default_rng(21)
+    B, E, N = 32, 100, 500
+    nb = (E + B - 1) // B
+    host = {k: rng.integers(0, N, 2 * nb * B).astype(np.int32) for k in ("u", "i", "j", "uniq_u", "uniq_i")}
+    host["n_uniq_u"] = rng.integers(1, B, 2 * nb).astype(np.int32)
+    host["n_uniq_i"] = rng.integers(1, B, 2 * nb).astype(np.int32)
+    dev_ep = {k: torch.from_numpy(v).to(DEV) for k, v in host.items()}
+    cpu_ep = {k: torch.from_numpy(v) for k, v in host.items()}
+
+    def buffers(dev):
+        return dict(stage={k: torch.full((B,), -1, dtype=torch.int32, device=dev) for k in ("u", "i", "j", "uniq_u", "uniq_i")},
+                    meta=torch.full((4,), -1, dtype=torch.int32, device=dev), mark=torch.zeros(N, dtype=torch.int32, device=dev))
+    for b in range(2 * nb + 1):                                       # (+ one batch past the end: 0 rows)
+        got, want = buffers(DEV), buffers("cpu")
+        ops.batch_fetch(dev_ep, E, B, torch.tensor([b, 9], dtype=torch.int64, device=DEV), got["stage"], got["meta"],
+                        row_mark=got["mark"], half_batches=nb)
+        cpu_ops.batch_fetch(cpu_ep, E, B, torch.tensor([b, 9], dtype=torch.int64), want["stage"], want["meta"],
+                            row_mark=want["mark"], half_batches=nb)
+        rows = int(want["meta"][0])
+        assert rows == (E - (nb - 1) * B if b % nb == nb - 1 and b < 2 * nb else (B if b < 2 * nb else 0)), (b, rows)
+        assert torch.equal(got["meta"].cpu(), want["meta"]) and torch.equal(got["mark"].cpu(), want["mark"]), b
+        for k in ("u", "i", "j"):
+            assert torch.equal(got["stage"][k][:rows].cpu(), want["stage"][k][:rows]), (b, k)
+        a, c = int(want["meta"][1]), int(want["meta"][2])
+        assert torch.equal(got["stage"]["uniq_u"][:a].cpu(), want["stage"]["uniq_u"][:a])
+        assert torch.equal(got["stage"]["uniq_i"][:c].cpu(), want["stage"]["uniq_i"][:c])
+
+
 # ------------------------------------------------------------------------------------------
 # (a-2) normalisation and edge-dropped views
 # ------------------------------------------------------------------------------------------

@@ -162,8 +162,9 @@ bench)
   tail -3 $OUT/bench.err; tail -1 $OUT/bench.log | cut -c1-3000;;
 benchworld2)
   # every line of bench.py's N > 1 path with N > 1 real ranks -- on ONE GPU, over gloo (figures meaningless)
-  for lay in ${W2_LAYOUTS:-dp cols}; do
-    SRH_DIST_BACKEND=gloo:device SRH_SHARD_LAYOUT=$lay timeout 600 python bench.py --gpus ${W2_RANKS:-2} --steps 300 --warmup 20 > $OUT/bench_world2_$lay.log 2> $OUT/bench_world2_$lay.err
+  for lay in ${W2_LAYOUTS:-auto}; do
+    # (auto: the headline = fixed-batch partition, then the dp sub-record; W2_LAYOUTS="auto rows" to force others first)
+    SRH_DIST_BACKEND=gloo:device SRH_SHARD_LAYOUT=$lay timeout 900 python bench.py --gpus ${W2_RANKS:-2} --steps ${W2_STEPS:-100} --warmup 10 --no-cpu-baseline > $OUT/bench_world2_$lay.log 2> $OUT/bench_world2_$lay.err
     echo "benchworld2 $lay exit $?"; grep -v "Gloo\|socket.cpp\|amdgpu.ids" $OUT/bench_world2_$lay.err | tail -5; tail -1 $OUT/bench_world2_$lay.log | cut -c1-1500
   done;;
 benchdriver)
