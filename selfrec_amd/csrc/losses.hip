@@ -600,11 +600,13 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const int dst = w.idx ? w.idx[ii] : ii;
   float4 O1 = f4_zero(), O2 = f4_zero();
   float l = 0.f;
-  for (int k0 = 0; k0 < splits; k0 += 8) {             // eight splits' loads in flight at a time
-    float4 p1[8], p2[8];
-    float lp[8];
+  constexpr int kW = 10;                                // splits whose loads are in flight at a time: the persistent passes
+                                                        // cut 8 .. 10 key ranges at the benchmark's shapes -- one round trip
+  for (int k0 = 0; k0 < splits; k0 += kW) {
+    float4 p1[kW], p2[kW];
+    float lp[kW];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kW; ++k) {
       p1[k] = p2[k] = f4_zero();
       lp[k] = 0.f;
       if (k0 + k < splits) {
@@ -614,7 +616,7 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                      // split order: the order pass 2 folded 1 / l in
+    for (int k = 0; k < kW; ++k) {                     // split order: the order pass 2 folded 1 / l in
       O1 = f4_add(O1, p1[k]);
       O2 = f4_add(O2, p2[k]);
       l += lp[k];

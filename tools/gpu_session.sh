@@ -221,11 +221,6 @@ pmc)
     --tail ${PMC_TAIL:-40} --out $OUT/spmm_dense_traffic${PMC_NAME:-}.json --summary "${PMC_SUMMARY:-profiles/r04_e_pmc_dense_spmm.txt}" \
     --what "${PMC_WHAT:-spmm_rows_kernel<16,false>, dominant launch of the step: dense value-free flavour, yelp2018-shape graph, d=64}" > /dev/null && echo "wrote $OUT/spmm_dense_traffic${PMC_NAME:-}.json"
   find $OUT/pmc_* -name "*.db" -size +30M -delete;;
-losspmc)
-  rm -rf $OUT/losspmc
-  (cd /tmp && LOSS_PROBE_ITERS=50 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d $OLDPWD/$OUT/losspmc -o pmc -- python $OLDPWD/tools/loss_probe.py > $OLDPWD/$OUT/losspmc.log 2>&1); echo "losspmc exit $?"
-  f=$(find $OUT/losspmc -name "*.db" | head -1); [ -n "$f" ] && python tools/pmc_summary.py "$f" | grep -E "nce_|bpr_" | tee $OUT/loss_pmc.txt
-  find $OUT/losspmc -name "*.db" -size +30M -delete;;
 evalpmc)
   # MFMA utilisation of the scoring GEMM (double-buffered gemm_nt_kernel<64, 8, filter>) + per-kernel times of the ranking
   rm -rf $OUT/evalpmc $OUT/evalprof
