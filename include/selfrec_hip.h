@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 27
+#define SRH_ABI_VERSION 28
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -353,16 +353,16 @@ srh_status_t srh_infonce_fwd_bwd_multi(const srh_infonce_problem_t* problems, in
                                        int32_t d, float tau, float loss_scale, double* d_loss,
                                        void* d_ws, int32_t precision, void* stream);
 
-/* Arithmetic of InfoNCE's two n x n x d products (util/loss_torch.py:46-47's matmul and its backward).  The
- * reference computes them in fp32.  Default (SRH_NCE_SPLIT16): operands carried as short sums of 16-bit pieces on the
- * 16-bit MFMA pipe with f32 accumulation -- the similarity product on scaled f16 hi + lo (x to 2^-22: logits as accurate
- * as an f32 dot product, the loss to f32 rounding), the P.V product on bf16 hi + mid (2^-18 per product; gradients within
- * 1e-6 relative of the f64 expression; the library can be built with SRH_NCE_PV_TERMS=6 for 2^-27).  SRH_NCE_F32
- * evaluates every multiply-add on the f32 MFMA at ~2.5x the time of the two passes.  The mode is an ARGUMENT of
- * srh_infonce_fwd_bwd_multi / srh_bpr_infonce_fwd_bwd (a trainer carries its own: two models in one process do not share
- * it); srh_infonce_set_precision sets the process DEFAULT that SRH_NCE_DEFAULT and srh_infonce_fwd_bwd resolve to, and the
- * environment variable SRH_NCE_F32 (set to anything) selects F32 as its initial value.  (SRH_NCE_SPLIT_BF16: the mode's name in
- * ABI <= 20, when both products ran on bf16 hi + lo and the logits were good to 2e-5 only.) */
+/* Arithmetic of InfoNCE's two n x n x d products (util/loss_torch.py:46-47's matmul and its backward).  The reference
+ * computes them in fp32, and so does the DEFAULT here (SRH_NCE_F32): every multiply-add on v_mfma_f32_16x16x4_f32 (exact
+ * f32 fma chains), d = 64 / 128 (d = 256 resolves to the split mode).  SRH_NCE_SPLIT16 is the faster opt-in: operands
+ * carried as short sums of 16-bit pieces on the 16-bit MFMA pipe with f32 accumulation -- the similarity product on scaled
+ * f16 hi + lo (x to 2^-22: logits as accurate as an f32 dot product), the P.V product on bf16 hi + mid (2^-18 per product;
+ * gradients within 1e-6 relative of the f64 expression).  The mode is an ARGUMENT of srh_infonce_fwd_bwd_multi /
+ * srh_bpr_infonce_fwd_bwd (a trainer carries its own: two models in one process do not share it);
+ * srh_infonce_set_precision sets the process DEFAULT that SRH_NCE_DEFAULT and srh_infonce_fwd_bwd resolve to, and the
+ * environment variable SRH_NCE_SPLIT16 (set to anything) selects the split mode as its initial value.  (SRH_NCE_SPLIT_BF16:
+ * the mode's name in ABI <= 20.) */
 #define SRH_NCE_SPLIT16 0
 #define SRH_NCE_SPLIT_BF16 SRH_NCE_SPLIT16
 #define SRH_NCE_F32 1

@@ -251,11 +251,11 @@ class GraphRecommender(Recommender):
             uid = np.fromiter((self.data.user[u] for u in users), dtype=np.int32, count=len(users))
             id2item = self.data.id2item
             names = np.array([id2item[i] for i in range(self.data.item_num)], dtype=object)
-            cached = self._test_users_cache = (self.data.test_set, users, uid, names, dict.fromkeys(users))
+            cached = self._test_users_cache = (self.data.test_set, users, uid, names, dict.fromkeys(users), names.tolist())
         return cached[1:]
 
     def test(self):
-        users, uid, names, keys = self._test_users()
+        users, uid, names, keys, names_list = self._test_users()
         # (the device top-K kernels keep K <= 128 candidates per user in LDS: a longer list, or one longer than the
         # catalogue, takes the reference's per-user loop below -- slow, but every config the reference runs, runs)
         on_device = self.max_N <= min(DEVICE_TOPK_MAX, self.data.item_num)
@@ -269,7 +269,7 @@ class GraphRecommender(Recommender):
             # reads like the reference's {user: [(item, score), ...]}; rows are built on access and
             # ranking_evaluation works on the arrays (same strings)
             return RankedLists(users, names, ids, scores, hit_flags=flags, truth_sizes=sizes, origin=self.data.test_set,
-                               per_user=got[3] if len(got) > 3 else None, keys=keys)
+                               per_user=got[3] if len(got) > 3 else None, keys=keys, names_list=names_list)
         rec_list = {}
         for user in users:                                   # models with a custom predict()
             candidates = self.predict(user)

@@ -87,7 +87,13 @@ class TwoHopRows:
     so a rank's link carries 2/G of a slab per partner instead of a whole one (Gr = 2, G = 8: 4x less time on the wire).
     With Gr > 2 hop 2 runs once per partner offset j = 1 .. Gr - 1 (rank k sends to rank t the piece it holds of the
     slab of t's j-th partner).  Pieces are padded to equal size; the slab's own piece never leaves the rank.
-    Same interface and same result as the direct group all-gather (tests/test_dist_cpu.py)."""
+    Same interface and same result as the direct group all-gather (tests/test_dist_cpu.py).
+
+    LOCKSTEP.  Hops 1 and 2 are ``all_to_all_single`` on the WORLD group, although the component gathers within one
+    column block: every rank of EVERY column block has to make the same sequence of ``all_gather`` calls with the same
+    ``n`` and dtype -- and therefore the same direct / two-hop decision -- or the job hangs instead of raising.  The engine
+    satisfies this by construction (all ranks run the same step on tables of the same padded shape); the first call of
+    every (n, dtype) checks it with one small all-reduce over WORLD and raises on a mismatch."""
 
     def __init__(self, direct, n_col_groups, n_row_parts):
         self.direct = direct                              # (tiny messages -- checksums, the D^-1/2 vector -- go direct)
@@ -100,6 +106,21 @@ class TwoHopRows:
     def assert_replicated(self, what, values, device):
         self.direct.assert_replicated(what, values, device)
 
+    def _check_lockstep(self, n, inp):
+        """first two-hop gather of this (n, dtype): every rank of the world is about to make the same call (else: raise,
+        on every rank, before the all-to-all that would hang)"""
+        key = ("lockstep", int(n), str(inp.dtype))
+        if key in self._buf:
+            return
+        sig = float(n) * 4.0 + inp.element_size()
+        t = torch.tensor([sig, -sig], dtype=torch.float64, device=inp.device)
+        _dist.all_reduce(t, op=_dist.ReduceOp.MAX)           # max(sig), max(-sig) = -min(sig): equal everywhere iff both are ours
+        if float(t[0]) != sig or float(t[1]) != -sig:
+            raise RuntimeError(f"TwoHopRows.all_gather: ranks disagree on the gather they are making (this rank: {n} elements "
+                               f"of {inp.dtype}; the world's range of n * 4 + itemsize: {-float(t[1])} .. {float(t[0])}) -- "
+                               "every rank of every column block must call it in lockstep")
+        self._buf[key] = True
+
     def _scratch(self, piece, dtype, device):
         key = (piece, dtype, str(device))
         if key not in self._buf:
@@ -111,6 +132,7 @@ class TwoHopRows:
         n = inp.numel()
         if n * inp.element_size() < self.min_bytes or out.numel() != self.Gr * n:
             return self.direct.all_gather(out, inp)
+        self._check_lockstep(n, inp)
         G, Gr = self.G, self.Gr
         piece = (n + G - 1) // G
         send, held, fwd = self._scratch(piece, inp.dtype, inp.device)

@@ -317,11 +317,12 @@ constexpr bool kNceWT = SRH_NCE_WT != 0;
 constexpr int kNceUsedSplits = SRH_NCE_SPLITS;   // key-range splits per query tile (NceBatch::splits; the finish kernels unroll over it)
 constexpr int kNcePvTerms = SRH_NCE_PV_TERMS;
 
-// Arithmetic of the two n x n x d products (srh_infonce_set_precision): split 16-bit operands on the 16-bit MFMA pipe
-// (default: the similarity product on scaled f16 hi + lo -- logits to 2^-22, the accuracy of an f32 dot product -- the
-// P.V product on bf16 hi + mid [+ lo]) or exact f32 multiply-adds on the f32 MFMA (~2.5x the time of the two passes).
-// The mode is an argument of the multi-problem entry points; this is the process DEFAULT (SRH_NCE_DEFAULT resolves to it).
-std::atomic<int> g_nce_precision{getenv("SRH_NCE_F32") ? SRH_NCE_F32 : SRH_NCE_SPLIT_BF16};
+// Arithmetic of the two n x n x d products (srh_infonce_set_precision).  The process DEFAULT is the reference's: exact f32
+// multiply-adds on the f32 MFMA (SRH_NCE_F32; d = 256, which those passes do not serve, resolves to the split mode).
+// SRH_NCE_SPLIT16 -- operands as short sums of 16-bit pieces on the 16-bit MFMA pipe: the similarity product on scaled f16
+// hi + lo (logits to 2^-22), the P.V product on bf16 hi + mid [+ lo] -- is the faster opt-in (the mode is an argument of
+// the multi-problem entry points; the environment variable SRH_NCE_SPLIT16 makes it the initial default).
+std::atomic<int> g_nce_precision{getenv("SRH_NCE_SPLIT16") ? SRH_NCE_SPLIT16 : SRH_NCE_F32};
 
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
@@ -1579,7 +1580,10 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
                                   const BprArgs* bpr) {
   SRH_REQUIRE(precision == SRH_NCE_DEFAULT || precision == SRH_NCE_SPLIT16 || precision == SRH_NCE_F32,
               "infonce_fwd_bwd: unknown precision %d", precision);
-  if (precision == SRH_NCE_DEFAULT) precision = g_nce_precision.load(std::memory_order_relaxed);
+  if (precision == SRH_NCE_DEFAULT) {
+    precision = g_nce_precision.load(std::memory_order_relaxed);
+    if (d == 256) precision = SRH_NCE_SPLIT16;            // (the f32 passes serve d = 64 / 128: the default never fails on d)
+  }
   SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
   SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);
   SRH_REQUIRE(d == 64 || d == 128 || d == 256, "infonce_fwd_bwd: d=%d unsupported (need 64, 128 or 256)", d);

@@ -75,7 +75,7 @@ class FusedTrainer:
         self.B = int(batch_size)
         self.noise_fn = noise_fn                  # (N, d) -> tensor; None = in-kernel counter RNG
         # arithmetic of InfoNCE's two n x n x d products, carried by THIS trainer and passed with every loss call ('split' |
-        # 'f32'; None = the process default of srh_infonce_set_precision / SRH_NCE_F32, resolved at launch / capture time)
+        # 'f32'; None = the process default -- f32 unless srh_infonce_set_precision / SRH_NCE_SPLIT16 says otherwise --, resolved at launch / capture time)
         if nce_precision is not None and nce_precision not in ops.NCE_PRECISIONS:
             raise SelfrecHipError(f"FusedTrainer: nce_precision {nce_precision!r}: one of {sorted(ops.NCE_PRECISIONS)} or None")
         self.nce_precision = nce_precision

@@ -585,7 +585,7 @@ def l2_reg_bwd(xs, reg, norms, gout, gxs):
 
 # SRH_NCE_SPLIT16, SRH_NCE_F32 (include/selfrec_hip.h); "bf16x3" is the round-1/2 name of the split mode, kept as an alias
 NCE_PRECISIONS = {"split": 0, "f32": 1, "bf16x3": 0}
-NCE_DEFAULT = -1               # SRH_NCE_DEFAULT: the process default (srh_infonce_set_precision / SRH_NCE_F32)
+NCE_DEFAULT = -1               # SRH_NCE_DEFAULT: the process default (f32 unless srh_infonce_set_precision / SRH_NCE_SPLIT16 says otherwise)
 
 
 def _nce_mode(precision):
@@ -598,8 +598,9 @@ def _nce_mode(precision):
 
 
 def set_infonce_precision(mode: str):
-    """'split' (default: operands as short sums of 16-bit pieces on the 16-bit MFMA pipe -- logits on scaled f16 hi + lo,
-    accurate to 2^-22 like an f32 dot product; P.V on bf16 pieces) or 'f32' (every multiply-add on the f32 MFMA).
+    """'f32' (the default: every multiply-add of InfoNCE's two n x n x d products on the f32 MFMA, the reference's
+    arithmetic) or 'split' (operands as short sums of 16-bit pieces on the 16-bit MFMA pipe -- logits on scaled f16 hi + lo,
+    accurate to 2^-22 like an f32 dot product; P.V on bf16 pieces: ~10 us per step faster at the Yelp2018 shape).
     The process DEFAULT: what calls that name no precision run on (the loss mirrors of the op-level tier); a trainer
     carries its own mode and passes it with every call (engine.FusedTrainer.nce_precision)."""
     if mode not in NCE_PRECISIONS:

@@ -21,13 +21,14 @@ class RankedLists(dict):
     """
 
     def __init__(self, users, item_names, ids, scores, hit_flags=None, truth_sizes=None, origin=None, per_user=None,
-                 keys=None):
+                 keys=None, names_list=None):
         # The KEYS are in the storage from the start (`keys`: a {user: None} dict of these users to copy -- the caller's
         # cached one -- else built here): C code that sizes a dict without asking it (json's encoder short-cuts an empty
         # one to "{}") sees the right length, and everything that then reads entries goes through the methods below.
         super().__init__(keys if keys is not None else dict.fromkeys(users))
         self.users = users if isinstance(users, list) else list(users)
         self._filled = False                   # the values are still placeholders
+        self._names_list = names_list          # item_names as a python list (the caller's cached one, else made on demand)
         self.item_names, self.ids, self.scores = item_names, ids, scores
         self.hit_flags, self.truth_sizes, self.origin = hit_flags, truth_sizes, origin
         # {N: (hits per user int32, DCG / IDCG per user float64)} when the ranking computed them (srh_metric_rows)
@@ -39,14 +40,19 @@ class RankedLists(dict):
         built (graph_recommender.py:52-53) -- in two bulk conversions instead of one row at a time."""
         if self._filled:
             return dict(dict.items(self))
-        # 630 k tuples at the Yelp2018 shape: the cyclic collector would run a generation-0 pass every 700 allocations over
-        # objects that cannot form a cycle (str, float) -- half of this function's time; it is paused for the construction
+        # 630 k tuples at the Yelp2018 shape, allocated in one pass of C (selfrec_amd/_reclist: csrc/reclist.c, built by the
+        # same make as the HIP library) -- exactly the objects that are returned, no intermediate lists; the cyclic collector,
+        # which would run a generation-0 pass every 700 allocations over objects that cannot form a cycle (str, float), is
+        # paused for the construction (together: 115 -> 45 ms where the python form was timed)
+        from .. import _reclist                              # (absent = the package was not built: make -C selfrec_amd/csrc)
+        if self._names_list is None:
+            self._names_list = self.item_names.tolist() if hasattr(self.item_names, "tolist") else list(self.item_names)
+        ids = np.ascontiguousarray(self.ids, dtype=np.int32)
+        scores = np.ascontiguousarray(self.scores, dtype=np.float32)
         was_on = gc.isenabled()
         gc.disable()
         try:
-            names = self.item_names[self.ids].tolist()          # (users x K) python strings
-            scores = self.scores.tolist()                       # (users x K) python floats
-            return {u: list(zip(n, s)) for u, n, s in zip(self.users, names, scores)}
+            return _reclist.build(self.users, self._names_list, ids, scores, int(ids.shape[1]))
         finally:
             if was_on:
                 gc.enable()

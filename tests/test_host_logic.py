@@ -276,6 +276,32 @@ def test_ranked_lists_reads_like_the_dict_and_reports_the_same_strings():
     assert not other and len(other) == 0
 
 
+def test_reclist_builder_checks_its_arguments():
+    """selfrec_amd/_reclist.build (csrc/reclist.c): the C construction of test()'s rec_list refuses ids outside the name
+    table and arrays of the wrong size instead of reading past them; rows come back in `users` order as plain lists of
+    (name, python float) tuples."""
+    from selfrec_amd import _reclist
+    users, names = ["a", "b", "c"], ["i0", "i1", "i2", "i3"]
+    ids = np.array([[3, 0], [1, 1], [2, 3]], dtype=np.int32)
+    sc = np.array([[0.5, 0.25], [2.0, -1.0], [0.0, 1e-9]], dtype=np.float32)
+    got = _reclist.build(users, names, ids, sc, 2)
+    assert type(got) is dict and list(got) == users
+    assert got["a"] == [("i3", 0.5), ("i0", 0.25)] and got["c"][1] == ("i3", float(np.float32(1e-9)))
+    assert all(type(row) is list and type(row[0]) is tuple and type(row[0][1]) is float for row in got.values())
+    bad = ids.copy(); bad[1, 0] = 4
+    with pytest.raises(IndexError):
+        _reclist.build(users, names, bad, sc, 2)
+    bad[1, 0] = -1
+    with pytest.raises(IndexError):
+        _reclist.build(users, names, bad, sc, 2)
+    with pytest.raises(ValueError):
+        _reclist.build(users, names, ids, sc, 3)
+    with pytest.raises(ValueError):
+        _reclist.build(users, names, ids[:2], sc, 2)
+    with pytest.raises(TypeError):
+        _reclist.build(tuple(users), names, ids, sc, 2)
+
+
 def test_xcd_share_calibration_controller(monkeypatch):
     """engine.FusedTrainer._calibrate_xcd_shares against a simulated chip: XCD k takes speed[k] us per workgroup of its
     queue.  The controller must move workgroups from the late XCDs to the early ones until they finish together, keep the

@@ -24,7 +24,7 @@ r.fence()
 rec = gr.GraphRecommender.__new__(gr.GraphRecommender)
 rec.data, rec.max_N, rec.topN = data, 20, [20]
 rec.user_emb, rec.item_emb = (t.contiguous() for t in tr.embeddings())
-users, uid, names, _keys = rec._test_users()
+users, uid, names, _keys, _names_list = rec._test_users()
 for _ in range(3):
     rec.rank_on_device(uid)
 

@@ -19,7 +19,7 @@ rec = GraphRecommender.__new__(GraphRecommender)
 rec.data, rec.max_N, rec.topN = data, 20, [20]
 rec.user_emb = torch.randn((data.user_num, 64), device="cuda") * 0.1
 rec.item_emb = torch.randn((data.item_num, 64), device="cuda") * 0.1
-users, uid, names, _keys = rec._test_users()
+users, uid, names, _keys, _names_list = rec._test_users()
 rec.test(); rec.test()
 
 

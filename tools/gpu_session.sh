@@ -93,6 +93,8 @@ ncestamps)
   cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so; cp tools/spmm_lab/alt/libselfrec_hip_stamps.so selfrec_amd/lib/libselfrec_hip.so
   timeout 300 python tools/nce_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/nce_stamps.txt; echo "ncestamps exit $?"; cat $OUT/nce_stamps.txt
   cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
+ncemodeab)
+  timeout 600 python tools/nce_mode_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/nce_mode_ab.txt; echo "ncemodeab exit $?"; cat $OUT/nce_mode_ab.txt;;
 testsk)
   # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
   timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
