@@ -1058,9 +1058,21 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
     }
     issue_chunk(1);
     issue_chunk(2);
-    // chunk 0 has landed once all but the 4 LPB youngest loads are back (lgkmcnt: the 1 / l stores)
-    if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // RESIDENT: the task's whole key range fits the ring (<= 8 blocks: every task of a batch of n <= 4096 rows) -- all of it
+    // is requested now and the key loop runs without a barrier.  (Each chunk boundary of the ring costs ~1.3 k cycles with
+    // the matrix pipe idle: all eight waves meet at the barrier, issue their two direct loads -- 60-185 cycles each -- and
+    // wait out an LDS round trip at the same time; a 7-block task has three of them.)
+    const bool resident = nblk <= Cfg::kSlots;
+    if (resident) {
+      issue_chunk(3);
+      // chunk 0 has landed once all but the 6 LPB youngest loads are back (lgkmcnt: the 1 / l stores)
+      if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      // ... all but the 4 LPB youngest
+      if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     // S operands of one block: K rows 16 h + c16, chunks g + 4 t   (kq[KQ h + t], element e <-> k-step 4 t + e)
     floatx4 kq[2 * KQ];
@@ -1239,7 +1251,10 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
       if (wave_live) {
         issue_k(0);
         lds_wait(kq);
-        s_product();
+        s_product();                                                // (block 0's 32 MFMAs cover the wait below)
+      }
+      if (resident) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the whole range is in, everywhere
+      if (wave_live) {
         issue_k(1);                                                 // (chunk 0 = blocks 0 and 1 has landed; one block: unused)
         lds_wait(kq);
       }
@@ -1248,9 +1263,10 @@ __global__ __launch_bounds__(512) void nce_tile_f32(NceBatch batch, float inv_ta
         load_e(0, e_now);
         load_e(1, e_next);
       }
+      if (resident) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     for (int j = 0; j < nblk; ++j) {
-      if ((j & 1) == 0) {
+      if (!resident && (j & 1) == 0) {
         // chunks <= c + 1 have landed once only chunk c + 2's loads are out; then every wave is past chunk c - 1 and its
         // slots take chunk c + 3
         if constexpr (LPB == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
