@@ -59,7 +59,7 @@ def eval_throughput(trainer, data, k=20):
     assert len(report) == 5
     # "up to and including the python rec_list" -- the same call with the reference's return value fully
     # built: {user: [(item name, score), ...]} for every test user, every tuple a python object (630 k of them here);
-    # test() itself returns a lazy Mapping over the arrays (rows are built on access) and the figure above times that
+    # test() itself returns the dict with its rows still unbuilt (RankedLists: built on first access) and the figure above times that
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -100,7 +100,7 @@ def eval_throughput(trainer, data, k=20):
             "rows_redone_in_reference_heap_order": getattr(rec, "_last_tie_rows", None),
             "kernels_users_per_s": round(len(uid) / t_dev, 1), "kernels_ms": round(t_dev * 1e3, 3),
             "end_to_end_users_per_s": round(len(out) / t_e2e, 1),
-            "end_to_end_what": "test() + ranking_evaluation(); test() returns a lazy Mapping over the (users x K) arrays",
+            "end_to_end_what": "test() + ranking_evaluation(); test() returns the dict with its rows still unbuilt",
             "end_to_end_materialised_users_per_s": round(len(out) / t_mat, 1),
             "end_to_end_materialised_what": "the same plus the reference's rec_list built in full: a dict of every user's "
                                             "list of (item name, score) tuples (SURVEY 8d's definition of eval time)",
