@@ -11,14 +11,17 @@ stays on ``sys.path`` and is imported as is:
     from model.graph.XSimGCL import XSimGCL           # unmodified reference file, HIP kernels underneath
 
 ``install(fuse=True)`` (or ``SRH_DROPIN_FUSE=1``) goes one step further for the five model files whose whole training
-step the fused engine implements (MF, LightGCN, XSimGCL, SimGCL, SGL): when such a file is imported and its bytes are
-the reference's (SHA-256 below -- "unchanged" is checked, not assumed), the class keeps everything it defines --
+step the fused engine implements (MF, LightGCN, XSimGCL, SimGCL, SGL): when such a file is imported and its bytes -- or,
+failing that, its syntax tree without comments and docstrings -- are the reference's (digests below: "unchanged" is checked,
+not assumed), the class keeps everything it defines --
 ``__init__`` (config keys, the torch encoder and its xavier-initialised ``embedding_dict``), ``save``, ``predict``,
 ``cal_cl_loss`` -- but ``train()`` is served by ``engine.FusedTrainer``: same batches (the global ``random`` stream is
 consumed and left as the file's own loop would leave it), same arithmetic (the parity tests of the engine are against
 this very file's CPU run), the encoder's parameters aliased to the engine's table so ``save()`` / ``predict()`` /
-checkpoints see the trained values.  An edited file -- any byte -- keeps its own ``train()`` on the op-level tier.
+checkpoints see the trained values.  A file whose CODE was edited keeps its own ``train()`` on the op-level tier, and a line
+on stderr says so.
 """
+import ast
 import hashlib
 import importlib
 import os
@@ -31,16 +34,52 @@ MIRRORED = {
 }
 
 
-# SHA-256 of the reference's model files at the surveyed commit (Coder-Yu/SELFRec @ 2025-07-25): facts about the
-# reference, not copies of it.  model/graph/<name>.py -> digest.
+def _canonical(node):
+    """A version-stable dump of a syntax tree: node class names and non-empty fields, no positions, no docstrings -- what
+    the file DOES, not how it is typed.  (ast.dump is not used: its text changes between python versions as node classes gain
+    optional fields.)"""
+    if isinstance(node, ast.AST):
+        fields = []
+        for name in sorted(node._fields):
+            value = getattr(node, name, None)
+            if value is None or value == []:
+                continue
+            if name == "body" and isinstance(value, list) and value and isinstance(value[0], ast.Expr) \
+                    and isinstance(getattr(value[0], "value", None), ast.Constant) and isinstance(value[0].value.value, str) \
+                    and isinstance(node, (ast.Module, ast.ClassDef, ast.FunctionDef, ast.AsyncFunctionDef)):
+                value = value[1:] or [ast.Pass()]                    # a docstring is a comment
+            if name in ("kind", "type_comment", "type_params", "type_ignores"):
+                continue
+            fields.append((name, _canonical(value)))
+        return (type(node).__name__, tuple(fields))
+    if isinstance(node, list):
+        return tuple(_canonical(v) for v in node)
+    return repr(node)
+
+
+def syntax_digest(source: str) -> str:
+    """SHA-256 of the canonical syntax dump of a python source text: unchanged by comments, blank lines, line breaks inside
+    expressions, quote style or docstrings; changed by any change of code."""
+    return hashlib.sha256(repr(_canonical(ast.parse(source))).encode()).hexdigest()
+
+
+# Digests of the reference's model files at the surveyed commit (Coder-Yu/SELFRec @ 2025-07-25) -- facts about the reference,
+# not copies of it (tests/golden/make_fusable_digests.py prints them): model/graph/<name>.py -> (SHA-256 of the bytes, SHA-256
+# of the canonical syntax dump).  A file is "the reference's" when EITHER matches: an upstream re-format, a licence header or
+# a comment does not drop a user to the op-level tier; a changed statement does -- and says so (maybe_fuse).
 FUSABLE = {
-    "XSimGCL": "621ed1ea0181e57ac2924c8ad14f82ceefc7e774080613362ad92c3ae3fe3f2e",
-    "LightGCN": "18707b19917c481ea0c1b3f9fcd1db0be2cb0ad0fa955b7affc498d89d52c8dd",
-    "SimGCL": "33d92e815b98f2f19d57fb8615d3076efac7014e16fd66d4aa3c02d870ad6f11",
-    "SGL": "ee53e7821791b7196d44bc84833b694ece64f2cc7d3b5f92dd360fab26c7452a",
-    "MF": "0564ad7cfc66cca9c79d004efbfa6fda0c51370af266110924a25e260bb563b3",
+    "XSimGCL": ("621ed1ea0181e57ac2924c8ad14f82ceefc7e774080613362ad92c3ae3fe3f2e",
+                "88a708970565de7183f3f4356bf2187658c9c636c49d7b05d3bbb6420386f56f"),
+    "LightGCN": ("18707b19917c481ea0c1b3f9fcd1db0be2cb0ad0fa955b7affc498d89d52c8dd",
+                 "38942f59c276693d5f0834169dd8e4314ebdc50c3f4a5ffb5ce3a1bbc86639db"),
+    "SimGCL": ("33d92e815b98f2f19d57fb8615d3076efac7014e16fd66d4aa3c02d870ad6f11",
+               "facec86c9e9af60cc11467bd6f7a11fcfbb2c8d849fb7d653b56e48dbff5bf00"),
+    "SGL": ("ee53e7821791b7196d44bc84833b694ece64f2cc7d3b5f92dd360fab26c7452a",
+            "f4a728dadee8df853608c12bbd811a0dea0d2638d830c8379c0030338c362f72"),
+    "MF": ("0564ad7cfc66cca9c79d004efbfa6fda0c51370af266110924a25e260bb563b3",
+           "1722940934668b7ab464f1e675debfe23cab13c9c08ea173d6ffd106ca497571"),
 }
-_state = {"fuse": False, "fused": []}
+_state = {"fuse": False, "fused": [], "matched": {}}
 
 
 def fuse_enabled() -> bool:
@@ -50,7 +89,8 @@ def fuse_enabled() -> bool:
 def maybe_fuse(cls) -> bool:
     """Called by the mirrored ``GraphRecommender.__init_subclass__`` for every model class: route ``cls.train`` to the
     fused engine iff fusing is on, the class is one of the five the engine implements, it is defined in a module named
-    ``model.graph.<its own name>`` and that module's file is byte-for-byte the reference's."""
+    ``model.graph.<its own name>`` and that module's file is the reference's: byte for byte, or -- comments, blank lines,
+    formatting and docstrings aside -- statement for statement."""
     name = cls.__name__
     if not fuse_enabled() or name not in FUSABLE or cls.__module__ != f"model.graph.{name}":
         return False
@@ -58,8 +98,19 @@ def maybe_fuse(cls) -> bool:
     if not path or not os.path.isfile(path):
         return False
     with open(path, "rb") as f:
-        if hashlib.sha256(f.read()).hexdigest() != FUSABLE[name]:
-            return False                                  # edited file: its own train() runs, on the op-level tier
+        raw = f.read()
+    how = "bytes" if hashlib.sha256(raw).hexdigest() == FUSABLE[name][0] else None
+    if how is None:
+        try:
+            how = "syntax" if syntax_digest(raw.decode()) == FUSABLE[name][1] else None
+        except (SyntaxError, UnicodeDecodeError):
+            how = None
+    if how is None:
+        # an edited file keeps its own train() on the op-level tier -- said once, not silently
+        print(f"[selfrec_amd.dropin] {path}: the code of {name} differs from the reference's -- its own train() runs on the "
+              f"op-level tier (HIP kernels under torch autograd), not on the fused engine", file=sys.stderr)
+        return False
+    _state["matched"][name] = how
     from .model.graph._fused import fused_train_of_reference_class
     cls._reference_train = cls.train
     cls.train = fused_train_of_reference_class

@@ -394,9 +394,10 @@ def test_loss_mirrors_evaluate_the_reference_expression_off_the_device(golden_op
         np.testing.assert_allclose(gb, golden_ops[f"ops_{n}_g_bpr"], rtol=1e-5, atol=1e-9)
 
 
-def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, monkeypatch):
+def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, monkeypatch, capsys):
     """dropin.install(fuse=True): a model class gets the fused engine's train() iff its module is model.graph.<Name> and
-    the file's SHA-256 is the reference's; one edited byte keeps the file's own train().  The
+    the file is the reference's -- by the SHA-256 of its bytes or of its syntax tree (comments and formatting aside); one
+    edited STATEMENT keeps the file's own train(), and stderr says so.  The
     reference checkout exists in the build container only -- skipped elsewhere (the GPU-side run of the fused route is
     tools/run_reference_models.py --fuse on a staged copy)."""
     import importlib
@@ -411,8 +412,10 @@ def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, m
     (stage / "model" / "graph").mkdir(parents=True)
     for name in dropin.FUSABLE:
         shutil.copy(os.path.join(ref, f"{name}.py"), stage / "model" / "graph" / f"{name}.py")
-    with open(stage / "model" / "graph" / "SimGCL.py", "a") as f:          # an edited file
-        f.write("\n# local change\n")
+    with open(stage / "model" / "graph" / "SimGCL.py", "a") as f:          # an edited file: one more STATEMENT
+        f.write("\nLOCAL_CHANGE = 1\n")
+    with open(stage / "model" / "graph" / "SGL.py", "a") as f:             # a comment and blank lines: still the reference's code
+        f.write("\n\n# re-formatted upstream\n")
     for d in (stage / "model", stage / "model" / "graph"):
         (d / "__init__.py").write_text("")
     monkeypatch.syspath_prepend(str(stage))
@@ -421,6 +424,7 @@ def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, m
         monkeypatch.delitem(sys.modules, k)
     monkeypatch.setitem(dropin._state, "fuse", False)
     monkeypatch.setitem(dropin._state, "fused", [])
+    monkeypatch.setitem(dropin._state, "matched", {})
     try:
         dropin.install(fuse=True)
         for name in ("XSimGCL", "LightGCN", "SGL", "MF"):
@@ -429,6 +433,8 @@ def test_fused_dropin_recognises_only_the_unmodified_reference_files(tmp_path, m
         cls = importlib.import_module("model.graph.SimGCL").SimGCL
         assert cls.train is not fused_train_of_reference_class and not hasattr(cls, "_reference_train")
         assert sorted(dropin._state["fused"]) == ["LightGCN", "MF", "SGL", "XSimGCL"]
+        assert dropin._state["matched"]["SGL"] == "syntax" and dropin._state["matched"]["XSimGCL"] == "bytes"
+        assert "SimGCL differs from the reference's" in capsys.readouterr().err          # (said, not silent)
         # without fuse: nothing is rerouted
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             del sys.modules[k]
@@ -585,3 +591,26 @@ def test_lazy_training_file_keeps_the_shuffles_as_a_pending_permutation(tmp_path
     random.seed(31)
     l = [b for b in next_batch_pairwise(lazy, 300)]
     assert a == l
+
+
+def test_fused_dropin_recognises_the_reference_files_by_their_code_not_their_bytes():
+    """dropin.maybe_fuse matches a model file by the SHA-256 of its bytes OR of its canonical syntax dump: comments, blank
+    lines, line breaks, quote style and docstrings do not enter the second one; any changed statement does."""
+    from selfrec_amd import dropin
+    a = 'import torch\n\nclass M(Base):\n    """doc"""\n    def train(self):\n        x = self.f(1, 2)  # comment\n        return x + 1\n'
+    b = ("# licence header\nimport torch\nclass M(Base):\n\n    def train( self ):\n        '''another doc'''\n"
+         "        x = self.f(1,\n                   2)\n        return x + 1\n")
+    c = a.replace("x + 1", "x + 2")
+    d = a.replace("def train", "def train2")
+    assert dropin.syntax_digest(a) == dropin.syntax_digest(b)
+    assert len({dropin.syntax_digest(t) for t in (a, c, d)}) == 3
+    # the table holds both digests for the five files the engine serves
+    assert set(dropin.FUSABLE) == {"XSimGCL", "LightGCN", "SimGCL", "SGL", "MF"}
+    assert all(len(v) == 2 and all(len(h) == 64 for h in v) for v in dropin.FUSABLE.values())
+    ref = "/root/reference/model/graph"
+    if os.path.isdir(ref):                      # (the build container: the digests ARE the reference's)
+        import hashlib
+        for name, (raw_sha, syn_sha) in dropin.FUSABLE.items():
+            src = open(os.path.join(ref, name + ".py"), "rb").read()
+            assert hashlib.sha256(src).hexdigest() == raw_sha and dropin.syntax_digest(src.decode()) == syn_sha
+            assert dropin.syntax_digest("# re-formatted upstream\n" + src.decode().replace("\n\n", "\n\n\n")) == syn_sha

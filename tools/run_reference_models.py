@@ -110,9 +110,9 @@ def main():
         shutil.copytree(os.path.join(os.path.abspath(args.ref), "model"), os.path.join(stage, "model"))
         for name in args.models.split(","):
             with open(os.path.join(stage, "model", "graph", f"{name}.py"), "a") as f:
-                f.write("\n# one comment line appended by tools/run_reference_models.py --edited\n")
+                f.write("\nEDITED_BY_RUN_REFERENCE_MODELS = True      # one STATEMENT appended by tools/run_reference_models.py --edited\n")
         args.ref = stage
-        print(f"# --edited: model files copied to {stage} with one comment line appended (SHA-256 no longer the reference's)")
+        print(f"# --edited: model files copied to {stage} with one statement appended (neither the byte nor the syntax digest is the reference's any more)")
     sys.path.insert(0, os.path.abspath(args.ref))
     golden = np.load(os.path.join(REPO, "tests", "golden", "shapes.npz"))
     with open(os.path.join(REPO, "tests", "golden", "shapes_meta.json")) as f:
@@ -131,8 +131,8 @@ def main():
         fused = name in dropin._state["fused"]
         assert fused == (bool(args.fuse) and not args.edited), (name, fused)
         if fused:
-            print(f"{name}: {os.path.relpath(src, os.path.abspath(args.ref))} is byte-for-byte the reference's "
-                  f"(SHA-256 {dropin.FUSABLE[name][:16]}...): train() -> engine.FusedTrainer")
+            print(f"{name}: {os.path.relpath(src, os.path.abspath(args.ref))} is the reference's (matched by "
+                  f"{dropin._state['matched'].get(name)}, SHA-256 {dropin.FUSABLE[name][0][:16]}...): train() -> engine.FusedTrainer")
         with tempfile.TemporaryDirectory() as tmp:
             os.chdir(tmp)
             try:
