@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 28
+#define SRH_ABI_VERSION 29
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -175,7 +175,8 @@ srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, cons
 int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d);
 void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
 
-enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4 };
+enum { SRH_EPI_PERTURB = 1, SRH_EPI_MEAN = 2, SRH_EPI_AXPY = 4, SRH_EPI_ADAM = 8 };
+#define SRH_MAX_ADAM_CLEAR 4
 #define SRH_MAX_PREV 8
 #define SRH_MAX_ADD 2
 #define SRH_MAX_EXTRA 2
@@ -240,6 +241,24 @@ typedef struct srh_spmm_epilogue {
    * noise row (torch.rand_like(h) in XSimGCL.py:90: d_valid columns) ends at noise_d_valid, so that F.normalize runs
    * over those columns alone.  0 = every column of the (whole) row is valid.  Tables of >= 64 columns. */
   int32_t noise_d_valid;
+  /* ADAM (d = 64 / 128 / 256, no PERTURB / MEAN / SCALE_OUT, no row marks; the launch is the LAST product of a backward
+   * chain, torch.optim.Adam(...).step() of XSimGCL.py:25,37 folded into it): the finished row -- the product after
+   * SCALE_IN and AXPY -- is d loss / d param[row].  It is NOT stored (d_y is not written); instead row `row` of
+   * d_adam_param / d_adam_m / d_adam_v takes srh_adam_step's update, operation for operation, with this step's
+   * {lr / (1 - beta1^t), sqrt(1 - beta2^t)} read from d_adam_coef (float[2]: srh_batch_fetch writes them, see
+   * d_adam_coef there).  As in srh_adam_step_reset: rows whose d_adam_clear_mark entry equals (int32)*d_mark_stamp are
+   * zeroed in the adam_n_clear tables d_adam_clear[] ((n_rows, d); they may be this launch's addends, they must not be
+   * its x), and d_adam_cursor (int64[2], or NULL) is advanced by one batch / one step -- d_mark_stamp must then point at
+   * a COPY of the step (srh_batch_fetch's d_now), since the cursor moves while the launch runs. */
+  float* d_adam_param;
+  float* d_adam_m;
+  float* d_adam_v;
+  const float* d_adam_coef;
+  float adam_beta1, adam_beta2, adam_eps;
+  int32_t adam_n_clear;
+  const int32_t* d_adam_clear_mark;
+  float* d_adam_clear[SRH_MAX_ADAM_CLEAR];
+  int64_t* d_adam_cursor;
 } srh_spmm_epilogue_t;
 enum { SRH_SCALE_IN = 1, SRH_SCALE_OUT = 2 };
 
@@ -412,7 +431,6 @@ srh_status_t srh_adam_step(float* d_param, const float* d_grad, float* d_m, floa
  * (the batch-sparse gradient buffers: optimizer.zero_grad() of XSimGCL.py:35 for the only rows that are non-zero),
  * and d_cursor_advance (int64[2], optional) is incremented.  d_step must then be srh_batch_fetch's d_now copy, not
  * the cursor itself.  A table to clear may be d_grad (MF: the gradient buffer is the batch-sparse one). */
-#define SRH_MAX_ADAM_CLEAR 4
 srh_status_t srh_adam_step_reset(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n_rows,
                                  int32_t d, const int64_t* d_step, float lr, float beta1, float beta2, float eps,
                                  const int32_t* d_row_mark, int32_t n_clear, float* const* d_clear_tables,
@@ -536,6 +554,10 @@ typedef struct {
                                       2 nb) -- batch no b >= nb is batch b - nb of the second: its rows are cut against
                                       n_edges with b - nb, its data sits at b.  The engine fills one half (a copy on its own
                                       stream) while the steps read the other: an epoch boundary costs a cursor write. */
+  float* d_adam_coef;              /* optional float[2]: this step's Adam constants {adam_lr / (1 - adam_beta1^t),
+                                      sqrt(1 - adam_beta2^t)}, t = d_cursor[1], computed in double as torch does -- what
+                                      an SRH_EPI_ADAM product of the step reads (one pow per step, not one per wave) */
+  float adam_lr, adam_beta1, adam_beta2;
 } srh_batch_fetch_args_t;
 srh_status_t srh_batch_fetch(const srh_batch_fetch_args_t* args, void* stream);
 /* srh_spmm_f32 for d = 64, 128, 256 (no column marks) that ALSO performs srh_batch_fetch(fetch): eight more workgroups at

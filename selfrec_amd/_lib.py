@@ -14,9 +14,10 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
-SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY = 1, 2, 4
+SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY, SRH_EPI_ADAM = 1, 2, 4, 8
+SRH_MAX_ADAM_CLEAR = 4
 SRH_SCALE_IN, SRH_SCALE_OUT = 1, 2
 SRH_MAX_PREV, SRH_MAX_ADD, SRH_MAX_EXTRA = 8, 2, 2
 
@@ -34,7 +35,8 @@ class BatchFetchArgs(C.Structure):
                 ("d_stage_uniq_u", C.c_void_p), ("d_stage_uniq_i", C.c_void_p), ("d_meta", C.c_void_p),
                 ("d_row_mark", C.c_void_p), ("mark_item_offset", C.c_int32), ("cat_item_offset", C.c_int32),
                 ("d_zero4", C.c_void_p), ("d_stage_cat", C.c_void_p), ("d_n_cat", C.c_void_p), ("d_now", C.c_void_p),
-                ("half_batches", C.c_int64)]
+                ("half_batches", C.c_int64), ("d_adam_coef", C.c_void_p), ("adam_lr", C.c_float),
+                ("adam_beta1", C.c_float), ("adam_beta2", C.c_float)]
 
 
 class InfonceProblem(C.Structure):
@@ -79,6 +81,9 @@ class SpmmEpilogue(C.Structure):
         ("noise_d_full", C.c_int32), ("noise_col0", C.c_int32),
         ("d_row_scale", C.c_void_p), ("scale_flags", C.c_int32), ("prev_unscale_mask", C.c_int32),
         ("add_rowscale_mask", C.c_int32), ("noise_d_valid", C.c_int32),
+        ("d_adam_param", C.c_void_p), ("d_adam_m", C.c_void_p), ("d_adam_v", C.c_void_p), ("d_adam_coef", C.c_void_p),
+        ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("adam_n_clear", C.c_int32),
+        ("d_adam_clear_mark", C.c_void_p), ("d_adam_clear", C.c_void_p * SRH_MAX_ADAM_CLEAR), ("d_adam_cursor", C.c_void_p),
     ]
 
 

@@ -34,6 +34,9 @@ srh_status_t check_fetch_args(const srh_batch_fetch_args_t* in, srh_batch_fetch_
   SRH_REQUIRE(!uq || (in->d_epoch_uniq_i && in->d_n_uniq_u && in->d_n_uniq_i && in->d_stage_uniq_u && in->d_stage_uniq_i),
               "batch_fetch: unique-id arrays must be given together");
   SRH_REQUIRE(in->n_edges > 0 && in->batch_size > 0, "batch_fetch: bad sizes");
+  SRH_REQUIRE(!in->d_adam_coef || (in->adam_lr > 0.f && in->adam_beta1 >= 0.f && in->adam_beta1 < 1.f &&
+                                   in->adam_beta2 >= 0.f && in->adam_beta2 < 1.f),
+              "batch_fetch: d_adam_coef needs adam_lr > 0 and betas in [0, 1)");
   out = *in;
   if (!uq) { out.d_stage_cat = nullptr; out.d_n_cat = nullptr; }
   return SRH_OK;

@@ -85,6 +85,13 @@ __device__ __forceinline__ void batch_fetch_body(const srh_batch_fetch_args_t& f
   if (f.d_n_cat && tid == 0) *f.d_n_cat = a + c;
   if (f.d_zero4 && tid < 4) f.d_zero4[tid] = 0.0;        // the step's loss accumulators
   if (f.d_now && tid < 2) f.d_now[tid] = f.d_cursor[tid];
+  if (f.d_adam_coef && tid == 0) {
+    // torch: bias_correction = 1 - beta ** step (python double), step_size = lr / bc1, denom = sqrt(v) / sqrt(bc2) + eps
+    // (the same expressions as adam_kernel, optim.hip -- same bits)
+    const double t = (double)f.d_cursor[1];
+    f.d_adam_coef[0] = (float)((double)f.adam_lr / (1.0 - pow((double)f.adam_beta1, t)));
+    f.d_adam_coef[1] = (float)sqrt(1.0 - pow((double)f.adam_beta2, t));
+  }
   if (tid == 0) {
     f.d_meta[0] = (int32_t)rows;
     f.d_meta[1] = a;
@@ -108,6 +115,17 @@ __device__ __forceinline__ void st_f4(float4* p, float4 v) {
   } else {
     *p = v;
   }
+}
+// One element of torch.optim.Adam's step (no weight decay, no amsgrad): the ONE definition both the stand-alone pass
+// (adam_kernel, optim.hip) and the SpMM epilogue (SRH_EPI_ADAM, spmm.hip) inline, so that they round alike.
+//   step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
+__device__ __forceinline__ void adam_element(float& m, float& v, float& p, const float g, const float b1, const float omb1,
+                                             const float b2, const float omb2, const float step_size, const float bc2_sqrt,
+                                             const float eps) {
+#pragma clang fp contract(off)    // the fused multiply-adds are the three written here, in every caller
+  m = fmaf(m, b1, omb1 * g);
+  v = fmaf(v, b2, omb2 * (g * g));
+  p = fmaf(-step_size, m / (sqrtf(v) / bc2_sqrt + eps), p);
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

@@ -46,10 +46,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const float4 gg = g[i];
     float4 mm = m[i], vv = v[i], pp = p[i];
-#define SRH_ADAM_LANE(c)                                   \
-    mm.c = mm.c * b1 + omb1 * gg.c;                        \
-    vv.c = vv.c * b2 + omb2 * (gg.c * gg.c);               \
-    pp.c -= step_size * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
+#define SRH_ADAM_LANE(c) adam_element(mm.c, vv.c, pp.c, gg.c, b1, omb1, b2, omb2, step_size, bc2_sqrt, eps);
     SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
 #undef SRH_ADAM_LANE
     st_f4<kAdamWT>(m + i, mm); st_f4<kAdamWT>(v + i, vv); st_f4<kAdamWT>(p + i, pp);

@@ -86,6 +86,14 @@ struct DevEpilogue {
   const float* row_scale;
   int32_t scale_flags, prev_unscale, add_rowscale;
   unsigned long long* stamps;    // srh_spmm_f32_probe: {begin, end, XCD} per wave (PROBE instantiations only)
+  // ADAM: the finished row is the gradient of adam_p's row -- updated here, the gradient is never stored
+  float4 *adam_p, *adam_m, *adam_v;
+  const float* adam_coef;        // {lr / bias_correction1, sqrt(bias_correction2)} of this step (batch_fetch_body)
+  float adam_b1, adam_b2, adam_eps;
+  int32_t adam_n_clear;
+  const int32_t* adam_clear_mark;
+  float4* adam_clear[SRH_MAX_ADAM_CLEAR];
+  int64_t* adam_cursor;
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -196,7 +204,7 @@ __device__ __forceinline__ float4 perturb_row(float4 y, int row, int sub, size_t
 
 // r: the row's scale factor (1 when the launch has none) -- loaded by the caller BEFORE its gathers: these waves run on
 // their chain of dependent round trips, and a load issued here would add one to every row
-template <int LPR>
+template <int LPR, bool ADAM = false>
 __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool store, float4* __restrict__ Y,
                                              const DevEpilogue& ep, const float r = 1.0f) {
   // (`store` is uniform over the row-group: a group that does not write -- groups 1.. of a cooperative task, the
@@ -214,6 +222,23 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
       const float sc = ((ep.add_rowscale >> t) & 1) ? ep.add_scale[t] * r : ep.add_scale[t];
       y = f4_fma(sc, a, y);
     }
+  }
+  if constexpr (ADAM) {
+    // (its own instantiation: the DevEpilogue fields below would otherwise sit in the SGPRs of every product)
+    // y = d loss / d param[row]: adam_kernel's update (optim.hip), operation for operation, on this lane's 16 bytes of
+    // the row; the 71 MB a separate pass spends writing and re-reading the gradient are never moved
+    const float step_size = ep.adam_coef[0], bc2_sqrt = ep.adam_coef[1];
+    const float b1 = ep.adam_b1, b2 = ep.adam_b2, omb1 = 1.0f - b1, omb2 = 1.0f - b2, aeps = ep.adam_eps;
+    float4 mm = ep.adam_m[at], vv = ep.adam_v[at], pp = ep.adam_p[at];
+#define SRH_ADAM_LANE(c) adam_element(mm.c, vv.c, pp.c, y.c, b1, omb1, b2, omb2, step_size, bc2_sqrt, aeps);
+    SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
+#undef SRH_ADAM_LANE
+    st_f4<kYWT>(ep.adam_m + at, mm); st_f4<kYWT>(ep.adam_v + at, vv); st_f4<kYWT>(ep.adam_p + at, pp);
+    // this step's rows of the batch-sparse gradient buffers: read (as addends) by this row's task alone, above
+    if (ep.adam_n_clear > 0 && ep.adam_clear_mark[row] == (int)(*ep.mark_stamp)) {
+      for (int k = 0; k < ep.adam_n_clear; ++k) ep.adam_clear[k][at] = f4_zero();
+    }
+    return;
   }
   const bool out_scaled = (ep.scale_flags & SRH_SCALE_OUT) != 0;
   if (ep.flags & SRH_EPI_PERTURB) {
@@ -468,7 +493,9 @@ struct alignas(64) Task64 {
 // nothing after them: no values (pattern), no cross-group reduction, no split-row hand-off, no epilogue, no y.  A strict
 // subset of the product's work on the product's schedule, so it cannot come out slower than the product it bounds
 // (round 4's stand-alone gather probe walked the index array in its own order and did: 48 us against 40).
-template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false, bool FLOOR = false>
+// ADAM (srh_spmm_epilogue_t, SRH_EPI_ADAM): the row epilogue ends in the optimiser's update of the row instead of a store of
+// y, and wave 0 advances the step cursor.
+template <int LPR, bool COLMASK, bool PROBE = false, bool LATEPF = false, bool FLOOR = false, bool ADAM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rows_kernel(const Task64* __restrict__ tasks, int n_tasks,
                                                         const int32_t* __restrict__ indices,
                                                         const float* __restrict__ vals,
@@ -489,6 +516,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int wave = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x - n_fetch) * 256u + threadIdx.x) >> 6));
   if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
+  // (ADAM: the last launch of the step moves the cursor; everything here reads the step from batch_fetch's copy)
+  if constexpr (ADAM) {
+    if (ep.adam_cursor && wave == 0 && lane == 0) { ep.adam_cursor[0] += 1; ep.adam_cursor[1] += 1; }
+  }
   unsigned long long t_begin = 0;
   unsigned xcc = 0;
   if constexpr (PROBE) {
@@ -626,7 +657,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) a4 = f4_add(a4, f4_shfl_xor(a4, m));
     if (slot < 0) {
-      row_epilogue<LPR>(a4, row, sub, g == 0, Y, ep, r);
+      row_epilogue<LPR, ADAM>(a4, row, sub, g == 0, Y, ep, r);
       leave();
       return;
     }
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     float4 sum = sum_partials_agent(partial + (size_t)hfirst * LPR + sub, g, G, hn, LPR);
 #pragma unroll
     for (int m = LPR; m < 64; m <<= 1) sum = f4_add(sum, f4_shfl_xor(sum, m));
-    row_epilogue<LPR>(sum, row, sub, g == 0, Y, ep, r);
+    row_epilogue<LPR, ADAM>(sum, row, sub, g == 0, Y, ep, r);
     leave();
     return;
   }
@@ -675,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float4 a4 = total();
     if (a4.x == 123456.789f) Y[0] = a4;
   } else {
-    row_epilogue<LPR>(total(), row, sub, live, Y, ep, r);
+    row_epilogue<LPR, ADAM>(total(), row, sub, live, Y, ep, r);
   }
   leave();
 }
@@ -1309,7 +1340,8 @@ struct srh_spmm_plan {
 static srh_status_t translate_epilogue(const srh_spmm_epilogue_t* epi, int32_t d, const float* d_x, const float* d_y,
                                        DevEpilogue& ep) {
   if (epi) {
-    SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY)) == 0, "spmm_f32: unknown epilogue flag");
+    SRH_REQUIRE((epi->flags & ~(SRH_EPI_PERTURB | SRH_EPI_MEAN | SRH_EPI_AXPY | SRH_EPI_ADAM)) == 0,
+                "spmm_f32: unknown epilogue flag");
     ep.flags = epi->flags;
     ep.eps = epi->eps;
     ep.noise = epi->d_noise;
@@ -1375,6 +1407,30 @@ static srh_status_t translate_epilogue(const srh_spmm_epilogue_t* epi, int32_t d
         ep.add_scale[t] = epi->add_scale[t];
       }
     }
+  }
+  if (epi && (epi->flags & SRH_EPI_ADAM)) {
+    SRH_REQUIRE(d >= 64 && !(epi->flags & (SRH_EPI_PERTURB | SRH_EPI_MEAN)) && !(epi->scale_flags & SRH_SCALE_OUT) &&
+                    !epi->d_row_mark && !epi->noise_d_full,
+                "spmm_f32: ADAM runs on whole rows of >= 64 columns, after AXPY only (no PERTURB / MEAN / SCALE_OUT / row marks)");
+    SRH_REQUIRE(epi->d_adam_param && epi->d_adam_m && epi->d_adam_v && epi->d_adam_coef, "spmm_f32: ADAM: null table");
+    SRH_REQUIRE(epi->d_adam_param != d_x && epi->d_adam_m != d_x && epi->d_adam_v != d_x, "spmm_f32: ADAM updates a table the product reads");
+    SRH_REQUIRE(epi->adam_n_clear >= 0 && epi->adam_n_clear <= SRH_MAX_ADAM_CLEAR &&
+                    (epi->adam_n_clear == 0 || (epi->d_adam_clear_mark && epi->d_mark_stamp)),
+                "spmm_f32: ADAM: at most %d tables to clear, with their row marks and the stamp", SRH_MAX_ADAM_CLEAR);
+    SRH_REQUIRE(!epi->d_adam_cursor || (epi->d_mark_stamp != epi->d_adam_cursor && epi->d_mark_stamp != epi->d_adam_cursor + 1),
+                "spmm_f32: ADAM: d_mark_stamp must be a copy of the step when the launch advances the cursor");
+    ep.adam_p = reinterpret_cast<float4*>(epi->d_adam_param);
+    ep.adam_m = reinterpret_cast<float4*>(epi->d_adam_m);
+    ep.adam_v = reinterpret_cast<float4*>(epi->d_adam_v);
+    ep.adam_coef = epi->d_adam_coef;
+    ep.adam_b1 = epi->adam_beta1; ep.adam_b2 = epi->adam_beta2; ep.adam_eps = epi->adam_eps;
+    ep.adam_n_clear = epi->adam_n_clear;
+    ep.adam_clear_mark = epi->d_adam_clear_mark;
+    for (int k = 0; k < epi->adam_n_clear; ++k) {
+      SRH_REQUIRE(epi->d_adam_clear[k] && epi->d_adam_clear[k] != d_x, "spmm_f32: ADAM: table %d to clear is null or the product's x", k);
+      ep.adam_clear[k] = reinterpret_cast<float4*>(epi->d_adam_clear[k]);
+    }
+    ep.adam_cursor = epi->d_adam_cursor;
   }
   if (!ep.noise_d_full) { ep.noise_d_full = d; ep.noise_col0 = 0; }
   ep.noise_d_valid = ep.noise_d_full;
@@ -1731,6 +1787,8 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)
       ep.stamps = d_stamps;
+      SRH_REQUIRE(!(ep.flags & SRH_EPI_ADAM) || !(floor_only || d_stamps || ep.col_mark),
+                  "spmm_f32: ADAM runs on the plain launch (no column marks, not under the probes)");
       if (floor_only) {
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, false, false, true);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, false, false, true);
@@ -1744,6 +1802,10 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
         if (d == 64) SRH_LAUNCH_ROWS(16, 1, true, false);
         else if (d == 128) SRH_LAUNCH_ROWS(32, 2, true, false);
         else SRH_LAUNCH_ROWS(64, 3, true, false);
+      } else if (ep.flags & SRH_EPI_ADAM) {
+        if (d == 64) SRH_LAUNCH_ROWS(16, 1, false, false, false, false, true);
+        else if (d == 128) SRH_LAUNCH_ROWS(32, 2, false, false, false, false, true);
+        else SRH_LAUNCH_ROWS(64, 3, false, false, false, false, true);
       } else if (ep.row_mark && d == 64) {
         SRH_LAUNCH_ROWS(16, 1, false, false, true);              // row-masked launch: late prefetch (measured at d = 64)
       } else {

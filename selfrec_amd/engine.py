@@ -188,6 +188,15 @@ class FusedTrainer:
         # batch_fetch as a rider of the step's first product (see _step_front): models whose step starts with a plain
         # srh_spmm_f32 launch of a layer that is not the last
         self.ride_fetch = single and self.L >= 2 and self.d >= 64 and model in ("LightGCN", "XSimGCL", "SimGCL")
+        # Adam inside the LAST backward product's row epilogue (SRH_EPI_ADAM): the finished gradient row updates its
+        # parameter row where it is produced -- no 18 MB gradient written and read back, no separate 21 us pass; the same
+        # launch clears the batch rows of the sparse gradient buffers and advances the cursor (what Adam's pass did).  Whole
+        # rows on one GPU only: under dp the all-reduce sits between the product and the optimiser.  L >= 2: at L = 1 the
+        # product's x is gF itself, which the launch would be clearing.  SRH_FUSE_ADAM=0: the separate pass (A/B).
+        self.adam_coef = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.fuse_adam = (single and not self.sync.active and self.sparse_reset and self.L >= 2 and self.w >= 64
+                          and model != "MF" and tuple(self.m.shape) == tuple(self.E0.shape)
+                          and getattr(ops, "ADAM_EPILOGUE", False) and os.environ.get("SRH_FUSE_ADAM", "1") != "0")
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
@@ -592,8 +601,9 @@ class FusedTrainer:
         self._forward_pass(adj, b["Y"], b["F"], perturbed=True, include_ego=False, batch_rows_only=True,
                            start_layer=1, noises=nb, call_base=L)
 
-    def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None, accumulate=False):
-        """gE0 (+)= d loss / d E0 through one encoder pass (accumulate=False overwrites gE0).
+    def _backward_chain(self, adj, gF, *, include_ego, gCL=None, layer_cl=None, extra=None, accumulate=False, final=False):
+        """gE0 (+)= d loss / d E0 through one encoder pass (accumulate=False overwrites gE0).  final: the step's last chain
+        -- with fuse_adam its last product ends in the optimiser step (and gE0 is not written).
 
         H_L = s gF + [l*==L] gCL ;  H_k = A H_{k+1} + s gF + [l*==k] gCL ;
         gE0 += A H_1 + [ego] s gF + [l*==0] gCL (+ extra)       with s = 1/#averaged layers.
@@ -670,9 +680,21 @@ class FusedTrainer:
                 raise SelfrecHipError("internal: more than two addends without an accumulator")
             ops.axpby(sc.pop(), add.pop(), 1.0, self.gE0)
         skw, pkw = scale_kw(add, last=True)
+        akw = {}
+        if final and self.fuse_adam:
+            akw = dict(adam=dict(param=self.E0, m=self.m, v=self.v, coef=self.adam_coef, clear=self._sparse_tables(),
+                                 clear_mark=self.mark, cursor=self.cursor),
+                       mark_stamp=self.now[1:2])          # (the launch moves the cursor: marks compare with the copy)
         ops.spmm(plan_for(sparse_src), src, out=loc(self.gE0),
                  epilogue=ops.make_epilogue(add=[loc(a) for a in add], add_scale=sc, alpha=alpha,
-                                            **{**sparse_add(add), **sparse_src, **skw}), **pkw)
+                                            **{**sparse_add(add), **sparse_src, **skw, **akw}), **pkw)
+
+    def _sparse_tables(self):
+        """the gradient buffers that hold non-zeros on this step's batch rows only"""
+        clear = [self.gF] + [t for t in (self.gCL, self.gReg) if t is not None]
+        if self.model == "SGL":
+            clear += [v["gF"] for v in self.views]
+        return clear
 
     # ------------------------------------------------------------------------------------
     # one training step on the staged batch
@@ -710,7 +732,8 @@ class FusedTrainer:
         cat = dict(stage_cat=self.stage_cat, n_cat=self.n_cat) if m == "SGL" else {}
         fetch = ((self._epoch_dev, self.sampler.n_edges, self.B, self.cursor, st, self.meta),
                  dict(row_mark=self.mark, mark_item_offset=0, zero4=self.losses, now=self.now,
-                      half_batches=self.epoch_batches, **cat))
+                      half_batches=self.epoch_batches, **cat,
+                      **(dict(adam_coef=self.adam_coef, adam_lr=self.lr) if self.fuse_adam else {})))
         # The first product of the step does not depend on the batch (marks and staged ids enter at the last forward
         # layer and at the losses), so the fetch rides on its launch as eight extra workgroups instead of being a 5 us
         # launch of its own at the head of the step (srh_spmm_f32_with_fetch).
@@ -807,28 +830,28 @@ class FusedTrainer:
         if m == "MF":
             pass                                     # gF is gE0
         elif m == "XSimGCL":
-            self._backward_chain(adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl)
+            self._backward_chain(adj, self.gF, include_ego=False, gCL=self.gCL, layer_cl=self.layer_cl, final=True)
         elif m == "LightGCN":
-            self._backward_chain(adj, self.gF, include_ego=True, extra=self.gReg)
+            self._backward_chain(adj, self.gF, include_ego=True, extra=self.gReg, final=True)
         elif m == "SimGCL":
-            self._backward_chain(adj, self.gF, include_ego=False)
+            self._backward_chain(adj, self.gF, include_ego=False, final=True)
         else:                                        # SGL: three operators, three chains
             self._backward_chain(adj, self.gF, include_ego=True)
             for vi, v in enumerate(self.views):
-                self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True)
+                self._backward_chain(self.view_adj[vi], v["gF"], include_ego=True, accumulate=True,
+                                     final=vi == len(self.views) - 1)
 
     def _step_opt(self):
         """Adam on the (owned rows of the) table, row-wise resets of the batch-sparse gradient buffers, cursor advance."""
         m, st = self.model, self.stage
         rows_dev, nuu_dev, nui_dev = self.meta[0:1], self.meta[1:2], self.meta[2:3]
+        if self.fuse_adam:
+            return                      # done by the last backward product (_backward_chain, final=True)
         if self.fused_reset and self.sparse_reset:
             # Adam's pass over the table also clears this batch's rows (the marked ones) of the batch-sparse gradient
             # buffers and advances the cursor: the separate zero_rows launch (4.5 us) is gone.  Adam reads its step from
             # `now` (batch_fetch's copy), so the advance cannot race with it.
-            clear = [self.gF] + [t for t in (self.gCL, self.gReg) if t is not None]
-            if m == "SGL":
-                clear += [v["gF"] for v in self.views]
-            ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.now[1:2], lr=self.lr, clear=clear,
+            ops.adam_step(self.E0, self.gE0, self.m, self.v, step_dev=self.now[1:2], lr=self.lr, clear=self._sparse_tables(),
                           row_mark=self.mark, advance_cursor=self.cursor)
             if self.sync.active and self.gF is self.gE0:
                 self.gE0.zero_()        # MF: gE0 IS the accumulation buffer, and after the all-reduce it holds the OTHER

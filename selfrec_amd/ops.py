@@ -275,13 +275,20 @@ def column_class_order(indptr, indices, min_len: int, bit: int = 0):
     return perm, row_mid
 
 
+ADAM_EPILOGUE = True      # make_epilogue(adam=...) / batch_fetch_args(adam_coef=...) exist (engine.py: fuse_adam)
+
+
 def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng_step=None,
                   rng_stride=0, prev=None, mean_div=None, mean_out=None, add=None, add_scale=None, alpha=1.0,
                   row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
                   extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0,
-                  row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None, d_valid=0):
+                  row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None, d_valid=0,
+                  adam=None):
     """row_scale / scale_in / scale_out / prev_unscale / add_rowscale: per-row scaling for value-free products
-    (include/selfrec_hip.h: SRH_SCALE_*); prev_unscale / add_rowscale are lists of booleans aligned with prev / add."""
+    (include/selfrec_hip.h: SRH_SCALE_*); prev_unscale / add_rowscale are lists of booleans aligned with prev / add.
+    adam: dict(param, m, v, coef, beta1, beta2, eps, clear=[tables], clear_mark, cursor) -- SRH_EPI_ADAM: the product (after
+    AXPY) is the gradient of `param`, which takes the optimiser's step in the epilogue instead of the gradient being stored;
+    mark_stamp must then be batch_fetch's COPY of the step."""
     ep = SpmmEpilogue()
     if row_scale is not None:
         ep.d_row_scale = _p(row_scale, torch.float32, "row_scale")
@@ -339,6 +346,23 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
         ep.d_add_mark = _p(add_mark, torch.int32, "add_mark")
         ep.add_sparse_mask = sum(1 << t for t, f in enumerate(add_sparse or []) if f)
         keep += [row_mark, col_mark, mark_stamp, add_mark]
+    if adam is not None:
+        flags |= _lib.SRH_EPI_ADAM
+        ep.d_adam_param, ep.d_adam_m, ep.d_adam_v = (_p(adam[k], torch.float32, k) for k in ("param", "m", "v"))
+        ep.d_adam_coef = _p(adam["coef"], torch.float32, "coef")
+        ep.adam_beta1, ep.adam_beta2 = float(adam.get("beta1", 0.9)), float(adam.get("beta2", 0.999))
+        ep.adam_eps = float(adam.get("eps", 1e-8))
+        clear = list(adam.get("clear") or [])
+        if len(clear) > _lib.SRH_MAX_ADAM_CLEAR:
+            raise SelfrecHipError(f"at most {_lib.SRH_MAX_ADAM_CLEAR} tables to clear")
+        ep.adam_n_clear = len(clear)
+        for k, t in enumerate(clear):
+            ep.d_adam_clear[k] = _p(t, torch.float32, "clear")
+        ep.d_adam_clear_mark = _p(adam.get("clear_mark"), torch.int32, "clear_mark")
+        ep.d_adam_cursor = _p(adam.get("cursor"), torch.int64, "cursor")
+        if mark_stamp is not None and not ep.d_mark_stamp:
+            ep.d_mark_stamp = _p(mark_stamp, torch.int64, "mark_stamp")
+        keep += [adam, mark_stamp]
     ep.flags = flags
     ep._keepalive = keep + [row_scale]
     return ep
@@ -829,9 +853,10 @@ def zero_rows(lists, d, cursor_advance=None):
 
 
 def batch_fetch_args(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None, mark_item_offset=0, zero4=None,
-                     stage_cat=None, cat_item_offset=0, n_cat=None, now=None, half_batches=0):
+                     stage_cat=None, cat_item_offset=0, n_cat=None, now=None, half_batches=0, adam_coef=None, adam_lr=0.0,
+                     adam_beta1=0.9, adam_beta2=0.999):
     """srh_batch_fetch_args_t.  ep: dict of device int32 arrays for the epoch (two epochs back to back when half_batches >
-    0); stage: dict of staging buffers."""
+    0); stage: dict of staging buffers.  adam_coef: float32[2] that receives this step's Adam constants (SRH_EPI_ADAM)."""
     a = _lib.BatchFetchArgs()
     a.d_epoch_u, a.d_epoch_i, a.d_epoch_j = (_p(ep[k], torch.int32) for k in ("u", "i", "j"))
     a.d_epoch_uniq_u, a.d_epoch_uniq_i = _p(ep.get("uniq_u"), torch.int32), _p(ep.get("uniq_i"), torch.int32)
@@ -844,7 +869,9 @@ def batch_fetch_args(ep, n_edges, batch_size, cursor, stage, meta, row_mark=None
     a.d_zero4, a.d_stage_cat, a.d_n_cat = _p(zero4, torch.float64), _p(stage_cat, torch.int32), _p(n_cat, torch.int32)
     a.d_now = _p(now, torch.int64)
     a.half_batches = int(half_batches)
-    a._keepalive = [ep, cursor, stage, meta, row_mark, zero4, stage_cat, n_cat, now]
+    a.d_adam_coef = _p(adam_coef, torch.float32)
+    a.adam_lr, a.adam_beta1, a.adam_beta2 = float(adam_lr), float(adam_beta1), float(adam_beta2)
+    a._keepalive = [ep, cursor, stage, meta, row_mark, zero4, stage_cat, n_cat, now, adam_coef]
     return a
 
 

@@ -676,6 +676,66 @@ def test_split_bf16_filter_never_loses_a_top_k_item(d, scale):
 # ------------------------------------------------------------------------------------------
 # (a-9) Adam
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_adam_in_the_product_epilogue_equals_product_then_adam(d):
+    """SRH_EPI_ADAM: the last backward product with the optimiser step in its row epilogue leaves the bits of
+    srh_spmm_f32 (AXPY) followed by srh_adam_step_reset -- parameters, both moments, the cleared batch rows of the sparse
+    gradient buffers, the cursor -- with this step's constants written by srh_batch_fetch."""
+    rng = np.random.default_rng(90 + d)
+    m = powerlaw_csr(3000, 3000, 40000, seed=5, heavy_rows=3, heavy_len=1500, empty_rows=40)
+    N, B, E = 3000, 64, 64
+    csr = ops.DeviceCSR.from_scipy(m, split_len=64)            # (split rows: the epilogue runs in the last segment to arrive)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)     # noqa: E731
+    x = t(rng.standard_normal((N, d)) * 1e-3)
+    ids = {k: torch.from_numpy(rng.integers(0, N, E).astype(np.int32)).to(DEV) for k in ("u", "i", "j")}
+    step = 7
+
+    def state():
+        r = np.random.default_rng(3)
+        gF, gCL = np.zeros((N, d), np.float32), np.zeros((N, d), np.float32)
+        rows = np.unique(np.concatenate([v.cpu().numpy() for v in ids.values()]))
+        gF[rows] = r.standard_normal((rows.size, d)) * 1e-2
+        gCL[rows] = r.standard_normal((rows.size, d)) * 1e-2
+        return dict(p=t(r.standard_normal((N, d)) * 0.1), m=t(r.standard_normal((N, d)) * 1e-3),
+                    v=t(r.random((N, d)) * 1e-5), gF=t(gF), gCL=t(gCL), g=torch.zeros(N, d, device=DEV),
+                    cursor=torch.tensor([0, step], dtype=torch.int64, device=DEV), now=torch.zeros(2, dtype=torch.int64, device=DEV),
+                    mark=torch.zeros(N, dtype=torch.int32, device=DEV), coef=torch.zeros(2, device=DEV),
+                    stage={k: torch.zeros(B, dtype=torch.int32, device=DEV) for k in ("u", "i", "j")},
+                    meta=torch.zeros(4, dtype=torch.int32, device=DEV))
+
+    def fetch(s, **kw):
+        ops.batch_fetch(ids, E, B, s["cursor"], s["stage"], s["meta"], row_mark=s["mark"], now=s["now"], **kw)
+    a, b = state(), state()
+    # the separate pass
+    fetch(a)
+    ops.spmm(csr, x, out=a["g"], epilogue=ops.make_epilogue(add=[a["gF"], a["gCL"]], add_scale=[0.25, 1.0], alpha=0.25,
+                                                            add_mark=a["mark"], mark_stamp=a["now"][1:2], add_sparse=[True, True]))
+    ops.adam_step(a["p"], a["g"], a["m"], a["v"], step_dev=a["now"][1:2], lr=1e-3, clear=[a["gF"], a["gCL"]],
+                  row_mark=a["mark"], advance_cursor=a["cursor"])
+    # the fused launch
+    fetch(b, adam_coef=b["coef"], adam_lr=1e-3)
+    b1, b2, lr = (float(np.float32(c)) for c in (0.9, 0.999, 1e-3))        # (the C ABI takes the betas as float)
+    assert np.allclose(b["coef"].cpu().numpy(), (lr / (1 - b1 ** step), (1 - b2 ** step) ** 0.5), rtol=1e-6)
+    ops.spmm(csr, x, out=b["g"], epilogue=ops.make_epilogue(
+        add=[b["gF"], b["gCL"]], add_scale=[0.25, 1.0], alpha=0.25, add_mark=b["mark"], mark_stamp=b["now"][1:2],
+        add_sparse=[True, True],
+        adam=dict(param=b["p"], m=b["m"], v=b["v"], coef=b["coef"], clear=[b["gF"], b["gCL"]], clear_mark=b["mark"],
+                  cursor=b["cursor"])))
+    assert float(a["g"].abs().max()) > 0 and float(b["g"].abs().max()) == 0         # (the gradient is never stored)
+    for k in ("p", "m", "v", "gF", "gCL", "cursor"):
+        assert torch.equal(a[k], b[k]), k
+    assert b["cursor"].tolist() == [1, step + 1] and float(b["gF"].abs().max()) == 0
+    assert float((a["p"] - state()["p"]).abs().max()) > 0
+    # the stamp may not be the cursor the launch advances; no perturbation / mean next to the optimiser
+    with pytest.raises(ops.SelfrecHipError):
+        ops.spmm(csr, x, out=b["g"], epilogue=ops.make_epilogue(
+            mark_stamp=b["cursor"][1:2], adam=dict(param=b["p"], m=b["m"], v=b["v"], coef=b["coef"], clear=[b["gF"]],
+                                                   clear_mark=b["mark"], cursor=b["cursor"][0:2])))
+    with pytest.raises(ops.SelfrecHipError):
+        ops.spmm(csr, x, out=b["g"], epilogue=ops.make_epilogue(
+            perturb_eps=0.1, rng_seed=1, adam=dict(param=b["p"], m=b["m"], v=b["v"], coef=b["coef"])))
+
+
 def test_adam_matches_torch_optim():
     rng = np.random.default_rng(4)
     p0 = rng.standard_normal((1000, 64)).astype(np.float32) * 0.1

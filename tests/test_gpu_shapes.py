@@ -103,6 +103,9 @@ class PreAdamProbe:
                 self.noise.append(torch.as_tensor(t)[self.rows.cpu()].clone())
                 return t
             tr.noise_fn = noise_fn
+        # (the gradient exists in memory only when the optimiser is a pass of its own: the first step runs that way, the
+        # rest -- from a re-captured graph -- with Adam in the last backward product's epilogue, engine.py: fuse_adam)
+        self._fuse_adam, tr.fuse_adam = tr.fuse_adam, False
         self._real_adam = engine.ops.adam_step
 
         def adam_step(param, grad, *a, **k):
@@ -130,6 +133,7 @@ class PreAdamProbe:
     def after_first_step(self):
         tr, sh, tag = self.tr, self.shapes, self.tag
         self.engine.ops.adam_step = self._real_adam
+        tr.fuse_adam, tr._graph = self._fuse_adam, None
         assert tr.step_count == 1 and self.grad is not None
         rows, nu = self.rows, len(self.ru)
         live = (tr.mark[rows] == 1).cpu().numpy()                   # rows of batch 1 (stamp = optimiser step = 1)

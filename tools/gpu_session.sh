@@ -95,6 +95,8 @@ ncestamps)
   cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
 ncemodeab)
   timeout 600 python tools/nce_mode_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/nce_mode_ab.txt; echo "ncemodeab exit $?"; cat $OUT/nce_mode_ab.txt;;
+fuseadamab)
+  timeout 600 python tools/fuse_adam_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/fuse_adam_ab.txt; echo "fuseadamab exit $?"; cat $OUT/fuse_adam_ab.txt;;
 testsk)
   # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
   timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
