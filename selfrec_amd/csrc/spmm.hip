@@ -211,6 +211,10 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
   // row-groups of dead rows on a row-masked launch -- leaves before the addend / layer-mean loads and the noise hash)
   if (!store) return;
   const size_t at = (size_t)row * LPR + sub;
+  float4 mm, vv, pp;
+  if constexpr (ADAM) {     // (first: in flight together with the addends below, not a round trip after them)
+    mm = ep.adam_m[at]; vv = ep.adam_v[at]; pp = ep.adam_p[at];
+  }
   if (ep.scale_flags & SRH_SCALE_IN) y = f4_scale(y, r);
   if (ep.flags & SRH_EPI_AXPY) {
     y = f4_scale(y, ep.alpha);
@@ -229,7 +233,6 @@ __device__ __forceinline__ void row_epilogue(float4 y, int row, int sub, bool st
     // the row; the 71 MB a separate pass spends writing and re-reading the gradient are never moved
     const float step_size = ep.adam_coef[0], bc2_sqrt = ep.adam_coef[1];
     const float b1 = ep.adam_b1, b2 = ep.adam_b2, omb1 = 1.0f - b1, omb2 = 1.0f - b2, aeps = ep.adam_eps;
-    float4 mm = ep.adam_m[at], vv = ep.adam_v[at], pp = ep.adam_p[at];
 #define SRH_ADAM_LANE(c) adam_element(mm.c, vv.c, pp.c, y.c, b1, omb1, b2, omb2, step_size, bc2_sqrt, aeps);
     SRH_ADAM_LANE(x) SRH_ADAM_LANE(y) SRH_ADAM_LANE(z) SRH_ADAM_LANE(w)
 #undef SRH_ADAM_LANE

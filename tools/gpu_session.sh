@@ -97,6 +97,14 @@ ncemodeab)
   timeout 600 python tools/nce_mode_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/nce_mode_ab.txt; echo "ncemodeab exit $?"; cat $OUT/nce_mode_ab.txt;;
 fuseadamab)
   timeout 600 python tools/fuse_adam_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/fuse_adam_ab.txt; echo "fuseadamab exit $?"; cat $OUT/fuse_adam_ab.txt;;
+fuseadamlibs)
+  # the same A/B per alt library (FUSE_LIBS="nopf ..."), the product's own library first and last
+  cp selfrec_amd/lib/libselfrec_hip.so /tmp/orig.so
+  for N in product ${FUSE_LIBS:-nopf} product2; do
+    case $N in product*) cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;; *) cp tools/spmm_lab/alt/libselfrec_hip_$N.so selfrec_amd/lib/libselfrec_hip.so;; esac
+    echo "== $N"; AB_REPS=${AB_REPS:-3} timeout 600 python tools/fuse_adam_ab.py 2>&1 | grep -v amdgpu.ids | tee $OUT/fuse_adam_ab_$N.txt | tail -5
+  done
+  cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
 testsk)
   # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
   timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
