@@ -14,6 +14,7 @@ import bench  # noqa: E402
 from selfrec_amd import engine, ops  # noqa: E402
 from selfrec_amd.engine import FusedTrainer  # noqa: E402
 
+os.environ["SRH_FUSE_ADAM"] = "0"     # the gradient before Adam exists in memory only when the optimiser is a pass of its own
 args = bench.parse([])
 data, raw = bench.build_data(args.shape, args.seed)
 kw = dict(model="XSimGCL", n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048)
