@@ -234,3 +234,38 @@ def test_integration_md_names_only_declared_entry_points():
     named = set(re.findall(r"\b_lib\.(srh_\w+)\(", text)) | set(re.findall(r"`(srh_\w+)`", text))
     named = {n for n in named if not n.endswith("_") and not n.endswith("_t")}     # (`srh_sampler_*` prefixes, type names)
     assert named and named <= declared, sorted(named - declared)
+
+
+def test_ctypes_structures_have_the_layout_gcc_gives_the_header(tmp_path):
+    """Every structure that crosses the boundary by pointer: size and the offset of every field as a C compiler lays out
+    include/selfrec_hip.h, against the ctypes mirror in selfrec_amd/_lib.py -- same field names, same order.  (A field added
+    to one side only shifts everything behind it: the library would read pointers out of floats.)"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from selfrec_amd import _lib
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    pairs = {"srh_batch_fetch_args_t": _lib.BatchFetchArgs, "srh_infonce_problem_t": _lib.InfonceProblem,
+             "srh_l2_block_t": _lib.L2Block, "srh_bpr_problem_t": _lib.BprProblem, "srh_spmm_epilogue_t": _lib.SpmmEpilogue,
+             "srh_batch_lists_t": _lib.BatchLists}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "selfrec_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)     # (the header is plain C)
+    got = {}
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, field, value = line.split()
+        got[(cname, field)] = int(value)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert got[(cname, field)] == getattr(cls, field).offset, (cname, field)

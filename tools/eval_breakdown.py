@@ -52,6 +52,18 @@ ms_host, _ = wall(lambda: gr._to_host(ids_dev, sc_dev))
 ms_pageable, _ = wall(lambda: (ids_dev.cpu().numpy(), sc_dev.cpu().numpy()))
 ms_all, _ = wall(lambda: rec.rank_on_device(uid))
 ms_emb, _ = wall(lambda: rec._device_embeddings())
+ms_uid_owned, _ = wall(lambda: rec._device_user_ids(uid, ie.device))
+uid_copy = np.array(uid)
+ms_uid_foreign, _ = wall(lambda: rec._device_user_ids(uid_copy, ie.device))
+ms_all_foreign, _ = wall(lambda: rec.rank_on_device(uid_copy))
+ms_chunk, _ = wall(lambda: rec._filter_chunk_rows(ie.device))
+ms_ties_wall, marked = wall(lambda: rec._rank_marking_ties(ue, uid_dev, ie, g, 20))
+ids_h, sc_h = gr._to_host(marked[0], marked[1])
+tie_rows = np.flatnonzero(ids_h[:, 0] < 0)
+ms_redo, _ = wall(lambda: rec._heap_order_rows(tie_rows, ue, uid, ie, g, 20)) if tie_rows.size else (0.0, None)
+print(f"pieces: uid on the device (owned array, cached) {ms_uid_owned:.3f} ms, (a caller's array: upload) {ms_uid_foreign:.3f} | "
+      f"_filter_chunk_rows (hipMemGetInfo) {ms_chunk:.3f} | _rank_marking_ties (K + 1 columns, wall) {ms_ties_wall:.3f} | "
+      f"{tie_rows.size} tied rows redone in heap order {ms_redo:.3f} | rank_on_device on a caller's array {ms_all_foreign:.3f} ms")
 from selfrec_amd import ops  # noqa: E402
 _, _, counts, _ = ops.score_mask_topk_filtered(ue, uid_dev, ie, g.r_indptr, g.r_indices, 20, sample_items=gr.FILTER_SAMPLE_ITEMS,
                                                cap=gr.FILTER_CAP, chunk_rows=gr.FILTER_CHUNK_ROWS)
