@@ -176,12 +176,31 @@ def main():
         """warm-up to --warmup, then exactly --steps steps over an epoch boundary; the fields every record carries"""
         runner.run(max(0, args.warmup - runner.steps_done))
         extra = runner.align_to_epoch_boundary(args.steps)
+        seen = len(runner.boundary_ms)
+        # Short regions carry a timing event behind every step: `step_us` shows where inside the region the time goes (the
+        # last, partial batch of an epoch; the first step of the next).  Observed beside it, not understood: with the events in
+        # place the host's work at an epoch boundary (hand-over, sampler thread) no longer delays the steps behind it -- 20-step
+        # regions over a boundary: 0.290 ms per step in 20 runs of 22, against 0.287 .. 0.316 without
+        # (profiles/r05_o_epoch_boundary_host_cost.txt).  SRH_BENCH_STEP_EVENTS=0: without.
+        trace = os.environ.get("SRH_BENCH_STEP_EVENTS", "1") not in ("", "0") and args.steps <= 200
+        if trace:
+            runner.fence()
+            first = torch.cuda.Event(enable_timing=True)
+            first.record()
+            runner.step_events = [first]
         dt, bounds, per_rank = runner.timed(args.steps, f"{label}: timed region")
+        step_us = None
+        if trace:
+            evs, runner.step_events = runner.step_events, None
+            step_us = [round(a.elapsed_time(b) * 1e3, 1) for a, b in zip(evs[:-1], evs[1:])]
         dp = bool(getattr(trainer, "dp", False))
         pairs = args.batch * (world if dp else 1)
         return {"value": round(args.steps * pairs / dt, 1), "unit": "pairs/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
                 "steps": args.steps, "global_batch": pairs, "scaling": "weak" if dp else "strong",
                 "epoch_boundaries_inside": bounds, "untimed_steps_before": runner.steps_done - args.steps,
+                # host ms per boundary inside the region: (waiting for the sampled epoch, hand-over, restarting the sampler thread)
+                "epoch_boundary_host_ms": [list(t) for t in runner.boundary_ms[seen:]],
+                **({"step_us": step_us} if step_us is not None else {}),
                 "aligned_by_extra_steps": extra,
                 "ms_per_step_by_rank": [round(t / args.steps * 1e3, 4) for t in per_rank] if per_rank else None,
                 "launch": "hipGraph replay" if trainer.use_graph else "eager"}, dt
@@ -235,6 +254,8 @@ def main():
                    "rccl_ranks": comm["ranks_in_collective"] if comm and not shared_device else None,
                    "comm": comm, "launch": rec["launch"],
                    "epoch_boundaries_in_region": rec["epoch_boundaries_inside"],
+                   "epoch_boundary_host_ms": rec["epoch_boundary_host_ms"],
+                   **({"step_us": rec["step_us"]} if "step_us" in rec else {}),
                    "nce_products": "f32 MFMA (v_mfma_f32_16x16x4_f32)" if has_nce else None,
                    "perturbation_rng": "counter-based integer hash in the SpMM epilogue (not Philox): moments / decorrelation tested",
                    # workgroups of real tasks per XCD in the dense plan after the engine's start-up calibration

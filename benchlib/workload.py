@@ -69,18 +69,30 @@ class Runner:
         self.pre = EpochPrefetcher(trainer)
         self.pre.start()
         self.left, self.uploads, self.steps_done = 0, 0, 0
+        self.boundary_ms = []                      # per epoch boundary: host ms (waiting for the sampled epoch, hand-over, restart)
+        self.step_events = None                    # diagnostic (SRH_BENCH_STEP_EVENTS=1): a timing event behind every step
 
     def run(self, n_steps):
         done = 0
         while done < n_steps:
             if self.left == 0:
                 self.uploads += 1
-                self.trainer.upload_epoch(self.pre.take())
+                t0 = time.perf_counter()
+                epoch = self.pre.take()
+                t1 = time.perf_counter()
+                self.trainer.upload_epoch(epoch)
+                t2 = time.perf_counter()
                 self.pre.start()                       # host samples the next epoch while this one runs
+                self.boundary_ms.append((round((t1 - t0) * 1e3, 3), round((t2 - t1) * 1e3, 3),
+                                         round((time.perf_counter() - t2) * 1e3, 3)))
                 self.left = self.trainer.epoch_batches
             take = min(self.left, n_steps - done)
             for _ in range(take):
                 self.trainer.step()
+                if self.step_events is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.step_events.append(ev)
             self.left -= take
             done += take
         self.steps_done += n_steps

@@ -49,6 +49,8 @@ MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
 
 
 class FusedTrainer:
+    reuse_epoch_arrays = True     # EpochPrefetcher draws epochs into two sets of host arrays in turn (see its __init__)
+
     def __init__(self, data, emb_size, *, model, n_layers=2, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2,
                  tau=0.2, layer_cl=1, drop_rate=0.1, aug_type=1, batch_size=2048, user_emb=None, item_emb=None,
                  noise_fn=None, rng_seed=0x5E1F0EC, use_graph=False, device=None, shard=False, comm=None,
@@ -397,16 +399,18 @@ class FusedTrainer:
             return
         self.sampler.set_state_from_python()
 
-    def sample_epoch_host(self):
+    def sample_epoch_host(self, slot=None):
         """Host part of an epoch: SGL's two edge-dropped views are drawn first (SGL.py:28-29),
         then shuffle + batches.  Pure host work -- safe to run on a worker thread.  (The epoch that has been in the making
-        since construction -- ``sampler_seed`` -- is handed out first.)"""
+        since construction -- ``sampler_seed`` -- is handed out first.)  slot: see ops.Sampler.epoch -- the arrays of a
+        slot are the sampler's and are overwritten by the next epoch drawn into the same slot (EpochPrefetcher alternates
+        two); None = fresh arrays."""
         if self._first_epoch is not None:
             pre, self._first_epoch = self._first_epoch, None
             return pre.take()
-        return self._sample_epoch_host_now()
+        return self._sample_epoch_host_now(slot)
 
-    def _sample_epoch_host_now(self):
+    def _sample_epoch_host_now(self, slot=None):
         out = {}
         if self.model == "SGL":
             masks = []
@@ -427,7 +431,7 @@ class FusedTrainer:
                     mk[keep] = 1
                 masks.append(mk)
             out["masks"] = masks
-        ep = self.sampler.epoch(self.B, 1, with_unique=True)
+        ep = self.sampler.epoch(self.B, 1, with_unique=True, slot=slot)
         # node ids -> table rows (items follow the users; all-gather order when the rows are dealt)
         out.update(self.rows.epoch_to_table_rows(ep))
         return out
@@ -1027,10 +1031,22 @@ class EpochPrefetcher:
         self._result = None
         self._error = None
         self._first = first           # the trainer's own early start: draws directly (sample_epoch_host hands THIS one out)
+        # Epochs are drawn into two sets of host arrays in turn (ops.Sampler.epoch(slot=...)): by the time a set is drawn into
+        # again, the epoch it held has been replaced as the trainer's live one.  Fresh arrays per epoch are 25 MB unmapped and
+        # 25 MB page-faulted in at every epoch boundary, beside the thread that enqueues the steps -- and unmapping memory there
+        # stalls the GPU's supply of work (126 MB freed between two replays: + 2.2 ms, tools/host_cost_probe.py).
+        self._slots = bool(getattr(trainer, "reuse_epoch_arrays", False)) and not first
+        self._turn = 0
 
     def _work(self):
         try:
-            self._result = self.trainer._sample_epoch_host_now() if self._first else self.trainer.sample_epoch_host()
+            if self._first:
+                self._result = self.trainer._sample_epoch_host_now()
+            elif self._slots:
+                self._result = self.trainer.sample_epoch_host(slot=self._turn)
+                self._turn ^= 1
+            else:
+                self._result = self.trainer.sample_epoch_host()
             stage = getattr(self.trainer, "stage_epoch", None)
             if stage is not None and not self._first:      # (the early first epoch is drawn while the trainer is still being built)
                 self._result = stage(self._result)

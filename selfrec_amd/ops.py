@@ -79,6 +79,7 @@ class Sampler:
         check(self._lib.srh_sampler_create(C.byref(h), n_users, n_items, eu.size, pu, pi), "srh_sampler_create")
         self._h = h
         self._pushed = None            # the words this object last handed to python's generator (set_state_from_python)
+        self._epoch_slots = {}         # epoch(slot=...): arrays the sampler keeps and overwrites
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -142,21 +143,39 @@ class Sampler:
         assert out.value == cnt
         return u, i, j
 
-    def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False):
-        """shuffle + all batches.  Returns dict of numpy arrays (see srh_sampler_epoch)."""
+    def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False, slot=None):
+        """shuffle + all batches.  Returns dict of numpy arrays (see srh_sampler_epoch).
+        slot (None | 0 | 1 | ...): None -- fresh arrays, the caller's to keep.  An integer -- the arrays of that slot, owned
+        by the sampler and OVERWRITTEN by the next call with the same slot: a training loop that alternates two slots never
+        allocates or frees an epoch's 25 MB (freeing them -- munmap -- beside a thread that is enqueueing GPU work was
+        measured to stall it: 0.4 ms per epoch boundary, profiles/r05_o_epoch_boundary_host_cost.txt)."""
         e = self.n_edges
         nb = (e + batch_size - 1) // batch_size
-        u = np.empty(e, dtype=np.int32)
-        i = np.empty(e, dtype=np.int32)
-        j = np.empty(e * n_negs, dtype=np.int32)
-        res = {"u": u, "i": i, "j": j, "n_batches": nb}
-        uu = ui = nuu = nui = None
-        if with_unique:
-            uu = np.zeros(nb * batch_size, dtype=np.int32)
-            ui = np.zeros(nb * batch_size, dtype=np.int32)
-            nuu = np.zeros(nb, dtype=np.int32)
-            nui = np.zeros(nb, dtype=np.int32)
-            res.update(uniq_u=uu, uniq_i=ui, n_uniq_u=nuu, n_uniq_i=nui)
+        key = (slot, int(batch_size), int(n_negs), bool(with_unique))
+        held = None if slot is None else self._epoch_slots.get(key)
+        if held is not None:
+            u, i, j = held["u"], held["i"], held["j"]
+            res = {"u": u, "i": i, "j": j, "n_batches": nb}
+            uu = ui = nuu = nui = None
+            if with_unique:
+                uu, ui, nuu, nui = held["uniq_u"], held["uniq_i"], held["n_uniq_u"], held["n_uniq_i"]
+                for a in (uu, ui, nuu, nui):
+                    a.fill(0)
+                res.update(uniq_u=uu, uniq_i=ui, n_uniq_u=nuu, n_uniq_i=nui)
+        else:
+            u = np.empty(e, dtype=np.int32)
+            i = np.empty(e, dtype=np.int32)
+            j = np.empty(e * n_negs, dtype=np.int32)
+            res = {"u": u, "i": i, "j": j, "n_batches": nb}
+            uu = ui = nuu = nui = None
+            if with_unique:
+                uu = np.zeros(nb * batch_size, dtype=np.int32)
+                ui = np.zeros(nb * batch_size, dtype=np.int32)
+                nuu = np.zeros(nb, dtype=np.int32)
+                nui = np.zeros(nb, dtype=np.int32)
+                res.update(uniq_u=uu, uniq_i=ui, n_uniq_u=nuu, n_uniq_i=nui)
+            if slot is not None:
+                self._epoch_slots[key] = {k: v for k, v in res.items() if k != "n_batches"}
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
         self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_epoch(self._h, batch_size, n_negs, vp(u), vp(i), vp(j), vp(uu), vp(nuu),

@@ -269,3 +269,23 @@ def test_ctypes_structures_have_the_layout_gcc_gives_the_header(tmp_path):
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for field, _ in cls._fields_:
             assert got[(cname, field)] == getattr(cls, field).offset, (cname, field)
+
+
+def test_sampler_epoch_slots_hold_the_same_epochs_in_arrays_that_are_reused(golden_ops):
+    """ops.Sampler.epoch(slot=k): the epochs a training loop draws into two alternating slots are the epochs of fresh arrays,
+    and a slot's arrays are the SAME objects every time (nothing allocated or freed per epoch: engine.EpochPrefetcher)."""
+    g = golden_ops
+    fresh, slots = (ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300) for _ in range(2))
+    fresh.seed(11); slots.seed(11)
+    keys = ("u", "i", "j", "uniq_u", "uniq_i", "n_uniq_u", "n_uniq_i")
+    held = {}
+    for e in range(5):
+        want = fresh.epoch(64, 1, with_unique=True)
+        got = slots.epoch(64, 1, with_unique=True, slot=e & 1)
+        assert got["n_batches"] == want["n_batches"]
+        for k in keys:
+            assert np.array_equal(got[k], want[k]), (e, k)
+            assert held.setdefault((e & 1, k), got[k]) is got[k]          # the slot's own array, again
+    assert held[(0, "u")] is not held[(1, "u")]
+    assert slots.epoch(64, 1, with_unique=True)["u"] is not held[(0, "u")]          # slot=None: the caller's to keep
+    assert slots.epoch(32, 1, with_unique=True, slot=0)["uniq_u"] is not held[(0, "uniq_u")]      # (another batch size: other arrays)

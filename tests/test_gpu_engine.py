@@ -311,6 +311,34 @@ def test_hipgraph_replay_equals_eager(golden_models, golden_meta, tiny_data, nam
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["XSimGCL", "LightGCN", "SimGCL", "SGL"])
+def test_adam_in_the_last_backward_product_trains_like_the_separate_pass(golden_models, golden_meta, tiny_data, name, monkeypatch):
+    """engine.fuse_adam: the optimiser step inside the last backward product's row epilogue (SRH_EPI_ADAM) against the
+    srh_adam_step_reset pass after it (SRH_FUSE_ADAM=0) -- same batches, same noise counters, two epochs of captured steps:
+    the same parameters, moments, cursor and cleared gradient buffers.  (The kernel-level statement is bit for bit,
+    test_gpu_kernels.py; whole steps carry the atomics of the batch-gradient scatter in their low bits either way.)"""
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SRH_FUSE_ADAM", fuse)
+        tr = make_trainer(name, golden_models, golden_meta, tiny_data, noise_fn=None, use_graph=True)
+        assert tr.fuse_adam == (fuse == "1")
+        tr.sampler.seed(5)
+        for _ in range(2):
+            for _ in range(tr.begin_epoch()):
+                tr.step()
+        torch.cuda.synchronize()
+        sparse = [float(t.abs().max()) for t in tr._sparse_tables()]
+        outs.append((tr.E0.cpu().numpy(), tr.m.cpu().numpy(), tr.v.cpu().numpy(), tr.cursor.tolist(), tr.read_losses(), sparse))
+    assert np.isfinite(outs[0][0]).all() and outs[0][3] == outs[1][3]
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-4 and rel_err(outs[0][2], outs[1][2]) < 1e-4
+    np.testing.assert_allclose(outs[0][4], outs[1][4], rtol=1e-5)
+    assert outs[0][5] == outs[1][5] == [0.0] * len(outs[0][5])          # every batch row of the sparse buffers was cleared
+    # where the epilogue form does not apply, the pass stays: no propagation (MF), one layer (the product's x is gF itself)
+    monkeypatch.setenv("SRH_FUSE_ADAM", "1")
+    assert not make_trainer("MF", golden_models, golden_meta, tiny_data).fuse_adam
+    assert not make_trainer(name, golden_models, golden_meta, tiny_data, n_layers=1, layer_cl=1).fuse_adam
+
+
 def test_full_size_properties_yelp_shape():
     """Size-independent checks at BASELINE.json config 2/3 shape (31,668 x 38,048, ~1.26 M train edges)."""
     tu, ti, su, si, U, I = synth.make_dataset("yelp2018")

@@ -105,6 +105,13 @@ fuseadamlibs)
     echo "== $N"; AB_REPS=${AB_REPS:-3} timeout 600 python tools/fuse_adam_ab.py 2>&1 | grep -v amdgpu.ids | tee $OUT/fuse_adam_ab_$N.txt | tail -5
   done
   cp /tmp/orig.so selfrec_amd/lib/libselfrec_hip.so;;
+boundarytrace)
+  rm -rf $OUT/btrace; (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $OLDPWD/$OUT/btrace -o trace -- python $OLDPWD/tools/boundary_region.py > $OLDPWD/$OUT/boundary_region.log 2>&1); echo "boundarytrace exit $?"
+  grep -v amdgpu.ids $OUT/boundary_region.log | tail -6
+  f=$(find $OUT/btrace -name "*.db" | head -1); [ -n "$f" ] && python tools/boundary_gaps.py "$f" ${GAP_US:-25} ${GAP_LAST:-40000} | tail -60 | tee $OUT/boundary_gaps.txt
+  find $OUT/btrace -name "*.db" -size +30M -delete;;
+hostcost)
+  timeout 600 python tools/host_cost_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_cost_probe.txt;;
 testsk)
   # TESTS_K="expr" TESTS_FILES="tests/a.py tests/b.py"
   timeout 1500 python -m pytest ${TESTS_FILES:-tests} -m gpu -q --tb=short -p no:cacheprovider -k "${TESTS_K:-infonce}" > $OUT/tests_k.log 2>&1; echo "testsk exit $?"
