@@ -175,7 +175,7 @@ class GraphRecommender(Recommender):
         users = np.asarray(uid_host)[rows].astype(np.int64)
         for lo in range(0, len(rows), chunk):
             u = users[lo:lo + chunk]
-            scores = ops.gemm_nt(ue[torch.from_numpy(u).to(ue.device)].contiguous(), ie).cpu().numpy()
+            scores, = _to_host(ops.gemm_nt(ue[torch.from_numpy(u).to(ue.device)].contiguous(), ie))      # (pinned, one sync)
             for j, uu in enumerate(u.tolist()):
                 cand = scores[j]
                 cand[g.h_r_indices[g.h_r_indptr[uu]:g.h_r_indptr[uu + 1]]] = -10e8
