@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 29
+#define SRH_ABI_VERSION 30
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -85,6 +85,22 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
                                int32_t* h_u, int32_t* h_i, int32_t* h_j,
                                int32_t* h_uniq_u, int32_t* h_n_uniq_u,
                                int32_t* h_uniq_i, int32_t* h_n_uniq_i);
+/* The row -> slot lists of every batch of an epoch: what lets the batch gradients of XSimGCL.py:30-37 (emb[idx] gathers whose
+ * autograd is a scatter-ADD: a user / item that occurs in several pairs of a batch receives several contributions) be summed in
+ * ONE FIXED ORDER by one row group each, without float atomics -- a training step is then reproducible bit for bit, like the
+ * reference's single-threaded CPU step.  Host only, no draw from the generator; inputs are srh_sampler_epoch's outputs.
+ * Per batch b (cnt pairs), the ROW GROUPS are numbered
+ *     [0, nuu)                 the sorted unique users                    h_uniq_u[b B + g]
+ *     [nuu, nuu + nui)         the sorted unique positive items           h_uniq_i[b B + g - nuu]
+ *     [nuu + nui, groups)      the sorted unique negatives that are nobody's positive in this batch
+ *                              -> h_uniq_n[b B + k], count h_n_uniq_n[b]
+ * and group g owns entries [h_seg_end[b 3B + g - 1] (0 for g = 0), h_seg_end[b 3B + g]) of h_seg + b 3B: each entry is
+ * 4 * slot + role (role 0: the slot's user, 1: its positive item, 2: its negative item), slots ascending inside a group.
+ * h_uniq_n: nb * B, h_n_uniq_n: nb, h_seg_end / h_seg: nb * 3 B entries (nb = ceil(n_edges / B)). */
+srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, const int32_t* h_u, const int32_t* h_i,
+                                        const int32_t* h_j, const int32_t* h_uniq_u, const int32_t* h_n_uniq_u,
+                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t* h_uniq_n,
+                                        int32_t* h_n_uniq_n, int32_t* h_seg_end, int32_t* h_seg);
 /* random.sample(range(n), k) (data/augmentor.py:35 edge_dropout keep-set; :15-16 node
  * dropout) replayed on the sampler's MT stream.  h_out receives k indices in draw order. */
 srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out);
@@ -294,7 +310,30 @@ srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices
  * (w.r.t. the REG tables; may alias d_g_*).  d_losses[0] += bpr, d_losses[1] += reg
  * (double, caller zeroes).  d_n_rows: optional device int32 overriding B (graph replay).
  * d_ws: workspace of at least srh_bpr_ws_bytes(B) bytes.
+ * (Float atomics make the low bits of a row that several pairs name depend on arrival order.  The struct forms below --
+ * srh_bpr_l2_fwd_bwd_p, srh_bpr_infonce_fwd_bwd -- take the batch's row -> slot lists (srh_batch_segments_t) and sum
+ * every row's contributions in slot order instead: bit-reproducible, no atomics.)
  * ---------------------------------------------------------------------------------- */
+/* The batch's row groups and their slot lists on the DEVICE (srh_sampler_epoch_segments' arrays, uploaded).  Table rows,
+ * not node ids: whatever offset / permutation the caller applied to u / i / j is applied to the unique lists too.
+ * d_batch_no == NULL: d_uniq_n / d_seg_end / d_seg are this batch's slices and d_n_uniq_n its count.  d_batch_no != NULL
+ * (graph replay): they are the EPOCH arrays and batch b = *d_batch_no lives at d_uniq_n + b B, d_seg_end / d_seg + b 3B,
+ * d_n_uniq_n[b] (B = the problem's B). */
+typedef struct srh_batch_segments {
+  const int32_t* d_uniq_u;    /* this batch's sorted unique user rows / positive-item rows (e.g. srh_batch_fetch's staged lists) */
+  const int32_t* d_uniq_i;
+  const int32_t* d_n_uniq_u;  /* their device-side counts */
+  const int32_t* d_n_uniq_i;
+  const int32_t* d_uniq_n;
+  const int32_t* d_n_uniq_n;
+  const int32_t* d_seg_end;
+  const int32_t* d_seg;
+  const int32_t* d_batch_no;
+  int32_t nce_rows;           /* how the InfoNCE problems of the same call name these rows (srh_bpr_infonce_fwd_bwd):
+                                 0 none; 1: problem 0's row i is user group i, problem 1's row i is positive-item group i
+                                 (XSimGCL.py:46-49, SimGCL.py:44-49); 2: problem 0's rows are [users ; positive items]
+                                 (SGL.py:120-125).  Rows of a problem are then finished by the group that owns them. */
+} srh_batch_segments_t;
 int64_t srh_bpr_ws_bytes(int64_t B);
 srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item,
                                 const float* d_reg_user, const float* d_reg_item,
@@ -413,7 +452,14 @@ typedef struct srh_bpr_problem {
   float* d_greg_item;
   double* d_losses;
   void* d_ws; /* srh_bpr_ws_bytes(B) */
+  const srh_batch_segments_t* seg; /* HOST pointer or NULL.  Given: every touched row of the gradient tables is written by the
+                                      ONE row group that owns it -- read, add the row's contributions in slot order (and the
+                                      InfoNCE gradients of that row: nce_rows), store -- no float atomics: the same bits on
+                                      every run.  The user rows and the item rows must not alias (one table with the items
+                                      offset, or two tables).  NULL: atomic accumulation as srh_bpr_l2_fwd_bwd describes. */
 } srh_bpr_problem_t;
+/* srh_bpr_l2_fwd_bwd with its arguments in the struct (and the optional fixed-order reduction of `seg`). */
+srh_status_t srh_bpr_l2_fwd_bwd_p(const srh_bpr_problem_t* bpr, int32_t d, void* stream);
 srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* bpr, const srh_infonce_problem_t* problems,
                                      int32_t n_problems, int32_t d, float tau, float cl_scale,
                                      double* d_cl_loss, void* d_nce_ws, int32_t precision, void* stream);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY, SRH_EPI_ADAM = 1, 2, 4, 8
 SRH_MAX_ADAM_CLEAR = 4
@@ -53,13 +53,21 @@ class L2Block(C.Structure):
 SCALAR_WS_BYTES = 64         # SRH_SCALAR_WS_BYTES
 
 
+class BatchSegments(C.Structure):
+    """struct srh_batch_segments (include/selfrec_hip.h)."""
+    _fields_ = [("d_uniq_u", C.c_void_p), ("d_uniq_i", C.c_void_p), ("d_n_uniq_u", C.c_void_p), ("d_n_uniq_i", C.c_void_p),
+                ("d_uniq_n", C.c_void_p), ("d_n_uniq_n", C.c_void_p), ("d_seg_end", C.c_void_p), ("d_seg", C.c_void_p),
+                ("d_batch_no", C.c_void_p), ("nce_rows", C.c_int32)]
+
+
 class BprProblem(C.Structure):
     """struct srh_bpr_problem (include/selfrec_hip.h)."""
     _fields_ = [("d_user", C.c_void_p), ("d_item", C.c_void_p), ("d_reg_user", C.c_void_p), ("d_reg_item", C.c_void_p),
                 ("d_u_idx", C.c_void_p), ("d_i_idx", C.c_void_p), ("d_j_idx", C.c_void_p), ("B", C.c_int64),
                 ("d_n_rows", C.c_void_p), ("reg_coef", C.c_float), ("reg_include_neg", C.c_int32),
                 ("loss_scale", C.c_float), ("d_g_user", C.c_void_p), ("d_g_item", C.c_void_p),
-                ("d_greg_user", C.c_void_p), ("d_greg_item", C.c_void_p), ("d_losses", C.c_void_p), ("d_ws", C.c_void_p)]
+                ("d_greg_user", C.c_void_p), ("d_greg_item", C.c_void_p), ("d_losses", C.c_void_p), ("d_ws", C.c_void_p),
+                ("seg", C.POINTER(BatchSegments))]
 
 
 class SpmmEpilogue(C.Structure):
@@ -113,6 +121,7 @@ SIGNATURES = {
     "srh_sampler_get_order": (_i32, [_vp, _vp]),
     "srh_sampler_next_batch": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "srh_sampler_epoch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_sampler_epoch_segments": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
     "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "srh_mt19937_uniform_f32": (_i32, [_vp, C.POINTER(C.c_int32), _i64, _vp, C.c_float, _vp]),
@@ -129,6 +138,7 @@ SIGNATURES = {
     "srh_bpr_ws_bytes": (_i64, [_i64]),
     "srh_bpr_l2_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i32, _f32,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_bpr_l2_fwd_bwd_p": (_i32, [C.POINTER(BprProblem), _i32, _vp]),
     "srh_bpr_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "srh_bpr_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "srh_l2_reg_fwd": (_i32, [C.POINTER(L2Block), _i32, _f32, _vp, _vp, _vp, _vp]),

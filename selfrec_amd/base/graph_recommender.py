@@ -140,7 +140,7 @@ class GraphRecommender(Recommender):
         ids, sc = ops.topk_trim_mark_ties(*self._rank(ue, uid, ie, g, k + 1))
         return ids, sc, True
 
-    def _mark_ties_without_spare(self, ids, sc, ue, uid, ie, g, k, chunk=2048):
+    def _mark_ties_without_spare(self, ids, sc, ue, uid, ie, g, k, chunk=None):
         """ids with the tied rows marked (ids[row, 0] = -1 - id) when the kernels have no spare column for the (K + 1)-th
         score (K = 128, or K = the catalogue): a row is tied when two neighbours among its K scores are equal, or when MORE
         masked scores of its catalogue row equal its K-th score than its K places hold -- the second test re-scores the
@@ -148,6 +148,8 @@ class GraphRecommender(Recommender):
         scoring pass, paid only by this one K."""
         tied = (sc[:, 1:] == sc[:, :-1]).any(dim=1) if k > 1 else torch.zeros(sc.shape[0], dtype=torch.bool, device=sc.device)
         n_items = int(ie.shape[0])
+        if chunk is None:                      # the re-scored slab stays at 64 M scores (256 MB) whatever the catalogue
+            chunk = max(16, min(2048, (64 << 20) // max(1, n_items)))
         if k < n_items:
             kth = sc[:, k - 1]
             held = (sc == kth[:, None]).sum(dim=1)

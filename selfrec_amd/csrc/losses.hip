@@ -584,12 +584,12 @@ __device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, floa
 }
 
 
-// Finish of one row (the LPR lanes of a row-group): fold both passes' split partials, form the
-// gradients of both views through the normalisation and scatter them.  Returns the row's loss term
-// (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
+// Finish of one row (the LPR lanes of a row-group): fold both passes' split partials and form the
+// gradients of both views through the normalisation (dv1, dv2: w.r.t. row idx[i] of the two source tables).  Returns the
+// row's loss term (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
 template <int LPR>
-__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub, float4* scr,
-                                                 int splits) {
+__device__ __forceinline__ double nce_finish_row_grads(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub,
+                                                       int splits, float4& dv1, float4& dv2) {
   const bool valid = i < n;
   const int ii = valid ? i : 0;
   const size_t at = (size_t)ii * LPR + sub;
@@ -598,7 +598,6 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
   const float4 va = reinterpret_cast<const float4*>(w.v1n)[at];
   const float4 vb = reinterpret_cast<const float4*>(w.v2n)[at];
   const float n1 = w.norm1[ii], n2 = w.norm2[ii];
-  const int dst = w.idx ? w.idx[ii] : ii;
   float4 O1 = f4_zero(), O2 = f4_zero();
   float l = 0.f;
   constexpr int kW = 10;                                // splits whose loads are in flight at a time: the persistent passes
@@ -637,8 +636,23 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
                                  coef * (O1.z * il - off * vb.z), coef * (O1.w * il - off * vb.w));
   const float4 dn2 = make_float4(coef * (O2.x - off * va.x), coef * (O2.y - off * va.y), coef * (O2.z - off * va.z),
                                  coef * (O2.w - off * va.w));
-  const float4 dv1 = nce_norm_backward<LPR>(va, dn1, n1);
-  const float4 dv2 = nce_norm_backward<LPR>(vb, dn2, n2);
+  dv1 = nce_norm_backward<LPR>(va, dn1, n1);
+  dv2 = nce_norm_backward<LPR>(vb, dn2, n2);
+  // log(L) - (s_ii / tau - 1 / tau).  log1p(l / e_ii) is the cancellation-free form of it, but e_ii underflows once
+  // (1 - cos_ii) / tau > ~87 (below the tau >= 0.03 this entry accepts today: 2 / 0.03 = 67; kept for when that bound moves): there log(l) - (s_ii - 1 / tau) is exact to
+  // rounding (e_ii no longer reaches l's last bit) and stays finite, like the reference's log_softmax
+  const float li = (eii > 0.f && eii >= 1e-30f * l) ? log1pf(l / eii) : (logf(l) - (sii - a.inv_tau));
+  return (valid && sub == 0) ? (double)li : 0.0;
+}
+
+// ... and the scatter of the two gradients with float atomics (the entry points without row -> slot lists)
+template <int LPR>
+__device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub, float4* scr,
+                                                 int splits) {
+  const bool valid = i < n;
+  const int dst = w.idx ? w.idx[valid ? i : 0] : (valid ? i : 0);
+  float4 dv1, dv2;
+  const double li = nce_finish_row_grads<LPR>(w, a, n, i, sub, splits, dv1, dv2);
   if (valid) {
     // atomic: BPR phase 2 shares this launch and adds to the same rows of g1.  g2 is a plain read-add-store
     // when the caller declares its rows exclusive (srh_infonce_problem_t::g2_exclusive)
@@ -650,11 +664,7 @@ __device__ __forceinline__ double nce_finish_row(const NceWs& w, const NceFinish
       atomic_add_row<LPR>(w.g2 + (size_t)dst * LPR * 4, dv2, sub, scr);
     }
   }
-  // log(L) - (s_ii / tau - 1 / tau).  log1p(l / e_ii) is the cancellation-free form of it, but e_ii underflows once
-  // (1 - cos_ii) / tau > ~87 (below the tau >= 0.03 this entry accepts today: 2 / 0.03 = 67; kept for when that bound moves): there log(l) - (s_ii - 1 / tau) is exact to
-  // rounding (e_ii no longer reaches l's last bit) and stays finite, like the reference's log_softmax
-  const float li = (eii > 0.f && eii >= 1e-30f * l) ? log1pf(l / eii) : (logf(l) - (sii - a.inv_tau));
-  return (valid && sub == 0) ? (double)li : 0.0;
+  return li;
 }
 
 // LDS-staged form of nce_tile_bf16 (the default).  The register version is latency-bound: a workgroup's
@@ -1363,9 +1373,175 @@ __global__ __launch_bounds__(256) void nce_finish_bpr2(NceBatch batch, NceFinish
   nce_finish_both_body<LPR>(batch, a, k % fbx, k / fbx);
 }
 
+// ---- the fixed-order finish: one row group per touched row, no float atomics ---------------------------------------------
+// The reference's backward of `emb[idx]` (XSimGCL.py:30, 35-36) is index_put(accumulate): on one CPU thread the same sum every
+// run.  Here the batch's rows are known before the step (srh_sampler_epoch_segments: sorted unique users | positive items |
+// other negatives, each with the list of (slot, role) entries that name it), so the LPR lanes of ONE row group own a row:
+// they finish its InfoNCE gradients (if a problem names the row), walk its slot list in order adding the BPR / L2 terms, and
+// write the row once -- read, add, store.  Same arithmetic per term as the atomic form above; the sum's order is the list's.
+struct SegArgs {
+  const int32_t *uniq_u, *uniq_i, *uniq_n, *n_uniq_u, *n_uniq_i, *n_uniq_n, *seg_end, *seg, *batch_no;
+  int nce_rows;
+};
+
+__device__ __forceinline__ void rmw_add_row(float* table, int row, int lpr, int sub, float4 v) {
+  float4* p = reinterpret_cast<float4*>(table) + (size_t)row * lpr + sub;
+  *p = f4_add(*p, v);
+}
+
+template <int LPR>
+__device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const NceFinishArgs& fa, const BprArgs& a,
+                                                 const SegArgs& sg) {
+  constexpr int G = 64 / LPR;
+  const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
+  if (rows <= 0) return;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int grp = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + lane / LPR;
+  const int bno = sg.batch_no ? *sg.batch_no : 0;
+  const size_t off1 = sg.batch_no ? (size_t)bno * a.B : 0, off3 = 3 * off1;
+  const int nuu = *sg.n_uniq_u, nui = *sg.n_uniq_i, nun = sg.n_uniq_n[sg.batch_no ? bno : 0];
+  const int groups = nuu + nui + nun;
+  const bool live = grp < groups;
+  const int gq = live ? grp : 0;
+  const int kind = gq < nuu ? 0 : (gq < nuu + nui ? 1 : 2);            // user | positive item | negative only
+  // ---- loads that depend on nothing but the group number go first
+  const int row = kind == 0 ? sg.uniq_u[gq] : (kind == 1 ? sg.uniq_i[gq - nuu] : sg.uniq_n[off1 + gq - nuu - nui]);
+  const int e1 = live ? sg.seg_end[off3 + gq] : 0;
+  const int e0 = (live && gq > 0) ? sg.seg_end[off3 + gq - 1] : 0;
+  const float* reg_t = kind == 0 ? a.reg_user : a.reg_item;
+  const float4 rr = reinterpret_cast<const float4*>(reg_t)[(size_t)row * LPR + sub];
+  // ---- the InfoNCE gradients of this row (the problem that names it: SegArgs::nce_rows)
+  int pz = -1, pi = 0;
+  if (sg.nce_rows == 1 && kind < 2) { pz = kind; pi = kind == 0 ? gq : gq - nuu; }
+  if (sg.nce_rows == 2 && kind < 2) { pz = 0; pi = gq; }
+  const bool has_nce = live && pz >= 0 && pz < batch.count;
+  float4 dv1 = f4_zero(), dv2 = f4_zero();
+  if (batch.count > 0 && sg.nce_rows != 0) {
+    const int pq = has_nce ? pz : 0;
+    const NceWs& w = batch.w[pq];
+    const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+    int splits = batch.splits;
+    if (batch.slots > 0) splits = batch.w[0].plan->splits[pq];
+    const double li = nce_finish_row_grads<LPR>(w, fa, has_nce ? n : 0, pi, sub, splits, dv1, dv2);
+    if (has_nce && sub == 0) store_f64_sc1(w.losspart + pi, li);       // folded in row order by the last workgroup (below)
+  }
+  // ---- the fold of BPR phase 1's partials (every workgroup: the regulariser's gradient needs the three norms)
+  __shared__ double s_tot[4];
+  if (threadIdx.x < 64) {
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int k = threadIdx.x; k < a.n_blocks; k += 64) {
+      t0 += a.part[(size_t)k * 4 + 0]; t1 += a.part[(size_t)k * 4 + 1];
+      t2 += a.part[(size_t)k * 4 + 2]; t3 += a.part[(size_t)k * 4 + 3];
+    }
+    t0 = wave_sum_d(t0); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2); t3 = wave_sum_d(t3);
+    if (threadIdx.x == 0) { s_tot[0] = t0; s_tot[1] = t1; s_tot[2] = t2; s_tot[3] = t3; }
+  }
+  __syncthreads();
+  const float nu = (float)sqrt(s_tot[1]), np = (float)sqrt(s_tot[2]), nn = (float)sqrt(s_tot[3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float r = nu / (float)rows + np / (float)rows;
+    if (a.reg_include_neg) r += nn / (float)rows;
+    a.losses[0] += (double)a.loss_scale * s_tot[0] / (double)rows;
+    a.losses[1] += (double)(a.loss_scale * (r * a.reg_coef));
+  }
+  const float cs = a.loss_scale / (float)rows;
+  const float rs = a.reg_coef * a.loss_scale / (float)rows;
+  const float cu = nu > 0.f ? rs / nu : 0.f, cp = np > 0.f ? rs / np : 0.f;
+  const float cn = (a.reg_include_neg && nn > 0.f) ? rs / nn : 0.f;
+  const bool same_u = (a.reg_user == a.user) && (a.greg_user == a.g_user);
+  const bool same_i = (a.reg_item == a.item) && (a.greg_item == a.g_item);
+  const bool same = kind == 0 ? same_u : same_i;
+  // ---- the row's slot list, four entries' loads in flight at a time, summed in list order
+  float4 acc = f4_zero(), accr = f4_zero();
+  for (int e = e0; e < e1; e += 4) {
+    int ent[4];
+    float cf[4];
+    float4 x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ent[k] = sg.seg[off3 + min(e + k, e1 - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = ent[k] >> 2;
+      cf[k] = a.coef[b];
+      if (kind == 0) {
+        x[k] = reinterpret_cast<const float4*>(a.item)[(size_t)a.i_idx[b] * LPR + sub];
+        y[k] = reinterpret_cast<const float4*>(a.item)[(size_t)a.j_idx[b] * LPR + sub];
+      } else {
+        x[k] = reinterpret_cast<const float4*>(a.user)[(size_t)a.u_idx[b] * LPR + sub];
+        y[k] = f4_zero();
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (e + k >= e1) break;
+      const float c = cf[k] * cs;
+      float4 g;
+      float cr;
+      if (kind == 0) {
+        g = make_float4(c * (x[k].x - y[k].x), c * (x[k].y - y[k].y), c * (x[k].z - y[k].z), c * (x[k].w - y[k].w));
+        cr = cu;
+      } else if ((ent[k] & 3) == 1) {
+        g = f4_scale(x[k], c);
+        cr = cp;
+      } else {
+        g = f4_scale(x[k], -c);
+        cr = cn;
+      }
+      if (same) g = f4_fma(cr, rr, g);
+      else accr = f4_fma(cr, rr, accr);
+      acc = f4_add(acc, g);
+    }
+  }
+  // ---- one read-add-store per table the row belongs to
+  if (live) {
+    float* tb = kind == 0 ? a.g_user : a.g_item;
+    if (has_nce) {
+      const NceWs& w = batch.w[pz];
+      if (w.g1 == tb) acc = f4_add(acc, dv1);
+      if (w.g2 == tb) acc = f4_add(acc, dv2);
+      if (w.g1 != tb) rmw_add_row(w.g1, row, LPR, sub, w.g2 == w.g1 ? f4_add(dv1, dv2) : dv1);
+      if (w.g2 != tb && w.g2 != w.g1) rmw_add_row(w.g2, row, LPR, sub, dv2);
+    }
+    rmw_add_row(tb, row, LPR, sub, acc);
+    if (!same) rmw_add_row(kind == 0 ? a.greg_user : a.greg_item, row, LPR, sub, accr);
+  }
+  // ---- InfoNCE loss: the workgroup that arrives last folds the per-row terms in row order (bit-reproducible)
+  if (batch.count == 0 || sg.nce_rows == 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int s_last;
+  __shared__ double s_fold[4];
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(batch.w[0].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) __hip_atomic_store(batch.w[0].ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k = 0; k < batch.count; ++k) {
+    const NceWs& w = batch.w[k];
+    const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) t += w.losspart[i];
+    t = wave_sum_d(t);
+    if (lane == 0) s_fold[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0 && n > 0)
+      atomicAdd(fa.loss, (double)fa.loss_scale * ((s_fold[0] + s_fold[1]) + (s_fold[2] + s_fold[3])) / (double)n);
+    __syncthreads();
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_finish(NceBatch batch, NceFinishArgs fa, BprArgs bpr, SegArgs sg) {
+  rows_finish_body<LPR>(batch, fa, bpr, sg);
+}
+
 template <int D>
 srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float tau, float loss_scale, double* loss,
-                            void* ws, hipStream_t st, int precision, const BprArgs* bpr = nullptr) {
+                            void* ws, hipStream_t st, int precision, const BprArgs* bpr = nullptr,
+                            const SegArgs* seg = nullptr) {
   constexpr int LPR = D / 4, G = 64 / LPR;
   NceBatch batch{};
   batch.count = count;
@@ -1452,22 +1628,42 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     }
     SRH_LAUNCH_CHECK();
   }
-  if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
+  if (bpr && seg) rows_finish<LPR><<<(3 * bp.B + 4 * G - 1) / (4 * G), 256, 0, st>>>(batch, fa, bp, *seg);
+  else if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
   else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
   return SRH_OK;
 }
 
 template <int LPR>
-srh_status_t launch_bpr(const BprArgs& a, hipStream_t st) {
+srh_status_t launch_bpr(const BprArgs& a, hipStream_t st, const SegArgs* seg = nullptr) {
   constexpr int G = 64 / LPR;
   const int blocks = ((a.B + G - 1) / G + 3) / 4;
   BprArgs b = a;
   b.n_blocks = blocks;
   bpr_phase1<LPR><<<blocks, 256, 0, st>>>(b);
   SRH_LAUNCH_CHECK();
-  bpr_phase2<LPR><<<blocks, 256, 0, st>>>(b);
+  if (seg) {
+    NceBatch none{};
+    rows_finish<LPR><<<(3 * b.B + 4 * G - 1) / (4 * G), 256, 0, st>>>(none, NceFinishArgs{}, b, *seg);
+  } else {
+    bpr_phase2<LPR><<<blocks, 256, 0, st>>>(b);
+  }
   SRH_LAUNCH_CHECK();
+  return SRH_OK;
+}
+
+// srh_batch_segments_t -> SegArgs (checked)
+static srh_status_t seg_args(const srh_batch_segments_t* g, int n_problems, SegArgs& out) {
+  SRH_REQUIRE(g->d_uniq_u && g->d_uniq_i && g->d_uniq_n && g->d_n_uniq_u && g->d_n_uniq_i && g->d_n_uniq_n && g->d_seg_end && g->d_seg,
+              "batch segments: null array");
+  SRH_REQUIRE(g->nce_rows >= 0 && g->nce_rows <= 2, "batch segments: nce_rows must be 0, 1 or 2");
+  SRH_REQUIRE(g->nce_rows != 1 || n_problems == 2, "batch segments: nce_rows = 1 names two InfoNCE problems (users, positive items)");
+  SRH_REQUIRE(g->nce_rows != 2 || n_problems == 1, "batch segments: nce_rows = 2 names one InfoNCE problem ([users ; positive items])");
+  SRH_REQUIRE(g->nce_rows != 0 || n_problems == 0,
+              "batch segments: InfoNCE problems in the call need nce_rows 1 or 2 (their rows are finished by the row groups)");
+  out = SegArgs{g->d_uniq_u, g->d_uniq_i, g->d_uniq_n, g->d_n_uniq_u, g->d_n_uniq_i, g->d_n_uniq_n, g->d_seg_end, g->d_seg,
+                g->d_batch_no, g->nce_rows};
   return SRH_OK;
 }
 
@@ -1593,7 +1789,7 @@ int64_t srh_infonce_ws_bytes(int64_t n, int32_t d) {
 
 static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t n_problems, int32_t d, float tau,
                                   float loss_scale, double* d_loss, void* d_ws, int32_t precision, void* stream,
-                                  const BprArgs* bpr) {
+                                  const BprArgs* bpr, const SegArgs* seg = nullptr) {
   SRH_REQUIRE(precision == SRH_NCE_DEFAULT || precision == SRH_NCE_SPLIT16 || precision == SRH_NCE_F32,
               "infonce_fwd_bwd: unknown precision %d", precision);
   if (precision == SRH_NCE_DEFAULT) {
@@ -1615,9 +1811,9 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
     return SRH_ERR_UNSUPPORTED;
   }
   hipStream_t st = srh::as_stream(stream);
-  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
-  if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
-  return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr);
+  if (d == 64) return launch_infonce<64>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr, seg);
+  if (d == 128) return launch_infonce<128>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr, seg);
+  return launch_infonce<256>(problems, n_problems, tau, loss_scale, d_loss, d_ws, st, precision, bpr, seg);
 }
 
 #ifdef SRH_NCEF32_STAMPS
@@ -1654,7 +1850,35 @@ srh_status_t srh_bpr_infonce_fwd_bwd(const srh_bpr_problem_t* b, const srh_infon
             (int)b->B, b->reg_coef, b->loss_scale, b->reg_include_neg, b->d_g_user, b->d_g_item, b->d_greg_user,
             b->d_greg_item, b->d_losses, reinterpret_cast<double*>(b->d_ws),
             reinterpret_cast<float*>(reinterpret_cast<char*>(b->d_ws) + bpr_part_bytes(b->B)), 0};
-  return infonce_entry(problems, n_problems, d, tau, cl_scale, d_cl_loss, d_nce_ws, precision, stream, &a);
+  SegArgs sg{};
+  if (b->seg)
+    if (srh_status_t st = seg_args(b->seg, n_problems, sg)) return st;
+  return infonce_entry(problems, n_problems, d, tau, cl_scale, d_cl_loss, d_nce_ws, precision, stream, &a, b->seg ? &sg : nullptr);
+}
+
+srh_status_t srh_bpr_l2_fwd_bwd_p(const srh_bpr_problem_t* b, int32_t d, void* stream) {
+  SRH_REQUIRE(b, "bpr_l2_fwd_bwd_p: null bpr problem");
+  SRH_REQUIRE(b->d_user && b->d_item && b->d_reg_user && b->d_reg_item && b->d_u_idx && b->d_i_idx && b->d_j_idx,
+              "bpr_l2_fwd_bwd_p: null input");
+  SRH_REQUIRE(b->d_g_user && b->d_g_item && b->d_greg_user && b->d_greg_item && b->d_losses && b->d_ws,
+              "bpr_l2_fwd_bwd_p: null output");
+  SRH_REQUIRE(b->B > 0 && b->B < (int64_t(1) << 28), "bpr_l2_fwd_bwd_p: bad batch size");
+  SRH_REQUIRE(srh::dim_supported(d), "bpr_l2_fwd_bwd_p: d=%d unsupported", d);
+  BprArgs a{b->d_user, b->d_item, b->d_reg_user, b->d_reg_item, b->d_u_idx, b->d_i_idx, b->d_j_idx, b->d_n_rows,
+            (int)b->B, b->reg_coef, b->loss_scale, b->reg_include_neg, b->d_g_user, b->d_g_item, b->d_greg_user,
+            b->d_greg_item, b->d_losses, reinterpret_cast<double*>(b->d_ws),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(b->d_ws) + bpr_part_bytes(b->B)), 0};
+  SegArgs sg{};
+  if (b->seg)
+    if (srh_status_t st = seg_args(b->seg, 0, sg)) return st;
+  hipStream_t st = srh::as_stream(stream);
+  const SegArgs* sp = b->seg ? &sg : nullptr;
+  switch (d) {
+    case 32: return launch_bpr<8>(a, st, sp);
+    case 64: return launch_bpr<16>(a, st, sp);
+    case 128: return launch_bpr<32>(a, st, sp);
+    default: return launch_bpr<64>(a, st, sp);
+  }
 }
 
 srh_status_t srh_infonce_fwd_bwd(const float* d_v1, const float* d_v2, const int32_t* d_idx, int64_t n,

@@ -25,7 +25,11 @@ static PyObject* reclist_build(PyObject* self, PyObject* args) {
   {
     const int32_t* id = (const int32_t*)ids.buf;
     const float* sc = (const float*)scores.buf;
-    out = _PyDict_NewPresized(n_users);
+#if PY_VERSION_HEX < 0x030D0000
+    out = _PyDict_NewPresized(n_users);     /* (private, and internal-only from CPython 3.13 on: there the dict grows as it fills) */
+#else
+    out = PyDict_New();
+#endif
     if (!out) goto done;
     for (Py_ssize_t u = 0; u < n_users; ++u) {
       PyObject* row = PyList_New(k);

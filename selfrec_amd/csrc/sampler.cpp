@@ -118,6 +118,8 @@ struct srh_sampler {
   //   info >> 8  = first 64-bit word of user u's bitmap;  info & 255 = log2(bits) of it, 255 = exact item bitmap
   std::vector<uint64_t> sig_info;
   std::vector<uint64_t> seen_u, seen_i;     // scratch bitmaps for the per-batch sorted unique ids
+  std::vector<int32_t> pos_u, pos_i;        // scratch of srh_sampler_epoch_segments: id -> row group of the batch (-1)
+  std::vector<int32_t> seg_fill;            //   "       : next free entry of every row group's slot list
   MT19937 rng;
   bool seeded = false;
 
@@ -413,6 +415,62 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
       h_n_uniq_u[b] = sorted_unique(h_u + ptr, cnt, h_uniq_u + b * batch_size, s->seen_u, (size_t)(s->n_users + 63) / 64);
       h_n_uniq_i[b] = sorted_unique(h_i + ptr, cnt, h_uniq_i + b * batch_size, s->seen_i, (size_t)(s->n_items + 63) / 64);
     }
+    ptr += cnt;
+  }
+  return SRH_OK;
+}
+
+// The fixed-order row -> slot lists of every batch of an epoch (see include/selfrec_hip.h).  Pure host arithmetic on the
+// arrays srh_sampler_epoch filled: no draw from the generator.
+srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, const int32_t* h_u, const int32_t* h_i,
+                                        const int32_t* h_j, const int32_t* h_uniq_u, const int32_t* h_n_uniq_u,
+                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t* h_uniq_n,
+                                        int32_t* h_n_uniq_n, int32_t* h_seg_end, int32_t* h_seg) {
+  SRH_REQUIRE(s && h_u && h_i && h_j && h_uniq_u && h_n_uniq_u && h_uniq_i && h_n_uniq_i, "sampler_epoch_segments: null input");
+  SRH_REQUIRE(h_uniq_n && h_n_uniq_n && h_seg_end && h_seg, "sampler_epoch_segments: null output");
+  SRH_REQUIRE(batch_size > 0 && batch_size < (int64_t(1) << 28), "sampler_epoch_segments: bad batch_size");
+  if (s->pos_u.empty()) {
+    s->pos_u.assign((size_t)s->n_users, -1);
+    s->pos_i.assign((size_t)s->n_items, -1);
+  }
+  s->seg_fill.resize((size_t)(3 * batch_size));
+  int32_t* pos_u = s->pos_u.data();
+  int32_t* pos_i = s->pos_i.data();
+  int32_t* fill = s->seg_fill.data();
+  const size_t item_words = (size_t)(s->n_items + 63) / 64;
+  std::vector<int32_t> neg_only((size_t)batch_size);
+  int64_t b = 0;
+  for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
+    const int64_t cnt = std::min<int64_t>(batch_size, s->n_edges - ptr);
+    const int32_t *u = h_u + ptr, *it = h_i + ptr, *jt = h_j + ptr;
+    const int32_t *uu = h_uniq_u + b * batch_size, *ui = h_uniq_i + b * batch_size;
+    const int32_t nuu = h_n_uniq_u[b], nui = h_n_uniq_i[b];
+    int32_t* un = h_uniq_n + b * batch_size;
+    int32_t* end = h_seg_end + b * 3 * batch_size;
+    int32_t* seg = h_seg + b * 3 * batch_size;
+    for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = k;
+    for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = nuu + k;
+    // sorted unique negatives that are nobody's positive item in this batch
+    int64_t m = 0;
+    for (int64_t r = 0; r < cnt; ++r)
+      if (pos_i[jt[r]] < 0) neg_only[(size_t)m++] = jt[r];
+    const int32_t nun = sorted_unique(neg_only.data(), m, un, s->seen_i, item_words);
+    for (int32_t k = 0; k < nun; ++k) pos_i[un[k]] = nuu + nui + k;
+    const int32_t groups = nuu + nui + nun;
+    // counting sort of the 3 cnt (slot, role) entries by row group; inside a group: slot ascending, positive before negative
+    for (int32_t g = 0; g < groups; ++g) end[g] = 0;
+    for (int64_t r = 0; r < cnt; ++r) { ++end[pos_u[u[r]]]; ++end[pos_i[it[r]]]; ++end[pos_i[jt[r]]]; }
+    int32_t run = 0;
+    for (int32_t g = 0; g < groups; ++g) { fill[g] = run; run += end[g]; end[g] = run; }
+    for (int64_t r = 0; r < cnt; ++r) {
+      seg[fill[pos_u[u[r]]]++] = (int32_t)(r * 4 + 0);
+      seg[fill[pos_i[it[r]]]++] = (int32_t)(r * 4 + 1);
+      seg[fill[pos_i[jt[r]]]++] = (int32_t)(r * 4 + 2);
+    }
+    for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = -1;
+    for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = -1;
+    for (int32_t k = 0; k < nun; ++k) pos_i[un[k]] = -1;
+    h_n_uniq_n[b] = nun;
     ptr += cnt;
   }
   return SRH_OK;

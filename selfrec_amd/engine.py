@@ -200,6 +200,13 @@ class FusedTrainer:
                           and model != "MF" and tuple(self.m.shape) == tuple(self.E0.shape)
                           and getattr(ops, "ADAM_EPILOGUE", False) and os.environ.get("SRH_FUSE_ADAM", "1") != "0")
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
+        # Fixed-order batch gradients (srh_batch_segments_t): the sampler hands every batch's row -> slot lists over with the
+        # epoch, and the loss section's last kernel writes every touched gradient row ONCE, summed in slot order -- no float
+        # atomics, so a step is reproducible bit for bit (run twice, bit-compare; the reference's single-threaded
+        # index_put(accumulate) backward of XSimGCL.py:30 is).  Whole rows and columns on this rank (single, dp); the
+        # column-block layouts run the losses on compact slot tables and keep the atomic scatter.  SRH_DET_SCATTER=0: atomics.
+        self.det_scatter = (single and not self.colx.split and hasattr(ops, "_segments")
+                            and os.environ.get("SRH_DET_SCATTER", "1") != "0")
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
         if model in ("XSimGCL", "SimGCL", "SGL"):       # user side + item side share one workspace / launch set
@@ -214,11 +221,18 @@ class FusedTrainer:
         nb = self.epoch_batches
         self._epoch_slot = {"u": nb * B, "i": nb * B, "j": nb * B, "uniq_u": nb * B, "uniq_i": nb * B,
                             "n_uniq_u": nb, "n_uniq_i": nb}                       # entries of ONE half
+        if self.det_scatter:
+            self._epoch_slot.update({"uniq_n": nb * B, "n_uniq_n": nb, "seg_end": 3 * nb * B, "seg": 3 * nb * B})
         self._epoch_dev = {k: torch.zeros(2 * n, dtype=torch.int32, device=dev) for k, n in self._epoch_slot.items()}
         self._live_half = None                 # the half the steps read (None: nothing uploaded yet)
         self._half_free = [None, None]         # event on the step stream: every step that read this half has been enqueued
         self._copy_stream = None
         self._pinned = [None, None]
+        self._stage_pending = [None, None]     # event behind the last staged copy INTO each half (upload_epoch orders in-line copies behind it)
+        # stage_epoch (prefetch thread) allocates pinned memory, creates a stream, records and waits for events; a hipGraph
+        # capture in "global" error mode on the main thread is invalidated by such calls from ANY thread.  One lock: the worker
+        # makes no HIP call while a capture is open, and a capture does not open in the middle of a staging.
+        self._hip_lock = threading.RLock()
         self._epoch_ready = False
         self.step_count = 0
         # (a sharded step is captured only on request: RCCL collectives inside a hipGraph could not be
@@ -431,7 +445,8 @@ class FusedTrainer:
                     mk[keep] = 1
                 masks.append(mk)
             out["masks"] = masks
-        ep = self.sampler.epoch(self.B, 1, with_unique=True, slot=slot)
+        ep = self.sampler.epoch(self.B, 1, with_unique=True, slot=slot,
+                                **({"with_segments": True} if getattr(self, "det_scatter", False) else {}))
         # node ids -> table rows (items follow the users; all-gather order when the rows are dealt)
         out.update(self.rows.epoch_to_table_rows(ep))
         return out
@@ -451,6 +466,10 @@ class FusedTrainer:
         live one: the copy is ordered behind the event recorded when that epoch's last step had been enqueued."""
         if self.dev.type != "cuda" or "_staged" in host:
             return host
+        with self._hip_lock:
+            return self._stage_epoch_locked(host)
+
+    def _stage_epoch_locked(self, host):
         torch.cuda.set_device(self.dev)                                   # (a worker thread starts on device 0)
         half = self._next_half()
         if self._copy_stream is None:
@@ -472,6 +491,7 @@ class FusedTrainer:
             done = torch.cuda.Event()
             done.record(self._copy_stream)
         pin["_pin_done"] = done
+        self._stage_pending[half] = done
         host["_staged"] = (half, done)
         return host
 
@@ -486,7 +506,12 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_event(staged[1])           # the copy stream's work, ordered before the next step
         else:
             # in line, on the step stream (in order behind every step that read this half): tests, begin_epoch(), the CPU
-            # stand-ins -- or a staged copy that went to the other half (an epoch was uploaded in between)
+            # stand-ins -- or a staged copy that went to the other half (an epoch was uploaded in between).  A staged copy
+            # of ANOTHER epoch may still be in flight into this very half (begin_epoch() with a prefetch outstanding): the
+            # in-line copy goes behind it, so the late copy cannot overwrite the epoch that is about to go live.
+            pending = self._stage_pending[half]
+            if pending is not None and dev.type == "cuda":
+                torch.cuda.current_stream().wait_event(pending)
             for k, n in self._epoch_slot.items():
                 src = torch.from_numpy(host[k])
                 self._epoch_dev[k][half * n:half * n + src.numel()].copy_(src, non_blocking=True)
@@ -808,12 +833,18 @@ class FusedTrainer:
                    g_user=GT(self.gF), g_item=GT(self.gF), greg_user=GT(greg_t), greg_item=GT(greg_t),
                    losses=self.losses[0:2])
         bpr_in = (T(F), T(F), T(reg_t), T(reg_t), ix["u"], ix["i"], ix["j"])
+        seg = {}
+        if self.det_scatter:
+            ed = self._epoch_dev
+            seg = dict(seg=dict(uniq_u=st["uniq_u"], uniq_i=st["uniq_i"], n_uniq_u=nuu_dev, n_uniq_i=nui_dev,
+                                uniq_n=ed["uniq_n"], n_uniq_n=ed["n_uniq_n"], seg_end=ed["seg_end"], seg=ed["seg"],
+                                batch_no=self.meta[3:4]))
         nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws,
                    precision=self.nce_precision)
         # ---- recommendation + contrastive loss (a-5..a-8)
         if m == "XSimGCL":
             CL = self.E0 if self.layer_cl == 0 else self.Y[self.layer_cl - 1]
-            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=[
+            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, **seg, **({"nce_rows": 1} if seg else {}), problems=[
                 # (gCL's rows: the user-side problem names user rows, the item-side one item rows, nobody else writes them)
                 (T(F), T(CL), ix["uniq_u"], self.B, nuu_dev, GT(self.gF), GT(self.gCL), True),
                 (T(F), T(CL), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gCL), True)])
@@ -826,9 +857,10 @@ class FusedTrainer:
                             (T(a["F"]), T(b["F"]), ix["uniq_i"], self.B, nui_dev, GT(self.gF), GT(self.gF))]
             else:
                 problems = [(T(a["F"]), T(b["F"]), cat_idx, 2 * self.B, self.n_cat, GT(a["gF"]), GT(b["gF"]))]
-            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems)
+            ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=self.bpr_ws, **nce, problems=problems, **seg,
+                            **({"nce_rows": 1 if m == "SimGCL" else 2} if seg else {}))
         else:
-            ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=self.bpr_ws)
+            ops.bpr_l2_fwd_bwd(*bpr_in, **bpr, ws=self.bpr_ws, **seg)
         self.colx.scatter(self)                   # (column blocks: this rank's columns of the batch-row gradients go home)
         # ---- backward through the encoder (a-4) and optimiser (a-9)
         if m == "MF":
@@ -940,7 +972,8 @@ class FusedTrainer:
             gc.collect()
             gc.disable()
         try:
-            self._capture_guarded()
+            with self._hip_lock:                                 # (the prefetch thread's staging stays out of the window)
+                self._capture_guarded()
         finally:
             if guard and was_enabled:
                 gc.enable()

@@ -38,9 +38,11 @@ class FusedGraphModel(GraphRecommender):
         # reference's torch.rand_like does
         seed = get('seed', None)
         rng_seed = (int(seed) if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
-        # "f32" | "split": the arithmetic of InfoNCE's two products belongs to THIS model's trainer and travels with every
-        # loss call (no process-wide state: a model neither inherits nor leaves behind another model's setting)
-        self.nce_precision = str(get('engine.nce_precision', 'split'))
+        # "f32" | "split" | absent: the arithmetic of InfoNCE's two products belongs to THIS model's trainer and travels with
+        # every loss call (no process-wide state: a model neither inherits nor leaves behind another model's setting).  Absent
+        # = the library default: the reference's fp32 products (loss_torch.py:46-47); "split" is the faster opt-in.
+        prec = get('engine.nce_precision', None)
+        self.nce_precision = None if prec is None else str(prec)
         self.trainer = FusedTrainer(self.data, self.emb_size, model=self.engine_model, lr=self.lRate,
                                     reg=self.reg, batch_size=self.batch_size, rng_seed=rng_seed,
                                     use_graph=_as_bool(get('engine.hipgraph', True)), nce_precision=self.nce_precision,

@@ -143,8 +143,10 @@ class Sampler:
         assert out.value == cnt
         return u, i, j
 
-    def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False, slot=None):
+    def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False, slot=None, with_segments: bool = False):
         """shuffle + all batches.  Returns dict of numpy arrays (see srh_sampler_epoch).
+        with_segments: also the row -> slot lists of every batch (srh_sampler_epoch_segments: uniq_n, n_uniq_n, seg_end, seg)
+        behind the fixed-order batch-gradient reduction.
         slot (None | 0 | 1 | ...): None -- fresh arrays, the caller's to keep.  An integer -- the arrays of that slot, owned
         by the sampler and OVERWRITTEN by the next call with the same slot: a training loop that alternates two slots never
         allocates or frees an epoch's 25 MB (freeing them -- munmap -- beside a thread that is enqueueing GPU work was
@@ -180,6 +182,20 @@ class Sampler:
         self._pushed = None                      # (the C++ generator moves on: python's copy is behind until the next push)
         check(self._lib.srh_sampler_epoch(self._h, batch_size, n_negs, vp(u), vp(i), vp(j), vp(uu), vp(nuu),
                                           vp(ui), vp(nui)), "srh_sampler_epoch")
+        if with_segments:
+            if not with_unique or n_negs != 1:
+                raise SelfrecHipError("Sampler.epoch: with_segments needs with_unique and n_negs = 1")
+            seg = None if slot is None else self._epoch_slots.get(key + ("seg",))
+            if seg is None:
+                seg = {"uniq_n": np.zeros(nb * batch_size, dtype=np.int32), "n_uniq_n": np.zeros(nb, dtype=np.int32),
+                       "seg_end": np.zeros(3 * nb * batch_size, dtype=np.int32),
+                       "seg": np.zeros(3 * nb * batch_size, dtype=np.int32)}
+                if slot is not None:
+                    self._epoch_slots[key + ("seg",)] = seg
+            check(self._lib.srh_sampler_epoch_segments(self._h, batch_size, vp(u), vp(i), vp(j), vp(uu), vp(nuu), vp(ui), vp(nui),
+                                                       vp(seg["uniq_n"]), vp(seg["n_uniq_n"]), vp(seg["seg_end"]),
+                                                       vp(seg["seg"])), "srh_sampler_epoch_segments")
+            res.update(seg)
         return res
 
     def sample_range(self, n: int, k: int) -> np.ndarray:
@@ -567,9 +583,43 @@ def bpr_ws(batch: int, device):
     return torch.empty(int(_lib.load().srh_bpr_ws_bytes(batch)), dtype=torch.uint8, device=device)
 
 
+def _segments(seg, nce_rows):
+    """srh_batch_segments_t from a dict of device int32 tensors: uniq_u, uniq_i, n_uniq_u, n_uniq_i, uniq_n, n_uniq_n, seg_end, seg
+    [, batch_no: the last four are then EPOCH arrays]."""
+    g = _lib.BatchSegments()
+    for k in ("uniq_u", "uniq_i", "n_uniq_u", "n_uniq_i", "uniq_n", "n_uniq_n", "seg_end", "seg"):
+        setattr(g, "d_" + k, _p(seg[k], torch.int32))
+    g.d_batch_no = _p(seg.get("batch_no"), torch.int32)
+    g.nce_rows = int(nce_rows)
+    return g
+
+
+def _bpr_problem(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, batch, n_rows_dev, reg_coef, reg_include_neg, loss_scale,
+                 g_user, g_item, greg_user, greg_item, losses, ws, seg, nce_rows):
+    b = _lib.BprProblem()
+    b.d_user, b.d_item = _p(user, torch.float32), _p(item, torch.float32)
+    b.d_reg_user, b.d_reg_item = _p(reg_user, torch.float32), _p(reg_item, torch.float32)
+    b.d_u_idx, b.d_i_idx, b.d_j_idx = _p(u_idx, torch.int32), _p(i_idx, torch.int32), _p(j_idx, torch.int32)
+    b.B, b.d_n_rows = int(batch), _p(n_rows_dev, torch.int32)
+    b.reg_coef, b.reg_include_neg, b.loss_scale = float(reg_coef), int(bool(reg_include_neg)), float(loss_scale)
+    b.d_g_user, b.d_g_item = _p(g_user, torch.float32), _p(g_item, torch.float32)
+    b.d_greg_user, b.d_greg_item = _p(greg_user, torch.float32), _p(greg_item, torch.float32)
+    b.d_losses, b.d_ws = _p(losses, torch.float64), _p(ws)
+    if seg is not None:
+        b._seg = _segments(seg, nce_rows)          # (kept alive by the struct object)
+        b.seg = C.pointer(b._seg)
+    return b
+
+
 def bpr_l2_fwd_bwd(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
-                   reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, ws):
+                   reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, ws, seg=None):
+    """seg: the batch's row -> slot lists (see _segments): the gradients are summed row by row in slot order, no float atomics."""
     d = int(user.shape[1])
+    if seg is not None:
+        b = _bpr_problem(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, batch, n_rows_dev, reg_coef, reg_include_neg,
+                         loss_scale, g_user, g_item, greg_user, greg_item, losses, ws, seg, 0)
+        check(_lib.load().srh_bpr_l2_fwd_bwd_p(C.byref(b), d, _stream()), "srh_bpr_l2_fwd_bwd_p")
+        return
     check(_lib.load().srh_bpr_l2_fwd_bwd(
         _p(user, torch.float32), _p(item, torch.float32), _p(reg_user, torch.float32), _p(reg_item, torch.float32),
         _p(u_idx, torch.int32), _p(i_idx, torch.int32), _p(j_idx, torch.int32), int(batch),
@@ -691,19 +741,14 @@ def infonce_multi(problems, *, d, tau, loss_scale, loss, ws, precision=None):
 
 def bpr_infonce(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, *, batch, n_rows_dev=None, reg_coef,
                 reg_include_neg, loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws,
-                problems, tau, cl_scale, cl_loss, nce_ws, precision=None):
-    """bpr_l2_fwd_bwd + infonce_multi with their O(batch) kernels sharing launches (srh_bpr_infonce_fwd_bwd)."""
+                problems, tau, cl_scale, cl_loss, nce_ws, precision=None, seg=None, nce_rows=0):
+    """bpr_l2_fwd_bwd + infonce_multi with their O(batch) kernels sharing launches (srh_bpr_infonce_fwd_bwd).
+    seg / nce_rows: the batch's row -> slot lists and how the problems name those rows (srh_batch_segments_t): every
+    gradient row is then written once, by the row group that owns it, in slot order -- no float atomics."""
     lib = _lib.load()
     d = int(user.shape[1])
-    b = _lib.BprProblem()
-    b.d_user, b.d_item = _p(user, torch.float32), _p(item, torch.float32)
-    b.d_reg_user, b.d_reg_item = _p(reg_user, torch.float32), _p(reg_item, torch.float32)
-    b.d_u_idx, b.d_i_idx, b.d_j_idx = _p(u_idx, torch.int32), _p(i_idx, torch.int32), _p(j_idx, torch.int32)
-    b.B, b.d_n_rows = int(batch), _p(n_rows_dev, torch.int32)
-    b.reg_coef, b.reg_include_neg, b.loss_scale = float(reg_coef), int(bool(reg_include_neg)), float(loss_scale)
-    b.d_g_user, b.d_g_item = _p(g_user, torch.float32), _p(g_item, torch.float32)
-    b.d_greg_user, b.d_greg_item = _p(greg_user, torch.float32), _p(greg_item, torch.float32)
-    b.d_losses, b.d_ws = _p(losses, torch.float64), _p(bpr_ws)
+    b = _bpr_problem(user, item, reg_user, reg_item, u_idx, i_idx, j_idx, batch, n_rows_dev, reg_coef, reg_include_neg,
+                     loss_scale, g_user, g_item, greg_user, greg_item, losses, bpr_ws, seg, nce_rows)
     arr = (_lib.InfonceProblem * len(problems))()
     need = 0
     for k, (v1, v2, idx, n, n_dev, g1, g2, *rest) in enumerate(problems):

@@ -44,7 +44,10 @@ class RankedLists(dict):
         # same make as the HIP library) -- exactly the objects that are returned, no intermediate lists; the cyclic collector,
         # which would run a generation-0 pass every 700 allocations over objects that cannot form a cycle (str, float), is
         # paused for the construction (together: 115 -> 45 ms where the python form was timed)
-        from .. import _reclist                              # (absent = the package was not built: make -C selfrec_amd/csrc)
+        try:
+            from .. import _reclist                          # (absent = built for another interpreter, or not built at all)
+        except ImportError:
+            _reclist = None
         if self._names_list is None:
             self._names_list = self.item_names.tolist() if hasattr(self.item_names, "tolist") else list(self.item_names)
         ids = np.ascontiguousarray(self.ids, dtype=np.int32)
@@ -52,7 +55,12 @@ class RankedLists(dict):
         was_on = gc.isenabled()
         gc.disable()
         try:
-            return _reclist.build(self.users, self._names_list, ids, scores, int(ids.shape[1]))
+            if _reclist is not None:
+                return _reclist.build(self.users, self._names_list, ids, scores, int(ids.shape[1]))
+            # the same rows in python (host-only formatting of results the device already ranked: 2-3 x slower, same objects)
+            names = self._names_list
+            return {u: [(names[i], s) for i, s in zip(r_ids, r_sc)]
+                    for u, r_ids, r_sc in zip(self.users, ids.tolist(), scores.astype(np.float64).tolist())}
         finally:
             if was_on:
                 gc.enable()

@@ -11,6 +11,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "selfcheck: compares this library with itself (A/B), not with the oracle: collected last")
 
 
 @pytest.fixture(scope="session")
@@ -46,7 +47,26 @@ EDGE_TAGS = ["XSimGCL_d256", "LightGCN_d256", "XSimGCL_L1_s0", "XSimGCL_L1_s1", 
              "LightGCN_L1", "LightGCN_L4", "SimGCL_L1", "SimGCL_L4", "SGL_L1", "SGL_L4"]
 
 
+# Collection order of the GPU suite (the driver runs `pytest -x`: the first failure hides everything behind it).  Parity
+# against the oracle / the reference's own runs comes FIRST -- every BASELINE.json shape, then every kernel, then the engine
+# and the drop-in tiers -- and tests that compare this library with ITSELF (hipGraph replay vs eager launches, staged vs
+# in-line epochs, fused vs separate Adam: marked `selfcheck`) come last, so that an A/B disagreement cannot keep a parity
+# test from running.
+GPU_FILE_ORDER = ["test_gpu_shapes.py", "test_gpu_kernels.py", "test_gpu_engine.py", "test_gpu_dropin.py", "test_gpu_f4.py",
+                  "test_gpu_cols.py", "test_gpu_multiproc.py", "test_gpu_selfcheck.py"]
+
+
+def _gpu_rank(item):
+    name = os.path.basename(str(item.fspath))
+    where = GPU_FILE_ORDER.index(name) if name in GPU_FILE_ORDER else len(GPU_FILE_ORDER)
+    return (1 if "selfcheck" in item.keywords else 0, where)
+
+
 def pytest_collection_modifyitems(config, items):
+    gpu = [it for it in items if "gpu" in it.keywords]
+    if gpu:
+        ordered = iter(sorted(gpu, key=_gpu_rank))          # stable: the order inside a file stays
+        items[:] = [next(ordered) if "gpu" in it.keywords else it for it in items]
     import torch
     if torch.cuda.is_available():
         return
@@ -76,3 +96,29 @@ def tiny_data(golden_ops):
 @pytest.fixture()
 def fresh_tiny_data(golden_ops):
     return _tiny_interaction(golden_ops)
+
+
+def host_batch_segments(u, i, j, pad):
+    """One batch's row groups and (slot, role) lists as include/selfrec_hip.h defines them (srh_batch_segments_t), built
+    independently of csrc/sampler.cpp with numpy: dict of int32 arrays padded to `pad` (unique lists) / 3 `pad` (lists)."""
+    import numpy as np
+    u, i, j = (np.asarray(a, dtype=np.int64) for a in (u, i, j))
+    uu, ui = np.unique(u), np.unique(i)
+    un = np.setdiff1d(np.unique(j), ui)
+    slot = np.arange(u.size)
+    in_pos = np.isin(j, ui)
+    g_u = np.searchsorted(uu, u)
+    g_i = uu.size + np.searchsorted(ui, i)
+    g_j = np.where(in_pos, uu.size + np.searchsorted(ui, j), uu.size + ui.size + np.searchsorted(un, j))
+    group = np.concatenate([g_u, g_i, g_j])
+    entry = np.concatenate([4 * slot, 4 * slot + 1, 4 * slot + 2])
+    order = np.lexsort((entry, group))
+    n_groups = uu.size + ui.size + un.size
+    out = {k: np.zeros(pad, dtype=np.int32) for k in ("uniq_u", "uniq_i", "uniq_n")}
+    out["uniq_u"][:uu.size], out["uniq_i"][:ui.size], out["uniq_n"][:un.size] = uu, ui, un
+    out["seg_end"] = np.zeros(3 * pad, dtype=np.int32)
+    out["seg_end"][:n_groups] = np.cumsum(np.bincount(group, minlength=n_groups))
+    out["seg"] = np.zeros(3 * pad, dtype=np.int32)
+    out["seg"][:entry.size] = entry[order]
+    out["n_uniq_u"], out["n_uniq_i"], out["n_uniq_n"] = (np.array([n], dtype=np.int32) for n in (uu.size, ui.size, un.size))
+    return out

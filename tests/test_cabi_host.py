@@ -219,7 +219,8 @@ def test_integration_md_structs_match_the_binding():
             ns = {"C": C}
             exec(m.group(0), ns)                                  # (class statements only: ctypes field lists)
             found[m.group(1)] = ns[m.group(1)]
-    pairs = {"BprProblem": _lib.BprProblem, "InfonceProblem": _lib.InfonceProblem, "BatchLists": _lib.BatchLists}
+    pairs = {"BprProblem": _lib.BprProblem, "InfonceProblem": _lib.InfonceProblem, "BatchLists": _lib.BatchLists,
+             "BatchSegments": _lib.BatchSegments}
     assert set(pairs) <= set(found), sorted(found)
     for name, ref in pairs.items():
         doc = found[name]
@@ -249,7 +250,7 @@ def test_ctypes_structures_have_the_layout_gcc_gives_the_header(tmp_path):
         pytest.skip("no C compiler")
     pairs = {"srh_batch_fetch_args_t": _lib.BatchFetchArgs, "srh_infonce_problem_t": _lib.InfonceProblem,
              "srh_l2_block_t": _lib.L2Block, "srh_bpr_problem_t": _lib.BprProblem, "srh_spmm_epilogue_t": _lib.SpmmEpilogue,
-             "srh_batch_lists_t": _lib.BatchLists}
+             "srh_batch_lists_t": _lib.BatchLists, "srh_batch_segments_t": _lib.BatchSegments}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "selfrec_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
@@ -289,3 +290,39 @@ def test_sampler_epoch_slots_hold_the_same_epochs_in_arrays_that_are_reused(gold
     assert held[(0, "u")] is not held[(1, "u")]
     assert slots.epoch(64, 1, with_unique=True)["u"] is not held[(0, "u")]          # slot=None: the caller's to keep
     assert slots.epoch(32, 1, with_unique=True, slot=0)["uniq_u"] is not held[(0, "uniq_u")]      # (another batch size: other arrays)
+
+
+@pytest.mark.parametrize("bs", [64, 2048, 7])
+def test_epoch_segments_are_the_row_slot_lists_of_every_batch(golden_ops, bs):
+    """srh_sampler_epoch_segments: for every batch, the touched rows -- sorted unique users | sorted unique positive items |
+    sorted unique negatives that are nobody's positive -- and for each the (slot, role) entries that name it, slots ascending:
+    the lists behind the fixed-order (atomic-free) batch-gradient reduction.  Draws nothing from the generator."""
+    g = golden_ops
+    plain, seg = (ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300) for _ in range(2))
+    plain.seed(7); seg.seed(7)
+    want = plain.epoch(bs, 1, with_unique=True)
+    r = seg.epoch(bs, 1, with_unique=True, with_segments=True, slot=0)
+    for k in ("u", "i", "j", "uniq_u", "uniq_i", "n_uniq_u", "n_uniq_i"):
+        assert np.array_equal(r[k], want[k]), k
+    assert plain.next_u32() == seg.next_u32()                        # the same amount of the stream was consumed
+    for b in range(r["n_batches"]):
+        lo, hi = b * bs, min((b + 1) * bs, seg.n_edges)
+        u, i, j = r["u"][lo:hi], r["i"][lo:hi], r["j"][lo:hi]
+        uu, ui = np.unique(u), np.unique(i)
+        un = np.setdiff1d(np.unique(j), ui)
+        assert r["n_uniq_n"][b] == un.size
+        assert np.array_equal(r["uniq_n"][b * bs:b * bs + un.size], un)
+        end = r["seg_end"][3 * b * bs:3 * (b + 1) * bs]
+        ent = r["seg"][3 * b * bs:3 * (b + 1) * bs]
+        groups = [("u", x) for x in uu] + [("i", x) for x in ui] + [("i", x) for x in un]
+        assert end[len(groups) - 1] == 3 * (hi - lo)
+        start = 0
+        for gno, (side, x) in enumerate(groups):
+            if side == "u":
+                expect = [4 * s for s in np.nonzero(u == x)[0]]
+            else:
+                expect = sorted([4 * s + 1 for s in np.nonzero(i == x)[0]] + [4 * s + 2 for s in np.nonzero(j == x)[0]])
+            assert ent[start:end[gno]].tolist() == expect, (b, gno)
+            start = end[gno]
+    again = seg.epoch(bs, 1, with_unique=True, with_segments=True, slot=0)
+    assert again["seg"] is r["seg"] and again["uniq_n"] is r["uniq_n"]             # the slot's own arrays, refilled

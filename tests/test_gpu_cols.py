@@ -247,6 +247,7 @@ def test_virtual_ranks_match_reference_run(golden_models, golden_meta, tiny_data
     assert np.abs(du - (gm[f"{name}_param_user"] - gm[f"{name}_init_user"])).max() < 1e-5
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_virtual_ranks_counter_rng_equal_unsharded(golden_models, golden_meta, tiny_data, use_graph, monkeypatch):
     """In-kernel noise: the sharded run regenerates exactly the unsharded run's perturbation, eager and as two

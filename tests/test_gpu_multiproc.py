@@ -81,6 +81,7 @@ def _graph_worker(rank, world, port, layout, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("layout,world", [("dp", 2), ("cols", 2), ("2d", 4)])
 def test_captured_steps_around_the_collective_equal_eager_steps(tmp_path, layout, world):
     """bench.py at N > 1: two hipGraphs per step with the collective between them (engine._capture), here with more than one

@@ -331,6 +331,7 @@ def first_appearance_ids(raw):
     return rank[raw]
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("model", ["LightGCN", "XSimGCL"])
 def test_xcd_share_calibration_changes_placement_not_results(yelp_data, model):
     """engine.FusedTrainer calibrates the dense plan's XCD shares at start-up (probe launches -> unequal numbers of
