@@ -88,19 +88,23 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
 /* The row -> slot lists of every batch of an epoch: what lets the batch gradients of XSimGCL.py:30-37 (emb[idx] gathers whose
  * autograd is a scatter-ADD: a user / item that occurs in several pairs of a batch receives several contributions) be summed in
  * ONE FIXED ORDER by one row group each, without float atomics -- a training step is then reproducible bit for bit, like the
- * reference's single-threaded CPU step.  Host only, no draw from the generator; inputs are srh_sampler_epoch's outputs.
+ * reference's single-threaded CPU step.  Host only, no draw from the generator; inputs are srh_sampler_epoch's outputs (ids).
  * Per batch b (cnt pairs), the ROW GROUPS are numbered
- *     [0, nuu)                 the sorted unique users                    h_uniq_u[b B + g]
- *     [nuu, nuu + nui)         the sorted unique positive items           h_uniq_i[b B + g - nuu]
- *     [nuu + nui, groups)      the sorted unique negatives that are nobody's positive in this batch
- *                              -> h_uniq_n[b B + k], count h_n_uniq_n[b]
- * and group g owns entries [h_seg_end[b 3B + g - 1] (0 for g = 0), h_seg_end[b 3B + g]) of h_seg + b 3B: each entry is
- * 4 * slot + role (role 0: the slot's user, 1: its positive item, 2: its negative item), slots ascending inside a group.
- * h_uniq_n: nb * B, h_n_uniq_n: nb, h_seg_end / h_seg: nb * 3 B entries (nb = ceil(n_edges / B)). */
+ *     [0, nuu)                 the sorted unique users                    (h_uniq_u)
+ *     [nuu, nuu + nui)         the sorted unique positive items           (h_uniq_i)
+ *     [nuu + nui, groups)      the sorted unique negatives that are nobody's positive in this batch (count: h_n_uniq_n[b])
+ * h_seg_rows[b 3B + g] = the group's TABLE ROW (id + user_row0 for users, id + item_row0 for items: pass 0, n_users when
+ * the items follow the users in one table; -1 for g >= groups), and group g owns entries [h_seg_end[b 3B + g - 1] (0 for
+ * g = 0), h_seg_end[b 3B + g]) of the entry arrays at b 3B, slots ascending inside a group:
+ *     h_seg[e]   = 4 * slot + role   (role 0: the slot's user, 1: its positive item, 2: its negative item)
+ *     h_seg_a[e] = the table row the term needs: the slot's positive item (role 0), its user (roles 1, 2)
+ *     h_seg_b[b B + e] = the slot's negative item's table row (role 0 entries: they are the first cnt entries of a batch)
+ * Sizes: h_n_uniq_n nb; h_seg_rows / h_seg_end / h_seg / h_seg_a nb * 3 B; h_seg_b nb * B   (nb = ceil(n_edges / B)). */
 srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, const int32_t* h_u, const int32_t* h_i,
                                         const int32_t* h_j, const int32_t* h_uniq_u, const int32_t* h_n_uniq_u,
-                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t* h_uniq_n,
-                                        int32_t* h_n_uniq_n, int32_t* h_seg_end, int32_t* h_seg);
+                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t user_row0,
+                                        int32_t item_row0, int32_t* h_n_uniq_n, int32_t* h_seg_rows, int32_t* h_seg_end,
+                                        int32_t* h_seg, int32_t* h_seg_a, int32_t* h_seg_b);
 /* random.sample(range(n), k) (data/augmentor.py:35 edge_dropout keep-set; :15-16 node
  * dropout) replayed on the sampler's MT stream.  h_out receives k indices in draw order. */
 srh_status_t srh_sampler_sample_range(srh_sampler_t* s, int64_t n, int64_t k, int64_t* h_out);
@@ -314,25 +318,26 @@ srh_status_t srh_spmm3_f32(const srh_spmm_plan_t* plan, const int32_t* d_indices
  * srh_bpr_l2_fwd_bwd_p, srh_bpr_infonce_fwd_bwd -- take the batch's row -> slot lists (srh_batch_segments_t) and sum
  * every row's contributions in slot order instead: bit-reproducible, no atomics.)
  * ---------------------------------------------------------------------------------- */
-/* The batch's row groups and their slot lists on the DEVICE (srh_sampler_epoch_segments' arrays, uploaded).  Table rows,
- * not node ids: whatever offset / permutation the caller applied to u / i / j is applied to the unique lists too.
- * d_batch_no == NULL: d_uniq_n / d_seg_end / d_seg are this batch's slices and d_n_uniq_n its count.  d_batch_no != NULL
- * (graph replay): they are the EPOCH arrays and batch b = *d_batch_no lives at d_uniq_n + b B, d_seg_end / d_seg + b 3B,
- * d_n_uniq_n[b] (B = the problem's B). */
+/* The batch's row groups and their slot lists on the DEVICE (srh_sampler_epoch_segments' arrays, uploaded).
+ * d_batch_no == NULL: the arrays are this batch's slices and d_n_uniq_n its count.  d_batch_no != NULL (graph replay):
+ * they are the EPOCH arrays and batch b = *d_batch_no lives at + b 3B (d_seg_b: + b B), d_n_uniq_n[b] (B = the problem's B). */
 typedef struct srh_batch_segments {
-  const int32_t* d_uniq_u;    /* this batch's sorted unique user rows / positive-item rows (e.g. srh_batch_fetch's staged lists) */
-  const int32_t* d_uniq_i;
-  const int32_t* d_n_uniq_u;  /* their device-side counts */
+  const int32_t* d_n_uniq_u;  /* device-side counts of the batch's unique users / positive items (srh_batch_fetch's d_meta[1], [2]) */
   const int32_t* d_n_uniq_i;
-  const int32_t* d_uniq_n;
   const int32_t* d_n_uniq_n;
+  const int32_t* d_seg_rows;
   const int32_t* d_seg_end;
   const int32_t* d_seg;
+  const int32_t* d_seg_a;
+  const int32_t* d_seg_b;
   const int32_t* d_batch_no;
   int32_t nce_rows;           /* how the InfoNCE problems of the same call name these rows (srh_bpr_infonce_fwd_bwd):
                                  0 none; 1: problem 0's row i is user group i, problem 1's row i is positive-item group i
                                  (XSimGCL.py:46-49, SimGCL.py:44-49); 2: problem 0's rows are [users ; positive items]
                                  (SGL.py:120-125).  Rows of a problem are then finished by the group that owns them. */
+  int32_t rows_are_zero;      /* != 0: the caller guarantees that every row this batch names is ZERO in every gradient table
+                                 of the call (the engine clears exactly those rows after every step): rows are stored, not
+                                 read-added-stored -- one memory round trip less in a latency-bound launch */
 } srh_batch_segments_t;
 int64_t srh_bpr_ws_bytes(int64_t B);
 srh_status_t srh_bpr_l2_fwd_bwd(const float* d_user, const float* d_item,
@@ -455,8 +460,11 @@ typedef struct srh_bpr_problem {
   const srh_batch_segments_t* seg; /* HOST pointer or NULL.  Given: every touched row of the gradient tables is written by the
                                       ONE row group that owns it -- read, add the row's contributions in slot order (and the
                                       InfoNCE gradients of that row: nce_rows), store -- no float atomics: the same bits on
-                                      every run.  The user rows and the item rows must not alias (one table with the items
-                                      offset, or two tables).  NULL: atomic accumulation as srh_bpr_l2_fwd_bwd describes. */
+                                      every run.  The lists hold TABLE ROWS: user rows index d_user / d_reg_user / d_g_user /
+                                      d_greg_user, item rows the item tables (two tables with ids, or one table passed for
+                                      both with the items offset: user_row0 / item_row0 of srh_sampler_epoch_segments); an
+                                      InfoNCE problem's d_idx must name the same rows of ITS tables.  User rows and item rows
+                                      must not alias.  NULL: atomic accumulation as srh_bpr_l2_fwd_bwd describes. */
 } srh_bpr_problem_t;
 /* srh_bpr_l2_fwd_bwd with its arguments in the struct (and the optional fixed-order reduction of `seg`). */
 srh_status_t srh_bpr_l2_fwd_bwd_p(const srh_bpr_problem_t* bpr, int32_t d, void* stream);
@@ -678,6 +686,33 @@ srh_status_t srh_batch_unpack(const srh_batch_lists_t* lists, int32_t n_tables, 
 /* d_local_grads[p][node, :] += d_compact_grads[p][slot, col0 : col0 + dl] for every live slot. */
 srh_status_t srh_batch_scatter(const srh_batch_lists_t* lists, int32_t n_pairs, const float* const* d_compact_grads,
                                float* const* d_local_grads, int32_t d_full, int32_t col0, int32_t dl, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (e) Row-sharded tables -- SURVEY 8e's partition: rank r owns n rows of every (N, d) table (and the CSR rows of its nodes),
+ * tables are kept in all-gather order (row = owner * n + local row).  The reference has one implicit device
+ * (model/graph/XSimGCL.py:24,73); these are the exchanges its encoder (XSimGCL.py:83-101, one torch.sparse.mm per layer)
+ * needs once the rows are dealt over N > 1 GPUs:
+ *   forward,  before layer k:  srh_allgather_rows      every rank's (n, d) slice of E^(k-1) -> the whole (world n, d) table
+ *   backward, after  layer k:  srh_reducescatter_rows  every rank's partial sums over ALL rows -> the owners' (n, d) slices
+ *   (A_hat is symmetric: a backward product written by owners needs only the all-gather; the reduce-scatter serves
+ *   formulations that produce partial rows.)  srh_allreduce_sum_f32: the dense gradient of the data-parallel layout.
+ * Thin wrappers over RCCL (ncclAllGather / ncclReduceScatter / ncclAllReduce on ncclFloat32), asynchronous on `stream`.
+ * `comm` is an ncclComm_t passed as void*: made by srh_comm_init_rank, or the caller's own.  RCCL is not linked -- the
+ * symbols are resolved among what the process has loaded (then librccl.so.1), so the caller's copy of RCCL is the one
+ * used.  Without RCCL every call returns SRH_ERR_UNSUPPORTED with a message.  In-place is allowed where RCCL allows it
+ * (d_rows == d_table + rank * n * d).
+ * ---------------------------------------------------------------------------------- */
+#define SRH_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId), hands it to the others by any host channel; then every rank joins. */
+srh_status_t srh_comm_unique_id(uint8_t* h_id /* SRH_COMM_ID_BYTES */);
+srh_status_t srh_comm_init_rank(void** out_comm, int32_t world, int32_t rank, const uint8_t* h_id);
+srh_status_t srh_comm_destroy(void* comm);
+srh_status_t srh_comm_world(void* comm, int32_t* out_world);
+srh_status_t srh_allgather_rows(const float* d_rows /* (n_rows, d) */, float* d_table /* (world n_rows, d) */,
+                                int64_t n_rows, int32_t d, void* comm, void* stream);
+srh_status_t srh_reducescatter_rows(const float* d_table /* (world n_rows, d) */, float* d_rows /* (n_rows, d) */,
+                                    int64_t n_rows, int32_t d, void* comm, void* stream);
+srh_status_t srh_allreduce_sum_f32(float* d_buf, int64_t n_elem, void* comm, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (f-1) Dataset files -> id arrays -- replaces the python loops of data/loader.py:22-33

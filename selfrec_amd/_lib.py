@@ -55,9 +55,9 @@ SCALAR_WS_BYTES = 64         # SRH_SCALAR_WS_BYTES
 
 class BatchSegments(C.Structure):
     """struct srh_batch_segments (include/selfrec_hip.h)."""
-    _fields_ = [("d_uniq_u", C.c_void_p), ("d_uniq_i", C.c_void_p), ("d_n_uniq_u", C.c_void_p), ("d_n_uniq_i", C.c_void_p),
-                ("d_uniq_n", C.c_void_p), ("d_n_uniq_n", C.c_void_p), ("d_seg_end", C.c_void_p), ("d_seg", C.c_void_p),
-                ("d_batch_no", C.c_void_p), ("nce_rows", C.c_int32)]
+    _fields_ = [("d_n_uniq_u", C.c_void_p), ("d_n_uniq_i", C.c_void_p), ("d_n_uniq_n", C.c_void_p),
+                ("d_seg_rows", C.c_void_p), ("d_seg_end", C.c_void_p), ("d_seg", C.c_void_p), ("d_seg_a", C.c_void_p),
+                ("d_seg_b", C.c_void_p), ("d_batch_no", C.c_void_p), ("nce_rows", C.c_int32), ("rows_are_zero", C.c_int32)]
 
 
 class BprProblem(C.Structure):
@@ -121,7 +121,7 @@ SIGNATURES = {
     "srh_sampler_get_order": (_i32, [_vp, _vp]),
     "srh_sampler_next_batch": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "srh_sampler_epoch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "srh_sampler_epoch_segments": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srh_sampler_epoch_segments": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srh_sampler_sample_range": (_i32, [_vp, _i64, _i64, _vp]),
     "srh_sampler_next_u32": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "srh_mt19937_uniform_f32": (_i32, [_vp, C.POINTER(C.c_int32), _i64, _vp, C.c_float, _vp]),
@@ -168,6 +168,13 @@ SIGNATURES = {
     "srh_batch_pack": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "srh_batch_unpack": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "srh_batch_scatter": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "srh_comm_unique_id": (_i32, [_vp]),
+    "srh_comm_init_rank": (_i32, [C.POINTER(_vp), _i32, _i32, _vp]),
+    "srh_comm_destroy": (_i32, [_vp]),
+    "srh_comm_world": (_i32, [_vp, C.POINTER(_i32)]),
+    "srh_allgather_rows": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "srh_reducescatter_rows": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "srh_allreduce_sum_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "srh_dataset_load": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_char_p]),
     "srh_dataset_destroy": (None, [_vp]),
     "srh_dataset_sizes": (_i32, [_vp, _vp]),

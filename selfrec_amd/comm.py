@@ -73,6 +73,96 @@ class TorchComm:
                                   f"state for the batches); this rank is {self.rank}")
 
 
+class AbiComm:
+    """The same three methods over the LIBRARY's collectives -- ``srh_comm_init_rank`` / ``srh_allgather_rows`` /
+    ``srh_allreduce_sum_f32`` (include/selfrec_hip.h, csrc/collectives.cpp: thin RCCL wrappers) -- i.e. what a host that
+    binds the C header runs, without ``torch.distributed`` in the data path.  ``FusedTrainer(shard="rows", comm=AbiComm())``
+    / ``SRH_COLLECTIVES=abi`` for the default communicators (``default_comm``).  The 128-byte unique id reaches the other
+    ranks through ``bootstrap(id_bytes_or_None) -> id_bytes`` (default: ``torch.distributed.broadcast_object_list`` on an
+    initialised group of any backend; one rank needs none)."""
+
+    def __init__(self, world=None, rank=None, bootstrap=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib.load()
+        if world is None:
+            world, rank = (_dist.get_world_size(), _dist.get_rank()) if _dist.is_initialized() else (1, 0)
+        self.world, self.rank, self.group = int(world), int(rank), None
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _lib.check(self._lib.srh_comm_unique_id(uid), "srh_comm_unique_id")
+        if self.world > 1:
+            if bootstrap is None:
+                def bootstrap(mine):
+                    box = [mine]
+                    _dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            got = bootstrap(bytes(uid) if self.rank == 0 else None)
+            uid = (C.c_uint8 * 128)(*got)
+        h = C.c_void_p()
+        _lib.check(self._lib.srh_comm_init_rank(C.byref(h), self.world, self.rank, uid), "srh_comm_init_rank")
+        self._h = h
+        n = C.c_int32()
+        _lib.check(self._lib.srh_comm_world(self._h, C.byref(n)), "srh_comm_world")
+        if n.value != self.world:
+            raise SelfrecHipError(f"AbiComm: the communicator counts {n.value} ranks, expected {self.world}")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.srh_comm_destroy(h)
+            self._h = None
+
+    @staticmethod
+    def _as_f32(t):
+        if not t.is_contiguous():
+            raise SelfrecHipError("AbiComm: contiguous tensors only")
+        return t.view(-1) if t.dtype == torch.float32 else t.view(-1).view(torch.float32)     # (4- and 8-byte types: bit transport)
+
+    def all_gather(self, out, inp):
+        from . import _lib
+        o, i = self._as_f32(out), self._as_f32(inp)
+        if o.numel() != self.world * i.numel():
+            raise SelfrecHipError(f"AbiComm.all_gather: {o.numel()} != {self.world} x {i.numel()}")
+        _lib.check(self._lib.srh_allgather_rows(self._C.c_void_p(i.data_ptr()), self._C.c_void_p(o.data_ptr()), i.numel(), 1,
+                                                self._h, self._C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "srh_allgather_rows")
+
+    def reduce_scatter_sum(self, out, inp):
+        from . import _lib
+        if out.dtype != torch.float32 or inp.dtype != torch.float32 or inp.numel() != self.world * out.numel():
+            raise SelfrecHipError("AbiComm.reduce_scatter_sum: float32, world x the slice")
+        _lib.check(self._lib.srh_reducescatter_rows(self._C.c_void_p(inp.data_ptr()), self._C.c_void_p(out.data_ptr()),
+                                                    out.numel(), 1, self._h,
+                                                    self._C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "srh_reducescatter_rows")
+
+    def all_reduce_sum(self, t):
+        from . import _lib
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise SelfrecHipError("AbiComm.all_reduce_sum: contiguous float32")
+        _lib.check(self._lib.srh_allreduce_sum_f32(self._C.c_void_p(t.data_ptr()), t.numel(), self._h,
+                                                   self._C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "srh_allreduce_sum_f32")
+
+    def assert_replicated(self, what, values, device):
+        mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+        everyone = torch.empty((self.world, mine.numel()), dtype=torch.float64, device=device)
+        self.all_gather(everyone, mine)
+        bad = [r for r in range(self.world) if not torch.equal(everyone[r], everyone[0])]
+        if bad:
+            raise SelfrecHipError(f"{what} differs between ranks (rank 0 vs ranks {bad}); this rank is {self.rank}")
+
+
+def default_comm():
+    """The communicator of a placement nobody handed one: ``TorchComm`` over the default process group, or -- with
+    ``SRH_COLLECTIVES=abi`` -- the library's own RCCL wrappers (``AbiComm``)."""
+    how = os.environ.get("SRH_COLLECTIVES", "torch").lower()
+    if how not in ("torch", "abi"):
+        raise SelfrecHipError(f"SRH_COLLECTIVES={how!r}: torch or abi")
+    return AbiComm() if how == "abi" else TorchComm()
+
+
 class TwoHopRows:
     """The table-row all-gather of the 2-D layout, moved over EVERY xGMI link instead of the Gr - 1 direct ones.
 

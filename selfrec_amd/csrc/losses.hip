@@ -324,6 +324,8 @@ constexpr int kNcePvTerms = SRH_NCE_PV_TERMS;
 // the multi-problem entry points; the environment variable SRH_NCE_SPLIT16 makes it the initial default).
 std::atomic<int> g_nce_precision{getenv("SRH_NCE_SPLIT16") ? SRH_NCE_SPLIT16 : SRH_NCE_F32};
 
+constexpr unsigned long long kLossUnreported = ~0ull;      // (see rows_finish: a loss-partial slot nobody has written yet)
+
 struct NceWs {
   float *v1n, *v2n, *norm1, *norm2, *opart, *opart2, *lpart, *invl;
   float* ediag;         // split path: exp(s_ii / tau - 1 / tau) as pass 1's MFMA saw it (the pair's own weight is kept out of
@@ -459,6 +461,9 @@ __device__ __forceinline__ void nce_prep_body(const NceBatch& batch, const unsig
   const bool second = by == 1;
   if (bx == 0 && by == 0)
     for (int k = threadIdx.x; k <= (int)(w.np / 16); k += 256) w.ticket[k] = 0;
+  // rows_finish's per-workgroup loss partials: "not reported yet" (a bit pattern no sum of finite or non-finite terms has)
+  if (bx == 0 && by == 1)
+    for (int k = threadIdx.x; k < (int)w.np; k += 256) reinterpret_cast<unsigned long long*>(w.losspart)[k] = kLossUnreported;
   // the persistent passes' task list, cut ONCE per step from the live row counts: the passes and the finish read the record
   // (in every workgroup of the passes the same cut cost 4.9 k cycles of scalar divisions and dependent loads -- a tenth of
   // the kernel; tools/nce_stamps.py)
@@ -587,9 +592,12 @@ __device__ __forceinline__ float4 nce_norm_backward(float4 self, float4 dn, floa
 // Finish of one row (the LPR lanes of a row-group): fold both passes' split partials and form the
 // gradients of both views through the normalisation (dv1, dv2: w.r.t. row idx[i] of the two source tables).  Returns the
 // row's loss term (lse - s_ii) in the group's lane 0 (0 elsewhere / for padding rows).
-template <int LPR>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// after_loads(): called once, after the row's loads have been issued and before the first of them is waited for (the caller's
+// own next round trip goes out under this one's arithmetic)
+template <int LPR, class Hook = NoHook>
 __device__ __forceinline__ double nce_finish_row_grads(const NceWs& w, const NceFinishArgs& a, int n, int i, int sub,
-                                                       int splits, float4& dv1, float4& dv2) {
+                                                       int splits, float4& dv1, float4& dv2, Hook after_loads = Hook{}) {
   const bool valid = i < n;
   const int ii = valid ? i : 0;
   const size_t at = (size_t)ii * LPR + sub;
@@ -615,6 +623,7 @@ __device__ __forceinline__ double nce_finish_row_grads(const NceWs& w, const Nce
         lp[k] = w.lpart[(size_t)(k0 + k) * w.np + ii];
       }
     }
+    if (k0 == 0) after_loads();
 #pragma unroll
     for (int k = 0; k < kW; ++k) {                     // split order: the order pass 2 folded 1 / l in
       O1 = f4_add(O1, p1[k]);
@@ -627,6 +636,7 @@ __device__ __forceinline__ double nce_finish_row_grads(const NceWs& w, const Nce
   //   loss_i = log(L) - (s_ii / tau - 1 / tau) = log1p(l / e_ii),
   //   d/dn1_i = (O1 + e_ii v2_i) / L - v2_i = (O1 - l v2_i) / L,     d/dn2_i = O2 + (e_ii / L) v1_i - v1_i = O2 - (l / L) v1_i
   // -- no difference of nearly equal numbers anywhere, however sharp the softmax.
+  if (splits <= 0) after_loads();
   const float coef = a.loss_scale * a.inv_tau / (float)n;
   const float sii = group_sum<LPR>(f4_dot(va, vb)) * a.inv_tau;
   const float eii = expf(sii - a.inv_tau);
@@ -1379,64 +1389,116 @@ __global__ __launch_bounds__(256) void nce_finish_bpr2(NceBatch batch, NceFinish
 // other negatives, each with the list of (slot, role) entries that name it), so the LPR lanes of ONE row group own a row:
 // they finish its InfoNCE gradients (if a problem names the row), walk its slot list in order adding the BPR / L2 terms, and
 // write the row once -- read, add, store.  Same arithmetic per term as the atomic form above; the sum's order is the list's.
+#ifndef SRH_RF_SKIP          // (laboratory builds, tools/spmm_lab/build_alt.sh: bit 0 no InfoNCE rows, 1 no slot lists, 2 no loss
+#define SRH_RF_SKIP 0        //  fold -- what each part of rows_finish costs; the product is built with 0)
+#endif
 struct SegArgs {
-  const int32_t *uniq_u, *uniq_i, *uniq_n, *n_uniq_u, *n_uniq_i, *n_uniq_n, *seg_end, *seg, *batch_no;
-  int nce_rows;
+  const int32_t *n_uniq_u, *n_uniq_i, *n_uniq_n, *rows, *seg_end, *seg, *seg_a, *seg_b, *batch_no;
+  int nce_rows, rows_are_zero;
 };
 
-__device__ __forceinline__ void rmw_add_row(float* table, int row, int lpr, int sub, float4 v) {
+// row += v (ZERO: the caller guarantees the row holds zeros -- a plain store)
+template <bool ZERO>
+__device__ __forceinline__ void put_row(float* table, int row, int lpr, int sub, float4 v) {
   float4* p = reinterpret_cast<float4*>(table) + (size_t)row * lpr + sub;
-  *p = f4_add(*p, v);
+  if constexpr (ZERO) *p = v;
+  else *p = f4_add(*p, v);
 }
 
-template <int LPR>
+// The launch is a chain of dependent memory round trips for O(batch) bytes, so the lists are laid out to keep the chain short:
+//   1. counts, the group's table row and its list bounds            (nothing depends on the counts for an ADDRESS)
+//   2. the list's entries with the rows their terms read, the row's regulariser operand, the InfoNCE partials of the row
+//   3. the operand rows and the slots' coefficients
+//   4. the store
+template <int LPR, bool ZERO>
 __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const NceFinishArgs& fa, const BprArgs& a,
                                                  const SegArgs& sg) {
-  constexpr int G = 64 / LPR;
+  constexpr int G = 64 / LPR, GW = 4 * G;         // row groups per wave / per workgroup
   const int rows = a.d_n_rows ? min(*a.d_n_rows, a.B) : a.B;
   if (rows <= 0) return;
   const int lane = threadIdx.x & 63, sub = lane % LPR;
-  const int grp = (int)((blockIdx.x * 256u + threadIdx.x) >> 6) * G + lane / LPR;
+  const int gw = (int)(threadIdx.x >> 6) * G + lane / LPR;          // group within the workgroup
+  const int grp = (int)blockIdx.x * GW + gw;
   const int bno = sg.batch_no ? *sg.batch_no : 0;
   const size_t off1 = sg.batch_no ? (size_t)bno * a.B : 0, off3 = 3 * off1;
-  const int nuu = *sg.n_uniq_u, nui = *sg.n_uniq_i, nun = sg.n_uniq_n[sg.batch_no ? bno : 0];
-  const int groups = nuu + nui + nun;
-  const bool live = grp < groups;
-  const int gq = live ? grp : 0;
-  const int kind = gq < nuu ? 0 : (gq < nuu + nui ? 1 : 2);            // user | positive item | negative only
-  // ---- loads that depend on nothing but the group number go first
-  const int row = kind == 0 ? sg.uniq_u[gq] : (kind == 1 ? sg.uniq_i[gq - nuu] : sg.uniq_n[off1 + gq - nuu - nui]);
-  const int e1 = live ? sg.seg_end[off3 + gq] : 0;
-  const int e0 = (live && gq > 0) ? sg.seg_end[off3 + gq - 1] : 0;
+  const int row = grp < 3 * a.B ? sg.rows[off3 + grp] : -1;
+  const bool live = row >= 0;
+  const int e1 = grp < 3 * a.B ? sg.seg_end[off3 + grp] : 0;
+  const int e0g = (grp > 0 && grp < 3 * a.B) ? sg.seg_end[off3 + grp - 1] : 0;
+  const int nuu = *sg.n_uniq_u, nui = *sg.n_uniq_i;
+  const int e0 = live ? e0g : e1;
+  const int rq = live ? row : 0;
+  const int kind = grp < nuu ? 0 : (grp < nuu + nui ? 1 : 2);       // user | positive item | negative only
   const float* reg_t = kind == 0 ? a.reg_user : a.reg_item;
-  const float4 rr = reinterpret_cast<const float4*>(reg_t)[(size_t)row * LPR + sub];
+  const float* opd_t = kind == 0 ? a.item : a.user;                  // the table a term's operand rows come from
+  const float4 rr = reinterpret_cast<const float4*>(reg_t)[(size_t)rq * LPR + sub];
+  // ---- the first entries of the row's slot list: requested before anything else of this level
+  constexpr int WU = 8, WI = 8;                   // entries in flight per round trip: user groups / item groups
+  int ent[WI], ra[WI], rb[WU];
+  auto fetch_entries = [&](int e, auto wc, auto userc) {
+    constexpr int W = decltype(wc)::value;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int ek = min(e + k, e1 - 1);
+      ent[k] = sg.seg[off3 + ek];
+      ra[k] = sg.seg_a[off3 + ek];
+      if constexpr (decltype(userc)::value) rb[k] = sg.seg_b[off1 + ek];
+    }
+  };
+  const bool any = e0 < e1 && !(SRH_RF_SKIP & 2);
+  if (any) {
+    if (kind == 0) fetch_entries(e0, std::integral_constant<int, WU>{}, std::true_type{});
+    else fetch_entries(e0, std::integral_constant<int, WI>{}, std::false_type{});
+  }
   // ---- the InfoNCE gradients of this row (the problem that names it: SegArgs::nce_rows)
   int pz = -1, pi = 0;
-  if (sg.nce_rows == 1 && kind < 2) { pz = kind; pi = kind == 0 ? gq : gq - nuu; }
-  if (sg.nce_rows == 2 && kind < 2) { pz = 0; pi = gq; }
+  if (sg.nce_rows == 1 && kind < 2) { pz = kind; pi = kind == 0 ? grp : grp - nuu; }
+  if (sg.nce_rows == 2 && kind < 2) { pz = 0; pi = grp; }
   const bool has_nce = live && pz >= 0 && pz < batch.count;
   float4 dv1 = f4_zero(), dv2 = f4_zero();
-  if (batch.count > 0 && sg.nce_rows != 0) {
+  double li = 0.0;
+  const bool with_nce = batch.count > 0 && sg.nce_rows != 0;
+  if (with_nce && !(SRH_RF_SKIP & 1)) {
     const int pq = has_nce ? pz : 0;
     const NceWs& w = batch.w[pq];
     const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
     int splits = batch.splits;
     if (batch.slots > 0) splits = batch.w[0].plan->splits[pq];
-    const double li = nce_finish_row_grads<LPR>(w, fa, has_nce ? n : 0, pi, sub, splits, dv1, dv2);
-    if (has_nce && sub == 0) store_f64_sc1(w.losspart + pi, li);       // folded in row order by the last workgroup (below)
+    li = nce_finish_row_grads<LPR>(w, fa, has_nce ? n : 0, pi, sub, splits, dv1, dv2);
   }
+  // ---- InfoNCE loss, part 1: one partial per workgroup and problem, summed inside the workgroup in group order and PUBLISHED
+  // as soon as it exists (the loss terms are done long before the slot lists are): one 8-byte write-through store into a slot
+  // the prep kernel left at "unreported".  The launch's last workgroup -- whose groups are the dead tail of the 3 B slots --
+  // reads the slots until none is unreported and folds them in workgroup order while the others are still at their lists:
+  // no counter, no wait in any other workgroup, the fold off the launch's critical path.  (A ticket drawn by every workgroup
+  // from ONE counter, answer awaited: 384 same-address atomics serialise at ~11 ns each, 2.3 us in front of the lists; the
+  // last arrival then folding: 2.8 us behind them -- profiles/r06_c_rows_finish_parts.txt.)
+  __shared__ double s_li[GW];
+  __shared__ int s_pz[GW];
+  const bool fold_loss = with_nce && !(SRH_RF_SKIP & 4);
+  if (fold_loss && sub == 0) { s_li[gw] = li; s_pz[gw] = has_nce ? pz : -1; }
   // ---- the fold of BPR phase 1's partials (every workgroup: the regulariser's gradient needs the three norms)
   __shared__ double s_tot[4];
-  if (threadIdx.x < 64) {
+  if (threadIdx.x >= 64 && threadIdx.x < 128) {
+    const int t = threadIdx.x - 64;
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    for (int k = threadIdx.x; k < a.n_blocks; k += 64) {
+    for (int k = t; k < a.n_blocks; k += 64) {
       t0 += a.part[(size_t)k * 4 + 0]; t1 += a.part[(size_t)k * 4 + 1];
       t2 += a.part[(size_t)k * 4 + 2]; t3 += a.part[(size_t)k * 4 + 3];
     }
     t0 = wave_sum_d(t0); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2); t3 = wave_sum_d(t3);
-    if (threadIdx.x == 0) { s_tot[0] = t0; s_tot[1] = t1; s_tot[2] = t2; s_tot[3] = t3; }
+    if (t == 0) { s_tot[0] = t0; s_tot[1] = t1; s_tot[2] = t2; s_tot[3] = t3; }
   }
   __syncthreads();
+  const bool folder = blockIdx.x == gridDim.x - 1;
+  if (fold_loss && threadIdx.x < 64) {                    // wave 0 (the BPR fold above ran on wave 1)
+    if ((int)threadIdx.x < batch.count) {                 // problem k's partial of this workgroup: its losspart[blockIdx.x]
+      double t = 0.0;
+      for (int k = 0; k < GW; ++k)
+        if (s_pz[k] == (int)threadIdx.x) t += s_li[k];
+      store_f64_sc1(batch.w[threadIdx.x].losspart + blockIdx.x, t);
+    }
+  }
   const float nu = (float)sqrt(s_tot[1]), np = (float)sqrt(s_tot[2]), nn = (float)sqrt(s_tot[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float r = nu / (float)rows + np / (float)rows;
@@ -1451,91 +1513,110 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
   const bool same_u = (a.reg_user == a.user) && (a.greg_user == a.g_user);
   const bool same_i = (a.reg_item == a.item) && (a.greg_item == a.g_item);
   const bool same = kind == 0 ? same_u : same_i;
-  // ---- the row's slot list, four entries' loads in flight at a time, summed in list order
+  // ---- the row's slot list, summed in list order.  One round trip per W entries: a popular item is named by ~30 slots of a
+  // batch of 2048 (its group is the launch's critical path), so a group keeps the operand rows of 8 entries in flight
+  // (more costs the launch its second wave per SIMD: 256 VGPRs); 92 % of the groups have one entry.
   float4 acc = f4_zero(), accr = f4_zero();
-  for (int e = e0; e < e1; e += 4) {
-    int ent[4];
-    float cf[4];
-    float4 x[4], y[4];
+  auto sum_list = [&](auto wc, auto userc) {
+    constexpr int W = decltype(wc)::value;
+    constexpr bool USER = decltype(userc)::value;
+    for (int e = e0; e < e1; e += W) {
+      float4 x[W], y[USER ? W : 1];
+      float cf[W];
+      int role[W];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ent[k] = sg.seg[off3 + min(e + k, e1 - 1)];
+      for (int k = 0; k < W; ++k) {
+        x[k] = reinterpret_cast<const float4*>(opd_t)[(size_t)ra[k] * LPR + sub];
+        if constexpr (USER) y[k] = reinterpret_cast<const float4*>(opd_t)[(size_t)rb[k] * LPR + sub];
+        cf[k] = a.coef[ent[k] >> 2];
+        role[k] = ent[k] & 3;
+      }
+      if (e + W < e1) fetch_entries(e + W, wc, userc);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int b = ent[k] >> 2;
-      cf[k] = a.coef[b];
-      if (kind == 0) {
-        x[k] = reinterpret_cast<const float4*>(a.item)[(size_t)a.i_idx[b] * LPR + sub];
-        y[k] = reinterpret_cast<const float4*>(a.item)[(size_t)a.j_idx[b] * LPR + sub];
-      } else {
-        x[k] = reinterpret_cast<const float4*>(a.user)[(size_t)a.u_idx[b] * LPR + sub];
-        y[k] = f4_zero();
+      for (int k = 0; k < W; ++k) {
+        if (e + k >= e1) break;
+        const float c = cf[k] * cs;
+        float4 g;
+        float cr;
+        if constexpr (USER) {
+          g = make_float4(c * (x[k].x - y[k].x), c * (x[k].y - y[k].y), c * (x[k].z - y[k].z), c * (x[k].w - y[k].w));
+          cr = cu;
+        } else if (role[k] == 1) {
+          g = f4_scale(x[k], c);
+          cr = cp;
+        } else {
+          g = f4_scale(x[k], -c);
+          cr = cn;
+        }
+        if (same) g = f4_fma(cr, rr, g);
+        else accr = f4_fma(cr, rr, accr);
+        acc = f4_add(acc, g);
       }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (e + k >= e1) break;
-      const float c = cf[k] * cs;
-      float4 g;
-      float cr;
-      if (kind == 0) {
-        g = make_float4(c * (x[k].x - y[k].x), c * (x[k].y - y[k].y), c * (x[k].z - y[k].z), c * (x[k].w - y[k].w));
-        cr = cu;
-      } else if ((ent[k] & 3) == 1) {
-        g = f4_scale(x[k], c);
-        cr = cp;
-      } else {
-        g = f4_scale(x[k], -c);
-        cr = cn;
-      }
-      if (same) g = f4_fma(cr, rr, g);
-      else accr = f4_fma(cr, rr, accr);
-      acc = f4_add(acc, g);
-    }
+  };
+  if (any) {
+    if (kind == 0) sum_list(std::integral_constant<int, WU>{}, std::true_type{});
+    else sum_list(std::integral_constant<int, WI>{}, std::false_type{});
   }
-  // ---- one read-add-store per table the row belongs to
+  // ---- one write per table the row belongs to
   if (live) {
     float* tb = kind == 0 ? a.g_user : a.g_item;
     if (has_nce) {
       const NceWs& w = batch.w[pz];
       if (w.g1 == tb) acc = f4_add(acc, dv1);
       if (w.g2 == tb) acc = f4_add(acc, dv2);
-      if (w.g1 != tb) rmw_add_row(w.g1, row, LPR, sub, w.g2 == w.g1 ? f4_add(dv1, dv2) : dv1);
-      if (w.g2 != tb && w.g2 != w.g1) rmw_add_row(w.g2, row, LPR, sub, dv2);
+      if (w.g1 != tb) put_row<ZERO>(w.g1, row, LPR, sub, w.g2 == w.g1 ? f4_add(dv1, dv2) : dv1);
+      if (w.g2 != tb && w.g2 != w.g1) put_row<ZERO>(w.g2, row, LPR, sub, dv2);
     }
-    rmw_add_row(tb, row, LPR, sub, acc);
-    if (!same) rmw_add_row(kind == 0 ? a.greg_user : a.greg_item, row, LPR, sub, accr);
+    put_row<ZERO>(tb, row, LPR, sub, acc);
+    if (!same) put_row<ZERO>(kind == 0 ? a.greg_user : a.greg_item, row, LPR, sub, accr);
   }
-  // ---- InfoNCE loss: the workgroup that arrives last folds the per-row terms in row order (bit-reproducible)
-  if (batch.count == 0 || sg.nce_rows == 0) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ int s_last;
-  __shared__ double s_fold[4];
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(batch.w[0].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (threadIdx.x == 0) __hip_atomic_store(batch.w[0].ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int k = 0; k < batch.count; ++k) {
+  // ---- InfoNCE loss, part 2: the last workgroup of the grid reads the slots until every workgroup has reported (they were
+  // all dispatched before it: nothing it waits for can be waiting for it) and folds them in workgroup order, a wave per problem
+  if (!fold_loss || (SRH_RF_SKIP & 8) || !folder) return;
+  const int k = (int)(threadIdx.x >> 6);
+  if (k < batch.count) {
     const NceWs& w = batch.w[k];
     const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
+    const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(w.losspart);
     double t = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) t += w.losspart[i];
+    for (int j0 = 0; j0 < (int)gridDim.x; j0 += 512) {    // (eight slots per lane in flight: one round trip per poll)
+      unsigned long long v[8];
+      for (int spin = 0; spin < (1 << 16); ++spin) {      // (bounded: a lost report costs a wrong loss figure, never a hung device)
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = j0 + 64 * q + lane;
+          v[q] = j < (int)gridDim.x ? __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          missing = missing || v[q] == kLossUnreported;
+        }
+        if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += __builtin_bit_cast(double, v[q]);
+    }
     t = wave_sum_d(t);
-    if (lane == 0) s_fold[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0 && n > 0)
-      atomicAdd(fa.loss, (double)fa.loss_scale * ((s_fold[0] + s_fold[1]) + (s_fold[2] + s_fold[3])) / (double)n);
-    __syncthreads();
+    s_li[k] = n > 0 ? (double)fa.loss_scale * t / (double)n : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int j = 0; j < batch.count; ++j) t += s_li[j];
+    atomicAdd(fa.loss, t);
   }
 }
 
-template <int LPR>
+template <int LPR, bool ZERO>
 __global__ __launch_bounds__(256) void rows_finish(NceBatch batch, NceFinishArgs fa, BprArgs bpr, SegArgs sg) {
-  rows_finish_body<LPR>(batch, fa, bpr, sg);
+  rows_finish_body<LPR, ZERO>(batch, fa, bpr, sg);
+}
+template <int LPR>
+void launch_rows_finish(const NceBatch& batch, const NceFinishArgs& fa, const BprArgs& bp, const SegArgs& sg, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const int grid = (3 * bp.B + 4 * G - 1) / (4 * G);
+  if (sg.rows_are_zero) rows_finish<LPR, true><<<grid, 256, 0, st>>>(batch, fa, bp, sg);
+  else rows_finish<LPR, false><<<grid, 256, 0, st>>>(batch, fa, bp, sg);
 }
 
 template <int D>
@@ -1628,7 +1709,12 @@ srh_status_t launch_infonce(const srh_infonce_problem_t* pr, int count, float ta
     }
     SRH_LAUNCH_CHECK();
   }
-  if (bpr && seg) rows_finish<LPR><<<(3 * bp.B + 4 * G - 1) / (4 * G), 256, 0, st>>>(batch, fa, bp, *seg);
+  if (bpr && seg) {
+    for (int k = 0; k < count; ++k)             // (one loss partial per workgroup of the finish in every problem's losspart array)
+      SRH_REQUIRE(batch.w[k].np >= (3 * bp.B + 4 * G - 1) / (4 * G),
+                  "bpr_infonce_fwd_bwd: with batch segments every InfoNCE problem must be sized for the batch (n >= ~3 B d / 256)");
+    launch_rows_finish<LPR>(batch, fa, bp, *seg, st);
+  }
   else if (bpr) nce_finish_bpr2<LPR><<<n_bpr + (int)(fb.x * count), 256, 0, st>>>(batch, fa, bp, n_bpr, (int)fb.x);
   else nce_finish_both<LPR><<<fb, 256, 0, st>>>(batch, fa);
   SRH_LAUNCH_CHECK();
@@ -1645,7 +1731,7 @@ srh_status_t launch_bpr(const BprArgs& a, hipStream_t st, const SegArgs* seg = n
   SRH_LAUNCH_CHECK();
   if (seg) {
     NceBatch none{};
-    rows_finish<LPR><<<(3 * b.B + 4 * G - 1) / (4 * G), 256, 0, st>>>(none, NceFinishArgs{}, b, *seg);
+    launch_rows_finish<LPR>(none, NceFinishArgs{}, b, *seg, st);
   } else {
     bpr_phase2<LPR><<<blocks, 256, 0, st>>>(b);
   }
@@ -1655,15 +1741,15 @@ srh_status_t launch_bpr(const BprArgs& a, hipStream_t st, const SegArgs* seg = n
 
 // srh_batch_segments_t -> SegArgs (checked)
 static srh_status_t seg_args(const srh_batch_segments_t* g, int n_problems, SegArgs& out) {
-  SRH_REQUIRE(g->d_uniq_u && g->d_uniq_i && g->d_uniq_n && g->d_n_uniq_u && g->d_n_uniq_i && g->d_n_uniq_n && g->d_seg_end && g->d_seg,
+  SRH_REQUIRE(g->d_n_uniq_u && g->d_n_uniq_i && g->d_n_uniq_n && g->d_seg_rows && g->d_seg_end && g->d_seg && g->d_seg_a && g->d_seg_b,
               "batch segments: null array");
   SRH_REQUIRE(g->nce_rows >= 0 && g->nce_rows <= 2, "batch segments: nce_rows must be 0, 1 or 2");
   SRH_REQUIRE(g->nce_rows != 1 || n_problems == 2, "batch segments: nce_rows = 1 names two InfoNCE problems (users, positive items)");
   SRH_REQUIRE(g->nce_rows != 2 || n_problems == 1, "batch segments: nce_rows = 2 names one InfoNCE problem ([users ; positive items])");
   SRH_REQUIRE(g->nce_rows != 0 || n_problems == 0,
               "batch segments: InfoNCE problems in the call need nce_rows 1 or 2 (their rows are finished by the row groups)");
-  out = SegArgs{g->d_uniq_u, g->d_uniq_i, g->d_uniq_n, g->d_n_uniq_u, g->d_n_uniq_i, g->d_n_uniq_n, g->d_seg_end, g->d_seg,
-                g->d_batch_no, g->nce_rows};
+  out = SegArgs{g->d_n_uniq_u, g->d_n_uniq_i, g->d_n_uniq_n, g->d_seg_rows, g->d_seg_end, g->d_seg, g->d_seg_a, g->d_seg_b,
+                g->d_batch_no, g->nce_rows, g->rows_are_zero};
   return SRH_OK;
 }
 
@@ -1794,7 +1880,15 @@ static srh_status_t infonce_entry(const srh_infonce_problem_t* problems, int32_t
               "infonce_fwd_bwd: unknown precision %d", precision);
   if (precision == SRH_NCE_DEFAULT) {
     precision = g_nce_precision.load(std::memory_order_relaxed);
-    if (d == 256) precision = SRH_NCE_SPLIT16;            // (the f32 passes serve d = 64 / 128: the default never fails on d)
+    if (d == 256 && precision == SRH_NCE_F32) {
+      // the f32 passes serve d = 64 / 128.  The default must not fail on d, but it must not change arithmetic silently
+      // either: said once per process, on stderr (an explicit SRH_NCE_F32 at d = 256 is refused below)
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true))
+        fprintf(stderr, "[selfrec_hip] infonce: d = 256 has no all-f32 MFMA path; SRH_NCE_DEFAULT resolves to SRH_NCE_SPLIT16 "
+                        "(f16 hi+lo / bf16 hi+mid operands, f32 accumulation: logits to 2^-22) for these calls\n");
+      precision = SRH_NCE_SPLIT16;
+    }
   }
   SRH_REQUIRE(problems && d_loss && d_ws, "infonce_fwd_bwd: null argument");
   SRH_REQUIRE(n_problems >= 1 && n_problems <= kNceMaxProblems, "infonce_fwd_bwd: 1..%d problems per call", kNceMaxProblems);

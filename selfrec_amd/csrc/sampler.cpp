@@ -424,10 +424,11 @@ srh_status_t srh_sampler_epoch(srh_sampler_t* s, int64_t batch_size, int32_t n_n
 // arrays srh_sampler_epoch filled: no draw from the generator.
 srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, const int32_t* h_u, const int32_t* h_i,
                                         const int32_t* h_j, const int32_t* h_uniq_u, const int32_t* h_n_uniq_u,
-                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t* h_uniq_n,
-                                        int32_t* h_n_uniq_n, int32_t* h_seg_end, int32_t* h_seg) {
+                                        const int32_t* h_uniq_i, const int32_t* h_n_uniq_i, int32_t user_row0,
+                                        int32_t item_row0, int32_t* h_n_uniq_n, int32_t* h_seg_rows, int32_t* h_seg_end,
+                                        int32_t* h_seg, int32_t* h_seg_a, int32_t* h_seg_b) {
   SRH_REQUIRE(s && h_u && h_i && h_j && h_uniq_u && h_n_uniq_u && h_uniq_i && h_n_uniq_i, "sampler_epoch_segments: null input");
-  SRH_REQUIRE(h_uniq_n && h_n_uniq_n && h_seg_end && h_seg, "sampler_epoch_segments: null output");
+  SRH_REQUIRE(h_n_uniq_n && h_seg_rows && h_seg_end && h_seg && h_seg_a && h_seg_b, "sampler_epoch_segments: null output");
   SRH_REQUIRE(batch_size > 0 && batch_size < (int64_t(1) << 28), "sampler_epoch_segments: bad batch_size");
   if (s->pos_u.empty()) {
     s->pos_u.assign((size_t)s->n_users, -1);
@@ -438,38 +439,47 @@ srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, co
   int32_t* pos_i = s->pos_i.data();
   int32_t* fill = s->seg_fill.data();
   const size_t item_words = (size_t)(s->n_items + 63) / 64;
-  std::vector<int32_t> neg_only((size_t)batch_size);
+  std::vector<int32_t> neg_only((size_t)batch_size), un((size_t)batch_size);
   int64_t b = 0;
   for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
     const int64_t cnt = std::min<int64_t>(batch_size, s->n_edges - ptr);
     const int32_t *u = h_u + ptr, *it = h_i + ptr, *jt = h_j + ptr;
     const int32_t *uu = h_uniq_u + b * batch_size, *ui = h_uniq_i + b * batch_size;
     const int32_t nuu = h_n_uniq_u[b], nui = h_n_uniq_i[b];
-    int32_t* un = h_uniq_n + b * batch_size;
+    int32_t* rows = h_seg_rows + b * 3 * batch_size;
     int32_t* end = h_seg_end + b * 3 * batch_size;
     int32_t* seg = h_seg + b * 3 * batch_size;
+    int32_t* sa = h_seg_a + b * 3 * batch_size;
+    int32_t* sb = h_seg_b + b * batch_size;
     for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = k;
     for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = nuu + k;
-    // sorted unique negatives that are nobody's positive item in this batch
+    // sorted unique negatives that are nobody's positive in this batch
     int64_t m = 0;
     for (int64_t r = 0; r < cnt; ++r)
       if (pos_i[jt[r]] < 0) neg_only[(size_t)m++] = jt[r];
-    const int32_t nun = sorted_unique(neg_only.data(), m, un, s->seen_i, item_words);
-    for (int32_t k = 0; k < nun; ++k) pos_i[un[k]] = nuu + nui + k;
+    const int32_t nun = sorted_unique(neg_only.data(), m, un.data(), s->seen_i, item_words);
+    for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = nuu + nui + k;
     const int32_t groups = nuu + nui + nun;
+    for (int32_t k = 0; k < nuu; ++k) rows[k] = uu[k] + user_row0;
+    for (int32_t k = 0; k < nui; ++k) rows[nuu + k] = ui[k] + item_row0;
+    for (int32_t k = 0; k < nun; ++k) rows[nuu + nui + k] = un[(size_t)k] + item_row0;
+    for (int64_t g = groups; g < 3 * batch_size; ++g) rows[g] = -1;          // (no row: the group has nothing to do)
     // counting sort of the 3 cnt (slot, role) entries by row group; inside a group: slot ascending, positive before negative
     for (int32_t g = 0; g < groups; ++g) end[g] = 0;
     for (int64_t r = 0; r < cnt; ++r) { ++end[pos_u[u[r]]]; ++end[pos_i[it[r]]]; ++end[pos_i[jt[r]]]; }
     int32_t run = 0;
     for (int32_t g = 0; g < groups; ++g) { fill[g] = run; run += end[g]; end[g] = run; }
     for (int64_t r = 0; r < cnt; ++r) {
-      seg[fill[pos_u[u[r]]]++] = (int32_t)(r * 4 + 0);
-      seg[fill[pos_i[it[r]]]++] = (int32_t)(r * 4 + 1);
-      seg[fill[pos_i[jt[r]]]++] = (int32_t)(r * 4 + 2);
+      const int32_t eu = fill[pos_u[u[r]]]++;          // (user groups come first: eu < cnt)
+      seg[eu] = (int32_t)(r * 4 + 0); sa[eu] = it[r] + item_row0; sb[eu] = jt[r] + item_row0;
+      const int32_t ep = fill[pos_i[it[r]]]++;
+      seg[ep] = (int32_t)(r * 4 + 1); sa[ep] = u[r] + user_row0;
+      const int32_t en = fill[pos_i[jt[r]]]++;
+      seg[en] = (int32_t)(r * 4 + 2); sa[en] = u[r] + user_row0;
     }
     for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = -1;
     for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = -1;
-    for (int32_t k = 0; k < nun; ++k) pos_i[un[k]] = -1;
+    for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = -1;
     h_n_uniq_n[b] = nun;
     ptr += cnt;
   }

@@ -42,7 +42,7 @@ import torch.distributed as _dist
 
 from . import layouts, ops
 from ._lib import SelfrecHipError
-from .comm import TorchComm, TwoHopRows, shard_adjacency  # noqa: F401  (public: dist.py and the tests import them from here)
+from .comm import AbiComm, TorchComm, TwoHopRows, default_comm, shard_adjacency  # noqa: F401  (public: dist.py and the tests import them from here)
 from .layouts import SLICE_WIDTHS, parse_grid  # noqa: F401
 
 MODELS = ("MF", "LightGCN", "XSimGCL", "SimGCL", "SGL")
@@ -81,6 +81,16 @@ class FusedTrainer:
         if nce_precision is not None and nce_precision not in ops.NCE_PRECISIONS:
             raise SelfrecHipError(f"FusedTrainer: nce_precision {nce_precision!r}: one of {sorted(ops.NCE_PRECISIONS)} or None")
         self.nce_precision = nce_precision
+        if self.d == 256 and model in ("XSimGCL", "SimGCL", "SGL") and nce_precision in (None, "f32"):
+            # (the all-f32 MFMA passes serve d = 64 / 128: loss_torch.py:46-47's fp32 matmul has no exact counterpart here)
+            if nce_precision == "f32":
+                raise SelfrecHipError("FusedTrainer: nce_precision='f32' is served for embedding sizes up to 128; "
+                                      f"embedding.size = {emb_size} pads to 256 columns -- pass nce_precision='split'")
+            if ops.get_infonce_precision() == "f32":
+                import logging
+                logging.getLogger("selfrec_amd").warning(
+                    "%s with embedding.size = %d (256 columns): InfoNCE's two products run on split 16-bit operands "
+                    "(nce_precision='split'), not the library's fp32 default, which serves up to 128 columns", model, int(emb_size))
         self.rng_seed = int(rng_seed)
         if model != "MF" and self.L < 1:
             raise SelfrecHipError("n_layers must be >= 1")
@@ -93,7 +103,7 @@ class FusedTrainer:
         # ---- placement (layouts.py): who owns which rows and columns of the tables, what the ranks exchange per step.
         # `shard`: False (one GPU) | "rows" | "cols" | "2d[:GCxGR]" | "dp"; every layout is the SAME step code below,
         # run against the placement's three components -- self.rows, self.colx, self.sync.
-        self.place = layouts.make_placement(shard, comm, int(emb_size), TorchComm, TorchComm.grid)
+        self.place = layouts.make_placement(shard, comm, int(emb_size), default_comm, TorchComm.grid)
         self.rows, self.colx, self.sync = self.place.rows, self.place.colx, self.place.sync
         self.layout = self.place.name
         self.G, self.rank = self.place.G, self.place.rank
@@ -103,6 +113,14 @@ class FusedTrainer:
         self.rows.bind(N, self.U, dev)
         self.w, self.col0 = self.colx.w, self.colx.col0     # width / first column of this rank's tables
         self.n_pad, self.P = self.rows.n_pad, self.rows.P   # rows this rank owns / rows of a whole table
+        # Fixed-order batch gradients (srh_batch_segments_t): the sampler hands every batch's row -> slot lists over with the
+        # epoch, and the loss section's last kernel writes every touched gradient row ONCE, summed in slot order -- no float
+        # atomics, so a step is reproducible bit for bit (SURVEY.md 5: run twice, bit-compare; the reference's single-threaded
+        # index_put(accumulate) backward of XSimGCL.py:30 is).  Whole rows and columns on this rank (single, dp); the
+        # column-block layouts run the losses on compact slot tables and keep the atomic scatter.  SRH_DET_SCATTER=0: atomics.
+        # (Decided before the first epoch is drawn: the epoch carries the lists.)
+        self.det_scatter = (dev.type == "cuda" and self.place.single_gpu_step and not self.colx.split
+                            and hasattr(ops, "_segments") and os.environ.get("SRH_DET_SCATTER", "1") != "0")
         # The sampler needs the interaction arrays only: with `sampler_seed` given, the FIRST epoch is drawn on a host thread
         # from here on -- under the graph upload, the SpMM plans and the XCD calibration below (all of them C++ / device work
         # that releases the GIL) -- instead of after them: 3.6 of 13.3 s to the first trained step at 1 M x 500 k.
@@ -200,13 +218,6 @@ class FusedTrainer:
                           and model != "MF" and tuple(self.m.shape) == tuple(self.E0.shape)
                           and getattr(ops, "ADAM_EPILOGUE", False) and os.environ.get("SRH_FUSE_ADAM", "1") != "0")
         self.n_cat = torch.zeros(1, dtype=torch.int32, device=dev)
-        # Fixed-order batch gradients (srh_batch_segments_t): the sampler hands every batch's row -> slot lists over with the
-        # epoch, and the loss section's last kernel writes every touched gradient row ONCE, summed in slot order -- no float
-        # atomics, so a step is reproducible bit for bit (SURVEY.md 5: run twice, bit-compare; the reference's single-threaded
-        # index_put(accumulate) backward of XSimGCL.py:30 is).  Whole rows and columns on this rank (single, dp); the
-        # column-block layouts run the losses on compact slot tables and keep the atomic scatter.  SRH_DET_SCATTER=0: atomics.
-        self.det_scatter = (single and not self.colx.split and hasattr(ops, "_segments")
-                            and os.environ.get("SRH_DET_SCATTER", "1") != "0")
         self.bpr_ws = ops.bpr_ws(B, dev)
         self.nce_ws = None
         if model in ("XSimGCL", "SimGCL", "SGL"):       # user side + item side share one workspace / launch set
@@ -222,7 +233,8 @@ class FusedTrainer:
         self._epoch_slot = {"u": nb * B, "i": nb * B, "j": nb * B, "uniq_u": nb * B, "uniq_i": nb * B,
                             "n_uniq_u": nb, "n_uniq_i": nb}                       # entries of ONE half
         if self.det_scatter:
-            self._epoch_slot.update({"uniq_n": nb * B, "n_uniq_n": nb, "seg_end": 3 * nb * B, "seg": 3 * nb * B})
+            self._epoch_slot.update({"n_uniq_n": nb, "seg_rows": 3 * nb * B, "seg_end": 3 * nb * B, "seg": 3 * nb * B,
+                                     "seg_a": 3 * nb * B, "seg_b": nb * B})
         self._epoch_dev = {k: torch.zeros(2 * n, dtype=torch.int32, device=dev) for k, n in self._epoch_slot.items()}
         self._live_half = None                 # the half the steps read (None: nothing uploaded yet)
         self._half_free = [None, None]         # event on the step stream: every step that read this half has been enqueued
@@ -446,7 +458,7 @@ class FusedTrainer:
                 masks.append(mk)
             out["masks"] = masks
         ep = self.sampler.epoch(self.B, 1, with_unique=True, slot=slot,
-                                **({"with_segments": True} if getattr(self, "det_scatter", False) else {}))
+                                **({"with_segments": self.rows.segment_row_offsets()} if self.det_scatter else {}))
         # node ids -> table rows (items follow the users; all-gather order when the rows are dealt)
         out.update(self.rows.epoch_to_table_rows(ep))
         return out
@@ -834,11 +846,12 @@ class FusedTrainer:
                    losses=self.losses[0:2])
         bpr_in = (T(F), T(F), T(reg_t), T(reg_t), ix["u"], ix["i"], ix["j"])
         seg = {}
-        if self.det_scatter:
+        if self.det_scatter and not getattr(self, "_seg_off", False):     # (_seg_off: tools/det_scatter_ab.py's A/B switch)
             ed = self._epoch_dev
-            seg = dict(seg=dict(uniq_u=st["uniq_u"], uniq_i=st["uniq_i"], n_uniq_u=nuu_dev, n_uniq_i=nui_dev,
-                                uniq_n=ed["uniq_n"], n_uniq_n=ed["n_uniq_n"], seg_end=ed["seg_end"], seg=ed["seg"],
-                                batch_no=self.meta[3:4]))
+            # (rows_are_zero: the batch rows of every batch-sparse gradient table were cleared by the previous step's last launch)
+            seg = dict(seg=dict(n_uniq_u=nuu_dev, n_uniq_i=nui_dev, n_uniq_n=ed["n_uniq_n"], seg_rows=ed["seg_rows"],
+                                seg_end=ed["seg_end"], seg=ed["seg"], seg_a=ed["seg_a"], seg_b=ed["seg_b"],
+                                batch_no=self.meta[3:4], rows_are_zero=self.sparse_reset))
         nce = dict(tau=self.tau, cl_scale=self.cl_rate, cl_loss=self.losses[2:3], nce_ws=self.nce_ws,
                    precision=self.nce_precision)
         # ---- recommendation + contrastive loss (a-5..a-8)

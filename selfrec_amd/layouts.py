@@ -66,10 +66,13 @@ class RowsWhole:
         return t[self.U:]
 
     def epoch_to_table_rows(self, ep):
-        for k in ("i", "j", "uniq_i", "uniq_n"):        # items follow the users
-            if k in ep:
-                ep[k] += self.U
+        for k in ("i", "j", "uniq_i"):                  # items follow the users
+            ep[k] += self.U
         return ep
+
+    def segment_row_offsets(self):
+        """(user_row0, item_row0) of the row -> slot lists (srh_sampler_epoch_segments): ids -> table rows."""
+        return 0, self.U
 
     def epoch_node_ids(self, host, n_rows):
         return host["u"], host["i"] - self.U, host["j"] - self.U
@@ -121,9 +124,8 @@ class RowParts(RowsWhole):
 
     def epoch_to_table_rows(self, ep):
         pos_u, pos_i = self.pos[:self.U], self.pos[self.U:]
-        for k, table in (("u", pos_u), ("i", pos_i), ("j", pos_i), ("uniq_u", pos_u), ("uniq_i", pos_i), ("uniq_n", pos_i)):
-            if k in ep:
-                ep[k] = table[ep[k]]
+        for k, table in (("u", pos_u), ("i", pos_i), ("j", pos_i), ("uniq_u", pos_u), ("uniq_i", pos_i)):
+            ep[k] = table[ep[k]]
         return ep
 
     def epoch_node_ids(self, host, n_rows):

@@ -145,8 +145,9 @@ class Sampler:
 
     def epoch(self, batch_size: int, n_negs: int = 1, with_unique: bool = False, slot=None, with_segments: bool = False):
         """shuffle + all batches.  Returns dict of numpy arrays (see srh_sampler_epoch).
-        with_segments: also the row -> slot lists of every batch (srh_sampler_epoch_segments: uniq_n, n_uniq_n, seg_end, seg)
-        behind the fixed-order batch-gradient reduction.
+        with_segments (True | (user_row0, item_row0)): also the row -> slot lists of every batch (srh_sampler_epoch_segments:
+        n_uniq_n, seg_rows, seg_end, seg, seg_a, seg_b -- table rows = ids + the offsets) behind the fixed-order
+        batch-gradient reduction.
         slot (None | 0 | 1 | ...): None -- fresh arrays, the caller's to keep.  An integer -- the arrays of that slot, owned
         by the sampler and OVERWRITTEN by the next call with the same slot: a training loop that alternates two slots never
         allocates or frees an epoch's 25 MB (freeing them -- munmap -- beside a thread that is enqueueing GPU work was
@@ -185,16 +186,17 @@ class Sampler:
         if with_segments:
             if not with_unique or n_negs != 1:
                 raise SelfrecHipError("Sampler.epoch: with_segments needs with_unique and n_negs = 1")
+            user_row0, item_row0 = (0, 0) if with_segments is True else (int(with_segments[0]), int(with_segments[1]))
             seg = None if slot is None else self._epoch_slots.get(key + ("seg",))
             if seg is None:
-                seg = {"uniq_n": np.zeros(nb * batch_size, dtype=np.int32), "n_uniq_n": np.zeros(nb, dtype=np.int32),
-                       "seg_end": np.zeros(3 * nb * batch_size, dtype=np.int32),
-                       "seg": np.zeros(3 * nb * batch_size, dtype=np.int32)}
+                seg = {"n_uniq_n": np.zeros(nb, dtype=np.int32), "seg_b": np.zeros(nb * batch_size, dtype=np.int32)}
+                seg.update({k: np.zeros(3 * nb * batch_size, dtype=np.int32) for k in ("seg_rows", "seg_end", "seg", "seg_a")})
                 if slot is not None:
                     self._epoch_slots[key + ("seg",)] = seg
             check(self._lib.srh_sampler_epoch_segments(self._h, batch_size, vp(u), vp(i), vp(j), vp(uu), vp(nuu), vp(ui), vp(nui),
-                                                       vp(seg["uniq_n"]), vp(seg["n_uniq_n"]), vp(seg["seg_end"]),
-                                                       vp(seg["seg"])), "srh_sampler_epoch_segments")
+                                                       user_row0, item_row0, vp(seg["n_uniq_n"]), vp(seg["seg_rows"]),
+                                                       vp(seg["seg_end"]), vp(seg["seg"]), vp(seg["seg_a"]), vp(seg["seg_b"])),
+                       "srh_sampler_epoch_segments")
             res.update(seg)
         return res
 
@@ -584,13 +586,14 @@ def bpr_ws(batch: int, device):
 
 
 def _segments(seg, nce_rows):
-    """srh_batch_segments_t from a dict of device int32 tensors: uniq_u, uniq_i, n_uniq_u, n_uniq_i, uniq_n, n_uniq_n, seg_end, seg
-    [, batch_no: the last four are then EPOCH arrays]."""
+    """srh_batch_segments_t from a dict of device int32 tensors: n_uniq_u, n_uniq_i, n_uniq_n, seg_rows, seg_end, seg, seg_a, seg_b
+    [, batch_no: the arrays are then EPOCH arrays] [, rows_are_zero: bool]."""
     g = _lib.BatchSegments()
-    for k in ("uniq_u", "uniq_i", "n_uniq_u", "n_uniq_i", "uniq_n", "n_uniq_n", "seg_end", "seg"):
+    for k in ("n_uniq_u", "n_uniq_i", "n_uniq_n", "seg_rows", "seg_end", "seg", "seg_a", "seg_b"):
         setattr(g, "d_" + k, _p(seg[k], torch.int32))
     g.d_batch_no = _p(seg.get("batch_no"), torch.int32)
     g.nce_rows = int(nce_rows)
+    g.rows_are_zero = int(bool(seg.get("rows_are_zero", False)))
     return g
 
 

@@ -98,9 +98,10 @@ def fresh_tiny_data(golden_ops):
     return _tiny_interaction(golden_ops)
 
 
-def host_batch_segments(u, i, j, pad):
+def host_batch_segments(u, i, j, pad, user_row0=0, item_row0=0):
     """One batch's row groups and (slot, role) lists as include/selfrec_hip.h defines them (srh_batch_segments_t), built
-    independently of csrc/sampler.cpp with numpy: dict of int32 arrays padded to `pad` (unique lists) / 3 `pad` (lists)."""
+    independently of csrc/sampler.cpp with numpy: dict of int32 arrays (seg_rows, seg_end, seg, seg_a: 3 `pad` entries;
+    seg_b: `pad`; the three counts)."""
     import numpy as np
     u, i, j = (np.asarray(a, dtype=np.int64) for a in (u, i, j))
     uu, ui = np.unique(u), np.unique(i)
@@ -112,13 +113,17 @@ def host_batch_segments(u, i, j, pad):
     g_j = np.where(in_pos, uu.size + np.searchsorted(ui, j), uu.size + ui.size + np.searchsorted(un, j))
     group = np.concatenate([g_u, g_i, g_j])
     entry = np.concatenate([4 * slot, 4 * slot + 1, 4 * slot + 2])
+    opd_a = np.concatenate([i + item_row0, u + user_row0, u + user_row0])
     order = np.lexsort((entry, group))
     n_groups = uu.size + ui.size + un.size
-    out = {k: np.zeros(pad, dtype=np.int32) for k in ("uniq_u", "uniq_i", "uniq_n")}
-    out["uniq_u"][:uu.size], out["uniq_i"][:ui.size], out["uniq_n"][:un.size] = uu, ui, un
-    out["seg_end"] = np.zeros(3 * pad, dtype=np.int32)
+    out = {k: np.zeros(3 * pad, dtype=np.int32) for k in ("seg_end", "seg", "seg_a")}
+    out["seg_rows"] = np.full(3 * pad, -1, dtype=np.int32)
+    out["seg_rows"][:n_groups] = np.concatenate([uu + user_row0, ui + item_row0, un + item_row0])
     out["seg_end"][:n_groups] = np.cumsum(np.bincount(group, minlength=n_groups))
-    out["seg"] = np.zeros(3 * pad, dtype=np.int32)
     out["seg"][:entry.size] = entry[order]
+    out["seg_a"][:entry.size] = opd_a[order]
+    out["seg_b"] = np.zeros(pad, dtype=np.int32)
+    users_first = order[:u.size]                       # the user groups' entries are the first `cnt` of the batch
+    out["seg_b"][:u.size] = (j + item_row0)[entry[users_first] >> 2]
     out["n_uniq_u"], out["n_uniq_i"], out["n_uniq_n"] = (np.array([n], dtype=np.int32) for n in (uu.size, ui.size, un.size))
     return out

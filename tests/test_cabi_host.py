@@ -295,34 +295,61 @@ def test_sampler_epoch_slots_hold_the_same_epochs_in_arrays_that_are_reused(gold
 @pytest.mark.parametrize("bs", [64, 2048, 7])
 def test_epoch_segments_are_the_row_slot_lists_of_every_batch(golden_ops, bs):
     """srh_sampler_epoch_segments: for every batch, the touched rows -- sorted unique users | sorted unique positive items |
-    sorted unique negatives that are nobody's positive -- and for each the (slot, role) entries that name it, slots ascending:
-    the lists behind the fixed-order (atomic-free) batch-gradient reduction.  Draws nothing from the generator."""
+    sorted unique negatives that are nobody's positive -- as table rows, and for each the (slot, role) entries that name it
+    with the rows their terms read, slots ascending: the lists behind the fixed-order (atomic-free) batch-gradient reduction,
+    against an independent numpy construction (tests/conftest.py).  Draws nothing from the generator."""
+    from .conftest import host_batch_segments
     g = golden_ops
-    plain, seg = (ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], 200, 300) for _ in range(2))
+    U = 200
+    plain, seg = (ops.Sampler(g["graph_train_u_ids"], g["graph_train_i_ids"], U, 300) for _ in range(2))
     plain.seed(7); seg.seed(7)
     want = plain.epoch(bs, 1, with_unique=True)
-    r = seg.epoch(bs, 1, with_unique=True, with_segments=True, slot=0)
+    r = seg.epoch(bs, 1, with_unique=True, with_segments=(0, U), slot=0)
     for k in ("u", "i", "j", "uniq_u", "uniq_i", "n_uniq_u", "n_uniq_i"):
         assert np.array_equal(r[k], want[k]), k
     assert plain.next_u32() == seg.next_u32()                        # the same amount of the stream was consumed
     for b in range(r["n_batches"]):
         lo, hi = b * bs, min((b + 1) * bs, seg.n_edges)
-        u, i, j = r["u"][lo:hi], r["i"][lo:hi], r["j"][lo:hi]
-        uu, ui = np.unique(u), np.unique(i)
-        un = np.setdiff1d(np.unique(j), ui)
-        assert r["n_uniq_n"][b] == un.size
-        assert np.array_equal(r["uniq_n"][b * bs:b * bs + un.size], un)
-        end = r["seg_end"][3 * b * bs:3 * (b + 1) * bs]
-        ent = r["seg"][3 * b * bs:3 * (b + 1) * bs]
-        groups = [("u", x) for x in uu] + [("i", x) for x in ui] + [("i", x) for x in un]
-        assert end[len(groups) - 1] == 3 * (hi - lo)
-        start = 0
-        for gno, (side, x) in enumerate(groups):
-            if side == "u":
-                expect = [4 * s for s in np.nonzero(u == x)[0]]
-            else:
-                expect = sorted([4 * s + 1 for s in np.nonzero(i == x)[0]] + [4 * s + 2 for s in np.nonzero(j == x)[0]])
-            assert ent[start:end[gno]].tolist() == expect, (b, gno)
-            start = end[gno]
-    again = seg.epoch(bs, 1, with_unique=True, with_segments=True, slot=0)
-    assert again["seg"] is r["seg"] and again["uniq_n"] is r["uniq_n"]             # the slot's own arrays, refilled
+        ref = host_batch_segments(r["u"][lo:hi], r["i"][lo:hi], r["j"][lo:hi], bs, 0, U)
+        n_groups = int(ref["n_uniq_u"][0] + ref["n_uniq_i"][0] + ref["n_uniq_n"][0])
+        n_ent = 3 * (hi - lo)
+        assert r["n_uniq_n"][b] == ref["n_uniq_n"][0]
+        assert np.array_equal(r["seg_rows"][3 * b * bs:3 * (b + 1) * bs], ref["seg_rows"])          # (-1 past the last group)
+        assert np.array_equal(r["seg_end"][3 * b * bs:3 * b * bs + n_groups], ref["seg_end"][:n_groups])
+        for k in ("seg", "seg_a"):
+            assert np.array_equal(r[k][3 * b * bs:3 * b * bs + n_ent], ref[k][:n_ent]), (b, k)
+        assert np.array_equal(r["seg_b"][b * bs:b * bs + hi - lo], ref["seg_b"][:hi - lo])
+        # the definition, spelled out for one batch: group g's entries are the slots that name its row, ascending
+        if b == 0:
+            u, i, j = r["u"][lo:hi], r["i"][lo:hi], r["j"][lo:hi]
+            start = 0
+            for gno in range(n_groups):
+                row, end = ref["seg_rows"][gno], ref["seg_end"][gno]
+                if gno < ref["n_uniq_u"][0]:
+                    expect = [4 * s for s in np.nonzero(u == row)[0]]
+                else:
+                    expect = sorted([4 * s + 1 for s in np.nonzero(i + U == row)[0]] + [4 * s + 2 for s in np.nonzero(j + U == row)[0]])
+                assert ref["seg"][start:end].tolist() == expect, gno
+                start = end
+    again = seg.epoch(bs, 1, with_unique=True, with_segments=(0, U), slot=0)
+    assert again["seg"] is r["seg"] and again["seg_rows"] is r["seg_rows"]         # the slot's own arrays, refilled
+
+
+def test_collective_entry_points_resolve_rccl_and_refuse_bad_arguments():
+    """srh_comm_* / srh_allgather_rows / srh_reducescatter_rows / srh_allreduce_sum_f32 (SURVEY 8b's ABI list): RCCL is looked
+    up at first use (here: the copy torch has loaded), a unique id can be made without a GPU, and null / empty arguments come
+    back as error codes with a message -- nothing is launched, nothing throws."""
+    import ctypes as C
+    lib = _lib.load()
+    uid = (C.c_uint8 * 128)()
+    assert lib.srh_comm_unique_id(uid) == 0 and any(uid)
+    other = (C.c_uint8 * 128)()
+    assert lib.srh_comm_unique_id(other) == 0 and bytes(other) != bytes(uid)
+    assert lib.srh_comm_unique_id(None) == -1 and b"null" in lib.srh_last_error_string()
+    h = C.c_void_p()
+    assert lib.srh_comm_init_rank(C.byref(h), 2, 5, uid) == -1 and b"rank 5 of 2" in lib.srh_last_error_string()
+    fake = C.c_void_p(4096)
+    assert lib.srh_allgather_rows(fake, fake, 4, 64, None, None) == -1 and b"null" in lib.srh_last_error_string()
+    assert lib.srh_reducescatter_rows(fake, fake, 0, 64, fake, None) == -1 and b"bad shape" in lib.srh_last_error_string()
+    assert lib.srh_allreduce_sum_f32(None, 8, fake, None) == -1
+    assert lib.srh_comm_destroy(None) == 0

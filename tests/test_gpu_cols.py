@@ -519,3 +519,42 @@ def test_dp_layout_through_rccl_single_rank(golden_models, golden_meta, tiny_dat
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", ["rows", "dp"])
+def test_layouts_through_the_c_abi_collectives_single_rank(golden_models, golden_meta, tiny_data, layout):
+    """The collectives behind the C ABI (include/selfrec_hip.h: srh_comm_init_rank, srh_allgather_rows,
+    srh_reducescatter_rows, srh_allreduce_sum_f32 -- thin RCCL wrappers; comm.AbiComm binds them): a real RCCL communicator of
+    ONE rank made through the header, the row-sharded step's all-gather after every product (rows) and the data-parallel
+    step's gradient all-reduce (dp) issued through it on the step's stream -- no torch.distributed in the data path -- and the
+    reference's own 3-step run reproduced.  (More ranks than one need more GPUs than this box has: the call shapes are the
+    ones tests/test_dist_cpu.py drives at world 2-8 over gloo.)"""
+    from selfrec_amd.comm import AbiComm
+    comm = AbiComm(world=1, rank=0)
+    x = torch.arange(24, dtype=torch.float32, device="cuda").reshape(6, 4)
+    out = torch.zeros_like(x)
+    comm.all_gather(out, x)
+    rs = torch.zeros_like(x)
+    comm.reduce_scatter_sum(rs, x)
+    ar = x.clone()
+    comm.all_reduce_sum(ar)
+    torch.cuda.synchronize()
+    assert torch.equal(out, x) and torch.equal(rs, x) and torch.equal(ar, x)
+    comm.assert_replicated("a checksum", [1.5, 2.5], torch.device("cuda"))
+    gm, meta = golden_models, golden_meta
+    name = "XSimGCL"
+    kw = make_kw(name, gm, meta)
+    gen = torch.Generator().manual_seed(kw.pop("noise_seed"))
+    tr = ShardedTrainer(tiny_data, meta[name]["emb"], layout=layout, comm=comm,
+                        noise_fn=lambda shape: torch.rand(shape, generator=gen), **kw)
+    assert tr.layout == layout and tr.comm is comm
+    random.seed(meta[name]["sampler_seed"])
+    tr.seed_sampler_from_python()
+    bpr = []
+    for _ in range(tr.begin_epoch()):
+        tr.step()
+        bpr.append(tr.read_losses()[0])
+    np.testing.assert_allclose(bpr, gm[f"{name}_loss_bpr"], rtol=1e-5)
+    pu, pi = tr.parameters_full()
+    assert rel_err(pu.cpu().numpy(), gm[f"{name}_param_user"]) < 1e-4
+    assert rel_err(pi.cpu().numpy(), gm[f"{name}_param_item"]) < 1e-4

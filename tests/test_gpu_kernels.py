@@ -594,12 +594,14 @@ def test_f32_infonce_is_the_same_bits_fifty_times_over(ns, d):
             assert all(torch.equal(x, y) for x, y in zip(first, got)), rep
 
 
-def dev_segments(u, i, j, pad):
+def dev_segments(u, i, j, pad, rows_are_zero=False):
     from .conftest import host_batch_segments
-    return {k: torch.from_numpy(v).to(DEV) for k, v in host_batch_segments(u, i, j, pad).items()}
+    seg = {k: torch.from_numpy(v).to(DEV) for k, v in host_batch_segments(u, i, j, pad).items()}
+    seg["rows_are_zero"] = rows_are_zero
+    return seg
 
 
-@pytest.mark.parametrize("segmented", [False, True], ids=["atomics", "segments"])
+@pytest.mark.parametrize("segmented", [False, True, "store"], ids=["atomics", "segments", "segments-store"])
 def test_bpr_l2_fused_matches_oracle_with_duplicates(segmented):
     rng = np.random.default_rng(0)
     U, I, d, B = 300, 400, 64, 1000
@@ -623,7 +625,7 @@ def test_bpr_l2_fused_matches_oracle_with_duplicates(segmented):
         for t, src in zip(idx, (ui, pi, ni)):
             t[:B] = torch.from_numpy(src.astype(np.int32)).to(DEV)
         # (segmented: every row written once by the row group that owns it, its slots summed in order -- srh_bpr_l2_fwd_bwd_p)
-        kw = dict(seg=dev_segments(ui, pi, ni, B + 24)) if segmented else {}
+        kw = dict(seg=dev_segments(ui, pi, ni, B + 24, rows_are_zero=segmented == "store")) if segmented else {}
         runs = []
         for rep in range(3 if segmented else 1):
             for t in (gu, gi, gru, gri):
@@ -643,7 +645,7 @@ def test_bpr_l2_fused_matches_oracle_with_duplicates(segmented):
             assert all(torch.equal(x, y) for x, y in zip(runs[0], other))
 
 
-@pytest.mark.parametrize("segmented", [False, True], ids=["atomics", "segments"])
+@pytest.mark.parametrize("segmented", [False, True, "store"], ids=["atomics", "segments", "segments-store"])
 @pytest.mark.parametrize("d,B", [(64, 2048), (128, 600), (256, 500)])
 def test_bpr_infonce_one_call_matches_oracle(d, B, nce_precision, segmented):
     if nce_precision == "f32" and d == 256:
@@ -670,7 +672,7 @@ def test_bpr_infonce_one_call_matches_oracle(d, B, nce_precision, segmented):
     nce_ws = torch.empty(2 * ops.infonce_ws(B, d, DEV).numel(), dtype=torch.uint8, device=DEV)
     # segmented: the rows' (slot, role) lists come with the call (srh_batch_segments_t, nce_rows = 1: the user-side problem's
     # row i is user group i, the item-side one's positive-item group i) and every gradient row is written exactly once
-    kw = dict(seg=dev_segments(ui, pi, ni, B), nce_rows=1) if segmented else {}
+    kw = dict(seg=dev_segments(ui, pi, ni, B, rows_are_zero=segmented == "store"), nce_rows=1) if segmented else {}
     runs = []
     for rep in range(3):                     # the workspaces re-arm themselves: a second call gives the same
         gF.zero_(); gC.zero_(); losses.zero_()

@@ -36,5 +36,12 @@ for _ in range(int(os.environ.get("LOSS_PROBE_ITERS", "200"))):
     ops.infonce_multi(problems, d=64, tau=0.2, loss_scale=0.2, loss=tr.losses[2:3], ws=tr.nce_ws)   # prep, 2 tiles, finish_both
     ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=tr.bpr_ws, problems=problems, tau=0.2, cl_scale=0.2, cl_loss=tr.losses[2:3],
                     nce_ws=tr.nce_ws)                                                       # the fused 4-launch form
+    if tr.det_scatter:                                                                     # ... and its fixed-order form: rows_finish
+        ed = tr._epoch_dev
+        seg = dict(n_uniq_u=nuu, n_uniq_i=nui, n_uniq_n=ed["n_uniq_n"], seg_rows=ed["seg_rows"], seg_end=ed["seg_end"],
+                   seg=ed["seg"], seg_a=ed["seg_a"], seg_b=ed["seg_b"], batch_no=tr.meta[3:4],
+                   rows_are_zero=os.environ.get("LOSS_PROBE_RMW") is None)
+        ops.bpr_infonce(*bpr_in, **bpr, bpr_ws=tr.bpr_ws, problems=problems, tau=0.2, cl_scale=0.2, cl_loss=tr.losses[2:3],
+                        nce_ws=tr.nce_ws, seg=seg, nce_rows=1)
 torch.cuda.synchronize()
 print("rows", int(tr.meta[0]), "uniq users", int(tr.meta[1]), "uniq items", int(tr.meta[2]))

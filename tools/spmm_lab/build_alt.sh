@@ -20,9 +20,9 @@ while [ $# -ge 2 ]; do
   done
   wait
   OBJS=""
-  for o in common sampler loader spmm graph losses optim eval exchange; do
+  for o in common sampler loader collectives spmm graph losses optim eval exchange; do
     if [[ " $SRCS " == *" $o "* ]]; then OBJS="$OBJS tools/spmm_lab/alt/${o}_$NAME.o"; else OBJS="$OBJS $B/$o.o"; fi
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o tools/spmm_lab/alt/libselfrec_hip_$NAME.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o tools/spmm_lab/alt/libselfrec_hip_$NAME.so
   echo "built tools/spmm_lab/alt/libselfrec_hip_$NAME.so  ($SRCS: $FLAGS)"
 done
