@@ -1458,7 +1458,11 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
   float4 dv1 = f4_zero(), dv2 = f4_zero();
   double li = 0.0;
   const bool with_nce = batch.count > 0 && sg.nce_rows != 0;
-  if (with_nce && !(SRH_RF_SKIP & 1)) {
+  // (workgroup-uniform: the groups past the positive items -- other negatives, the dead tail of the 3 B slots: 40 % of the
+  //  grid at the Yelp2018 shape -- name no InfoNCE row; their workgroups skip the row finish and report no loss partial)
+  const int nce_wgs = with_nce ? (nuu + nui + GW - 1) / GW : 0;
+  const bool wg_nce = (int)blockIdx.x < nce_wgs;
+  if (wg_nce && !(SRH_RF_SKIP & 1)) {
     const int pq = has_nce ? pz : 0;
     const NceWs& w = batch.w[pq];
     const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
@@ -1476,7 +1480,7 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
   __shared__ double s_li[GW];
   __shared__ int s_pz[GW];
   const bool fold_loss = with_nce && !(SRH_RF_SKIP & 4);
-  if (fold_loss && sub == 0) { s_li[gw] = li; s_pz[gw] = has_nce ? pz : -1; }
+  if (fold_loss && wg_nce && sub == 0) { s_li[gw] = li; s_pz[gw] = has_nce ? pz : -1; }
   // ---- the fold of BPR phase 1's partials (every workgroup: the regulariser's gradient needs the three norms)
   __shared__ double s_tot[4];
   if (threadIdx.x >= 64 && threadIdx.x < 128) {
@@ -1491,7 +1495,7 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
   }
   __syncthreads();
   const bool folder = blockIdx.x == gridDim.x - 1;
-  if (fold_loss && threadIdx.x < 64) {                    // wave 0 (the BPR fold above ran on wave 1)
+  if (fold_loss && wg_nce && threadIdx.x < 64) {          // wave 0 (the BPR fold above ran on wave 1)
     if ((int)threadIdx.x < batch.count) {                 // problem k's partial of this workgroup: its losspart[blockIdx.x]
       double t = 0.0;
       for (int k = 0; k < GW; ++k)
@@ -1580,14 +1584,14 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
     const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
     const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(w.losspart);
     double t = 0.0;
-    for (int j0 = 0; j0 < (int)gridDim.x; j0 += 512) {    // (eight slots per lane in flight: one round trip per poll)
+    for (int j0 = 0; j0 < nce_wgs; j0 += 512) {           // (eight slots per lane in flight: one round trip per poll)
       unsigned long long v[8];
       for (int spin = 0; spin < (1 << 16); ++spin) {      // (bounded: a lost report costs a wrong loss figure, never a hung device)
         bool missing = false;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int j = j0 + 64 * q + lane;
-          v[q] = j < (int)gridDim.x ? __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          v[q] = j < nce_wgs ? __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
           missing = missing || v[q] == kLossUnreported;
         }
         if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
