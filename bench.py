@@ -68,6 +68,7 @@ def launch_check(args, rank, world, backend, wd_seconds, coll_timeout):
                           "headline": {"layout": pick_layout(args.emb, world, head, None), "scaling": scaling_of(head),
                                        "global_batch": args.batch * (world if head == "dp" else 1),
                                        "parallelism": describe_layout(args.emb, world, head)},
+                          "baseline_partition": baseline_partition_note(pick_layout(args.emb, world, head, None)),
                           "sub_records": sub_record_layouts(args, world, head)}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -85,16 +86,26 @@ def scaling_of(layout):
 
 
 def sub_record_layouts(args, world, head):
-    """Layouts timed after the headline: data parallel (weak scaling) always; on the gather-bound 1 M x 500 k graph also
-    the plain row partition BASELINE.json names, beside pick_layout's 2-D grid."""
+    """Layouts timed after the headline: data parallel (weak scaling), and -- at EVERY shape -- the plain row partition
+    BASELINE.json's north_star names (tables and graph rows dealt over the ranks, an all-gather of (N, d) after every
+    product: `layout_rows`), so that the first line from real multi-GPU hardware holds that configuration's number whatever
+    pick_layout chose for the headline (column blocks at the Yelp2018 shape, the 2-D grid at 1 M x 500 k)."""
     if os.environ.get("SRH_SUB_RECORDS", "1") == "0" or world < 2:
         return []
     subs = [s for s in (os.environ.get("SRH_SUB_LAYOUTS") or "").split(",") if s]
     if not subs:
         subs = ["dp"] if head != "dp" else ["auto"]
-        if args.shape == "1m-500k" and head not in ("rows",):
+        if head != "rows":
             subs.append("rows")
     return subs
+
+
+def baseline_partition_note(chosen):
+    """config.baseline_partition: which record of this line is the partition BASELINE.json / SURVEY.md 8(e) name."""
+    if chosen == "rows":
+        return "this record: rows (tables + graph rows dealt over the ranks, one all-gather of (N, d) per product)"
+    return (f"the `layout_rows` sub-record (tables + graph rows dealt over the ranks, one all-gather of (N, d) per product); the "
+            f"headline is pick_layout's choice for this shape ({chosen}), same fixed global batch")
 
 
 def main():
@@ -251,6 +262,9 @@ def main():
                                f"B={args.batch}, Adam lr=1e-3",
                    "global_batch": rec["global_batch"],
                    "parallelism": parallelism_of(trainer) if sharded else "single",
+                   **({"baseline_partition": baseline_partition_note(str(trainer.layout))} if sharded and world > 1 else {}),
+                   # every sum of the step has one fixed order (no float atomics): two runs give the same bits
+                   "bit_reproducible_step": bool(getattr(trainer, "det_scatter", False)),
                    "rccl_ranks": comm["ranks_in_collective"] if comm and not shared_device else None,
                    "comm": comm, "launch": rec["launch"],
                    "epoch_boundaries_in_region": rec["epoch_boundaries_inside"],

@@ -7,11 +7,12 @@ import time
 import numpy as np
 import torch
 
-from .probes import eval_mfma_busy
+from .probes import eval_kernel_us, eval_mfma_busy
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PFLOP/s headline includes 2:1 sparsity)
 
 
 def ops_filtered(ue, uid_dev, ie, g, k, gr):
@@ -104,18 +105,39 @@ def eval_throughput(trainer, data, k=20):
             "end_to_end_materialised_users_per_s": round(len(out) / t_mat, 1),
             "end_to_end_materialised_what": "the same plus the reference's rec_list built in full: a dict of every user's "
                                             "list of (item name, score) tuples (SURVEY 8d's definition of eval time)",
-            "scoring_tflops": round(flops / t_kernel / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFLOPS,
             "filter_survivors_per_user": survivors,
-            "roofline": {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
-                         "achieved": round(flops / t_kernel / 1e12, 2),
-                         "frac": round(flops / t_kernel / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                         "what": "2 * users * items * d flops of full-catalogue scoring / the whole device-side ranking "
-                                 "(exact-f32 MFMA chain, masks, top-K, ids + scores to the host)",
-                         "gemm_alone_tflops": round(gemm_tflops, 2),
-                         "gemm_alone_frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                         # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of filter16_kernel (the ranking's largest kernel; one bf16 product per 16 dimensions since round 4, three before
-                         # -- a third of the MFMAs in about the same time: the pipe is not what bounds it): NOT the algorithmic fraction above
-                         "mfma_busy": eval_mfma_busy()[0], "mfma_busy_source": eval_mfma_busy()[1]}}
+            "roofline": _eval_roofline(flops, len(uid), _gr.FILTER_CHUNK_ROWS, gemm_tflops, t_dev)}
+
+
+def _eval_roofline(flops, n_users, chunk_rows, gemm_tflops, t_dev):
+    """Per KERNEL, each against the pipe it runs on -- no pipeline total is divided by a peak (the decide pass runs on the
+    bf16 pipe: 2 U I d "f32 flops" over the ranking's time exceeds the f32 MFMA rate and is not a fraction of anything)."""
+    busy, busy_src = eval_mfma_busy()
+    kus, kus_src = eval_kernel_us()
+    launches = (n_users + chunk_rows - 1) // chunk_rows
+    out = {"what": "one entry per kernel of the ranking, each priced against the pipe it runs on; durations of the filter / re-score "
+                   "kernels from the committed rocprofv3 pass of tools/eval_probe.py on this csrc/eval.hip (bench.py cannot run under "
+                   "rocprofv3 itself), the exact-f32 scoring GEMM timed live",
+           "kernels_only_ms_live": round(t_dev * 1e3, 3),
+           "gemm_nt_f32 (the exact f32 scoring product alone, one 4096-user slab)":
+               {"bound": "mfma_f32", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS, "achieved": round(gemm_tflops, 2),
+                "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4), "timed": "live (HIP events, 10 launches)"}}
+    main = next((k for k in kus if k.startswith("filter16_kernel") and "false" in k), None)
+    if main:
+        us = kus[main]["avg_us"]
+        tf = flops / launches / (us * 1e-6) / 1e12
+        out["filter16_kernel (decide pass: every user x every item on bf16 operands, survivors kept)"] = {
+            "bound": "mfma_bf16", "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round(tf, 1),
+            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "duration_us": us, "launches_per_ranking": launches,
+            "flops_per_launch": flops / launches, "mfma_busy": busy, "mfma_busy_source": busy_src,
+            "what_bounds_it": "the epilogue: ~45 VALU instructions per 32 x 32 tile against 4 bf16 MFMAs (DESIGN.md 4.4)"}
+        rest = {k: v["avg_us"] for k, v in kus.items() if k != main}
+        out["other_kernels_avg_us (exact f32 re-score of the survivors, bounds, row splits: VALU / latency bound, no MFMA)"] = rest
+        out["durations_source"] = kus_src
+    else:
+        out["filter16_kernel"] = {"note": "no committed kernel-stats pass for this csrc/eval.hip (tools/gpu_session.sh evalpmc)",
+                                  "mfma_busy": busy, "mfma_busy_source": busy_src}
+    return out
 
 
 def eval_throughput_sharded(trainer, data, dist, rank, world, k=20):

@@ -60,6 +60,19 @@ def eval_mfma_busy():
     return rec["mfma_busy_filter16"], f"{rec['summary']}: {rec['how']}"
 
 
+def eval_kernel_us():
+    """{kernel: {"calls", "avg_us"}} of the ranking's kernels from the committed rocprofv3 --kernel-trace --stats pass of
+    tools/eval_probe.py (profiles/eval_mfma_busy.json: kernel_us), or {} when the record is of another csrc/eval.hip."""
+    path = os.path.join(REPO, "profiles", "eval_mfma_busy.json")
+    if not os.path.exists(path):
+        return {}, None
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("eval_hip_blob") != git_blob_hash(os.path.join(REPO, "selfrec_amd", "csrc", "eval.hip")):
+        return {}, None
+    return rec.get("kernel_us") or {}, rec.get("kernel_us_source")
+
+
 def pmc_traffic_cols(args, w):
     """Same for one rank's launch on (N, w) tables in the column-sharded layout: profiles/spmm_cols_traffic.json."""
     path = os.path.join(REPO, "profiles", "spmm_cols_traffic.json")

@@ -301,7 +301,8 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
     # columns per rank), strong scaling; data parallel (N x 2048 pairs per step) is the sub-record
     assert rec["headline"]["global_batch"] == 2048 and rec["headline"]["scaling"] == "strong"
     assert rec["headline"]["layout"] == "cols" and rec["headline"]["parallelism"].startswith("column-sharded tables x2")
-    assert rec["sub_records"] == ["dp"]
+    # ... and so is the plain row partition BASELINE.json names (the headline at this shape is column blocks)
+    assert rec["sub_records"] == ["dp", "rows"] and "layout_rows" in rec["baseline_partition"]
     assert "torch.distributed.run" in p.stderr
     # the rendezvous port is picked free per launch, never a fixed number
     assert rec["master_port"] != 29511 and f"--master-port {rec['master_port']}" in p.stderr
@@ -310,7 +311,7 @@ def test_bench_gpus_n_launches_itself_under_torchrun():
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_headline_keeps_the_global_batch_at_2048(world):
     """whatever N, the first record of `bench.py --gpus N` is the fixed-batch partition (B = 2048, strong);
-    on the 1 M x 500 k graph the plain row partition BASELINE.json names is timed beside pick_layout's grid."""
+    the plain row partition BASELINE.json names is timed beside pick_layout's choice at every shape."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -322,7 +323,7 @@ def test_bench_headline_keeps_the_global_batch_at_2048(world):
         assert chosen != "dp" and bench.scaling_of(chosen) == "strong"
         assert args.batch * (world if chosen == "dp" else 1) == 2048
         subs = bench.sub_record_layouts(args, world, head)
-        assert subs[0] == "dp" and (("rows" in subs) == (shape == "1m-500k"))
+        assert subs[0] == "dp" and "rows" in subs          # north_star's row partition is timed at every shape
 
 
 def _bench(args, **env_extra):
