@@ -118,8 +118,13 @@ struct srh_sampler {
   //   info >> 8  = first 64-bit word of user u's bitmap;  info & 255 = log2(bits) of it, 255 = exact item bitmap
   std::vector<uint64_t> sig_info;
   std::vector<uint64_t> seen_u, seen_i;     // scratch bitmaps for the per-batch sorted unique ids
-  std::vector<int32_t> pos_u, pos_i;        // scratch of srh_sampler_epoch_segments: id -> row group of the batch (-1)
-  std::vector<int32_t> seg_fill;            //   "       : next free entry of every row group's slot list
+  // srh_sampler_epoch_segments: one scratch set per worker thread, kept between epochs (280 KB each at the Yelp2018 shape:
+  // freed and re-mapped every epoch they would be munmap traffic beside the thread that feeds the GPU)
+  struct SegScratch {
+    std::vector<int32_t> pos_u, pos_i, fill, neg_only, un;
+    std::vector<uint64_t> seen;
+  };
+  std::vector<SegScratch> seg_scratch;
   MT19937 rng;
   bool seeded = false;
 
@@ -430,58 +435,82 @@ srh_status_t srh_sampler_epoch_segments(srh_sampler_t* s, int64_t batch_size, co
   SRH_REQUIRE(s && h_u && h_i && h_j && h_uniq_u && h_n_uniq_u && h_uniq_i && h_n_uniq_i, "sampler_epoch_segments: null input");
   SRH_REQUIRE(h_n_uniq_n && h_seg_rows && h_seg_end && h_seg && h_seg_a && h_seg_b, "sampler_epoch_segments: null output");
   SRH_REQUIRE(batch_size > 0 && batch_size < (int64_t(1) << 28), "sampler_epoch_segments: bad batch_size");
-  if (s->pos_u.empty()) {
-    s->pos_u.assign((size_t)s->n_users, -1);
-    s->pos_i.assign((size_t)s->n_items, -1);
-  }
-  s->seg_fill.resize((size_t)(3 * batch_size));
-  int32_t* pos_u = s->pos_u.data();
-  int32_t* pos_i = s->pos_i.data();
-  int32_t* fill = s->seg_fill.data();
+  // batches are independent: a few host threads, each with its own id -> row-group scratch (the sampler's draws are one
+  // sequential stream; this is not)
+  const int64_t n_batches = (s->n_edges + batch_size - 1) / batch_size;
+  int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2)),
+                                                         n_batches / 16));
+  if (const char* forced = std::getenv("SRH_SAMPLER_THREADS")) n_thr = std::max(1, std::min(64, std::atoi(forced)));
   const size_t item_words = (size_t)(s->n_items + 63) / 64;
-  std::vector<int32_t> neg_only((size_t)batch_size), un((size_t)batch_size);
-  int64_t b = 0;
-  for (int64_t ptr = 0; ptr < s->n_edges; ++b) {
-    const int64_t cnt = std::min<int64_t>(batch_size, s->n_edges - ptr);
-    const int32_t *u = h_u + ptr, *it = h_i + ptr, *jt = h_j + ptr;
-    const int32_t *uu = h_uniq_u + b * batch_size, *ui = h_uniq_i + b * batch_size;
-    const int32_t nuu = h_n_uniq_u[b], nui = h_n_uniq_i[b];
-    int32_t* rows = h_seg_rows + b * 3 * batch_size;
-    int32_t* end = h_seg_end + b * 3 * batch_size;
-    int32_t* seg = h_seg + b * 3 * batch_size;
-    int32_t* sa = h_seg_a + b * 3 * batch_size;
-    int32_t* sb = h_seg_b + b * batch_size;
-    for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = k;
-    for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = nuu + k;
-    // sorted unique negatives that are nobody's positive in this batch
-    int64_t m = 0;
-    for (int64_t r = 0; r < cnt; ++r)
-      if (pos_i[jt[r]] < 0) neg_only[(size_t)m++] = jt[r];
-    const int32_t nun = sorted_unique(neg_only.data(), m, un.data(), s->seen_i, item_words);
-    for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = nuu + nui + k;
-    const int32_t groups = nuu + nui + nun;
-    for (int32_t k = 0; k < nuu; ++k) rows[k] = uu[k] + user_row0;
-    for (int32_t k = 0; k < nui; ++k) rows[nuu + k] = ui[k] + item_row0;
-    for (int32_t k = 0; k < nun; ++k) rows[nuu + nui + k] = un[(size_t)k] + item_row0;
-    for (int64_t g = groups; g < 3 * batch_size; ++g) rows[g] = -1;          // (no row: the group has nothing to do)
-    // counting sort of the 3 cnt (slot, role) entries by row group; inside a group: slot ascending, positive before negative
-    for (int32_t g = 0; g < groups; ++g) end[g] = 0;
-    for (int64_t r = 0; r < cnt; ++r) { ++end[pos_u[u[r]]]; ++end[pos_i[it[r]]]; ++end[pos_i[jt[r]]]; }
-    int32_t run = 0;
-    for (int32_t g = 0; g < groups; ++g) { fill[g] = run; run += end[g]; end[g] = run; }
-    for (int64_t r = 0; r < cnt; ++r) {
-      const int32_t eu = fill[pos_u[u[r]]]++;          // (user groups come first: eu < cnt)
-      seg[eu] = (int32_t)(r * 4 + 0); sa[eu] = it[r] + item_row0; sb[eu] = jt[r] + item_row0;
-      const int32_t ep = fill[pos_i[it[r]]]++;
-      seg[ep] = (int32_t)(r * 4 + 1); sa[ep] = u[r] + user_row0;
-      const int32_t en = fill[pos_i[jt[r]]]++;
-      seg[en] = (int32_t)(r * 4 + 2); sa[en] = u[r] + user_row0;
+  if ((int)s->seg_scratch.size() < n_thr) s->seg_scratch.resize((size_t)n_thr);
+  for (int t = 0; t < n_thr; ++t) {
+    srh_sampler::SegScratch& sc = s->seg_scratch[(size_t)t];
+    if (sc.pos_u.empty()) {
+      sc.pos_u.assign((size_t)s->n_users, -1);
+      sc.pos_i.assign((size_t)s->n_items, -1);
+      sc.seen.assign(item_words + (item_words + 63) / 64, 0);
     }
-    for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = -1;
-    for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = -1;
-    for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = -1;
-    h_n_uniq_n[b] = nun;
-    ptr += cnt;
+    if (sc.fill.size() < (size_t)(3 * batch_size)) {
+      sc.fill.resize((size_t)(3 * batch_size));
+      sc.neg_only.resize((size_t)batch_size);
+      sc.un.resize((size_t)batch_size);
+    }
+  }
+  auto work = [&](int t) {
+    srh_sampler::SegScratch& sc = s->seg_scratch[(size_t)t];
+    std::vector<int32_t>&neg_only = sc.neg_only, &un = sc.un;
+    std::vector<uint64_t>& seen = sc.seen;
+    int32_t* pos_u = sc.pos_u.data();
+    int32_t* pos_i = sc.pos_i.data();
+    int32_t* fill = sc.fill.data();
+    for (int64_t b = t; b < n_batches; b += n_thr) {
+      const int64_t ptr = b * batch_size;
+      const int64_t cnt = std::min<int64_t>(batch_size, s->n_edges - ptr);
+      const int32_t *u = h_u + ptr, *it = h_i + ptr, *jt = h_j + ptr;
+      const int32_t *uu = h_uniq_u + b * batch_size, *ui = h_uniq_i + b * batch_size;
+      const int32_t nuu = h_n_uniq_u[b], nui = h_n_uniq_i[b];
+      int32_t* rows = h_seg_rows + b * 3 * batch_size;
+      int32_t* end = h_seg_end + b * 3 * batch_size;
+      int32_t* seg = h_seg + b * 3 * batch_size;
+      int32_t* sa = h_seg_a + b * 3 * batch_size;
+      int32_t* sb = h_seg_b + b * batch_size;
+      for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = k;
+      for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = nuu + k;
+      // sorted unique negatives that are nobody's positive in this batch
+      int64_t m = 0;
+      for (int64_t r = 0; r < cnt; ++r)
+        if (pos_i[jt[r]] < 0) neg_only[(size_t)m++] = jt[r];
+      const int32_t nun = sorted_unique(neg_only.data(), m, un.data(), seen, item_words);
+      for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = nuu + nui + k;
+      const int32_t groups = nuu + nui + nun;
+      for (int32_t k = 0; k < nuu; ++k) rows[k] = uu[k] + user_row0;
+      for (int32_t k = 0; k < nui; ++k) rows[nuu + k] = ui[k] + item_row0;
+      for (int32_t k = 0; k < nun; ++k) rows[nuu + nui + k] = un[(size_t)k] + item_row0;
+      for (int64_t g = groups; g < 3 * batch_size; ++g) rows[g] = -1;          // (no row: the group has nothing to do)
+      // counting sort of the 3 cnt (slot, role) entries by row group; inside a group: slot ascending, positive before negative
+      for (int32_t g = 0; g < groups; ++g) end[g] = 0;
+      for (int64_t r = 0; r < cnt; ++r) { ++end[pos_u[u[r]]]; ++end[pos_i[it[r]]]; ++end[pos_i[jt[r]]]; }
+      int32_t run = 0;
+      for (int32_t g = 0; g < groups; ++g) { fill[g] = run; run += end[g]; end[g] = run; }
+      for (int64_t r = 0; r < cnt; ++r) {
+        const int32_t eu = fill[pos_u[u[r]]]++;          // (user groups come first: eu < cnt)
+        seg[eu] = (int32_t)(r * 4 + 0); sa[eu] = it[r] + item_row0; sb[eu] = jt[r] + item_row0;
+        const int32_t ep = fill[pos_i[it[r]]]++;
+        seg[ep] = (int32_t)(r * 4 + 1); sa[ep] = u[r] + user_row0;
+        const int32_t en = fill[pos_i[jt[r]]]++;
+        seg[en] = (int32_t)(r * 4 + 2); sa[en] = u[r] + user_row0;
+      }
+      for (int32_t k = 0; k < nuu; ++k) pos_u[uu[k]] = -1;
+      for (int32_t k = 0; k < nui; ++k) pos_i[ui[k]] = -1;
+      for (int32_t k = 0; k < nun; ++k) pos_i[un[(size_t)k]] = -1;
+      h_n_uniq_n[b] = nun;
+    }
+  };
+  if (n_thr == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
   }
   return SRH_OK;
 }

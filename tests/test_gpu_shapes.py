@@ -336,8 +336,8 @@ def first_appearance_ids(raw):
 def test_xcd_share_calibration_changes_placement_not_results(yelp_data, model):
     """engine.FusedTrainer calibrates the dense plan's XCD shares at start-up (probe launches -> unequal numbers of
     workgroups per XCD).  At the Yelp2018 shape it does move workgroups, and a trainer on the calibrated list takes the
-    same steps as one on the canonical list: same batches, same losses, same embeddings (to the order of the loss
-    section's atomics).  The decision is on the record (trainer.xcd_calibration, logger "selfrec_amd")."""
+    same steps as one on the canonical list: same batches, same losses, same embeddings, bit for bit.  The decision is on the
+    record (trainer.xcd_calibration, logger "selfrec_amd")."""
     kw = dict(model=model, n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048)
 
     def run(tr):
@@ -358,20 +358,42 @@ def test_xcd_share_calibration_changes_placement_not_results(yelp_data, model):
     torch.manual_seed(5)
     b = FusedTrainer(yelp_data, 64, **kw)                       # (the plan is marked calibrated: b does not probe again)
     lb, eb = run(b)
-    np.testing.assert_allclose(la, lb, rtol=2e-6)
-    # Two runs of ONE trainer configuration already differ (tools/determinism_probe.py, profiles/r03_c_determinism.txt:
-    # the loss section scatters with atomics -- 12 % of the gradient elements differ in their last bits, 5e-8 relative --
-    # and three Adam steps later the embeddings by 2.5e-7).  LightGCN: nothing amplifies that -- all but 1e-5 of the
-    # elements within 2e-6, every element within 2e-5; a placement bug (a task dropped or run twice) moves whole rows by
-    # O(1).  XSimGCL: once in a few runs such a last-bit difference lands on a layer-output element within rounding of
-    # zero, where XSimGCL.py:90's sign(h) turns it into a 2 eps |unit| jump that the next two products spread over the
-    # element's two-hop neighbourhood (observed: 1,600 of 2 M elements above 2e-6, the largest 1.8e-4: round 4's
-    # gpurun session c) -- so there the bulk is held to 2e-6 on all but 0.5 % of the elements and every element to 2e-3.
-    frac, worst = (1e-5, 2e-5) if model == "LightGCN" else (5e-3, 2e-3)
+    # same tasks, same sums in the same order wherever they run -- and no float atomics anywhere in the step (engine.det_scatter):
+    # the same bits (rounds 1-5 held this to 2e-6 / 2e-3: the atomic scatter's last bits, amplified by XSimGCL.py:90's sign())
+    assert np.array_equal(la, lb)
     for x, y in zip(ea, eb):
-        err = np.abs(x.astype(np.float64) - y) / np.abs(y).max()
-        assert (err > 2e-6).mean() < frac and err.max() < worst, ((err > 2e-6).mean(), err.max())
+        assert np.array_equal(x, y)
     ops.spmm_set_xcd_shares(a.adj, 64, shares)                  # leave the module's shared graph as the engine set it
+
+
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("model", ["XSimGCL", "SGL"])
+def test_live_task_lists_change_the_launch_not_the_step(yelp_data, model, monkeypatch):
+    """engine.live_stride: the step's row-masked products (the last forward layer: batch rows only) run the plan records that
+    hold the batch's rows instead of the whole list (srh_spmm_plan_live_tasks, one list per batch, uploaded with the epoch).
+    Same records on the same rows: captured steps over an epoch boundary leave the same bits in the table and the moments as
+    the launch over the whole list (SRH_LIVE_TASKS=0)."""
+    kw = dict(model=model, n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048,
+              use_graph=True)
+    outs = []
+    for live in ("1", "0"):
+        monkeypatch.setenv("SRH_LIVE_TASKS", live)
+        torch.manual_seed(5)
+        tr = FusedTrainer(yelp_data, 64, **kw)
+        assert (tr.live_stride > 0) == (live == "1")
+        tr.sampler.seed(11)
+        nb = tr.begin_epoch()
+        tr.cursor[0:1] += nb - 4                         # (the epoch's last four batches, then the next epoch's first four)
+        for _ in range(4):
+            tr.step()
+        assert tr.begin_epoch() == nb
+        for _ in range(4):
+            tr.step()
+        torch.cuda.synchronize()
+        outs.append((tr.E0.clone(), tr.m.clone(), tr.v.clone(), tr.losses.clone()))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][1].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
