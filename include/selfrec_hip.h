@@ -40,7 +40,7 @@ enum {
 };
 
 /* ABI version: bumped whenever a signature or struct below changes. */
-#define SRH_ABI_VERSION 31
+#define SRH_ABI_VERSION 30
 int32_t srh_abi_version(void);
 const char* srh_last_error_string(void);
 /* Number of visible HIP devices (0 when there is none -- never an error). */
@@ -191,17 +191,6 @@ srh_status_t srh_spmm_plan_create(srh_spmm_plan_t** out, int64_t n_rows, int64_t
  * captured launch of this plan must be re-captured afterwards.  The engine calibrates the shares once at start-up
  * from srh_spmm_f32_probe (engine.py). */
 srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_blocks_per_xcd);
-/* Live-task lists for row-masked launches (srh_spmm_epilogue_t::d_live_list).  Host only.
- * srh_spmm_plan_live_stride: prepares the plan for such launches on d-column tables (a device copy of the canonical list:
- *   call it from the thread that owns the device, outside any stream capture) and returns the record count no list of at
- *   most max_rows rows can exceed (max_rows + the further segments of the plan's split rows); -1 on error.
- * srh_spmm_plan_live_tasks: for each of n_lists row lists (h_rows + b rows_stride: table rows, ended by -1 or the stride --
- *   e.g. srh_sampler_epoch_segments' h_seg_rows), the records of the canonical list that hold any of its rows, ascending
- *   (split rows' segments first), at h_live + b live_stride, their number in h_n_live[b].  Thread-safe against launches
- *   of the plan. */
-int64_t srh_spmm_plan_live_stride(srh_spmm_plan_t* plan, int32_t d, int64_t max_rows);
-srh_status_t srh_spmm_plan_live_tasks(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_rows, int64_t n_lists,
-                                      int64_t rows_stride, int32_t* h_live, int64_t live_stride, int32_t* h_n_live);
 /* records in the list a launch on d-column tables runs now (a multiple of 32 once shares are set); -1: no such list */
 int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d);
 void srh_spmm_plan_destroy(srh_spmm_plan_t* plan);
@@ -290,17 +279,6 @@ typedef struct srh_spmm_epilogue {
   const int32_t* d_adam_clear_mark;
   float* d_adam_clear[SRH_MAX_ADAM_CLEAR];
   int64_t* d_adam_cursor;
-  /* LIVE TASKS of a row-masked launch (d_row_mark != NULL; d = 64 / 128 / 256).  Only the batch's rows are computed by such
-   * a launch (XSimGCL.py:95-98: the last layer and the mean feed nothing but emb[idx] of the batch), yet every record of the
-   * plan's list costs a wave slot three dependent loads to find that out: 31 k waves of which 5 k work, ~10 of 21 us at the
-   * Yelp2018 shape.  With d_live_list the launch runs records d_live_list[b live_stride + k], k < d_live_count[b], of the
-   * plan's canonical list instead (b = *d_live_batch_no, 0 when NULL): srh_spmm_plan_live_tasks' lists, uploaded.  Same
-   * records, same sums bit for bit.  The lists must name EVERY record that holds a marked row (rows not listed are not
-   * computed); marks are still honoured inside a record (a short-row record holds up to 4 rows). */
-  const int32_t* d_live_list;
-  const int32_t* d_live_count;
-  const int32_t* d_live_batch_no;
-  int32_t live_stride;
 } srh_spmm_epilogue_t;
 enum { SRH_SCALE_IN = 1, SRH_SCALE_OUT = 2 };
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libselfrec_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 30
 
 SRH_EPI_PERTURB, SRH_EPI_MEAN, SRH_EPI_AXPY, SRH_EPI_ADAM = 1, 2, 4, 8
 SRH_MAX_ADAM_CLEAR = 4
@@ -92,7 +92,6 @@ class SpmmEpilogue(C.Structure):
         ("d_adam_param", C.c_void_p), ("d_adam_m", C.c_void_p), ("d_adam_v", C.c_void_p), ("d_adam_coef", C.c_void_p),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("adam_n_clear", C.c_int32),
         ("d_adam_clear_mark", C.c_void_p), ("d_adam_clear", C.c_void_p * SRH_MAX_ADAM_CLEAR), ("d_adam_cursor", C.c_void_p),
-        ("d_live_list", C.c_void_p), ("d_live_count", C.c_void_p), ("d_live_batch_no", C.c_void_p), ("live_stride", C.c_int32),
     ]
 
 
@@ -130,8 +129,6 @@ SIGNATURES = {
     "srh_spmm_plan_create": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _i32, _i64, _vp]),
     "srh_spmm_plan_set_xcd_shares": (_i32, [_vp, _i32, _vp]),
     "srh_spmm_plan_run_tasks": (_i32, [_vp, _i32]),
-    "srh_spmm_plan_live_stride": (_i64, [_vp, _i32, _i64]),
-    "srh_spmm_plan_live_tasks": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _i64, _vp]),
     "srh_spmm_f32_probe": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "srh_spmm_gather_bound": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "srh_gather_floor_probe": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),

@@ -25,8 +25,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <new>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -96,13 +94,6 @@ struct DevEpilogue {
   const int32_t* adam_clear_mark;
   float4* adam_clear[SRH_MAX_ADAM_CLEAR];
   int64_t* adam_cursor;
-  // LIVE TASKS (row-masked launches): the launch runs the live_count[b] records tasks_canon[live_list[b * live_stride + k]]
-  // instead of the whole list (b = *live_batch_no, 0 when NULL) -- see srh_spmm_plan_live_tasks
-  const int32_t* live_list;
-  const int32_t* live_count;
-  const int32_t* live_batch_no;
-  int32_t live_stride;
-  const void* live_tasks;        // const Task64* (the plan's canonical list on the device)
 };
 
 // Counter-based noise: every element's uniform is a pure function of (seed, counter, element),
@@ -526,18 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(((blockIdx.x - n_fetch) * 256u + threadIdx.x) >> 6));
-  // Row-masked launches with a live-task list (DevEpilogue::live_list): 92 % of the records of such a launch name rows that
-  // are not in the batch, and a wave that finds that out has cost its slot three dependent loads -- 31 k waves of which 5 k do
-  // any work: ~10 of the launch's 21 us at the Yelp2018 shape.  The host knows the batch's rows one epoch ahead
-  // (srh_sampler_epoch_segments) and the plan knows which records hold them: the launch runs those records only.
-  const Task64* tp = tasks + wave;       // uniform address: s_load
-  if (ep.live_list) {
-    const int bno = ep.live_batch_no ? *ep.live_batch_no : 0;
-    if (wave >= ep.live_count[bno]) return;
-    tp = reinterpret_cast<const Task64*>(ep.live_tasks) + ep.live_list[(size_t)bno * ep.live_stride + wave];
-  } else if (wave >= n_tasks) {
-    return;
-  }
+  if (wave >= n_tasks) return;
   const int lane = threadIdx.x & 63;
   // (ADAM: the last launch of the step moves the cursor; everything here reads the step from batch_fetch's copy)
   if constexpr (ADAM) {
@@ -565,6 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
   for (int t = 0; t < 8; ++t) xx[t] = zero;
 
+  const Task64* tp = tasks + wave;       // uniform address: s_load
   const int kind = tp->kind, count = tp->count, slot = tp->slot;
   int row = tp->row[0], s = tp->start[0], e = tp->end[0];
   if (kind == 1 && G > 1) {
@@ -1356,13 +1337,6 @@ struct srh_spmm_plan {
   int32_t* d_slot_owner = nullptr;
   int32_t* d_tickets = nullptr;    // one arrival counter per split row, self re-arming
   float* d_partial = nullptr;      // n_slots * 256 floats (enough for d <= 256)
-  // live-task lists (srh_spmm_plan_live_tasks): the canonical list on the device (never re-dealt), and row -> the records
-  // of the canonical list that hold it (a short row: one; a split row: one per segment), built on first use
-  Task64* d_canon64[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  std::vector<int64_t> row_task_ptr[5];
-  std::vector<int32_t> row_task_ids[5];
-  int32_t n_coop[5] = {0, 0, 0, 0, 0};      // records beyond the first of every row, summed (split rows' further segments)
-  std::mutex live_mutex;
 };
 
 // host view of the epilogue (include/selfrec_hip.h) -> the kernels' argument block, with every check the ABI promises
@@ -1648,7 +1622,6 @@ void srh_spmm_plan_destroy(srh_spmm_plan_t* p) {
   if (p->d_tsegs) (void)hipFree(p->d_tsegs);
   for (int gi = 0; gi < 5; ++gi) if (p->d_tasks[gi]) (void)hipFree(p->d_tasks[gi]);
   for (int gi = 0; gi < 5; ++gi) if (p->d_tasks64[gi]) (void)hipFree(p->d_tasks64[gi]);
-  for (int gi = 0; gi < 5; ++gi) if (p->d_canon64[gi]) (void)hipFree(p->d_canon64[gi]);
   delete p;
 }
 
@@ -1724,106 +1697,6 @@ int32_t srh_spmm_plan_run_tasks(const srh_spmm_plan_t* plan, int32_t d) {
   return d == 64 ? plan->n_run[1] : d == 128 ? plan->n_run[2] : d == 256 ? plan->n_run[3] : -1;
 }
 
-// ---- live-task lists of row-masked launches ------------------------------------------------------------------------------
-static int live_gi(int32_t d) { return d == 64 ? 1 : d == 128 ? 2 : d == 256 ? 3 : -1; }
-
-// row -> records of the canonical list (once per plan and width; the plan's host lists never change after creation)
-static void live_index(srh_spmm_plan_t* p, int gi) {
-  std::lock_guard<std::mutex> lock(p->live_mutex);
-  if (!p->row_task_ptr[gi].empty()) return;
-  const std::vector<Task64>& canon = p->h_tasks64[gi];
-  std::vector<int64_t> ptr((size_t)p->n_rows + 1, 0);
-  auto each = [&](auto&& fn) {
-    for (size_t t = 0; t < canon.size(); ++t) {
-      const Task64& k = canon[t];
-      if (k.kind == 0) fn(k.row[0], (int32_t)t);
-      else for (int g = 0; g < k.count; ++g) fn(k.row[g], (int32_t)t);
-    }
-  };
-  each([&](int32_t row, int32_t) { ++ptr[(size_t)row + 1]; });
-  int64_t extra = 0;                       // records beyond the first of every row (split rows: one per further segment)
-  for (int64_t r = 0; r < p->n_rows; ++r) extra += std::max<int64_t>(0, ptr[(size_t)r + 1] - 1);
-  for (int64_t r = 0; r < p->n_rows; ++r) ptr[(size_t)r + 1] += ptr[(size_t)r];
-  std::vector<int32_t> ids((size_t)ptr[(size_t)p->n_rows]);
-  std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-  each([&](int32_t row, int32_t t) { ids[(size_t)fill[(size_t)row]++] = t; });
-  p->n_coop[gi] = (int32_t)std::min<int64_t>(extra, INT32_MAX);
-  p->row_task_ids[gi] = std::move(ids);
-  p->row_task_ptr[gi] = std::move(ptr);
-}
-
-int64_t srh_spmm_plan_live_stride(srh_spmm_plan_t* plan, int32_t d, int64_t max_rows) {
-  const int gi = live_gi(d);
-  if (!plan || gi < 0 || max_rows <= 0) { srh::set_error("spmm_plan_live_stride: bad argument"); return -1; }
-  live_index(plan, gi);
-  if (!plan->d_canon64[gi]) {              // (a device allocation: the caller's thread, never inside a stream capture)
-    const std::vector<Task64>& canon = plan->h_tasks64[gi];
-    Task64* dev = nullptr;
-    hipError_t err = hipMalloc(&dev, sizeof(Task64) * std::max<size_t>(1, canon.size()));
-    if (err == hipSuccess && !canon.empty()) err = hipMemcpy(dev, canon.data(), sizeof(Task64) * canon.size(), hipMemcpyHostToDevice);
-    if (err != hipSuccess) { srh::set_error("spmm_plan_live_stride: %s", hipGetErrorString(err)); return -1; }
-    plan->d_canon64[gi] = dev;
-  }
-  // every listed row brings one record, and all split rows together n_coop further ones (their segments beyond the first):
-  // no list of max_rows distinct rows can need more
-  return std::min<int64_t>(max_rows + plan->n_coop[gi], (int64_t)plan->h_tasks64[gi].size());
-}
-
-srh_status_t srh_spmm_plan_live_tasks(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_rows, int64_t n_lists,
-                                      int64_t rows_stride, int32_t* h_live, int64_t live_stride, int32_t* h_n_live) {
-  const int gi = live_gi(d);
-  SRH_REQUIRE(plan && gi > 0 && h_rows && h_live && h_n_live && n_lists >= 0 && rows_stride > 0 && live_stride > 0,
-              "spmm_plan_live_tasks: bad argument");
-  live_index(plan, gi);
-  const std::vector<int64_t>& ptr = plan->row_task_ptr[gi];
-  const std::vector<int32_t>& ids = plan->row_task_ids[gi];
-  const size_t n_words = (plan->h_tasks64[gi].size() + 63) / 64;
-  // lists are independent: a few host threads, each with its own bitmap over the plan's records (a list marks its records
-  // and reads them back in ascending order -- no sort: 5 k records of 31 k per list at the Yelp2018 shape)
-  int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2)),
-                                                         n_lists / 16));
-  if (const char* forced = std::getenv("SRH_LIVE_THREADS")) n_thr = std::max(1, std::min(64, std::atoi(forced)));
-  std::vector<int> bad((size_t)n_thr, 0);              // 1: a row outside the plan, 2: a list longer than live_stride
-  auto work = [&](int t) {
-    std::vector<uint64_t> bits(n_words, 0);
-    for (int64_t b = t; b < n_lists; b += n_thr) {
-      const int32_t* rows = h_rows + b * rows_stride;
-      int32_t* out = h_live + b * live_stride;
-      size_t lo = n_words, hi = 0;
-      for (int64_t k = 0; k < rows_stride && rows[k] >= 0; ++k) {
-        if (rows[k] >= plan->n_rows) { bad[(size_t)t] = 1; return; }
-        for (int64_t q = ptr[(size_t)rows[k]]; q < ptr[(size_t)rows[k] + 1]; ++q) {
-          const size_t rec = (size_t)ids[(size_t)q], w = rec >> 6;
-          bits[w] |= 1ull << (rec & 63);
-          lo = std::min(lo, w); hi = std::max(hi, w);
-        }
-      }
-      int64_t n = 0;
-      for (size_t w = lo; w <= hi && w < n_words; ++w) {      // ascending = canonical order: the split rows' segments lead
-        uint64_t v = bits[w];
-        bits[w] = 0;
-        while (v) {
-          if (n >= live_stride) { bad[(size_t)t] = 2; return; }
-          out[n++] = (int32_t)((w << 6) + (size_t)__builtin_ctzll(v));
-          v &= v - 1;
-        }
-      }
-      h_n_live[b] = (int32_t)n;
-    }
-  };
-  if (n_thr == 1) work(0);
-  else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
-  }
-  for (int t = 0; t < n_thr; ++t) {
-    SRH_REQUIRE(bad[(size_t)t] != 1, "spmm_plan_live_tasks: a listed row lies outside the plan's %lld rows", (long long)plan->n_rows);
-    SRH_REQUIRE(bad[(size_t)t] != 2, "spmm_plan_live_tasks: a list needs more than live_stride = %lld records", (long long)live_stride);
-  }
-  return SRH_OK;
-}
-
 srh_status_t srh_spmm_plan_set_xcd_shares(srh_spmm_plan_t* plan, int32_t d, const int32_t* h_blocks_per_xcd) {
   SRH_REQUIRE(plan, "spmm_plan_set_xcd_shares: null plan");
   SRH_REQUIRE(d == 64 || d == 128 || d == 256, "spmm_plan_set_xcd_shares: d=%d unsupported (64, 128 or 256)", d);
@@ -1896,20 +1769,6 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
               (long long)plan->n_cols, d);
   DevEpilogue ep{};
   if (srh_status_t rc = translate_epilogue(epi, d, d_x, d_y, ep)) return rc;
-  int live_grid = 0;                       // workgroups of a live-task launch (0: the whole list)
-  if (epi && epi->d_live_list) {
-    const int gi = d == 64 ? 1 : d == 128 ? 2 : d == 256 ? 3 : -1;
-    SRH_REQUIRE(gi > 0 && epi->d_row_mark && epi->d_live_count && epi->live_stride > 0 && !fetch && !d_stamps && !floor_only &&
-                    !epi->d_col_mark && !(epi->flags & SRH_EPI_ADAM),
-                "spmm_f32: a live-task list goes with a row-masked launch (d = 64 / 128 / 256, d_row_mark, d_live_count, live_stride)");
-    SRH_REQUIRE(plan->d_canon64[gi], "spmm_f32: live-task list without srh_spmm_plan_live_stride(plan, d, ...) having been called");
-    ep.live_list = epi->d_live_list;
-    ep.live_count = epi->d_live_count;
-    ep.live_batch_no = epi->d_live_batch_no;
-    ep.live_stride = epi->live_stride;
-    ep.live_tasks = plan->d_canon64[gi];
-    live_grid = (epi->live_stride + 3) / 4;
-  }
   hipStream_t st = srh::as_stream(stream);
   // one kernel per table width: a row-group of d/4 lanes per gathered x row (d >= 16), two lanes per row at d = 8
 #define SRH_LAUNCH(KERNEL, GI, XT, YT)                                                                              \
@@ -1926,7 +1785,7 @@ static srh_status_t spmm_launch(const srh_spmm_plan_t* plan, const int32_t* d_in
       SRH_REQUIRE(plan->n_cols * (int64_t)d * 4 < (int64_t(1) << 31), "spmm_f32: x (%lld rows x %d) must be smaller than 2 GiB",
                   (long long)plan->n_cols, d);
 #define SRH_LAUNCH_ROWS(LPRV, GI, CM, PR, ...)                                                                       \
-  spmm_rows_kernel<LPRV, CM, PR, ##__VA_ARGS__><<<(live_grid ? live_grid : (plan->n_run[GI] + 3) / 4) + n_fetch, 256, 0, st>>>( \
+  spmm_rows_kernel<LPRV, CM, PR, ##__VA_ARGS__><<<(plan->n_run[GI] + 3) / 4 + n_fetch, 256, 0, st>>>(           \
       plan->d_tasks64[GI], plan->n_run[GI], d_indices, d_vals, reinterpret_cast<const float4*>(d_x),                \
       reinterpret_cast<float4*>(d_y), reinterpret_cast<float4*>(plan->d_partial), plan->d_heavy, plan->d_slot_owner, \
       plan->d_tickets, ep, n_fetch, fetch_args)

@@ -223,15 +223,6 @@ class FusedTrainer:
         if model in ("XSimGCL", "SimGCL", "SGL"):       # user side + item side share one workspace / launch set
             one = ops.infonce_ws(2 * B if model == "SGL" else B, d, dev)
             self.nce_ws = torch.empty(one.numel() * (1 if model == "SGL" else 2), dtype=torch.uint8, device=dev)
-        # Live-task lists of the row-masked launches (srh_spmm_epilogue_t::d_live_list): the last forward product of a step
-        # computes the batch's rows only, and the host knows them an epoch ahead (the segments' seg_rows) -- the launch runs the
-        # plan records that hold them instead of all of them.  SRH_LIVE_TASKS=0: the whole list with row marks.
-        self.live_stride = 0
-        if (self.det_scatter and self.L >= 1 and self.d >= 64 and self.use_marks and os.environ.get("SRH_LIVE_TASKS", "1") != "0"):
-            stride = ops.spmm_live_stride(self.adj, self.d, 3 * B)
-            if stride <= 16 * B and 2 * stride <= ops.spmm_plan_run_tasks(self.adj, self.d):
-                self.live_stride = int(stride)
-        self._live_host = {}
         E = self.sampler.n_edges
         self.epoch_batches = (E + B - 1) // B
         # The device holds TWO epochs back to back (srh_batch_fetch_args_t::half_batches): the steps read one half while the
@@ -244,8 +235,6 @@ class FusedTrainer:
         if self.det_scatter:
             self._epoch_slot.update({"n_uniq_n": nb, "seg_rows": 3 * nb * B, "seg_end": 3 * nb * B, "seg": 3 * nb * B,
                                      "seg_a": 3 * nb * B, "seg_b": nb * B})
-        if self.live_stride:
-            self._epoch_slot.update({"live": nb * self.live_stride, "n_live": nb})
         self._epoch_dev = {k: torch.zeros(2 * n, dtype=torch.int32, device=dev) for k, n in self._epoch_slot.items()}
         self._live_half = None                 # the half the steps read (None: nothing uploaded yet)
         self._half_free = [None, None]         # event on the step stream: every step that read this half has been enqueued
@@ -444,9 +433,7 @@ class FusedTrainer:
         two); None = fresh arrays."""
         if self._first_epoch is not None:
             pre, self._first_epoch = self._first_epoch, None
-            host = pre.take()
-            self._add_live_tasks(host)                 # (drawn before the propagation plan existed)
-            return host
+            return pre.take()
         return self._sample_epoch_host_now(slot)
 
     def _sample_epoch_host_now(self, slot=None):
@@ -474,22 +461,7 @@ class FusedTrainer:
                                 **({"with_segments": self.rows.segment_row_offsets()} if self.det_scatter else {}))
         # node ids -> table rows (items follow the users; all-gather order when the rows are dealt)
         out.update(self.rows.epoch_to_table_rows(ep))
-        self._add_live_tasks(out, slot)
         return out
-
-    def _add_live_tasks(self, host, slot=None):
-        """the epoch's live-task lists (per batch: the plan records that hold the batch's rows), once the plan exists -- the
-        epoch that has been in the making since construction gets them at upload time"""
-        if not getattr(self, "live_stride", 0) or "live" in host or "seg_rows" not in host:
-            return
-        nb, stride = self.epoch_batches, self.live_stride
-        held = self._live_host.get(slot) if slot is not None else None
-        if held is None:
-            held = (np.zeros(nb * stride, dtype=np.int32), np.zeros(nb, dtype=np.int32))
-            if slot is not None:
-                self._live_host[slot] = held
-        host["live"], host["n_live"] = ops.spmm_live_tasks(self.adj, self.d, host["seg_rows"], nb, 3 * self.B, stride,
-                                                           out=held[0], counts=held[1])
 
     def epoch_node_ids(self, host=None):
         """(u, i, j) of an epoch as the reference's user / item ids (the staged arrays hold table rows)."""
@@ -540,7 +512,6 @@ class FusedTrainer:
         if "masks" in host:
             for v, mk in enumerate(host["masks"]):
                 self.view_adj[v] = self.graph.dropped_view(torch.from_numpy(mk).to(dev), out=self._view_vals[v])
-        self._add_live_tasks(host)
         half = self._next_half()
         staged = host.pop("_staged", None)
         if staged is not None and staged[0] == half:
@@ -627,10 +598,6 @@ class FusedTrainer:
                     kw.update(prev_unscale=([False] if include_ego else []) + [True] * (L - 1))
                 if batch_rows_only and self.use_marks:
                     kw.update(row_mark=self._loc(self.mark), mark_stamp=self.cursor[1:2])
-                    if (self.live_stride and not getattr(self, "_live_off", False)
-                            and getattr(getattr(adj, "_plan", None), "value", None) == self.adj._plan.value):
-                        kw.update(live=dict(list=self._epoch_dev["live"], count=self._epoch_dev["n_live"],
-                                            stride=self.live_stride, batch_no=self.meta[3:4]))
             if vf:
                 # layer 1 reads the true table E0 through the value array; later layers read pre-scaled tables through
                 # the pattern.  Every layer but the last stores its output pre-scaled.

@@ -320,10 +320,8 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
                   row_mark=None, col_mark=None, mark_stamp=None, add_mark=None, add_sparse=None,
                   extra_out=None, extra_noise=None, extra_rng_offset=None, main_clean=False, d_full=0, col0=0,
                   row_scale=None, scale_in=False, scale_out=False, prev_unscale=None, add_rowscale=None, d_valid=0,
-                  adam=None, live=None):
-    """live: dict(list, count, stride[, batch_no]) -- a row-masked launch that runs only the plan records holding the batch's
-    rows (srh_spmm_epilogue_t::d_live_list; spmm_live_stride / spmm_live_tasks make the lists).
-    row_scale / scale_in / scale_out / prev_unscale / add_rowscale: per-row scaling for value-free products
+                  adam=None):
+    """row_scale / scale_in / scale_out / prev_unscale / add_rowscale: per-row scaling for value-free products
     (include/selfrec_hip.h: SRH_SCALE_*); prev_unscale / add_rowscale are lists of booleans aligned with prev / add.
     adam: dict(param, m, v, coef, beta1, beta2, eps, clear=[tables], clear_mark, cursor) -- SRH_EPI_ADAM: the product (after
     AXPY) is the gradient of `param`, which takes the optimiser's step in the epilogue instead of the gradient being stored;
@@ -402,14 +400,6 @@ def make_epilogue(*, perturb_eps=None, noise=None, rng_seed=0, rng_offset=0, rng
         if mark_stamp is not None and not ep.d_mark_stamp:
             ep.d_mark_stamp = _p(mark_stamp, torch.int64, "mark_stamp")
         keep += [adam, mark_stamp]
-    if live is not None:
-        if row_mark is None:
-            raise SelfrecHipError("make_epilogue: live task lists go with row marks")
-        ep.d_live_list = _p(live["list"], torch.int32, "live list")
-        ep.d_live_count = _p(live["count"], torch.int32, "live count")
-        ep.d_live_batch_no = _p(live.get("batch_no"), torch.int32, "live batch_no")
-        ep.live_stride = int(live["stride"])
-        keep += [live]
     ep.flags = flags
     ep._keepalive = keep + [row_scale]
     return ep
@@ -470,28 +460,6 @@ def spmm_any(csr: DeviceCSR, x: torch.Tensor) -> torch.Tensor:
         y = spmm(csr, pad_cols(x[:, c0:c0 + wb], padded_width(wb, SPMM_WIDTHS)))
         out[:, c0:c0 + wb] = y[:, :wb]
     return out
-
-
-def spmm_live_stride(csr: DeviceCSR, d: int, max_rows: int) -> int:
-    """Prepare csr's plan for live-task launches on d-column tables; returns the record count no list of <= max_rows rows
-    exceeds (srh_spmm_plan_live_stride).  Device allocation: the owning thread, outside a capture."""
-    n = int(_lib.load().srh_spmm_plan_live_stride(csr._plan, int(d), int(max_rows)))
-    if n < 0:
-        check(-1, "srh_spmm_plan_live_stride")
-    return n
-
-
-def spmm_live_tasks(csr: DeviceCSR, d: int, rows: np.ndarray, n_lists: int, rows_stride: int, live_stride: int, out=None,
-                    counts=None):
-    """Per row list (rows[b * rows_stride ...], ended by -1): the plan records holding any of its rows (host int32 arrays
-    (n_lists * live_stride,), (n_lists,)) -- srh_spmm_plan_live_tasks.  out / counts: arrays to fill (else fresh)."""
-    rows = np.ascontiguousarray(rows, dtype=np.int32)
-    out = np.zeros(n_lists * live_stride, dtype=np.int32) if out is None else out
-    counts = np.zeros(n_lists, dtype=np.int32) if counts is None else counts
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    check(_lib.load().srh_spmm_plan_live_tasks(csr._plan, int(d), vp(rows), int(n_lists), int(rows_stride), vp(out),
-                                               int(live_stride), vp(counts)), "srh_spmm_plan_live_tasks")
-    return out, counts
 
 
 def spmm_plan_run_tasks(csr: DeviceCSR, d: int) -> int:

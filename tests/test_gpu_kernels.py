@@ -256,49 +256,6 @@ def test_spmm_with_column_class_schedule_matches_scipy(d, min_len):
     assert rel_err(got_m.cpu().numpy(), want_m) < 2e-6
 
 
-@pytest.mark.parametrize("d", [64, 128, 256])
-def test_row_masked_launch_on_live_task_lists_equals_the_marked_launch(d):
-    """srh_spmm_epilogue_t::d_live_list: a row-masked launch (the step's last forward product: batch rows only) that runs only
-    the plan records holding the listed rows -- srh_spmm_plan_live_tasks' lists, one per batch, picked on the device by a batch
-    number -- computes exactly what the launch over the whole list computes on those rows (split rows included: every segment
-    of a listed row is in the list), bit for bit, agrees with scipy, and leaves every other row alone."""
-    rng = np.random.default_rng(d)
-    m = powerlaw_csr(3000, 2500, 50000, 5 + d, heavy_rows=4, heavy_len=2400, empty_rows=30)
-    csr = ops.DeviceCSR.from_scipy(m, DEV)
-    x = torch.from_numpy(rng.standard_normal((2500, d)).astype(np.float32)).to(DEV)
-    want = torch.from_numpy((m @ x.cpu().numpy()).astype(np.float32))
-    max_rows = 256
-    stride = ops.spmm_live_stride(csr, d, max_rows)
-    assert 0 < stride <= ops.spmm_plan_run_tasks(csr, d)
-    lists = [np.sort(rng.choice(3000, size=n, replace=False)) for n in (200, 1, 256)]
-    lists[0][-4:] = [2996, 2997, 2998, 2999]                       # the heavy (split) rows
-    lists[0] = np.unique(lists[0])
-    rows = np.full((3, max_rows), -1, dtype=np.int32)
-    for b, r in enumerate(lists):
-        rows[b, :r.size] = r
-    live, counts = ops.spmm_live_tasks(csr, d, rows.reshape(-1), 3, max_rows, stride)
-    assert (counts > 0).all() and (counts <= stride).all() and counts[1] >= 1
-    dlive, dcounts = torch.from_numpy(live).to(DEV), torch.from_numpy(counts).to(DEV)
-    stamp = torch.tensor([7], dtype=torch.int64, device=DEV)
-    for b, r in enumerate(lists):
-        mark = torch.zeros(3000, dtype=torch.int32, device=DEV)
-        mark[torch.from_numpy(r.astype(np.int64)).to(DEV)] = 7
-        whole = torch.full((3000, d), float("nan"), device=DEV)
-        ops.spmm(csr, x, out=whole, epilogue=ops.make_epilogue(row_mark=mark, mark_stamp=stamp))
-        listed = torch.full((3000, d), float("nan"), device=DEV)
-        ops.spmm(csr, x, out=listed, epilogue=ops.make_epilogue(
-            row_mark=mark, mark_stamp=stamp, live=dict(list=dlive, count=dcounts, stride=stride,
-                                                       batch_no=torch.tensor([b], dtype=torch.int32, device=DEV))))
-        torch.cuda.synchronize()
-        sel = torch.from_numpy(r.astype(np.int64))
-        assert torch.equal(listed.cpu()[sel], whole.cpu()[sel])
-        assert rel_err(listed.cpu()[sel].numpy(), want[sel].numpy()) < 1e-5
-        rest = np.setdiff1d(np.arange(3000), r)
-        assert torch.isnan(listed.cpu()[torch.from_numpy(rest)]).all()            # nobody else's row was written
-    with pytest.raises(ops.SelfrecHipError):                                      # a stride the lists do not fit: refused
-        ops.spmm_live_tasks(csr, d, rows.reshape(-1), 3, max_rows, 8)
-
-
 def test_spmm_rng_perturbation_properties():
     d, n = 64, 500
     m = powerlaw_csr(n, n, 6000, seed=9)

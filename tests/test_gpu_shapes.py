@@ -366,36 +366,6 @@ def test_xcd_share_calibration_changes_placement_not_results(yelp_data, model):
     ops.spmm_set_xcd_shares(a.adj, 64, shares)                  # leave the module's shared graph as the engine set it
 
 
-@pytest.mark.selfcheck
-@pytest.mark.parametrize("model", ["XSimGCL", "SGL"])
-def test_live_task_lists_change_the_launch_not_the_step(yelp_data, model, monkeypatch):
-    """engine.live_stride: the step's row-masked products (the last forward layer: batch rows only) run the plan records that
-    hold the batch's rows instead of the whole list (srh_spmm_plan_live_tasks, one list per batch, uploaded with the epoch).
-    Same records on the same rows: captured steps over an epoch boundary leave the same bits in the table and the moments as
-    the launch over the whole list (SRH_LIVE_TASKS=0)."""
-    kw = dict(model=model, n_layers=3, lr=1e-3, reg=1e-4, cl_rate=0.2, eps=0.2, tau=0.2, layer_cl=1, batch_size=2048,
-              use_graph=True)
-    outs = []
-    for live in ("1", "0"):
-        monkeypatch.setenv("SRH_LIVE_TASKS", live)
-        torch.manual_seed(5)
-        tr = FusedTrainer(yelp_data, 64, **kw)
-        assert (tr.live_stride > 0) == (live == "1")
-        tr.sampler.seed(11)
-        nb = tr.begin_epoch()
-        tr.cursor[0:1] += nb - 4                         # (the epoch's last four batches, then the next epoch's first four)
-        for _ in range(4):
-            tr.step()
-        assert tr.begin_epoch() == nb
-        for _ in range(4):
-            tr.step()
-        torch.cuda.synchronize()
-        outs.append((tr.E0.clone(), tr.m.clone(), tr.v.clone(), tr.losses.clone()))
-    assert torch.isfinite(outs[0][0]).all() and float(outs[0][1].abs().max()) > 0
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
 def test_1m_500k_xsimgcl_step_matches_reference_run(shapes, smeta):
     """BASELINE.json configs[3]: XSimGCL L=3, d = 128 on the synthetic 1 M x 500 k graph (40.3 M train interactions) --
     one step of the reference (8 torch threads, ~25 GB of python objects) against the fused engine on one MI355X.
