@@ -1422,17 +1422,15 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
   const int bno = sg.batch_no ? *sg.batch_no : 0;
   const size_t off1 = sg.batch_no ? (size_t)bno * a.B : 0, off3 = 3 * off1;
   const int row = grp < 3 * a.B ? sg.rows[off3 + grp] : -1;
-  const bool live = row >= 0;
   const int e1 = grp < 3 * a.B ? sg.seg_end[off3 + grp] : 0;
   const int e0g = (grp > 0 && grp < 3 * a.B) ? sg.seg_end[off3 + grp - 1] : 0;
   const int nuu = *sg.n_uniq_u, nui = *sg.n_uniq_i;
-  const int e0 = live ? e0g : e1;
-  const int rq = live ? row : 0;
   const int kind = grp < nuu ? 0 : (grp < nuu + nui ? 1 : 2);       // user | positive item | negative only
   const float* reg_t = kind == 0 ? a.reg_user : a.reg_item;
   const float* opd_t = kind == 0 ? a.item : a.user;                  // the table a term's operand rows come from
-  const float4 rr = reinterpret_cast<const float4*>(reg_t)[(size_t)rq * LPR + sub];
-  // ---- the first entries of the row's slot list: requested before anything else of this level
+  // ---- what hangs off the group's row and list bounds (the loads above): its regulariser operand and the first entries of
+  // its slot list.  Requested from INSIDE the InfoNCE row finish, after that row's own loads -- which hang off nothing but
+  // the counts -- have gone out: the two chains run side by side instead of one behind the other.
   constexpr int WU = 8, WI = 8;                   // entries in flight per round trip: user groups / item groups
   int ent[WI], ra[WI], rb[WU];
   auto fetch_entries = [&](int e, auto wc, auto userc) {
@@ -1445,16 +1443,24 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
       if constexpr (decltype(userc)::value) rb[k] = sg.seg_b[off1 + ek];
     }
   };
-  const bool any = e0 < e1 && !(SRH_RF_SKIP & 2);
-  if (any) {
-    if (kind == 0) fetch_entries(e0, std::integral_constant<int, WU>{}, std::true_type{});
-    else fetch_entries(e0, std::integral_constant<int, WI>{}, std::false_type{});
-  }
+  bool live = false, any = false;
+  int e0 = 0;
+  float4 rr = f4_zero();
+  auto on_row = [&]() {
+    live = row >= 0;
+    e0 = live ? e0g : e1;
+    rr = reinterpret_cast<const float4*>(reg_t)[(size_t)(live ? row : 0) * LPR + sub];
+    any = e0 < e1 && !(SRH_RF_SKIP & 2);
+    if (any) {
+      if (kind == 0) fetch_entries(e0, std::integral_constant<int, WU>{}, std::true_type{});
+      else fetch_entries(e0, std::integral_constant<int, WI>{}, std::false_type{});
+    }
+  };
   // ---- the InfoNCE gradients of this row (the problem that names it: SegArgs::nce_rows)
   int pz = -1, pi = 0;
   if (sg.nce_rows == 1 && kind < 2) { pz = kind; pi = kind == 0 ? grp : grp - nuu; }
   if (sg.nce_rows == 2 && kind < 2) { pz = 0; pi = grp; }
-  const bool has_nce = live && pz >= 0 && pz < batch.count;
+  const bool has_nce = grp < nuu + nui && pz >= 0 && pz < batch.count;      // (the groups below nuu + nui all have a row)
   float4 dv1 = f4_zero(), dv2 = f4_zero();
   double li = 0.0;
   const bool with_nce = batch.count > 0 && sg.nce_rows != 0;
@@ -1468,7 +1474,9 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
     const int n = w.d_n ? min(*w.d_n, w.n_max) : w.n_max;
     int splits = batch.splits;
     if (batch.slots > 0) splits = batch.w[0].plan->splits[pq];
-    li = nce_finish_row_grads<LPR>(w, fa, has_nce ? n : 0, pi, sub, splits, dv1, dv2);
+    li = nce_finish_row_grads<LPR>(w, fa, has_nce ? n : 0, pi, sub, splits, dv1, dv2, on_row);
+  } else {
+    on_row();
   }
   // ---- InfoNCE loss, part 1: one partial per workgroup and problem, summed inside the workgroup in group order and PUBLISHED
   // as soon as it exists (the loss terms are done long before the slot lists are): one 8-byte write-through store into a slot
