@@ -1389,8 +1389,8 @@ __global__ __launch_bounds__(256) void nce_finish_bpr2(NceBatch batch, NceFinish
 // other negatives, each with the list of (slot, role) entries that name it), so the LPR lanes of ONE row group own a row:
 // they finish its InfoNCE gradients (if a problem names the row), walk its slot list in order adding the BPR / L2 terms, and
 // write the row once -- read, add, store.  Same arithmetic per term as the atomic form above; the sum's order is the list's.
-#ifndef SRH_RF_SKIP          // (laboratory builds, tools/spmm_lab/build_alt.sh: bit 0 no InfoNCE rows, 1 no slot lists, 2 no loss
-#define SRH_RF_SKIP 0        //  fold -- what each part of rows_finish costs; the product is built with 0)
+#ifndef SRH_RF_SKIP          // (laboratory builds, tools/spmm_lab/build_alt.sh: bit 0 no InfoNCE rows, 1 no slot lists, 2 no loss fold, 3 no final
+#define SRH_RF_SKIP 0        //  fold only -- what each part of rows_finish costs, tools/rf_ab.sh; the product is built with 0)
 #endif
 struct SegArgs {
   const int32_t *n_uniq_u, *n_uniq_i, *n_uniq_n, *rows, *seg_end, *seg, *seg_a, *seg_b, *batch_no;

@@ -524,3 +524,21 @@ def check_dp_against_oracle(tmp_path, model, world):
         ref.opt.step()
     want = torch.cat([ref.user_emb, ref.item_emb]).detach().numpy()
     np.testing.assert_allclose(r[0]["E0"], want, rtol=1e-4, atol=2e-6)
+
+
+def test_abi_communicator_has_the_call_shape_the_gloo_worlds_exercise():
+    """comm.AbiComm (the placement exchanges through include/selfrec_hip.h's RCCL wrappers) needs a GPU per rank; what the
+    world-2 .. 8 tests above drive over gloo is comm.TorchComm.  The two are interchangeable for a placement only if they
+    expose the same calls with the same parameters: all_gather(out, inp), all_reduce_sum(t), assert_replicated(what, values,
+    device), world / rank / group -- checked here, so that a change to one side cannot leave the other behind."""
+    import inspect
+    from selfrec_amd.comm import AbiComm, TorchComm
+    for name in ("all_gather", "all_reduce_sum", "assert_replicated"):
+        a, t = inspect.signature(getattr(AbiComm, name)), inspect.signature(getattr(TorchComm, name))
+        assert list(a.parameters) == list(t.parameters), name
+    src = inspect.getsource(AbiComm)
+    for sym in ("srh_comm_unique_id", "srh_comm_init_rank", "srh_comm_world", "srh_allgather_rows", "srh_reducescatter_rows",
+                "srh_allreduce_sum_f32", "srh_comm_destroy"):
+        assert sym in src, sym
+    for attr in ("self.world", "self.rank", "self.group"):
+        assert attr in src
