@@ -1594,8 +1594,9 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
     double t = 0.0;
     for (int j0 = 0; j0 < nce_wgs; j0 += 512) {           // (eight slots per lane in flight: one round trip per poll)
       unsigned long long v[8];
-      for (int spin = 0; spin < (1 << 16); ++spin) {      // (bounded: a lost report costs a wrong loss figure, never a hung device)
-        bool missing = false;
+      bool missing = false;
+      for (int spin = 0; spin < (1 << 16); ++spin) {      // (bounded: a lost report never hangs the device ...)
+        missing = false;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int j = j0 + 64 * q + lane;
@@ -1606,7 +1607,7 @@ __device__ __forceinline__ void rows_finish_body(const NceBatch& batch, const Nc
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += __builtin_bit_cast(double, v[q]);
+      for (int q = 0; q < 8; ++q) t += __builtin_bit_cast(double, v[q]);    // (... and shows: an unreported slot is a NaN pattern)
     }
     t = wave_sum_d(t);
     s_li[k] = n > 0 ? (double)fa.loss_scale * t / (double)n : 0.0;
