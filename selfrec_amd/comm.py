@@ -110,7 +110,10 @@ class AbiComm:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            self._lib.srh_comm_destroy(h)
+            try:
+                self._lib.srh_comm_destroy(h)
+            except Exception:        # (interpreter shutdown: the library or RCCL may be gone already)
+                pass
             self._h = None
 
     @staticmethod

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = a list of stages; everything lands in gpurun_out/.
-# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsall testsf4 testsnew bench benchquick benchdriver benchbig benchworld2 prof profeval evalprobe evalab evalpmc lossprobe nceab nceprec pmc big cols oplevel refmodels refmodelsfuse determinism precision lab*
+# usage: tools/gpu_session.sh [stage ...]      stages: smoke tests testsall testsf4 testsnew rfab detab bench benchquick benchdriver benchbig benchworld2 prof profeval evalprobe evalab evalpmc lossprobe nceab nceprec pmc big cols oplevel refmodels refmodelsfuse determinism precision lab*
 # (budget note from round 2: a call is charged for getting the box as well as for the run -- 20 s when a warm box is at hand,
 #  3-5 min when not, whatever the command: batch stages into one call, and keep the last minutes for a final check)
 set -u
@@ -259,6 +259,12 @@ sharded1)
   done;;
 modelmatrix)
   timeout 1200 python tools/model_matrix.py > $OUT/model_matrix.log 2>&1; echo "modelmatrix exit $?"; grep -v amdgpu.ids $OUT/model_matrix.log | tail -12;;
+rfab)
+  # rows_finish (the fixed-order loss finish) part by part: tools/spmm_lab/build_alt.sh rf1 "-DSRH_RF_SKIP=1" ... first (ALT_SRC=losses)
+  RF_LIBS="${RF_LIBS:-base}" bash tools/rf_ab.sh 2>&1 | grep -E "^==|rows_finish|nce_finish" | tee $OUT/rf_ab.txt;;
+detab)
+  # the step with the fixed-order batch-gradient reduction against the atomic scatter, one process, alternating regions
+  timeout 900 python tools/det_scatter_ab.py 2>&1 | grep -v amdgpu.ids | tee $OUT/det_scatter_ab.txt | tail -14;;
 benchdriver20)
   # the driver's literal command line
   timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver20.log 2> $OUT/bench_driver20.err; echo "benchdriver20 exit $?"
